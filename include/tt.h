@@ -1,0 +1,100 @@
+/*
+ * tt.h -- C ABI of libtt.so: the MI355X (gfx950) implementation of the
+ * two-tower retrieval hot path of jpe17/TwoTowerMLRetrieval.
+ *
+ * The reference is pure Python and has no FFI seam: the
+ * arithmetic of this path is stock PyTorch calls.  Each entry point below
+ * replaces one of those call sites (cited as reference file:line, paths
+ * relative to the reference repository root); INTEGRATION.md shows the
+ * ctypes stub a reference maintainer would add to bind them.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; every pointer is a DEVICE pointer unless
+ *    the parameter comment says "host".  All matrices are row-major, dense.
+ *  - the library never allocates or frees user-visible memory and keeps no
+ *    reference past return: outputs and workspace are caller-owned; workspace
+ *    size comes from the matching *_workspace_bytes() query.
+ *  - every call is asynchronous on `stream` (a hipStream_t; NULL = the null
+ *    stream), issues no hipDeviceSynchronize and may be captured in a hipGraph.
+ *  - every call returns an int status (TT_OK = 0) and never throws;
+ *    tt_last_error() returns a thread-local message for the last failure.
+ *  - re-entrant: no global mutable state besides that thread-local string.
+ */
+#ifndef TT_H
+#define TT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void *tt_stream_t; /* hipStream_t */
+
+enum tt_status {
+    TT_OK = 0,
+    TT_ERR_BAD_SHAPE = 1,   /* -> ValueError / RuntimeError in the Python shim */
+    TT_ERR_BAD_INDEX = 2,   /* token id outside [0,V): IndexError (g10_errors.json) */
+    TT_ERR_ZERO_LENGTH = 3, /* a row with no non-zero id: RuntimeError (model.py:55-57) */
+    TT_ERR_UNSUPPORTED = 4, /* shape/dtype outside what the kernels are built for */
+    TT_ERR_WORKSPACE = 5,   /* workspace NULL or too small */
+    TT_ERR_HIP = 6          /* a HIP runtime call failed; message has hipGetErrorString */
+};
+
+const char *tt_version(void);
+const char *tt_last_error(void);
+
+/* ------------------------------------------------------------------ */
+/* Brute-force scoring + top-k                                         */
+/* ------------------------------------------------------------------ */
+
+/*
+ * Replaces  torch.matmul(q, D.t()) ; torch.topk(scores, k)
+ *   backend/evaluators.py:185-186, :269-272 ; backend/trainer.py:62-65
+ * Q [B,d] f32, D [N,d] f32 -> out_val [B,k] f32 (descending), out_idx [B,k]
+ * int64 = idx_offset + row of D.  The [B,N] score matrix is never formed.
+ * Score = fp32 FMA chain over the feature index in ascending order (exactly
+ * oracle/tt_oracle.c:o_score_topk).  Ties: (score desc, index asc).  When
+ * N < k the tail is (-inf, -1).  Supported: d in {64,128,256}, 1 <= k <= 64,
+ * N < 2^31 - 64 per call (shard larger corpora; idx_offset makes indices global).
+ * Inputs must be finite (a NaN score is never selected).
+ */
+size_t tt_score_topk_workspace_bytes(int B, int64_t N, int d, int k);
+int tt_score_topk_f32(const float *Q, int B, int d, const float *D, int64_t N, int k,
+                      int64_t idx_offset, float *out_val, int64_t *out_idx, void *workspace,
+                      size_t workspace_bytes, tt_stream_t stream);
+
+/*
+ * First half of tt_score_topk_f32 alone: the streaming score + per-tile top-k kernel.
+ * Leaves [B, *part_m] unordered candidates (idx -1 = empty) in the workspace and returns
+ * host pointers-to-device-pointers to them; follow with tt_topk_merge.  Exposed so a
+ * sharded caller can gather candidates itself and so bench.py can time the kernel alone.
+ */
+int tt_score_topk_partials_f32(const float *Q, int B, int d, const float *D, int64_t N, int k,
+                               int64_t idx_offset, void *workspace, size_t workspace_bytes,
+                               const float **part_val /*host out*/, const int64_t **part_idx /*host out*/,
+                               int *part_m /*host out*/, tt_stream_t stream);
+
+/*
+ * Merge of partial top-k lists (per tile, per shard after the RCCL all-gather:
+ * SURVEY 8e) into the global top-k: in_val/in_idx [B,M] candidates in any
+ * order, idx < 0 = padding; out [B,k], (score desc, index asc), tail (-inf,-1).
+ * New in the build (the reference is single-device); oracle: o_topk_merge.
+ */
+int tt_topk_merge(const float *in_val, const int64_t *in_idx, int B, int M, int k, float *out_val,
+                  int64_t *out_idx, tt_stream_t stream);
+
+/*
+ * Rank (1-based) of one designated document per query under (score desc,
+ * index asc), what BatchEvaluator extracts from a full sort per row.
+ *   backend/evaluators.py:50,58-65
+ * Q [B,d], D [N,d], target [B] int64 (row of D) -> rank [B] int64.
+ */
+int tt_score_rank_f32(const float *Q, int B, int d, const float *D, int64_t N, const int64_t *target,
+                      int64_t *rank, tt_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TT_H */

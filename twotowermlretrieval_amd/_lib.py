@@ -1,0 +1,59 @@
+"""ctypes binding of libtt.so (include/tt.h).  There is NO fallback: if the HIP
+library is missing or a call fails, the error is raised to the caller."""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+_PKG = Path(__file__).resolve().parent
+LIB_PATH = _PKG / "libtt.so"
+
+TT_OK, TT_ERR_BAD_SHAPE, TT_ERR_BAD_INDEX, TT_ERR_ZERO_LENGTH, TT_ERR_UNSUPPORTED, TT_ERR_WORKSPACE, TT_ERR_HIP = range(7)
+
+
+class TTError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"libtt error {code}: {msg}")
+        self.code = code
+
+
+_vp, _i, _i64, _sz, _f = C.c_void_p, C.c_int, C.c_int64, C.c_size_t, C.c_float
+
+# name -> (restype, argtypes); mirrors include/tt.h one to one
+SIGNATURES = {
+    "tt_version": (C.c_char_p, []),
+    "tt_last_error": (C.c_char_p, []),
+    "tt_score_topk_workspace_bytes": (_sz, [_i, _i64, _i, _i]),
+    "tt_score_topk_f32": (_i, [_vp, _i, _i, _vp, _i64, _i, _i64, _vp, _vp, _vp, _sz, _vp]),
+    "tt_score_topk_partials_f32": (_i, [_vp, _i, _i, _vp, _i64, _i, _i64, _vp, _sz, _vp, _vp, _vp, _vp]),
+    "tt_topk_merge": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "tt_score_rank_f32": (_i, [_vp, _i, _i, _vp, _i64, _vp, _vp, _vp]),
+}
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            raise ImportError(
+                f"{LIB_PATH} is missing: build it with `python -m twotowermlretrieval_amd.build` "
+                "(hipcc, gfx950).  There is no CPU or PyTorch fallback for this path.")
+        l = C.CDLL(str(LIB_PATH))
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(rc: int) -> None:
+    if rc != TT_OK:
+        msg = lib().tt_last_error().decode("utf-8", "replace")
+        if rc == TT_ERR_BAD_INDEX:
+            raise IndexError(msg)
+        if rc == TT_ERR_BAD_SHAPE:
+            raise ValueError(msg)
+        raise TTError(rc, msg)

@@ -1,0 +1,75 @@
+"""Build libtt.so (hand-written HIP for gfx950) in-tree with hipcc.
+
+    python -m twotowermlretrieval_amd.build [--force]
+
+hipcc cross-compiles without a GPU; the .so sits next to this file so it
+travels with the source tree (it is git-ignored, not gpurun-ignored).
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+from pathlib import Path
+
+PKG = Path(__file__).resolve().parent
+CSRC = PKG / "csrc"
+LIB = PKG / "libtt.so"
+ARCH = "gfx950"
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and Path(cand).exists():
+            return cand
+    raise RuntimeError("hipcc not found (set HIPCC or install ROCm)")
+
+
+def sources():
+    return sorted(CSRC.glob("*.hip"))
+
+
+def needs_build() -> bool:
+    if not LIB.exists():
+        return True
+    t = LIB.stat().st_mtime
+    deps = list(CSRC.glob("*")) + [PKG.parent / "include" / "tt.h"]
+    return any(p.stat().st_mtime > t for p in deps)
+
+
+def build(force: bool = False, verbose: bool = False) -> Path:
+    if not force and not needs_build():
+        return LIB
+    objdir = PKG / "build"
+    objdir.mkdir(exist_ok=True)
+    hipcc = _hipcc()
+    flags = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
+             "-Wall", "-Wno-unused-function"]
+    objs = []
+    procs = []
+    for src in sources():
+        obj = objdir / (src.stem + ".o")
+        objs.append(obj)
+        dep_newer = (not obj.exists()) or force or any(
+            p.stat().st_mtime > obj.stat().st_mtime for p in (src, CSRC / "tt_common.h", PKG.parent / "include" / "tt.h"))
+        if dep_newer:
+            cmd = [hipcc, *flags, "-c", str(src), "-o", str(obj)]
+            if verbose:
+                print(" ".join(cmd))
+            procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    for src, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {src.name}:\n{out}")
+        if verbose and out.strip():
+            print(out)
+    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", str(LIB), *map(str, objs)]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"link failed:\n{r.stdout}")
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

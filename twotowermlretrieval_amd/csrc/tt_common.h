@@ -1,0 +1,29 @@
+// Shared host/device helpers for libtt.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/tt.h"
+
+#define TT_EXPORT extern "C" __attribute__((visibility("default")))
+
+int tt_fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+
+#define TT_HIP_CHECK(expr)                                                                   \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess)                                                                \
+            return tt_fail(TT_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                           __FILE__, __LINE__);                                              \
+    } while (0)
+
+#define TT_LAUNCH_CHECK() TT_HIP_CHECK(hipGetLastError())
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+static inline size_t tt_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+#define TT_WAVE 64

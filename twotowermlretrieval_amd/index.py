@@ -1,0 +1,178 @@
+"""Exact brute-force cosine/dot top-k over a resident document-embedding matrix.
+
+Drop-in for the reference's scoring idiom
+
+    sim = torch.matmul(query_emb, doc_embeddings.t()); torch.topk(sim, k)
+    (backend/evaluators.py:185-186, :269-272; backend/trainer.py:62-65)
+
+with the same return convention as torch.topk: (values [B,k] f32 descending,
+indices [B,k] int64).  The [B,N] score matrix is never materialised.  Ties are
+DEFINED (score desc, index asc); torch.topk leaves them unspecified.
+
+Everything here runs through libtt.so (hand-written HIP, gfx950).  There is no
+PyTorch/CPU fallback: inputs must be CUDA(ROCm) tensors.
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional, Tuple
+
+import torch
+
+from . import _lib
+
+__all__ = ["score_topk", "topk_merge", "score_rank", "BruteForceIndex", "ShardedIndex", "shard_bounds"]
+
+
+def _stream(t: torch.Tensor) -> int:
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _need_cuda(*ts: torch.Tensor) -> None:
+    for t in ts:
+        if not t.is_cuda:
+            raise RuntimeError("twotowermlretrieval_amd: this path runs only on an AMD GPU via libtt.so; "
+                               f"got a {t.device} tensor (no CPU fallback exists)")
+
+
+def _f32c(t: torch.Tensor) -> torch.Tensor:
+    if t.dtype != torch.float32:
+        raise TypeError(f"expected float32, got {t.dtype}")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def score_topk(q: torch.Tensor, docs: torch.Tensor, k: int, idx_offset: int = 0,
+               workspace: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """topk(q @ docs.T, k) fused.  q [B,d] or [d]; docs [N,d] (row i <-> document i)."""
+    squeeze = q.dim() == 1
+    if squeeze:
+        q = q.unsqueeze(0)
+    _need_cuda(q, docs)
+    q, docs = _f32c(q), _f32c(docs)
+    B, d = q.shape
+    N = docs.shape[0]
+    if docs.dim() != 2 or docs.shape[1] != d:
+        raise ValueError(f"shape mismatch: q {tuple(q.shape)} vs docs {tuple(docs.shape)}")
+    L = _lib.lib()
+    vals = torch.empty((B, k), dtype=torch.float32, device=q.device)
+    idx = torch.empty((B, k), dtype=torch.int64, device=q.device)
+    need = L.tt_score_topk_workspace_bytes(B, N, d, k)
+    if workspace is None or workspace.numel() < need:
+        workspace = torch.empty(max(need, 16), dtype=torch.uint8, device=q.device)
+    with torch.cuda.device(q.device):
+        _lib.check(L.tt_score_topk_f32(q.data_ptr(), B, d, docs.data_ptr(), N, k, idx_offset, vals.data_ptr(),
+                                       idx.data_ptr(), workspace.data_ptr(), workspace.numel(), _stream(q)))
+    return (vals[0], idx[0]) if squeeze else (vals, idx)
+
+
+def topk_merge(vals: torch.Tensor, idx: torch.Tensor, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Top-k of [B,M] unordered candidates (idx < 0 = padding); (score desc, index asc)."""
+    _need_cuda(vals, idx)
+    vals = _f32c(vals)
+    idx = idx.contiguous()
+    if idx.dtype != torch.int64 or vals.shape != idx.shape or vals.dim() != 2:
+        raise ValueError("topk_merge wants vals f32 [B,M] and idx int64 [B,M]")
+    B, M = vals.shape
+    ov = torch.empty((B, k), dtype=torch.float32, device=vals.device)
+    oi = torch.empty((B, k), dtype=torch.int64, device=vals.device)
+    with torch.cuda.device(vals.device):
+        _lib.check(_lib.lib().tt_topk_merge(vals.data_ptr(), idx.data_ptr(), B, M, k, ov.data_ptr(), oi.data_ptr(),
+                                            _stream(vals)))
+    return ov, oi
+
+
+def score_rank(q: torch.Tensor, docs: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
+    """1-based rank of docs[target[b]] for query b (BatchEvaluator's sort + nonzero, evaluators.py:58-65)."""
+    _need_cuda(q, docs, target)
+    q, docs = _f32c(q), _f32c(docs)
+    target = target.to(torch.int64).contiguous()
+    B, d = q.shape
+    if ((target < 0) | (target >= docs.shape[0])).any():
+        raise IndexError("score_rank: target out of range")
+    rank = torch.empty(B, dtype=torch.int64, device=q.device)
+    with torch.cuda.device(q.device):
+        _lib.check(_lib.lib().tt_score_rank_f32(q.data_ptr(), B, d, docs.data_ptr(), docs.shape[0], target.data_ptr(),
+                                                rank.data_ptr(), _stream(q)))
+    return rank
+
+
+class BruteForceIndex:
+    """A [N,d] fp32 document matrix resident in HBM (document_embeddings.npy layout,
+    backend/main.py:125-138: row i <-> documents[i]) with exact top-k search."""
+
+    def __init__(self, doc_embeddings: torch.Tensor, idx_offset: int = 0):
+        _need_cuda(doc_embeddings)
+        self.docs = _f32c(doc_embeddings)
+        self.idx_offset = int(idx_offset)
+        self._ws: Optional[torch.Tensor] = None
+
+    @property
+    def ntotal(self) -> int:
+        return self.docs.shape[0]
+
+    def search(self, q: torch.Tensor, k: int = 10) -> Tuple[torch.Tensor, torch.Tensor]:
+        B = 1 if q.dim() == 1 else q.shape[0]
+        need = _lib.lib().tt_score_topk_workspace_bytes(B, self.docs.shape[0], self.docs.shape[1], k)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(max(need, 16), dtype=torch.uint8, device=self.docs.device)
+        return score_topk(q, self.docs, k, self.idx_offset, self._ws)
+
+
+def shard_bounds(n_total: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous row shard of rank r: [r*N/W, (r+1)*N/W) with the remainder spread over the
+    first ranks."""
+    base, rem = divmod(n_total, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+class ShardedIndex:
+    """Row-sharded corpus: every rank holds rows [lo,hi) and the SAME queries; search =
+    local top-k' (global indices) -> one all-gather (RCCL over xGMI when the group's backend
+    is nccl) -> merge on every rank.  Result is identical on all ranks and identical to the
+    single-GPU search for any world size (global top-k is a subset of the union of shard top-k).
+
+    `local_search` / `merge` exist so the host logic can be exercised over gloo on CPU tensors
+    by the tests (which inject the oracle); the defaults are the HIP kernels.
+    """
+
+    def __init__(self, local_docs: torch.Tensor, row_offset: int, group=None, shard_k: int = 50,
+                 local_search: Optional[Callable] = None, merge: Optional[Callable] = None):
+        self.group = group
+        self.row_offset = int(row_offset)
+        self.shard_k = int(shard_k)
+        if local_search is None:
+            self._index = BruteForceIndex(local_docs, idx_offset=row_offset)
+            self._search = self._index.search
+        else:
+            self._index = None
+            self._search = lambda q, k: local_search(q, local_docs, k, row_offset)
+        self._merge = merge or topk_merge
+
+    @classmethod
+    def from_global(cls, docs: torch.Tensor, group=None, **kw) -> "ShardedIndex":
+        import torch.distributed as dist
+        world = dist.get_world_size(group) if dist.is_initialized() else 1
+        rank = dist.get_rank(group) if dist.is_initialized() else 0
+        lo, hi = shard_bounds(docs.shape[0], rank, world)
+        return cls(docs[lo:hi], lo, group=group, **kw)
+
+    def search(self, q: torch.Tensor, k: int = 10) -> Tuple[torch.Tensor, torch.Tensor]:
+        import torch.distributed as dist
+        kp = max(k, self.shard_k)
+        vals, idx = self._search(q, kp)
+        world = dist.get_world_size(self.group) if dist.is_initialized() else 1
+        if world == 1:
+            return self._merge(vals, idx, k)
+        B = vals.shape[0]
+        # one collective: [vals bytes | idx bytes] per rank
+        packed = torch.cat([vals.contiguous().view(torch.uint8).reshape(-1),
+                            idx.contiguous().view(torch.uint8).reshape(-1)])
+        out = torch.empty(world * packed.numel(), dtype=torch.uint8, device=packed.device)
+        dist.all_gather_into_tensor(out, packed, group=self.group)
+        out = out.view(world, -1)
+        nv = B * kp * 4
+        gv = out[:, :nv].contiguous().view(torch.float32).view(world, B, kp)
+        gi = out[:, nv:].contiguous().view(torch.int64).view(world, B, kp)
+        gv = gv.permute(1, 0, 2).reshape(B, world * kp).contiguous()
+        gi = gi.permute(1, 0, 2).reshape(B, world * kp).contiguous()
+        return self._merge(gv, gi, k)
