@@ -40,6 +40,7 @@ constexpr int DMA_PER_SLAB = 4;      // global_load_lds_dwordx4 per slab per wav
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void gbl_void;
 
+struct Cand;
 struct ScoreParams {
     const float *Q;
     const float *D;
@@ -54,6 +55,9 @@ struct ScoreParams {
     float *pval;   // [n_qtiles*32][n_chunks][k]
     int64_t *pidx; // same shape, global indices (idx_offset applied), -1 = empty
     int64_t idx_offset;
+    struct Cand *cand;  // [n_tasks][32][CAP] candidate buffers (workspace)
+    const float *thr0;  // optional per-query lower bound of the final k-th score
+    int thr0_stride, thr0_off;
 };
 
 __device__ __forceinline__ int xcd_remap(int b, int nblk)
@@ -65,46 +69,85 @@ __device__ __forceinline__ int xcd_remap(int b, int nblk)
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
 }
 
-// Cooperative sorted insert of (s, doc) into one query's list (lane t owns slot t).
-// Returns the list's new k-th value.  Order: score desc, index asc.
-template <int KPAD>
-__device__ __forceinline__ float list_insert(float *lv, int *li, int k, int lane, float s, int doc)
+// One candidate: (score, document index relative to D).  8 bytes, one store.
+struct __attribute__((aligned(8))) Cand {
+    float v;
+    int x;
+};
+
+__device__ __forceinline__ Cand cand_load_l2(const Cand *p)
 {
-    float v = -INFINITY;
-    int ix = INT_MAX;
-    if (lane < KPAD) {
-        v = lv[lane];
-        ix = li[lane];
-    }
-    bool before = (lane < k) && (v > s || (v == s && ix < doc));
-    int pos = __popcll(__ballot(before));
-    float vprev = __shfl_up(v, 1);
-    int iprev = __shfl_up(ix, 1);
-    if (pos < k) {
-        if (lane == pos) {
-            lv[lane] = s;
-            li[lane] = doc;
-            v = s;
-        } else if (lane > pos && lane < k) {
-            lv[lane] = vprev;
-            li[lane] = iprev;
-            v = vprev;
-        }
-    }
-    return __shfl(v, k - 1);
+    // sc1 load: served by L2, never by a stale line in this CU's L1 (the wave re-reads what it wrote)
+    unsigned long long u = __hip_atomic_load((const unsigned long long *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    Cand c;
+    c.v = __uint_as_float((unsigned)u);
+    c.x = (int)(u >> 32);
+    return c;
 }
 
-template <int NS, int KPAD>
+// Wave-cooperative compaction of one query's candidate buffer: keeps the k best of its n
+// entries (score desc, index asc), SORTED, at the front.  Lane t owns entries t, t+64, ...
+// rank(e) = #{entries ranking before e}; ranks are a permutation because (score,index) pairs
+// are distinct.  Returns through the references the new count and, when n >= k, the k-th score.
+template <int CAP>
+__device__ __forceinline__ void compact_query(Cand *base, int n, int k, int lane, int &n_new, float &kth,
+                                              bool &have_kth)
+{
+    constexpr int E = CAP / 64;
+    float v[E];
+    int x[E], rank[E];
+#pragma unroll
+    for (int i = 0; i < E; ++i) {
+        const int e = lane + 64 * i;
+        Cand c;
+        c.v = -INFINITY;
+        c.x = INT_MAX;
+        if (e < n)
+            c = cand_load_l2(base + e);
+        v[i] = c.v;
+        x[i] = c.x;
+        rank[i] = 0;
+    }
+#pragma unroll
+    for (int i2 = 0; i2 < E; ++i2) {
+        const int lim = min(n - 64 * i2, 64);
+        for (int l2 = 0; l2 < lim; ++l2) {
+            const float sv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v[i2]), l2));
+            const int sx = __builtin_amdgcn_readlane(x[i2], l2);
+#pragma unroll
+            for (int i = 0; i < E; ++i)
+                rank[i] += (sv > v[i] || (sv == v[i] && sx < x[i])) ? 1 : 0;
+        }
+    }
+    have_kth = n >= k;
+    kth = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < E; ++i) {
+        const bool live = lane + 64 * i < n;
+        if (live && rank[i] < k) {
+            Cand c;
+            c.v = v[i];
+            c.x = x[i];
+            base[rank[i]] = c;
+        }
+        const unsigned long long bk = __ballot(live && rank[i] == k - 1);
+        if (bk)
+            kth = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v[i]), __ffsll((long long)bk) - 1));
+    }
+    n_new = min(n, k);
+}
+
+// MAXONLY = true is the sample pass: no candidate buffers, each (wave, query) only tracks the
+// maximum score over its documents (one partial entry, index = chunk id).
+template <int NS, int CAP, bool MAXONLY>
 __global__ __launch_bounds__(WPB * 64, 2) void score_topk_kernel(ScoreParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int WAVE_LDS = NSTAGE * SLAB_BYTES + 32 * KPAD * 8;
+    constexpr int WAVE_LDS = NSTAGE * SLAB_BYTES;
     constexpr int ROW_BYTES = NS * 128;
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     char *ring = smem + wid * WAVE_LDS;
-    float *lval = (float *)(ring + NSTAGE * SLAB_BYTES);
-    int *lidx = (int *)(lval + 32 * KPAD);
 
     const int task = xcd_remap(blockIdx.x, gridDim.x) * WPB + wid;
     if (task >= p.n_tasks)
@@ -117,12 +160,6 @@ __global__ __launch_bounds__(WPB * 64, 2) void score_topk_kernel(ScoreParams p)
     const int h = lane >> 5;
     const int j = lane & 31;
 
-    // ---- list init -------------------------------------------------------
-    for (int e = lane; e < 32 * KPAD; e += 64) {
-        lval[e] = -INFINITY;
-        lidx[e] = INT_MAX;
-    }
-
     // ---- query operand: lane (j,h) keeps Q[qrow][2s+h] --------------------
     const int qrow = qtile * 32 + j;
     float qreg[NS * 16];
@@ -133,7 +170,34 @@ __global__ __launch_bounds__(WPB * 64, 2) void score_topk_kernel(ScoreParams p)
         for (int s = 0; s < NS * 16; ++s)
             qreg[s] = live ? qp[2 * s] : 0.0f;
     }
-    float thr = qrow < p.B ? -INFINITY : INFINITY; // padded queries never qualify
+    // Selection state of query j, replicated in lanes j and j+32:
+    //   thr = a proven lower bound of the query's final k-th score (documents below it are dropped),
+    //   cnt = entries in this wave's candidate buffer for the query.
+    // thr starts from the caller's bound (k-th score over a sample of the corpus, or -inf).
+    float thr = INFINITY; // padded queries never qualify
+    if (qrow < p.B)
+        thr = (!MAXONLY && p.thr0) ? p.thr0[(size_t)qrow * p.thr0_stride + p.thr0_off] : -INFINITY;
+    int cnt = 0;
+    float runmax = -INFINITY;
+    Cand *const cbase = p.cand + ((size_t)task * 32 + j) * CAP; // this lane's query buffer
+
+    auto compact_where = [&](unsigned long long qmask) { // qmask: bit q set -> compact query q
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // candidate stores have reached L2
+        while (qmask) {
+            const int q = __ffsll((long long)qmask) - 1;
+            qmask &= qmask - 1;
+            const int n = __builtin_amdgcn_readlane(cnt, q);
+            int n_new;
+            float kth;
+            bool have;
+            compact_query<CAP>(p.cand + ((size_t)task * 32 + q) * CAP, n, k, lane, n_new, kth, have);
+            if (j == q) {
+                cnt = n_new;
+                if (have)
+                    thr = kth; // >= old thr: every entry was admitted under a bound <= it
+            }
+        }
+    };
 
     // ---- DMA state -------------------------------------------------------
     // DMA instruction jj moves docs 8jj..8jj+7 of the tile: lane -> (doc 8jj + lane>>3,
@@ -179,6 +243,7 @@ __global__ __launch_bounds__(WPB * 64, 2) void score_topk_kernel(ScoreParams p)
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
                 // slab (tile,s) has landed once at most (NSTAGE-2) younger slabs are pending
+                // (candidate stores also count in vmcnt: they only make this wait stricter)
                 asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_SLAB * (NSTAGE - 2)) : "memory");
                 const char *buf = rd_row + stage * SLAB_BYTES;
                 f32x4 frag[8];
@@ -201,6 +266,16 @@ __global__ __launch_bounds__(WPB * 64, 2) void score_topk_kernel(ScoreParams p)
             // ---- epilogue: acc[r] = score(doc tile*32 + (r&3)+8(r>>2)+4h, query j) ----
             const int tile_base = tile * TILE_DOCS;
             const bool partial = tile_base + TILE_DOCS > p.N;
+            if (MAXONLY) {
+                float m = -INFINITY;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int doc = tile_base + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    m = fmaxf(m, (!partial || doc < p.N) ? acc[r] : -INFINITY);
+                }
+                runmax = fmaxf(runmax, m);
+                continue;
+            }
             float m = acc[0];
 #pragma unroll
             for (int r = 1; r < 16; ++r)
@@ -208,51 +283,123 @@ __global__ __launch_bounds__(WPB * 64, 2) void score_topk_kernel(ScoreParams p)
             if (__ballot(m >= thr) != 0ull) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int roff = (r & 3) + 8 * (r >> 2);
-                    const bool ok = !partial || (tile_base + roff + 4 * h < p.N);
-                    unsigned long long mask = __ballot(ok && acc[r] >= thr);
-                    while (mask) {
-                        const int src = __ffsll((long long)mask) - 1;
-                        const float s = __shfl(acc[r], src);
-                        const int q = src & 31;
-                        const int doc = tile_base + roff + 4 * (src >> 5);
-                        const float nt = list_insert<KPAD>(lval + q * KPAD, lidx + q * KPAD, k, lane, s, doc);
-                        if (j == q)
-                            thr = nt;
-                        mask &= ~((2ull << src) - 1ull);
-                        mask &= __ballot(ok && acc[r] >= thr);
+                    const int doc = tile_base + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    const bool c = (!partial || doc < p.N) && acc[r] >= thr;
+                    const unsigned long long mask = __ballot(c);
+                    if (mask) { // append: the two halves of the wave hold two documents of query j
+                        const int c_lo = (int)((mask >> j) & 1ull), c_hi = (int)((mask >> (j + 32)) & 1ull);
+                        if (c) {
+                            Cand e;
+                            e.v = acc[r];
+                            e.x = doc;
+                            cbase[cnt + (h ? c_lo : 0)] = e;
+                        }
+                        cnt += c_lo + c_hi;
+                        const unsigned long long full = __ballot(cnt > CAP - 2) & 0xffffffffull;
+                        if (full)
+                            compact_where(full);
                     }
                 }
             }
         }
     }
-    // LDS-DMA still in flight would land after the wave has ended: drain it.
+    // LDS-DMA still in flight would land after the wave has ended: drain it (and the stores).
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
-    // ---- partial lists out --------------------------------------------------
-    for (int q = 0; q < 32; ++q) {
-        const int row = qtile * 32 + q;
-        if (row >= p.B)
-            break;
-        if (lane < k) {
-            const size_t o = ((size_t)row * p.n_chunks + chunk) * k + lane;
-            const int ix = lidx[q * KPAD + lane];
-            p.pval[o] = lval[q * KPAD + lane];
-            p.pidx[o] = ix == INT_MAX ? -1 : p.idx_offset + ix;
+    if (MAXONLY) {
+        runmax = fmaxf(runmax, __shfl_xor(runmax, 32));
+        if (h == 0 && qrow < p.B) {
+            const size_t o = (size_t)qrow * p.n_chunks + chunk;
+            p.pval[o] = runmax;
+            p.pidx[o] = t0 < t1 ? (int64_t)chunk : -1;
         }
+        return;
+    }
+
+    // ---- final compaction + partial lists out ---------------------------------
+    {
+        const unsigned long long over = __ballot(cnt > k) & 0xffffffffull;
+        if (over)
+            compact_where(over);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    // 32*k output slots, lanes take them round-robin so the candidate loads overlap
+    const int rows_live = min(32, p.B - qtile * 32);
+    for (int it = lane; it < rows_live * k; it += 64) {
+        const int q = it / k, t = it - q * k;
+        const int n = __shfl(cnt, q);
+        const size_t o = ((size_t)(qtile * 32 + q) * p.n_chunks + chunk) * k + t;
+        Cand c;
+        c.v = -INFINITY;
+        c.x = -1;
+        if (t < n)
+            c = cand_load_l2(p.cand + ((size_t)task * 32 + q) * CAP + t);
+        p.pval[o] = c.v;
+        p.pidx[o] = t < n ? p.idx_offset + c.x : -1;
     }
 }
 
 // ---------------------------------------------------------------------------
 // K5: top-k of M unordered candidates per query, (score desc, index asc).
-// k rounds; round r picks the best candidate that ranks strictly after the
-// previous pick, so the input is never modified.
+// One block per query.  The candidates are scanned ONCE: valid entries (idx >= 0; most
+// partial-list slots are padding) are packed into an LDS pool; whenever the pool could overflow
+// it is reduced to its k best.  The final reduction emits the sorted top-k.  A reduction is k
+// rounds of block-wide arg-best over the pool, each round picking the best entry that ranks
+// strictly after the previous pick.
 // ---------------------------------------------------------------------------
 constexpr int MERGE_THREADS = 256;
+constexpr int MERGE_POOL = 6144;                 // LDS pool entries (12 B each)
+constexpr int MERGE_SEG = MERGE_THREADS * 16;    // candidates scanned between overflow checks
+constexpr int MERGE_KMAX = 64;
 
 __device__ __forceinline__ bool ranks_before(float sa, int64_t ia, float sb, int64_t ib)
 {
     return sa > sb || (sa == sb && ia < ib);
+}
+
+// Block-wide: the best pool entry ranking strictly after (pv,pi).  Returns bi == INT64_MAX if none.
+__device__ __forceinline__ void pool_next_best(const float *pool_v, const int64_t *pool_i, int n, float pv,
+                                               int64_t pi, float *red_v, int64_t *red_i, float &bv, int64_t &bi)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    bv = -INFINITY;
+    bi = INT64_MAX;
+    for (int m = tid; m < n; m += MERGE_THREADS) {
+        const float cv = pool_v[m];
+        const int64_t ci = pool_i[m];
+        if (!ranks_before(pv, pi, cv, ci))
+            continue;
+        if (bi == INT64_MAX || ranks_before(cv, ci, bv, bi)) {
+            bv = cv;
+            bi = ci;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const float ov = __shfl_xor(bv, off);
+        const int64_t oi = __shfl_xor(bi, off);
+        if (oi != INT64_MAX && (bi == INT64_MAX || ranks_before(ov, oi, bv, bi))) {
+            bv = ov;
+            bi = oi;
+        }
+    }
+    if (lane == 0) {
+        red_v[wave] = bv;
+        red_i[wave] = bi;
+    }
+    __syncthreads();
+    bv = red_v[0];
+    bi = red_i[0];
+#pragma unroll
+    for (int w = 1; w < MERGE_THREADS / 64; ++w) {
+        const float ov = red_v[w];
+        const int64_t oi = red_i[w];
+        if (oi != INT64_MAX && (bi == INT64_MAX || ranks_before(ov, oi, bv, bi))) {
+            bv = ov;
+            bi = oi;
+        }
+    }
+    __syncthreads();
 }
 
 __global__ __launch_bounds__(MERGE_THREADS) void topk_merge_kernel(const float *__restrict__ in_val,
@@ -260,68 +407,69 @@ __global__ __launch_bounds__(MERGE_THREADS) void topk_merge_kernel(const float *
                                                                    int M, int k, float *out_val,
                                                                    int64_t *out_idx)
 {
-    __shared__ float sv[MERGE_THREADS / 64];
-    __shared__ int64_t si[MERGE_THREADS / 64];
-    const int b = blockIdx.x;
+    __shared__ float pool_v[MERGE_POOL];
+    __shared__ int64_t pool_i[MERGE_POOL];
+    __shared__ float top_v[MERGE_KMAX];
+    __shared__ int64_t top_i[MERGE_KMAX];
+    __shared__ float red_v[MERGE_THREADS / 64];
+    __shared__ int64_t red_i[MERGE_THREADS / 64];
+    __shared__ int pool_n;
+    const int b = blockIdx.x, tid = threadIdx.x;
     const float *v = in_val + (size_t)b * M;
     const int64_t *ix = in_idx + (size_t)b * M;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    float pv = INFINITY;
-    int64_t pi = -1;
-    for (int r = 0; r < k; ++r) {
-        float bv = -INFINITY;
-        int64_t bi = INT64_MAX;
-        for (int m = tid; m < M; m += MERGE_THREADS) {
-            const float cv = v[m];
-            const int64_t ci = ix[m];
-            if (ci < 0 || !ranks_before(pv, pi, cv, ci))
-                continue;
-            if (bi == INT64_MAX || ranks_before(cv, ci, bv, bi)) {
-                bv = cv;
-                bi = ci;
-            }
-        }
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-            const float ov = __shfl_xor(bv, off);
-            const int64_t oi = __shfl_xor(bi, off);
-            if (oi != INT64_MAX && (bi == INT64_MAX || ranks_before(ov, oi, bv, bi))) {
-                bv = ov;
-                bi = oi;
-            }
-        }
-        if (lane == 0) {
-            sv[wave] = bv;
-            si[wave] = bi;
-        }
-        __syncthreads();
-        bv = sv[0];
-        bi = si[0];
-#pragma unroll
-        for (int w = 1; w < MERGE_THREADS / 64; ++w) {
-            const float ov = sv[w];
-            const int64_t oi = si[w];
-            if (oi != INT64_MAX && (bi == INT64_MAX || ranks_before(ov, oi, bv, bi))) {
-                bv = ov;
-                bi = oi;
-            }
-        }
-        __syncthreads();
-        if (bi == INT64_MAX) { // nothing left: (-inf,-1) tail, and nothing ranks after it
+    if (tid == 0)
+        pool_n = 0;
+    __syncthreads();
+
+    // reduce the pool to its k best (sorted) in place; returns the new size
+    auto reduce_pool = [&]() {
+        const int n = pool_n;
+        float pv = INFINITY;
+        int64_t pi = -1;
+        int kept = 0;
+        for (int r = 0; r < k; ++r) {
+            float bv;
+            int64_t bi;
+            pool_next_best(pool_v, pool_i, n, pv, pi, red_v, red_i, bv, bi);
+            if (bi == INT64_MAX)
+                break;
             if (tid == 0) {
-                out_val[(size_t)b * k + r] = -INFINITY;
-                out_idx[(size_t)b * k + r] = -1;
-            }
-            pv = -INFINITY;
-            pi = INT64_MAX;
-        } else {
-            if (tid == 0) {
-                out_val[(size_t)b * k + r] = bv;
-                out_idx[(size_t)b * k + r] = bi;
+                top_v[r] = bv;
+                top_i[r] = bi;
             }
             pv = bv;
             pi = bi;
+            kept = r + 1;
         }
+        __syncthreads();
+        if (tid < kept) {
+            pool_v[tid] = top_v[tid];
+            pool_i[tid] = top_i[tid];
+        }
+        if (tid == 0)
+            pool_n = kept;
+        __syncthreads();
+        return kept;
+    };
+
+    for (int base = 0; base < M; base += MERGE_SEG) {
+        if (pool_n + MERGE_SEG > MERGE_POOL) // block-uniform (pool_n read after a barrier)
+            reduce_pool();
+        const int end = min(base + MERGE_SEG, M);
+        for (int m = base + tid; m < end; m += MERGE_THREADS) {
+            const int64_t ci = ix[m];
+            if (ci >= 0) {
+                const int slot = atomicAdd(&pool_n, 1);
+                pool_v[slot] = v[m];
+                pool_i[slot] = ci;
+            }
+        }
+        __syncthreads();
+    }
+    const int kept = reduce_pool();
+    if (tid < k) {
+        out_val[(size_t)b * k + tid] = tid < kept ? pool_v[tid] : -INFINITY;
+        out_idx[(size_t)b * k + tid] = tid < kept ? pool_i[tid] : -1;
     }
 }
 
@@ -367,9 +515,20 @@ __global__ __launch_bounds__(256) void score_rank_kernel(const float *__restrict
         rank[b] = 1 + (int64_t)cnt[0] + cnt[1] + cnt[2] + cnt[3];
 }
 
+// One launch of score_topk_kernel over docs [0,N): how the work is cut and where its
+// partial lists live inside the workspace.
+struct Pass {
+    int n_qtiles, n_tiles, n_chunks, tiles_per_chunk, n_tasks;
+    int64_t N;
+};
+
 struct Plan {
-    int kpad, n_qtiles, n_tiles, n_chunks, tiles_per_chunk, n_tasks;
-    size_t smem, ws_bytes, pidx_off;
+    int cap;       // candidate-buffer entries per (wave, query): 64 (k <= 16) or 128
+    size_t smem;   // dynamic LDS per block
+    Pass main, pre;
+    bool prepass;  // sample pass first: its k-th scores seed the main pass's thresholds
+    // workspace layout (byte offsets)
+    size_t cand_off, pval_off, pidx_off, pre_val_off, pre_idx_off, ws_bytes;
 };
 
 int device_cus()
@@ -383,54 +542,114 @@ int device_cus()
     return cus;
 }
 
+Pass make_pass(int B, int64_t N, int slots)
+{
+    Pass ps;
+    ps.N = N;
+    ps.n_qtiles = (B + 31) / 32;
+    ps.n_tiles = (int)((N + TILE_DOCS - 1) / TILE_DOCS);
+    int want = (slots + ps.n_qtiles - 1) / ps.n_qtiles;
+    want = want < 1 ? 1 : want;
+    want = want > ps.n_tiles ? ps.n_tiles : want;
+    want = want < 1 ? 1 : want;
+    ps.tiles_per_chunk = ps.n_tiles > 0 ? (ps.n_tiles + want - 1) / want : 1;
+    ps.n_chunks = ps.n_tiles > 0 ? (ps.n_tiles + ps.tiles_per_chunk - 1) / ps.tiles_per_chunk : 1;
+    ps.n_tasks = ps.n_qtiles * ps.n_chunks;
+    return ps;
+}
+
+// Prepass policy.  A wave's private list costs ~k(1+ln(n/k)) candidate appends per query for the
+// n documents it sees, so cutting the corpus over ~2048 waves multiplies the selection work.  When
+// chunks are short, first take the exact top-k of a 1/256 sample: its k-th score is a valid lower
+// bound of the final k-th score, and with it the main pass admits only ~256k candidates per query
+// in total.  Long chunks (large B) do not need it.
+constexpr int64_t PREPASS_MIN_N = 262144;
+constexpr int PREPASS_MAX_CHUNK_DOCS = 65536;
+constexpr int64_t PREPASS_MIN_SAMPLE = 16384;
+
 Plan make_plan(int B, int64_t N, int k)
 {
     Plan pl;
-    pl.kpad = k <= 16 ? 16 : 64;
-    pl.smem = (size_t)WPB * (NSTAGE * SLAB_BYTES + 32 * pl.kpad * 8);
-    const int waves_per_cu = pl.kpad == 16 ? 8 : 4;
-    const int slots = device_cus() * waves_per_cu;
-    pl.n_qtiles = (B + 31) / 32;
-    pl.n_tiles = (int)((N + TILE_DOCS - 1) / TILE_DOCS);
-    int want = (slots + pl.n_qtiles - 1) / pl.n_qtiles;
-    if (want < 1)
-        want = 1;
-    if (want > pl.n_tiles)
-        want = pl.n_tiles;
-    if (want < 1)
-        want = 1;
-    pl.tiles_per_chunk = pl.n_tiles > 0 ? (pl.n_tiles + want - 1) / want : 1;
-    pl.n_chunks = pl.n_tiles > 0 ? (pl.n_tiles + pl.tiles_per_chunk - 1) / pl.tiles_per_chunk : 1;
-    pl.n_tasks = pl.n_qtiles * pl.n_chunks;
-    const size_t cand = (size_t)pl.n_qtiles * 32 * pl.n_chunks * k;
-    pl.pidx_off = tt_align_up(cand * sizeof(float), 256);
-    pl.ws_bytes = pl.pidx_off + cand * sizeof(int64_t);
+    pl.cap = k <= 16 ? 64 : 128;
+    pl.smem = (size_t)WPB * NSTAGE * SLAB_BYTES;
+    const int slots = device_cus() * 8;
+    pl.main = make_pass(B, N, slots);
+    pl.prepass = N >= PREPASS_MIN_N && (int64_t)pl.main.tiles_per_chunk * TILE_DOCS < PREPASS_MAX_CHUNK_DOCS;
+    int max_tasks = pl.main.n_tasks;
+    if (pl.prepass) {
+        int64_t ns = N / 256;
+        ns = ns < PREPASS_MIN_SAMPLE ? PREPASS_MIN_SAMPLE : ns;
+        ns = (ns + TILE_DOCS - 1) / TILE_DOCS * TILE_DOCS;
+        pl.pre = make_pass(B, ns, slots);
+        max_tasks = pl.pre.n_tasks > max_tasks ? pl.pre.n_tasks : max_tasks;
+    } else {
+        pl.pre = make_pass(B, 0, slots);
+    }
+    const size_t rows = (size_t)pl.main.n_qtiles * 32;
+    size_t max_chunks = pl.main.n_chunks;
+    if (pl.prepass && (size_t)pl.pre.n_chunks > max_chunks)
+        max_chunks = pl.pre.n_chunks;
+    size_t off = 0;
+    pl.cand_off = off;
+    off = tt_align_up(off + (size_t)max_tasks * 32 * pl.cap * 8, 256);
+    pl.pval_off = off;
+    off = tt_align_up(off + rows * max_chunks * k * sizeof(float), 256);
+    pl.pidx_off = off;
+    off = tt_align_up(off + rows * max_chunks * k * sizeof(int64_t), 256);
+    pl.pre_val_off = off;
+    off = tt_align_up(off + rows * k * sizeof(float), 256);
+    pl.pre_idx_off = off;
+    off = tt_align_up(off + rows * k * sizeof(int64_t), 256);
+    pl.ws_bytes = off;
     return pl;
 }
 
-template <int NS, int KPAD>
-int launch_score(const ScoreParams &sp, const Plan &pl, hipStream_t st)
+template <int NS, int CAP, bool MAXONLY>
+int launch_score_t(const ScoreParams &sp, const Plan &pl, hipStream_t st)
 {
-    auto kern = score_topk_kernel<NS, KPAD>;
+    auto kern = score_topk_kernel<NS, CAP, MAXONLY>;
     TT_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.smem));
-    const int grid = (pl.n_tasks + WPB - 1) / WPB;
+    const int grid = (sp.n_tasks + WPB - 1) / WPB;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(WPB * 64), pl.smem, st, sp);
     TT_LAUNCH_CHECK();
     return TT_OK;
 }
 
-} // namespace
-
-TT_EXPORT size_t tt_score_topk_workspace_bytes(int B, int64_t N, int d, int k)
+int launch_score(int d, const ScoreParams &sp, const Plan &pl, hipStream_t st, bool maxonly)
 {
-    (void)d;
-    if (B <= 0 || N < 0 || k <= 0)
-        return 0;
-    return make_plan(B, N, k).ws_bytes;
+    if (maxonly)
+        return d == 256 ? launch_score_t<8, 64, true>(sp, pl, st) : d == 128 ? launch_score_t<4, 64, true>(sp, pl, st) : launch_score_t<2, 64, true>(sp, pl, st);
+    if (pl.cap == 64)
+        return d == 256 ? launch_score_t<8, 64, false>(sp, pl, st) : d == 128 ? launch_score_t<4, 64, false>(sp, pl, st) : launch_score_t<2, 64, false>(sp, pl, st);
+    return d == 256 ? launch_score_t<8, 128, false>(sp, pl, st) : d == 128 ? launch_score_t<4, 128, false>(sp, pl, st) : launch_score_t<2, 128, false>(sp, pl, st);
 }
 
-static int score_partials(const float *Q, int B, int d, const float *D, int64_t N, int k, int64_t idx_offset,
-                          void *workspace, size_t workspace_bytes, hipStream_t st, Plan *plan_out, const char *who)
+ScoreParams pass_params(const Pass &ps, const float *Q, int B, const float *D, int k, int64_t idx_offset, char *ws,
+                        const Plan &pl)
+{
+    ScoreParams sp;
+    sp.Q = Q;
+    sp.D = D;
+    sp.B = B;
+    sp.N = (int)ps.N;
+    sp.k = k;
+    sp.n_qtiles = ps.n_qtiles;
+    sp.n_chunks = ps.n_chunks;
+    sp.tiles_per_chunk = ps.tiles_per_chunk;
+    sp.n_tiles = ps.n_tiles;
+    sp.n_tasks = ps.n_tasks;
+    sp.pval = (float *)(ws + pl.pval_off);
+    sp.pidx = (int64_t *)(ws + pl.pidx_off);
+    sp.idx_offset = idx_offset;
+    sp.cand = (Cand *)(ws + pl.cand_off);
+    sp.thr0 = nullptr;
+    sp.thr0_stride = 0;
+    sp.thr0_off = 0;
+    return sp;
+}
+
+int score_partials(const float *Q, int B, int d, const float *D, int64_t N, int k, int64_t idx_offset,
+                   void *workspace, size_t workspace_bytes, hipStream_t st, Plan *plan_out, const char *who)
 {
     if (B <= 0 || N <= 0 || k <= 0)
         return tt_fail(TT_ERR_BAD_SHAPE, "%s: B=%d N=%lld k=%d", who, B, (long long)N, k);
@@ -445,27 +664,39 @@ static int score_partials(const float *Q, int B, int d, const float *D, int64_t 
     const Plan pl = make_plan(B, N, k);
     if (!workspace || workspace_bytes < pl.ws_bytes)
         return tt_fail(TT_ERR_WORKSPACE, "%s: workspace %zu < %zu bytes", who, workspace_bytes, pl.ws_bytes);
-    if (((uintptr_t)D & 15) || ((uintptr_t)Q & 3))
-        return tt_fail(TT_ERR_BAD_SHAPE, "%s: D must be 16-byte aligned", who);
-
-    ScoreParams sp;
-    sp.Q = Q;
-    sp.D = D;
-    sp.B = B;
-    sp.N = (int)N;
-    sp.k = k;
-    sp.n_qtiles = pl.n_qtiles;
-    sp.n_chunks = pl.n_chunks;
-    sp.tiles_per_chunk = pl.tiles_per_chunk;
-    sp.n_tiles = pl.n_tiles;
-    sp.n_tasks = pl.n_tasks;
-    sp.pval = (float *)workspace;
-    sp.pidx = (int64_t *)((char *)workspace + pl.pidx_off);
-    sp.idx_offset = idx_offset;
+    if (((uintptr_t)D & 15) || ((uintptr_t)Q & 3) || ((uintptr_t)workspace & 255))
+        return tt_fail(TT_ERR_BAD_SHAPE, "%s: D must be 16-byte and the workspace 256-byte aligned", who);
+    char *ws = (char *)workspace;
     *plan_out = pl;
-    if (pl.kpad == 16)
-        return d == 256 ? launch_score<8, 16>(sp, pl, st) : d == 128 ? launch_score<4, 16>(sp, pl, st) : launch_score<2, 16>(sp, pl, st);
-    return d == 256 ? launch_score<8, 64>(sp, pl, st) : d == 128 ? launch_score<4, 64>(sp, pl, st) : launch_score<2, 64>(sp, pl, st);
+    const float *thr0 = nullptr;
+    if (pl.prepass) {
+        // sample pass over D[0:ns): per-(wave,query) maxima, then their k-th largest per query.
+        // k distinct documents score at least that much, so it bounds the final k-th score from below.
+        ScoreParams pp = pass_params(pl.pre, Q, B, D, k, 0, ws, pl);
+        int rc = launch_score(d, pp, pl, st, true);
+        if (rc != TT_OK)
+            return rc;
+        hipLaunchKernelGGL(topk_merge_kernel, dim3(B), dim3(MERGE_THREADS), 0, st, (const float *)pp.pval,
+                           (const int64_t *)pp.pidx, pl.pre.n_chunks, k, (float *)(ws + pl.pre_val_off),
+                           (int64_t *)(ws + pl.pre_idx_off));
+        TT_LAUNCH_CHECK();
+        thr0 = (const float *)(ws + pl.pre_val_off);
+    }
+    ScoreParams sp = pass_params(pl.main, Q, B, D, k, idx_offset, ws, pl);
+    sp.thr0 = thr0;
+    sp.thr0_stride = k;
+    sp.thr0_off = k - 1;
+    return launch_score(d, sp, pl, st, false);
+}
+
+} // namespace
+
+TT_EXPORT size_t tt_score_topk_workspace_bytes(int B, int64_t N, int d, int k)
+{
+    (void)d;
+    if (B <= 0 || N < 0 || k <= 0)
+        return 0;
+    return make_plan(B, N, k).ws_bytes;
 }
 
 TT_EXPORT int tt_score_topk_partials_f32(const float *Q, int B, int d, const float *D, int64_t N, int k,
@@ -479,11 +710,11 @@ TT_EXPORT int tt_score_topk_partials_f32(const float *Q, int B, int d, const flo
     if (rc != TT_OK)
         return rc;
     if (part_val)
-        *part_val = (const float *)workspace;
+        *part_val = (const float *)((const char *)workspace + pl.pval_off);
     if (part_idx)
         *part_idx = (const int64_t *)((const char *)workspace + pl.pidx_off);
     if (part_m)
-        *part_m = pl.n_chunks * k;
+        *part_m = pl.main.n_chunks * k;
     return TT_OK;
 }
 
@@ -512,8 +743,9 @@ TT_EXPORT int tt_score_topk_f32(const float *Q, int B, int d, const float *D, in
     int rc = score_partials(Q, B, d, D, N, k, idx_offset, workspace, workspace_bytes, st, &pl, "tt_score_topk_f32");
     if (rc != TT_OK)
         return rc;
-    hipLaunchKernelGGL(topk_merge_kernel, dim3(B), dim3(MERGE_THREADS), 0, st, (const float *)workspace,
-                       (const int64_t *)((const char *)workspace + pl.pidx_off), pl.n_chunks * k, k, out_val, out_idx);
+    const char *ws = (const char *)workspace;
+    hipLaunchKernelGGL(topk_merge_kernel, dim3(B), dim3(MERGE_THREADS), 0, st, (const float *)(ws + pl.pval_off),
+                       (const int64_t *)(ws + pl.pidx_off), pl.main.n_chunks * k, k, out_val, out_idx);
     TT_LAUNCH_CHECK();
     return TT_OK;
 }
