@@ -1,0 +1,206 @@
+#!/usr/bin/env python3
+"""Headline benchmark: queries/sec of exact top-10 over a 10M x 256-d fp32 corpus (BASELINE.json).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One step = one pass of the hot path over one batch of B=1024 synthetic queries: every rank scores
+the batch against its contiguous row shard of the SAME 10M-document corpus (fused fp32 MFMA
+score + top-k kernel, corpus resident in HBM), and for N > 1 the per-shard top-50 lists are
+all-gathered over RCCL and merged to the global top-10 on every rank (strong scaling: the corpus
+is fixed, the shard shrinks with N).  Rank 0 prints ONE JSON line.
+
+Extra legs on rank 0 (untimed w.r.t. `value`): `roofline` (kernel-only HIP-event timing of the
+dominant kernel), `roofline_hbm` (same kernel in its HBM-bound regime, B=32), and at N=1
+`cpu_baseline` (the reference's torch CPU idiom on a bounded sample).
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+N_DOCS = 10_000_000
+DIM = 256
+BATCH = 1024
+TOPK = 10
+SHARD_K = 50
+GEN_BLOCK = 1_000_000  # corpus is generated in seeded 1M-row blocks -> identical for every world size
+HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: HBM3E peak
+MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 MFMA peak
+
+
+def gen_rows(lo: int, hi: int, device) -> torch.Tensor:
+    """Rows [lo,hi) of the synthetic corpus: randn, L2-normalised, seed = 1000 + block."""
+    out = torch.empty((hi - lo, DIM), dtype=torch.float32, device=device)
+    b0, b1 = lo // GEN_BLOCK, (hi - 1) // GEN_BLOCK
+    for blk in range(b0, b1 + 1):
+        g = torch.Generator(device=device).manual_seed(1000 + blk)
+        x = torch.randn((GEN_BLOCK, DIM), dtype=torch.float32, device=device, generator=g)
+        x /= x.norm(dim=1, keepdim=True).clamp_min(1e-12)
+        s, e = max(lo, blk * GEN_BLOCK), min(hi, (blk + 1) * GEN_BLOCK)
+        out[s - lo:e - lo] = x[s - blk * GEN_BLOCK:e - blk * GEN_BLOCK]
+        del x
+    return out
+
+
+def gen_queries(n: int, device, seed: int = 7) -> torch.Tensor:
+    g = torch.Generator(device=device).manual_seed(seed)
+    q = torch.randn((n, DIM), dtype=torch.float32, device=device, generator=g)
+    return q / q.norm(dim=1, keepdim=True)
+
+
+def kernel_only_ms(q, docs, k, iters=5, warm=2):
+    """Average duration of the streaming score+top-k launch alone (HIP events on torch's current
+    stream, which is the stream the kernel is launched on)."""
+    from twotowermlretrieval_amd import _lib
+    L = _lib.lib()
+    B, d = q.shape
+    N = docs.shape[0]
+    ws = torch.empty(L.tt_score_topk_workspace_bytes(B, N, d, k), dtype=torch.uint8, device=q.device)
+    pv, pi, pm = C.c_void_p(), C.c_void_p(), C.c_int()
+    st = torch.cuda.current_stream().cuda_stream
+
+    def call():
+        _lib.check(L.tt_score_topk_partials_f32(q.data_ptr(), B, d, docs.data_ptr(), N, k, 0, ws.data_ptr(),
+                                                ws.numel(), C.byref(pv), C.byref(pi), C.byref(pm), st))
+    for _ in range(warm):
+        call()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        call()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def pmc_traffic(name: str):
+    """HBM bytes per launch from committed rocprofv3 PMC passes (profiles/pmc_traffic.json), or None."""
+    f = ROOT / "profiles" / "pmc_traffic.json"
+    if f.exists():
+        try:
+            return json.loads(f.read_text()).get(name)
+        except Exception:  # noqa: BLE001
+            return None
+    return None
+
+
+def cpu_baseline(q_gpu, docs_gpu):
+    from oracle import torch_ref
+    n_s = 1_000_000
+    cores = min(len(os.sched_getaffinity(0)), 64)
+    torch.set_num_threads(cores)
+    qs = q_gpu.cpu()
+    ds = docs_gpu[:n_s].cpu()
+    t = torch_ref.time_scoring_idiom(qs, ds, TOPK, warmup=1, reps=3)
+    scale = N_DOCS / n_s
+    return {"value": round(BATCH / (t * scale), 2), "unit": "queries/s", "cores": cores, "kind": "port",
+            "sample": f"B={BATCH} queries x first {n_s} of the {N_DOCS} docs, torch.matmul+torch.topk on CPU "
+                      f"(reference idiom evaluators.py:185-186), median of 3 = {t:.3f} s, time scaled x{scale:.0f}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus != world:
+        if world == 1 and a.gpus > 1:
+            sys.exit(f"--gpus {a.gpus} needs a launcher: python -m torch.distributed.run --nproc-per-node {a.gpus} "
+                     f"--master-addr 127.0.0.1 bench.py --gpus {a.gpus} ...")
+        sys.exit(f"--gpus {a.gpus} != WORLD_SIZE {world}")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import twotowermlretrieval_amd as tt
+    lo, hi = tt.shard_bounds(N_DOCS, rank, world)
+    docs = gen_rows(lo, hi, dev)
+    q = gen_queries(BATCH, dev)
+    if world > 1:
+        index = tt.ShardedIndex(docs, lo, shard_k=SHARD_K)
+        step = lambda: index.search(q, TOPK)  # noqa: E731
+    else:
+        index = tt.BruteForceIndex(docs)
+        step = lambda: index.search(q, TOPK)  # noqa: E731
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        out = step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        out = step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    vals, idx = out
+    assert vals.shape == (BATCH, TOPK) and bool((vals[:, 1:] <= vals[:, :-1]).all()) and int(idx.min()) >= 0
+
+    if rank == 0:
+        n_shard = hi - lo
+        kp = TOPK if world == 1 else SHARD_K
+        ms = kernel_only_ms(q, docs, kp)
+        flops = 2.0 * BATCH * n_shard * DIM
+        roof = {"bound": "mfma", "kernel": "score_topk_kernel<8,*,false> (fp32 MFMA 32x32x2)",
+                "achieved": round(flops / ms / 1e9, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(flops / ms / 1e9 / MFMA_F32_PEAK_TFLOPS, 4), "traffic": pmc_traffic("b1024"),
+                "kernel_ms": round(ms, 4), "batch": BATCH, "docs_per_gpu": n_shard,
+                "hbm_GBps_same_launch": round((n_shard * DIM * 4 + BATCH * DIM * 4 + BATCH * kp * 12) / ms / 1e6, 1)}
+        qb = q[:32].contiguous()
+        ms32 = kernel_only_ms(qb, docs, TOPK)
+        byts = n_shard * DIM * 4 + 32 * DIM * 4 + 32 * TOPK * 12
+        roof_hbm = {"bound": "hbm", "kernel": "score_topk_kernel<8,64,false> (+ sample pass, B=32)",
+                    "achieved": round(byts / ms32 / 1e6, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "frac": round(byts / ms32 / 1e6 / HBM_PEAK_GBPS, 4), "traffic": pmc_traffic("b32"),
+                    "kernel_ms": round(ms32, 4), "batch": 32, "docs_per_gpu": n_shard,
+                    "qps": round(32 / ms32 * 1e3, 1)}
+        line = {
+            "metric": "queries/sec top-k over 10M x 256-d docs", "value": round(BATCH * a.steps / dt, 2),
+            "unit": "queries/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"exact cosine top-{TOPK} of B={BATCH} queries over {N_DOCS} x {DIM} fp32 unit-norm "
+                                   f"passages resident in HBM (BASELINE configs[3]; configs[1] batch), row-sharded "
+                                   f"over {world} GPU(s)" + (f", per-shard top-{SHARD_K} + RCCL all-gather + merge" if world > 1 else ""),
+                       "n_docs": N_DOCS, "dim": DIM, "batch": BATCH, "k": TOPK, "parallelism": f"rowshard{world}"},
+            "roofline": roof, "roofline_hbm": roof_hbm,
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(q, docs)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
