@@ -94,6 +94,38 @@ int tt_topk_merge(const float *in_val, const int64_t *in_idx, int B, int M, int 
 int tt_score_rank_f32(const float *Q, int B, int d, const float *D, int64_t N, const int64_t *target,
                       int64_t *rank, tt_stream_t stream);
 
+/* ------------------------------------------------------------------ */
+/* Encoder tower (GloVe gather -> GRU -> L2-normalise)                 */
+/* ------------------------------------------------------------------ */
+
+/*
+ * Replaces RNNEncoder.forward for rnn_type GRU            backend/model.py:48-75
+ *   embedded = self.embedding(x)                           :49
+ *   lengths = (x != 0).sum(dim=1)  (count of non-zero ids) :52
+ *   pack_padded_sequence + nn.GRU (gate order r,z,n)       :55-62
+ *   h_n[-1], or cat(h_n[-2], h_n[-1]) -> Linear(2H,H)      :65-71
+ *   F.normalize(p=2, dim=1, eps 1e-12)                     :73-74
+ * ids [B,T] int64 right-padded with 0; table [V,E] f32 (row 0 is a real word vector and IS
+ * used when id 0 occurs inside the first `length` positions); out [B,H] f32.
+ * weights: HOST array of 4*num_layers*ndir DEVICE pointers, index (layer*ndir + dir)*4 +
+ * {0: weight_ih [3H,I], 1: weight_hh [3H,H], 2: bias_ih [3H], 3: bias_hh [3H]} = the reference's
+ * state_dict tensors rnn.{weight_ih,weight_hh,bias_ih,bias_hh}_l{layer}[_reverse]; I = E for
+ * layer 0, ndir*H above.  proj_w [H,2H], proj_b [H] only when bidirectional.  Inter-layer
+ * dropout is the identity (eval mode / DROPOUT 0).
+ * Lengths are computed on the device; nothing synchronises with the host.  Data errors cannot be
+ * returned synchronously, so they are reported through `status` (device int32, nullable), written
+ * on the stream: bit 0 = a row with no non-zero id (the reference raises RuntimeError), bit 1 = an
+ * id outside [0,V) (IndexError).  Such rows produce finite garbage, never a fault.
+ * train != 0 keeps the activations the backward pass needs inside the workspace: the SAME workspace
+ * (sized with train = 1) must then be passed, untouched, to tt_encoder_backward_f32.
+ * Supported: H multiple of 32 in [32,512], E multiple of 4, 1 <= num_layers <= 4.
+ */
+size_t tt_encoder_workspace_bytes(int B, int T, int E, int H, int num_layers, int bidirectional, int train);
+int tt_encoder_forward_f32(const int64_t *ids, int B, int T, const float *table, int64_t V, int E, int H,
+                           int num_layers, int bidirectional, const float *const *weights /*host array*/,
+                           const float *proj_w, const float *proj_b, int normalize, int train, float *out,
+                           void *workspace, size_t workspace_bytes, int32_t *status, tt_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -62,7 +62,7 @@ def ref_encoder(V, E, H, table, sd, num_layers=1, bidirectional=False, normalize
 def g1():
     out = {}
     # small case with every quirk: trailing pads, interior id 0, length-1 row, full row
-    V, E, H, seed = 64, 16, 16, 101
+    V, E, H, seed = 64, 16, 32, 101
     table = synth.make_table(seed, V, E)
     sd = synth.make_encoder_state(seed + 1, E, H)
     ids = synth.make_ids(seed + 2, B=12, T=9, V=V, zero_inside=0.25)
@@ -87,7 +87,7 @@ def g1():
 
 
 def g2():
-    V, E, H, seed = 80, 20, 16, 303
+    V, E, H, seed = 80, 20, 32, 303
     table = synth.make_table(seed, V, E)
     sd = synth.make_encoder_state(seed + 1, E, H, num_layers=2, bidirectional=True)
     ids = synth.make_ids(seed + 2, B=10, T=11, V=V, zero_inside=0.15)
@@ -98,7 +98,7 @@ def g2():
 
 
 def g3():
-    V, E, H, seed = 64, 16, 16, 404
+    V, E, H, seed = 64, 16, 32, 404
     table = synth.make_table(seed, V, E)
     sd = synth.make_encoder_state(seed + 1, E, H)
     ids = synth.make_ids(seed + 2, B=8, T=7, V=V)
@@ -126,7 +126,7 @@ def _two_tower(V, E, H, seed, num_layers=1, bidirectional=False):
 def g4():
     out = {}
     for tag, (layers, bi) in {"uni": (1, False), "bi": (2, True)}.items():
-        V, E, H, seed = 64, 12, 16, 505 + (7 if bi else 0)
+        V, E, H, seed = 64, 12, 32, 505 + (7 if bi else 0)
         m, cfg, table = _two_tower(V, E, H, seed, layers, bi)
         m.train()
         q = synth.make_ids(seed + 1, B=8, T=5, V=V)
@@ -267,7 +267,7 @@ def g8():
 
 
 def g9():
-    V0, E, H, seed = len(_vocab()), 20, 16, 909
+    V0, E, H, seed = len(_vocab()), 20, 32, 909
     with tempfile.TemporaryDirectory() as td:
         td = Path(td)
         (td / "frontend").mkdir()
@@ -303,7 +303,7 @@ def g9():
 
 
 def g10():
-    V, E, H, seed = 64, 16, 16, 101
+    V, E, H, seed = 64, 16, 32, 101
     table = synth.make_table(seed, V, E)
     sd = synth.make_encoder_state(seed + 1, E, H)
     enc = ref_encoder(V, E, H, table, sd)

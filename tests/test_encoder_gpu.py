@@ -1,0 +1,150 @@
+"""GPU parity tests for the encoder tower (K1-K3) through the drop-in Python surface
+(twotowermlretrieval_amd.model) and the C ABI.  Tolerance: 1e-5 absolute on the (unit-norm)
+outputs -- north_star's cosine tolerance; the kernels use exact-fp32 MFMA, so the only drift is
+summation order and the v_exp/v_rcp based sigmoid/tanh (observed ~1e-6)."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+import synth
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+ATOL = 1e-5
+
+
+def make_encoder(V, E, H, seed, layers=1, bi=False, normalize=True):
+    from twotowermlretrieval_amd.model import RNNEncoder
+    table = synth.make_table(seed, V, E)
+    sd = synth.make_encoder_state(seed + 1, E, H, layers, bi)
+    enc = RNNEncoder(V, E, H, pretrained_embeddings=table, num_layers=layers, bidirectional=bi,
+                     normalize_output=normalize)
+    full = {"embedding.weight": torch.from_numpy(table)}
+    full.update({k: torch.from_numpy(v) for k, v in sd.items()})
+    enc.load_state_dict(full)  # exact reference key names, strict
+    return enc.cuda().eval(), table, sd
+
+
+def run(enc, ids):
+    with torch.no_grad():
+        y = enc(torch.from_numpy(ids).cuda())
+    torch.cuda.synchronize()
+    return y.cpu().numpy()
+
+
+def test_g1_small_all_quirks(golden, oracle):
+    g = golden("g1_encoder_uni.npz")
+    V, E, H, seed = [int(x) for x in g["small_dims"]]
+    enc, table, sd = make_encoder(V, E, H, seed)
+    y = run(enc, g["small_ids"])
+    np.testing.assert_allclose(y, g["small_out"], atol=ATOL, rtol=0)
+    np.testing.assert_allclose(np.linalg.norm(y, axis=1), 1.0, atol=1e-6)
+    assert np.array_equal(y[2], y[3])  # interior-zero quirk: tokens beyond count_nonzero are dropped
+    o = oracle.encoder_forward(g["small_ids"], table, synth.weight_quads(sd), H)
+    np.testing.assert_allclose(y, o, atol=ATOL, rtol=0)
+
+
+def test_g1_northstar_shape(golden):
+    g = golden("g1_encoder_uni.npz")
+    V, E, H, seed = [int(x) for x in g["big_dims"]]
+    enc, _, _ = make_encoder(V, E, H, seed)
+    np.testing.assert_allclose(run(enc, g["big_ids"]), g["big_out"], atol=ATOL, rtol=0)
+
+
+def test_g2_two_layer_bidirectional_projection(golden):
+    g = golden("g2_encoder_bi.npz")
+    V, E, H, seed = [int(x) for x in g["dims"]]
+    enc, _, _ = make_encoder(V, E, H, seed, layers=2, bi=True)
+    np.testing.assert_allclose(run(enc, g["ids"]), g["out"], atol=ATOL, rtol=0)
+
+
+def test_g3_normalize_off(golden):
+    g = golden("g3_encoder_nonorm.npz")
+    V, E, H, seed = [int(x) for x in g["dims"]]
+    enc, _, _ = make_encoder(V, E, H, seed, normalize=False)
+    np.testing.assert_allclose(run(enc, g["ids"]), g["out"], atol=ATOL, rtol=0)
+
+
+@pytest.mark.parametrize("B,T,E,H,layers,bi", [
+    (70, 40, 300, 256, 1, False),   # north-star tower, ragged batch, > 4 recurrence blocks
+    (33, 17, 200, 128, 2, True),    # config.json family (E=200, stacked, bidirectional)
+    (5, 250, 300, 256, 1, False),   # long passages
+    (130, 9, 52, 64, 3, False),
+    (16, 12, 100, 512, 1, True),    # widest supported hidden size
+])
+def test_random_batches_vs_oracle(oracle, B, T, E, H, layers, bi):
+    V, seed = 500, 31 + B
+    enc, table, sd = make_encoder(V, E, H, seed, layers, bi)
+    ids = synth.make_ids(seed + 5, B, T, V, zero_inside=0.05)
+    y = run(enc, ids)
+    o = oracle.encoder_forward(ids, table, synth.weight_quads(sd, layers, bi), H, layers, bi,
+                               sd.get("projection.weight"), sd.get("projection.bias"), True)
+    np.testing.assert_allclose(y, o, atol=ATOL, rtol=0)
+
+
+def test_state_dict_keys_match_reference_layout():
+    from twotowermlretrieval_amd.model import TwoTowerModel
+    m = TwoTowerModel({"VOCAB_SIZE": 50, "EMBED_DIM": 20, "HIDDEN_DIM": 32, "NUM_LAYERS": 2, "BIDIRECTIONAL": True},
+                      synth.make_table(1, 50, 20))
+    keys = set(m.state_dict().keys())
+    want = set()
+    for tower in ("query_encoder.", "doc_encoder."):
+        want.add(tower + "embedding.weight")
+        for layer in range(2):
+            for sfx in ("", "_reverse"):
+                for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh"):
+                    want.add(f"{tower}rnn.{n}_l{layer}{sfx}")
+        want |= {tower + "projection.weight", tower + "projection.bias"}
+    assert keys == want
+    assert m.query_encoder.embedding.embedding_dim == 20          # read by backend/main.py:104
+    assert not m.query_encoder.embedding.weight.requires_grad     # frozen GloVe table (model.py:25-27)
+    assert sum(p.numel() for p in m.parameters() if p.requires_grad) == 2 * (
+        3 * 32 * (20 + 32 + 2) + 3 * 32 * (20 + 32 + 2) + 2 * 3 * 32 * (64 + 32 + 2) + 32 * 64 + 32)
+
+
+def test_two_tower_towers_are_independent(oracle):
+    from twotowermlretrieval_amd.model import TwoTowerModel
+    V, E, H = 80, 24, 64
+    table = synth.make_table(9, V, E)
+    m = TwoTowerModel({"VOCAB_SIZE": V, "EMBED_DIM": E, "HIDDEN_DIM": H}, table)
+    sd = {}
+    quads = {}
+    for i, tower in enumerate(("query_encoder.", "doc_encoder.")):
+        sd[tower + "embedding.weight"] = torch.from_numpy(table)
+        st = synth.make_encoder_state(20 + i, E, H, prefix=tower)
+        quads[tower] = synth.weight_quads(st, prefix=tower)
+        sd.update({k: torch.from_numpy(v) for k, v in st.items()})
+    m.load_state_dict(sd)
+    m = m.cuda().eval()
+    m.device = torch.device("cuda")  # callers set this attribute (backend/main.py:196)
+    q = synth.make_ids(1, 6, 5, V)
+    d = synth.make_ids(2, 6, 13, V)
+    with torch.no_grad():
+        eq, ed = m(torch.from_numpy(q).cuda(), torch.from_numpy(d).cuda())
+    np.testing.assert_allclose(eq.cpu().numpy(), oracle.encoder_forward(q, table, quads["query_encoder."], H), atol=ATOL)
+    np.testing.assert_allclose(ed.cpu().numpy(), oracle.encoder_forward(d, table, quads["doc_encoder."], H), atol=ATOL)
+
+
+def test_error_behaviour_matches_reference():
+    err = json.loads((GOLDEN / "g10_errors.json").read_text())
+    enc, _, _ = make_encoder(64, 16, 32, 101)
+    with pytest.raises(RuntimeError, match="Length of all samples has to be greater than 0"):
+        enc(torch.tensor([[3, 4, 0], [0, 0, 0]]).cuda())
+    assert err["all_zero_row"].startswith("RuntimeError: Length of all samples")
+    with pytest.raises(IndexError):
+        enc(torch.tensor([[1, 64, 2]]).cuda())
+    with pytest.raises((RuntimeError, ValueError), match="Cannot pack empty tensors"):
+        enc(torch.zeros((1, 0), dtype=torch.long).cuda())
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        enc(torch.tensor([[1, 2]]))
+    enc.check_inputs = False  # async mode: no host sync, bad rows give finite garbage
+    y = enc(torch.tensor([[3, 4, 0], [0, 0, 0]]).cuda())
+    assert torch.isfinite(y).all()
+
+
+def test_unsupported_tower_types_fail_loudly():
+    from twotowermlretrieval_amd.model import RNNEncoder
+    with pytest.raises(NotImplementedError):
+        RNNEncoder(10, 8, 32, rnn_type="LSTM")

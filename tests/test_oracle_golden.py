@@ -180,11 +180,11 @@ def test_g10_error_cases(oracle):
     err = json.loads((GOLDEN / "g10_errors.json").read_text())
     assert err["all_zero_row"].startswith("RuntimeError")
     table = synth.make_table(101, 64, 16)
-    quads = synth.weight_quads(synth.make_encoder_state(102, 16, 16))
+    quads = synth.weight_quads(synth.make_encoder_state(102, 16, 32))
     with pytest.raises(oracle.OracleError) as e:
-        oracle.encoder_forward(np.array([[3, 4, 0], [0, 0, 0]]), table, quads, 16)
+        oracle.encoder_forward(np.array([[3, 4, 0], [0, 0, 0]]), table, quads, 32)
     assert e.value.code == oracle.O_ERR_ZERO_LENGTH
     assert err["index_out_of_range"].startswith("IndexError")
     with pytest.raises(oracle.OracleError) as e:
-        oracle.encoder_forward(np.array([[1, 64, 2]]), table, quads, 16)
+        oracle.encoder_forward(np.array([[1, 64, 2]]), table, quads, 32)
     assert e.value.code == oracle.O_ERR_BAD_INDEX

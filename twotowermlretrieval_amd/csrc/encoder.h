@@ -1,0 +1,83 @@
+// Workspace layout shared by the encoder forward (encoder.hip) and backward (encoder_bwd.hip).
+#pragma once
+#include "tt_common.h"
+
+constexpr int ENC_MAX_LAYERS = 4;
+constexpr int ENC_RB = 16; // batch rows per recurrence block (one 16x16x4 MFMA M-tile)
+
+// All offsets are bytes from the start of the caller's workspace.  Token-indexed buffers use
+// the PACKED token order: row b's position t lives at tok_off[b] + t (t < len[b]); their
+// capacity is the upper bound MT = B*T because the valid count is only known on the device.
+struct EncLayout {
+    int B, T, E, H, L, ndir, train;
+    int64_t MT;
+    size_t len, tok_off, perm, ids, flag;        // int32 metadata (tok_off has B+1 entries)
+    size_t x[ENC_MAX_LAYERS + 1];                // x[l+1] = output sequence of layer l: [MT][ndir*H]
+    size_t gates[ENC_MAX_LAYERS][2];             // train: [MT][4][H] = r, z, n, W_hn h + b_hn
+    size_t hfin;                                 // [ndir][B][H] final hidden of the LAST layer
+    size_t hid;                                  // [B][H] head output before normalisation
+    size_t gi[2];                                // scratch: input projections [MT][3H] per direction
+    size_t wp[2];                                // scratch: W_hh packed for the MFMA B operand
+    size_t fwd_end;
+    // backward scratch (train only)
+    size_t d_hfin;                               // [ndir][B][H]
+    size_t dgi[2];                               // [MT][3H] per direction
+    size_t dghn[2];                              // [MT][H]: the n-gate column of dGh (= dn_pre * r)
+    size_t dx[2];                                // ping-pong [MT][ndir*H]: gradient w.r.t. a layer's input
+    size_t wtp[2];                               // W_hh packed for dh_prev = dGh * W_hh
+    size_t slabs;                                // split-K partial products
+    size_t total;
+};
+
+constexpr int ENC_SPLITK = 32;
+
+static inline EncLayout enc_layout(int B, int T, int E, int H, int L, int bidir, int train)
+{
+    EncLayout lo;
+    lo.B = B; lo.T = T; lo.E = E; lo.H = H; lo.L = L; lo.ndir = bidir ? 2 : 1; lo.train = train;
+    lo.MT = (int64_t)B * T;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = tt_align_up(off + bytes, 256); return o; };
+    lo.len = take(sizeof(int32_t) * B);
+    lo.tok_off = take(sizeof(int32_t) * (B + 1));
+    lo.perm = take(sizeof(int32_t) * B);
+    lo.ids = take(sizeof(int32_t) * lo.MT);
+    lo.flag = take(256);
+    const size_t seq = sizeof(float) * lo.MT * lo.ndir * H;
+    lo.x[0] = 0;
+    for (int l = 0; l < L; ++l) {
+        if (train)
+            lo.x[l + 1] = take(seq);
+        else if (l + 1 < L)
+            lo.x[l + 1] = l < 2 ? take(seq) : lo.x[l - 1]; // inference: two ping-pong buffers
+        else
+            lo.x[l + 1] = 0; // last layer's sequence is not needed for inference
+        for (int d = 0; d < 2; ++d)
+            lo.gates[l][d] = (train && d < lo.ndir) ? take(sizeof(float) * lo.MT * 4 * H) : 0;
+    }
+    lo.hfin = take(sizeof(float) * lo.ndir * B * H);
+    lo.hid = take(sizeof(float) * B * H);
+    for (int d = 0; d < 2; ++d) {
+        lo.gi[d] = d < lo.ndir ? take(sizeof(float) * lo.MT * 3 * H) : 0;
+        lo.wp[d] = d < lo.ndir ? take(sizeof(float) * 3 * H * H) : 0;
+    }
+    lo.fwd_end = off;
+    lo.d_hfin = lo.slabs = 0;
+    for (int d = 0; d < 2; ++d)
+        lo.dgi[d] = lo.dghn[d] = lo.dx[d] = lo.wtp[d] = 0;
+    if (train) {
+        lo.d_hfin = take(sizeof(float) * lo.ndir * B * H);
+        for (int d = 0; d < lo.ndir; ++d) {
+            lo.dgi[d] = take(sizeof(float) * lo.MT * 3 * H);
+            lo.dghn[d] = take(sizeof(float) * lo.MT * H);
+            lo.wtp[d] = take(sizeof(float) * 3 * H * H);
+        }
+        if (L > 1)
+            for (int i = 0; i < 2; ++i)
+                lo.dx[i] = take(seq);
+        const size_t in_max = (size_t)(E > lo.ndir * H ? E : lo.ndir * H);
+        lo.slabs = take(sizeof(float) * ENC_SPLITK * 3 * H * (in_max > (size_t)H ? in_max : (size_t)H));
+    }
+    lo.total = off;
+    return lo;
+}

@@ -1,0 +1,455 @@
+// K1-K3: RNNEncoder.forward (GRU) -- backend/model.py:48-75 -- on gfx950.
+//
+//   prep      lengths = count of non-zero ids (model.py:52, computed ON DEVICE: the reference's
+//             .cpu() sync is not reproduced), id range check, exclusive scan -> packed token
+//             offsets, counting sort of rows by length (so a recurrence block's 16 rows have
+//             similar lengths), packed id list.
+//   K1        input projections for ALL valid tokens at once: Gi = X W_ih^T + b_ih as one fp32
+//             MFMA GEMM whose A rows are gathered straight from the embedding table
+//             (model.py:49 + the x-side half of nn.GRU, model.py:59-62); padded positions are
+//             never computed (packed token order).
+//   K2        the recurrence: one workgroup = 16 batch rows x all H hidden units, persistent over
+//             the T steps of its rows; h lives in LDS (double-buffered, fp32) and in registers;
+//             per step Gh = h W_hh^T + b_hh on v_mfma_f32_16x16x4_f32 with W_hh streamed from L2 in
+//             a pre-packed, fully coalesced B-operand order; gates r,z,n and the blend are lane-local
+//             (the three gates of one (row, unit) sit in the same lane).
+//   K3        head: (bidirectional) cat + Linear(2H,H) (model.py:65-69), F.normalize eps 1e-12
+//             (model.py:73-74).
+#include "encoder.h"
+#include "sgemm.h"
+
+#include <limits.h>
+
+namespace {
+
+// ------------------------------------------------------------------ prep
+__global__ __launch_bounds__(256) void prep_len_kernel(const int64_t *__restrict__ ids, int B, int T, int64_t V,
+                                                       int32_t *__restrict__ len, int32_t *__restrict__ flag)
+{
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B)
+        return;
+    int c = 0, bad = 0;
+    for (int t = lane; t < T; t += 64) {
+        const int64_t id = ids[(size_t)b * T + t];
+        c += id != 0;
+        bad |= (id < 0 || id >= V);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        c += __shfl_xor(c, off);
+        bad |= __shfl_xor(bad, off);
+    }
+    if (lane == 0) {
+        len[b] = c;
+        if (c == 0)
+            atomicOr(flag, 1); // zero-length row: pack_padded_sequence raises (model.py:55-57)
+        if (bad)
+            atomicOr(flag, 2); // id outside [0,V): nn.Embedding raises IndexError
+    }
+}
+
+constexpr int SORT_BINS = 4096;
+
+// Single block: tok_off = exclusive scan of len; perm = rows sorted by length, longest first.
+__global__ __launch_bounds__(1024) void prep_scan_sort_kernel(const int32_t *__restrict__ len, int B, int T,
+                                                              int32_t *__restrict__ tok_off, int32_t *__restrict__ perm)
+{
+    __shared__ int hist[SORT_BINS];
+    __shared__ int wsum[16];
+    __shared__ int carry;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < SORT_BINS; i += 1024)
+        hist[i] = 0;
+    if (tid == 0)
+        carry = 0;
+    __syncthreads();
+    const int nb = min(T + 1, SORT_BINS);
+    auto bin_of = [&](int l) { return nb - 1 - (int)((int64_t)l * nb / (T + 1)); }; // long rows -> low bins
+    for (int base = 0; base < B; base += 1024) {
+        const int b = base + tid;
+        const int v = b < B ? len[b] : 0;
+        if (b < B)
+            atomicAdd(&hist[bin_of(v)], 1);
+        int x = v; // inclusive wave scan
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int y = __shfl_up(x, off);
+            if (lane >= off)
+                x += y;
+        }
+        if (lane == 63)
+            wsum[wave] = x;
+        __syncthreads();
+        int pre = carry;
+        for (int w = 0; w < wave; ++w)
+            pre += wsum[w];
+        if (b < B)
+            tok_off[b] = pre + x - v;
+        __syncthreads();
+        if (tid == 1023)
+            carry = pre + x;
+        __syncthreads();
+    }
+    if (tid == 0)
+        tok_off[B] = carry;
+    // exclusive scan of the histogram (4 bins per thread)
+    {
+        int loc[4], s = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            loc[i] = hist[tid * 4 + i];
+            s += loc[i];
+        }
+        int x = s;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int y = __shfl_up(x, off);
+            if (lane >= off)
+                x += y;
+        }
+        if (lane == 63)
+            wsum[wave] = x;
+        __syncthreads();
+        int pre = 0;
+        for (int w = 0; w < wave; ++w)
+            pre += wsum[w];
+        int run = pre + x - s;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            hist[tid * 4 + i] = run;
+            run += loc[i];
+        }
+        __syncthreads();
+    }
+    for (int b = tid; b < B; b += 1024)
+        perm[atomicAdd(&hist[bin_of(len[b])], 1)] = b;
+}
+
+__global__ __launch_bounds__(256) void prep_pack_ids_kernel(const int64_t *__restrict__ ids, int B, int T,
+                                                            const int32_t *__restrict__ len,
+                                                            const int32_t *__restrict__ tok_off, int64_t V,
+                                                            int32_t *__restrict__ packed)
+{
+    const int b = blockIdx.x;
+    const int L = len[b], o = tok_off[b];
+    for (int t = threadIdx.x; t < L; t += 256) {
+        int64_t id = ids[(size_t)b * T + t];
+        packed[o + t] = (int32_t)(id < 0 || id >= V ? 0 : id); // out-of-range ids are flagged, never dereferenced
+    }
+}
+
+// ------------------------------------------------------------------ W_hh -> MFMA B-operand order
+// wp[(((w*3 + g)*2 + ct)*(H/16) + c)*256 + lane*4 + e] = W_hh[g*H + 32w + 16ct + (lane&15)][16c + 4(lane>>4) + e]
+__global__ __launch_bounds__(256) void pack_whh_kernel(const float *__restrict__ W, int H, float *__restrict__ wp)
+{
+    const int n = 3 * H * H / 4;
+    const int nc = H / 16;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const int lane = i & 63;
+        int r = i >> 6;
+        const int c = r % nc;
+        r /= nc;
+        const int ct = r & 1;
+        r >>= 1;
+        const int g = r % 3, w = r / 3;
+        const int row = g * H + 32 * w + 16 * ct + (lane & 15);
+        const int col = 16 * c + 4 * (lane >> 4);
+        *(f32x4 *)(wp + (size_t)i * 4) = *(const f32x4 *)(W + (size_t)row * H + col);
+    }
+}
+
+// ------------------------------------------------------------------ K2 recurrence
+struct GruDir {
+    const float *gi;   // [M][3H] packed tokens
+    const float *wp;   // packed W_hh
+    const float *b_hh; // [3H]
+    float *out_seq;    // nullable, [M][out_ld]
+    float *gates;      // nullable, [M][4][H]
+    float *h_final;    // [B][H]
+    int out_col0;
+    int reverse;
+};
+
+struct GruParams {
+    GruDir dir[2];
+    const int32_t *len, *tok_off, *perm;
+    int B, H, out_ld;
+};
+
+__device__ __forceinline__ float fast_sigmoid(float x)
+{
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
+__device__ __forceinline__ float fast_tanh(float x)
+{
+    return 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.8853900817779268f * x)) - 1.0f;
+}
+
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+template <int MAXW>
+__global__ __launch_bounds__(MAXW * 64) void gru_seq_kernel(GruParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) float hbuf[]; // [2][16][H+4]
+    const GruDir d = p.dir[blockIdx.y];
+    const int H = p.H, LDH = H + 4, nc = H / 16;
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 15, kq = lane >> 4;
+    const int row0 = blockIdx.x * ENC_RB;
+
+    int len_e[4], off_e[4], rid_e[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int br = row0 + kq * 4 + e;
+        rid_e[e] = br < p.B ? p.perm[br] : -1;
+        len_e[e] = rid_e[e] >= 0 ? p.len[rid_e[e]] : 0;
+        off_e[e] = rid_e[e] >= 0 ? p.tok_off[rid_e[e]] : 0;
+    }
+    int steps = max(max(len_e[0], len_e[1]), max(len_e[2], len_e[3])); // block-wide max length
+    steps = max(steps, __shfl_xor(steps, 16));
+    steps = max(steps, __shfl_xor(steps, 32));
+    int unit[2];
+    float bias[3][2];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+        unit[ct] = 32 * w + 16 * ct + j;
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+            bias[g][ct] = d.b_hh[g * H + unit[ct]];
+    }
+    for (int i = threadIdx.x; i < 2 * ENC_RB * LDH; i += blockDim.x)
+        hbuf[i] = 0.0f;
+    float hreg[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+    __syncthreads();
+
+    const float *wbase = d.wp + (size_t)w * 6 * nc * 256 + lane * 4;
+    const int H3 = 3 * H;
+    int cur = 0;
+    for (int s = 0; s < steps; ++s) {
+        bool act[4];
+        size_t tok[4];
+        float giv[3][2][4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            act[e] = s < len_e[e];
+            const int t = d.reverse ? len_e[e] - 1 - s : s;
+            tok[e] = (size_t)(off_e[e] + (act[e] ? t : 0));
+#pragma unroll
+            for (int g = 0; g < 3; ++g)
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct)
+                    giv[g][ct][e] = act[e] ? d.gi[tok[e] * H3 + g * H + unit[ct]] : 0.0f;
+        }
+        f32x4v acc[3][2];
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+                acc[g][ct] = (f32x4v){bias[g][ct], bias[g][ct], bias[g][ct], bias[g][ct]};
+
+        const float *hA = hbuf + cur * ENC_RB * LDH + j * LDH + 4 * kq;
+        for (int c = 0; c < nc; ++c) {
+            const f32x4v a = *(const f32x4v *)(hA + 16 * c);
+            f32x4v b[3][2];
+#pragma unroll
+            for (int g = 0; g < 3; ++g)
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct)
+                    b[g][ct] = *(const f32x4v *)(wbase + ((size_t)(g * 2 + ct) * nc + c) * 256);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int g = 0; g < 3; ++g)
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct)
+                        acc[g][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b[g][ct][e], acc[g][ct], 0, 0, 0);
+        }
+
+        float *hN = hbuf + (cur ^ 1) * ENC_RB * LDH;
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float r = fast_sigmoid(giv[0][ct][e] + acc[0][ct][e]);
+                const float z = fast_sigmoid(giv[1][ct][e] + acc[1][ct][e]);
+                const float ghn = acc[2][ct][e];
+                const float n = fast_tanh(giv[2][ct][e] + r * ghn);
+                const float hn = (hreg[ct][e] - n) * z + n;
+                if (act[e]) {
+                    hreg[ct][e] = hn;
+                    if (d.out_seq)
+                        d.out_seq[tok[e] * p.out_ld + d.out_col0 + unit[ct]] = hn;
+                    if (d.gates) {
+                        float *gs = d.gates + tok[e] * 4 * H + unit[ct];
+                        gs[0] = r;
+                        gs[H] = z;
+                        gs[2 * H] = n;
+                        gs[3 * H] = ghn;
+                    }
+                }
+                hN[(kq * 4 + e) * LDH + unit[ct]] = hreg[ct][e];
+            }
+        __syncthreads();
+        cur ^= 1;
+    }
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (rid_e[e] >= 0)
+                d.h_final[(size_t)rid_e[e] * H + unit[ct]] = hreg[ct][e];
+}
+
+// ------------------------------------------------------------------ K3 head
+__global__ __launch_bounds__(256) void head_kernel(const float *__restrict__ hfin, int B, int H, int ndir,
+                                                   const float *__restrict__ proj_w,
+                                                   const float *__restrict__ proj_b, int normalize,
+                                                   float *__restrict__ hid_out, float *__restrict__ out)
+{
+    __shared__ float cat[1024];
+    __shared__ float hid[512];
+    __shared__ float red[4];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    for (int i = tid; i < ndir * H; i += 256)
+        cat[i] = hfin[(size_t)(i / H) * B * H + (size_t)b * H + (i % H)];
+    __syncthreads();
+    float ss = 0.0f;
+    for (int u = tid; u < H; u += 256) {
+        float v;
+        if (ndir == 2) {
+            v = proj_b[u];
+            const float *wr = proj_w + (size_t)u * 2 * H;
+            for (int k = 0; k < 2 * H; ++k)
+                v += cat[k] * wr[k];
+        } else {
+            v = cat[u];
+        }
+        hid[u] = v;
+        if (hid_out)
+            hid_out[(size_t)b * H + u] = v;
+        ss += v * v;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1)
+        ss += __shfl_xor(ss, off);
+    if ((tid & 63) == 0)
+        red[tid >> 6] = ss;
+    __syncthreads();
+    const float nrm = fmaxf(sqrtf(red[0] + red[1] + red[2] + red[3]), 1e-12f);
+    for (int u = tid; u < H; u += 256)
+        out[(size_t)b * H + u] = normalize ? hid[u] / nrm : hid[u];
+}
+
+} // namespace
+
+int enc_check_shape(const char *who, int B, int T, int E, int H, int L, int64_t V)
+{
+    if (B <= 0 || T <= 0)
+        return tt_fail(TT_ERR_BAD_SHAPE, "%s: Cannot pack empty tensors (B=%d T=%d)", who, B, T);
+    if (H < 32 || H > 512 || (H & 31))
+        return tt_fail(TT_ERR_UNSUPPORTED, "%s: HIDDEN_DIM=%d (supported: multiples of 32 in [32,512])", who, H);
+    if (E < 4 || (E & 3))
+        return tt_fail(TT_ERR_UNSUPPORTED, "%s: EMBED_DIM=%d must be a multiple of 4", who, E);
+    if (L < 1 || L > ENC_MAX_LAYERS)
+        return tt_fail(TT_ERR_UNSUPPORTED, "%s: NUM_LAYERS=%d (supported: 1..%d)", who, L, ENC_MAX_LAYERS);
+    if ((int64_t)B * T >= INT_MAX / 4 || V <= 0 || V >= INT_MAX)
+        return tt_fail(TT_ERR_UNSUPPORTED, "%s: B*T or V too large for 32-bit token indices", who);
+    return TT_OK;
+}
+
+TT_EXPORT size_t tt_encoder_workspace_bytes(int B, int T, int E, int H, int num_layers, int bidirectional, int train)
+{
+    if (B <= 0 || T <= 0 || num_layers < 1 || num_layers > ENC_MAX_LAYERS)
+        return 0;
+    return enc_layout(B, T, E, H, num_layers, bidirectional, train).total;
+}
+
+TT_EXPORT int tt_encoder_forward_f32(const int64_t *ids, int B, int T, const float *table, int64_t V, int E, int H,
+                                     int num_layers, int bidirectional, const float *const *weights,
+                                     const float *proj_w, const float *proj_b, int normalize, int train, float *out,
+                                     void *workspace, size_t workspace_bytes, int32_t *status, tt_stream_t stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    int rc = enc_check_shape("tt_encoder_forward_f32", B, T, E, H, num_layers, V);
+    if (rc != TT_OK)
+        return rc;
+    if (!ids || !table || !weights || !out || (bidirectional && (!proj_w || !proj_b)))
+        return tt_fail(TT_ERR_BAD_SHAPE, "tt_encoder_forward_f32: null pointer");
+    const EncLayout lo = enc_layout(B, T, E, H, num_layers, bidirectional, train);
+    if (!workspace || workspace_bytes < lo.total || ((uintptr_t)workspace & 255))
+        return tt_fail(TT_ERR_WORKSPACE, "tt_encoder_forward_f32: workspace %zu < %zu bytes (or not 256-B aligned)",
+                       workspace_bytes, lo.total);
+    char *ws = (char *)workspace;
+    int32_t *len = (int32_t *)(ws + lo.len), *tok_off = (int32_t *)(ws + lo.tok_off);
+    int32_t *perm = (int32_t *)(ws + lo.perm), *idsp = (int32_t *)(ws + lo.ids), *flag = (int32_t *)(ws + lo.flag);
+    const int ndir = lo.ndir;
+
+    TT_HIP_CHECK(hipMemsetAsync(flag, 0, 256, st));
+    hipLaunchKernelGGL(prep_len_kernel, dim3((B + 3) / 4), dim3(256), 0, st, ids, B, T, V, len, flag);
+    hipLaunchKernelGGL(prep_scan_sort_kernel, dim3(1), dim3(1024), 0, st, len, B, T, tok_off, perm);
+    hipLaunchKernelGGL(prep_pack_ids_kernel, dim3(B), dim3(256), 0, st, ids, B, T, len, tok_off, V, idsp);
+    TT_LAUNCH_CHECK();
+    if (status)
+        TT_HIP_CHECK(hipMemcpyAsync(status, flag, sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+
+    const size_t lds = sizeof(float) * 2 * ENC_RB * (H + 4);
+    for (int l = 0; l < num_layers; ++l) {
+        const int I = l == 0 ? E : ndir * H;
+        GruParams gp;
+        gp.len = len;
+        gp.tok_off = tok_off;
+        gp.perm = perm;
+        gp.B = B;
+        gp.H = H;
+        gp.out_ld = ndir * H;
+        const bool last = l == num_layers - 1;
+        float *xout = (last && !train) ? nullptr : (float *)(ws + lo.x[l + 1]);
+        for (int d = 0; d < ndir; ++d) {
+            const float *const *w = weights + ((size_t)l * ndir + d) * 4;
+            SgemmParams g;
+            g.A = l == 0 ? table : (const float *)(ws + lo.x[l]);
+            g.a_map = l == 0 ? idsp : nullptr;
+            g.B = w[0];
+            g.b_map = nullptr;
+            g.C = (float *)(ws + lo.gi[d]);
+            g.bias = w[2];
+            g.m_dyn = tok_off + B;
+            g.k_dyn = nullptr;
+            g.M = (int)lo.MT;
+            g.N = 3 * H;
+            g.K = I;
+            g.lda = I;
+            g.ldb = I;
+            g.ldc = 3 * H;
+            g.slab_stride = 0;
+            g.accumulate = 0;
+            rc = tt_sgemm(g, false, false, 1, st);
+            if (rc != TT_OK)
+                return rc;
+            hipLaunchKernelGGL(pack_whh_kernel, dim3(96), dim3(256), 0, st, w[1], H, (float *)(ws + lo.wp[d]));
+            gp.dir[d].gi = (const float *)(ws + lo.gi[d]);
+            gp.dir[d].wp = (const float *)(ws + lo.wp[d]);
+            gp.dir[d].b_hh = w[3];
+            gp.dir[d].out_seq = xout;
+            gp.dir[d].gates = train ? (float *)(ws + lo.gates[l][d]) : nullptr;
+            // only the last layer's final hidden state is used (model.py:65-71)
+            gp.dir[d].h_final = (float *)(ws + lo.hfin) + (size_t)d * B * H;
+            gp.dir[d].out_col0 = d * H;
+            gp.dir[d].reverse = d;
+        }
+        if (ndir == 1)
+            gp.dir[1] = gp.dir[0];
+        if (H <= 256)
+            hipLaunchKernelGGL(gru_seq_kernel<8>, dim3((B + ENC_RB - 1) / ENC_RB, ndir), dim3(H / 32 * 64), lds, st, gp);
+        else
+            hipLaunchKernelGGL(gru_seq_kernel<16>, dim3((B + ENC_RB - 1) / ENC_RB, ndir), dim3(H / 32 * 64), lds, st, gp);
+        TT_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(head_kernel, dim3(B), dim3(256), 0, st, (const float *)(ws + lo.hfin), B, H, ndir, proj_w,
+                       proj_b, normalize, train ? (float *)(ws + lo.hid) : (float *)nullptr, out);
+    TT_LAUNCH_CHECK();
+    return TT_OK;
+}

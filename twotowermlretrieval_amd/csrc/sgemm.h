@@ -1,0 +1,33 @@
+// Generic LDS-tiled fp32 GEMM on v_mfma_f32_32x32x2_f32 (exact fp32, gfx950).
+// Used by the encoder for the input projections (K1), the weight-gradient products and
+// the input-gradient products (K7).  Not the product's roofline kernel: these GEMMs are
+// < 10 % of an encoder step; the recurrence dominates.
+#pragma once
+#include "tt_common.h"
+
+struct SgemmParams {
+    // C[M,N] (+ bias[N]) (+= when accumulate) = opA(A) * opB(B)
+    //   A_T == false: A is [M,K] row-major (lda), row m read from source row a_map ? a_map[m] : m
+    //   A_T == true : A is [K,M] row-major (lda) (the product sums over A's ROWS), source row of
+    //                 reduction index k is a_map ? a_map[k] : k
+    //   B_T == false: B is [N,K] row-major (ldb)  ("weights" layout: C = A * B^T)
+    //   B_T == true : B is [K,N] row-major (ldb), source row of k is b_map ? b_map[k] : k
+    const float *A;
+    const float *B;
+    float *C;
+    const float *bias;
+    const int32_t *a_map;
+    const int32_t *b_map;
+    const int *m_dyn; // optional device scalar: effective M = min(M, *m_dyn)
+    const int *k_dyn; // optional device scalar: effective K = min(K, *k_dyn)
+    int M, N, K;
+    int64_t lda, ldb, ldc;
+    int64_t slab_stride; // split-K: slice z writes C + z*slab_stride (0 when gridDim.z == 1)
+    int accumulate;      // C += result (gridDim.z must be 1)
+};
+
+// Launch: grid (ceil(N/128), ceil(M/128), splits), block 256.
+int tt_sgemm(const SgemmParams &p, bool a_t, bool b_t, int splits, hipStream_t st);
+
+// out[i] (+)= sum_z slabs[z][i], fixed order (deterministic split-K reduction)
+int tt_slab_reduce(const float *slabs, int nslab, int64_t n, float *out, int accumulate, hipStream_t st);

@@ -1,0 +1,165 @@
+#include "sgemm.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 16, LDT = 20; // LDS row stride 20 floats: conflict-free b128 reads
+
+// Stage one operand tile [128 rows][BK] (k contiguous in LDS) from global memory.
+//  TR == false: source [rows][K]: thread -> (row t>>1, 8 consecutive k)
+//  TR == true : source [K][rows]: thread -> (k t>>4, 8 consecutive rows), scattered into LDS
+template <bool TR>
+__device__ __forceinline__ void stage_tile(float *__restrict__ tile, const float *__restrict__ src, int64_t ld,
+                                           const int32_t *__restrict__ map, int row0, int rows_eff, int k0,
+                                           int k_end, int tid)
+{
+    if (!TR) {
+        const int r = tid >> 1, kc = (tid & 1) * 8;
+        const int row = row0 + r;
+        f32x4 v0 = {0, 0, 0, 0}, v1 = {0, 0, 0, 0};
+        if (row < rows_eff) {
+            const int64_t srow = map ? (int64_t)map[row] : (int64_t)row;
+            const float *p = src + srow * ld + k0 + kc;
+            if (k0 + kc < k_end)
+                v0 = *(const f32x4 *)p;
+            if (k0 + kc + 4 < k_end)
+                v1 = *(const f32x4 *)(p + 4);
+        }
+        *(f32x4 *)(tile + r * LDT + kc) = v0;
+        *(f32x4 *)(tile + r * LDT + kc + 4) = v1;
+    } else {
+        const int kk = tid >> 4, rc = (tid & 15) * 8;
+        const int k = k0 + kk;
+        f32x4 v0 = {0, 0, 0, 0}, v1 = {0, 0, 0, 0};
+        if (k < k_end) {
+            const int64_t srow = map ? (int64_t)map[k] : (int64_t)k;
+            const float *p = src + srow * ld + row0 + rc;
+            if (row0 + rc < rows_eff)
+                v0 = *(const f32x4 *)p;
+            if (row0 + rc + 4 < rows_eff)
+                v1 = *(const f32x4 *)(p + 4);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            tile[(rc + e) * LDT + kk] = v0[e];
+            tile[(rc + 4 + e) * LDT + kk] = v1[e];
+        }
+    }
+}
+
+template <bool A_T, bool B_T>
+__global__ __launch_bounds__(256) void sgemm_kernel(SgemmParams p)
+{
+    __shared__ __attribute__((aligned(16))) float As[BM * LDT];
+    __shared__ __attribute__((aligned(16))) float Bs[BN * LDT];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int M = p.m_dyn ? min(p.M, *p.m_dyn) : p.M;
+    const int K = p.k_dyn ? min(p.K, *p.k_dyn) : p.K;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    if (m0 >= M)
+        return;
+    // split-K range (multiples of BK)
+    const int splits = gridDim.z;
+    int kchunk = (K + splits - 1) / splits;
+    kchunk = (kchunk + BK - 1) / BK * BK;
+    const int kb = blockIdx.z * kchunk, ke = min(kb + kchunk, K);
+    float *C = p.C + (size_t)blockIdx.z * p.slab_stride;
+
+    const int wr = wave >> 1, wc = wave & 1, i = lane & 31, h = lane >> 5;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                acc[a][b][r] = 0.0f;
+
+    for (int k0 = kb; k0 < ke; k0 += BK) {
+        stage_tile<A_T>(As, p.A, p.lda, p.a_map, m0, M, k0, ke, tid);
+        stage_tile<B_T>(Bs, p.B, p.ldb, p.b_map, n0, p.N, k0, ke, tid);
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            f32x4 a[2], b[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                a[t] = *(const f32x4 *)(As + (64 * wr + 32 * t + i) * LDT + 8 * c + 4 * h);
+                b[t] = *(const f32x4 *)(Bs + (64 * wc + 32 * t + i) * LDT + 8 * c + 4 * h);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt][e], b[nt][e], acc[mt][nt], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const int col = n0 + 64 * wc + 32 * nt + i;
+            if (col >= p.N)
+                continue;
+            const float bv = (p.bias && blockIdx.z == 0) ? p.bias[col] : 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + 64 * wr + 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (row < M) {
+                    float *dst = C + (size_t)row * p.ldc + col;
+                    const float v = acc[mt][nt][r] + bv;
+                    *dst = p.accumulate ? *dst + v : v;
+                }
+            }
+        }
+}
+
+__global__ void slab_reduce_kernel(const float *__restrict__ slabs, int nslab, int64_t n, float *out, int accumulate)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float s = 0.0f;
+        for (int z = 0; z < nslab; ++z)
+            s += slabs[(size_t)z * n + i];
+        out[i] = accumulate ? out[i] + s : s;
+    }
+}
+
+} // namespace
+
+int tt_sgemm(const SgemmParams &p, bool a_t, bool b_t, int splits, hipStream_t st)
+{
+    if (p.M <= 0 || p.N <= 0 || p.K <= 0)
+        return TT_OK;
+    if ((p.K & 3) || (a_t && (p.M & 3)) || (b_t && (p.N & 3)) || (p.lda & 3) || (p.ldb & 3))
+        return tt_fail(TT_ERR_UNSUPPORTED, "tt_sgemm: dims must be multiples of 4 (M=%d N=%d K=%d)", p.M, p.N, p.K);
+    if (splits < 1)
+        splits = 1;
+    if (splits > 1 && p.accumulate)
+        return tt_fail(TT_ERR_BAD_SHAPE, "tt_sgemm: accumulate with split-K");
+    dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM, splits);
+    if (!a_t && !b_t)
+        hipLaunchKernelGGL((sgemm_kernel<false, false>), grid, dim3(256), 0, st, p);
+    else if (!a_t && b_t)
+        hipLaunchKernelGGL((sgemm_kernel<false, true>), grid, dim3(256), 0, st, p);
+    else if (a_t && !b_t)
+        hipLaunchKernelGGL((sgemm_kernel<true, false>), grid, dim3(256), 0, st, p);
+    else
+        hipLaunchKernelGGL((sgemm_kernel<true, true>), grid, dim3(256), 0, st, p);
+    TT_LAUNCH_CHECK();
+    return TT_OK;
+}
+
+int tt_slab_reduce(const float *slabs, int nslab, int64_t n, float *out, int accumulate, hipStream_t st)
+{
+    if (n <= 0)
+        return TT_OK;
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 2048)
+        blocks = 2048;
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, st, slabs, nslab, n, out, accumulate);
+    TT_LAUNCH_CHECK();
+    return TT_OK;
+}

@@ -1,0 +1,280 @@
+"""Drop-in mirror of the reference's backend/model.py public surface, computed by libtt.so.
+
+    RNNEncoder(vocab_size, embed_dim, hidden_dim, pretrained_embeddings=None, rnn_type='GRU',
+               num_layers=1, dropout=0.0, bidirectional=False, normalize_output=True)   model.py:11-46
+    RNNEncoder.forward(LongTensor[B,T]) -> FloatTensor[B,H]                              model.py:48-75
+    TwoTowerModel(config, pretrained_embeddings).encode_query / encode_document / forward model.py:78-106
+    triplet_loss_cosine((q, p, n), margin=0.2) -> 0-d tensor                             model.py:109-114
+
+Same constructor arguments, attribute names (`query_encoder.embedding.embedding_dim` is read by
+backend/main.py:104) and state_dict keys ({query,doc}_encoder.{embedding.weight,
+rnn.weight_ih_l0[_reverse], ..., projection.weight/bias}), so a model.pth written by either side
+loads in the other.  The nn.Module objects here only OWN the parameters; every forward/backward
+runs in hand-written HIP kernels (csrc/encoder*.hip, train.hip).  There is no PyTorch fallback:
+CPU tensors and LSTM / vanilla-RNN towers raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+__all__ = ["RNNEncoder", "TwoTowerModel", "triplet_loss_cosine"]
+
+
+def _stream(dev) -> int:
+    return torch.cuda.current_stream(dev).cuda_stream
+
+
+class _GRUParams(nn.Module):
+    """Parameter container with torch.nn.GRU's names, shapes and default init (U(-1/sqrt(H), 1/sqrt(H)))."""
+
+    def __init__(self, input_size: int, hidden_size: int, num_layers: int, bidirectional: bool):
+        super().__init__()
+        self.input_size, self.hidden_size = input_size, hidden_size
+        self.num_layers, self.bidirectional = num_layers, bidirectional
+        k = 1.0 / math.sqrt(hidden_size)
+        ndir = 2 if bidirectional else 1
+        for layer in range(num_layers):
+            I = input_size if layer == 0 else ndir * hidden_size
+            for d in range(ndir):
+                sfx = f"_l{layer}" + ("_reverse" if d else "")
+                for name, shape in (("weight_ih", (3 * hidden_size, I)), ("weight_hh", (3 * hidden_size, hidden_size)),
+                                    ("bias_ih", (3 * hidden_size,)), ("bias_hh", (3 * hidden_size,))):
+                    self.register_parameter(name + sfx, nn.Parameter(torch.empty(shape).uniform_(-k, k)))
+
+    def quads(self):
+        """[(W_ih, W_hh, b_ih, b_hh)] ordered (layer, dir): the order of the C ABI's `weights` array."""
+        out = []
+        for layer in range(self.num_layers):
+            for d in range(2 if self.bidirectional else 1):
+                sfx = f"_l{layer}" + ("_reverse" if d else "")
+                out.append(tuple(getattr(self, n + sfx) for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")))
+        return out
+
+
+class _LinearParams(nn.Module):
+    """Parameter container with nn.Linear's names and default init."""
+
+    def __init__(self, in_features: int, out_features: int):
+        super().__init__()
+        k = 1.0 / math.sqrt(in_features)
+        self.in_features, self.out_features = in_features, out_features
+        self.weight = nn.Parameter(torch.empty(out_features, in_features).uniform_(-k, k))
+        self.bias = nn.Parameter(torch.empty(out_features).uniform_(-k, k))
+
+
+def _ptr_array(tensors):
+    arr = (C.c_void_p * len(tensors))()
+    for i, t in enumerate(tensors):
+        arr[i] = t.data_ptr()
+    return arr
+
+
+def _raise_status(status: int) -> None:
+    if status & 2:
+        raise IndexError("index out of range in self")  # nn.Embedding's message (tests/golden/g10_errors.json)
+    if status & 1:
+        raise RuntimeError("Length of all samples has to be greater than 0, but found an element in 'lengths' "
+                           "that is <= 0")  # pack_padded_sequence's message (model.py:55-57)
+
+
+class _EncoderFn(torch.autograd.Function):
+    """forward = tt_encoder_forward_f32 (train=1), backward = tt_encoder_backward_f32."""
+
+    @staticmethod
+    def forward(ctx, enc: "RNNEncoder", ids: torch.Tensor, *params: torch.Tensor):
+        out, ws, status = enc._run_forward(ids, train=True)
+        ctx.enc, ctx.ids, ctx.ws, ctx.status = enc, ids, ws, status
+        ctx.n_params = len(params)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out: torch.Tensor):
+        grads = ctx.enc._run_backward(ctx.ids, ctx.ws, d_out.contiguous())
+        ctx.ws = None
+        return (None, None, *grads)
+
+
+class RNNEncoder(nn.Module):
+    """GRU text encoder: embedding gather -> (stacked / bidirectional) GRU -> final hidden -> L2-normalise."""
+
+    def __init__(self, vocab_size: int, embed_dim: int, hidden_dim: int,
+                 pretrained_embeddings: Optional[np.ndarray] = None, rnn_type: str = "GRU", num_layers: int = 1,
+                 dropout: float = 0.0, bidirectional: bool = False, normalize_output: bool = True):
+        super().__init__()
+        self.embedding = nn.Embedding(vocab_size, embed_dim, padding_idx=0)  # parameter owner only
+        if pretrained_embeddings is not None:
+            # every row is copied, row 0 included (it is the GloVe word "the"), and the table is frozen
+            self.embedding.weight.data.copy_(torch.from_numpy(np.asarray(pretrained_embeddings)))
+            self.embedding.weight.requires_grad = False
+        self.rnn_type = rnn_type.upper()
+        if self.rnn_type != "GRU":
+            raise NotImplementedError(f"RNN_TYPE={rnn_type!r}: only the GRU tower has HIP kernels; there is no "
+                                      "PyTorch fallback in this package")
+        self.bidirectional = bidirectional
+        self.num_layers = num_layers
+        self.hidden_dim = hidden_dim
+        self.dropout = float(dropout) if num_layers > 1 else 0.0
+        self.rnn = _GRUParams(embed_dim, hidden_dim, num_layers, bidirectional)
+        self.normalize_output = normalize_output
+        self.projection = _LinearParams(hidden_dim * 2, hidden_dim) if bidirectional else None
+        self.check_inputs = True  # read the device status word after each call (one 4-byte D2H sync)
+        self._ws: Optional[torch.Tensor] = None
+
+    # ---- plumbing ---------------------------------------------------------------
+    def _flat_params(self):
+        ps = [w for quad in self.rnn.quads() for w in quad]
+        if self.projection is not None:
+            ps += [self.projection.weight, self.projection.bias]
+        return ps
+
+    def _check_device(self, x: torch.Tensor):
+        if not x.is_cuda:
+            raise RuntimeError("twotowermlretrieval_amd.RNNEncoder runs only on an AMD GPU via libtt.so "
+                               f"(got ids on {x.device}; there is no CPU fallback)")
+        for p in self.parameters():
+            if p.device != x.device:
+                raise RuntimeError(f"parameter on {p.device} but ids on {x.device}: call model.to(device) first")
+            if p.dtype != torch.float32:
+                raise TypeError("parameters must be float32")
+
+    def _run_forward(self, x: torch.Tensor, train: bool):
+        L = _lib.lib()
+        ids = x.contiguous()
+        if ids.dtype != torch.int64:
+            ids = ids.to(torch.int64)
+        if ids.dim() != 2:
+            raise ValueError(f"expected ids [B,T], got {tuple(ids.shape)}")
+        B, T = ids.shape
+        V, E = self.embedding.weight.shape
+        H = self.hidden_dim
+        need = L.tt_encoder_workspace_bytes(B, max(T, 1), E, H, self.num_layers, int(self.bidirectional), int(train))
+        if train:
+            ws = torch.empty(max(need, 256), dtype=torch.uint8, device=ids.device)  # owned by the autograd node
+        else:
+            if self._ws is None or self._ws.numel() < need or self._ws.device != ids.device:
+                self._ws = torch.empty(max(need, 256), dtype=torch.uint8, device=ids.device)
+            ws = self._ws
+        out = torch.empty((B, H), dtype=torch.float32, device=ids.device)
+        status = torch.zeros(1, dtype=torch.int32, device=ids.device)
+        quads = [w.detach().contiguous() for quad in self.rnn.quads() for w in quad]
+        wptr = _ptr_array(quads)
+        pw = self.projection.weight.detach().contiguous() if self.projection is not None else None
+        pb = self.projection.bias.detach().contiguous() if self.projection is not None else None
+        table = self.embedding.weight.detach()
+        with torch.cuda.device(ids.device):
+            _lib.check(L.tt_encoder_forward_f32(
+                ids.data_ptr(), B, T, table.data_ptr(), V, E, H, self.num_layers, int(self.bidirectional), wptr,
+                pw.data_ptr() if pw is not None else None, pb.data_ptr() if pb is not None else None,
+                int(self.normalize_output), int(train), out.data_ptr(), ws.data_ptr(), ws.numel(),
+                status.data_ptr(), _stream(ids.device)))
+        if self.check_inputs:
+            _raise_status(int(status.item()))
+        return out, ws, status
+
+    def _run_backward(self, ids: torch.Tensor, ws: torch.Tensor, d_out: torch.Tensor):
+        L = _lib.lib()
+        B, T = ids.shape
+        V, E = self.embedding.weight.shape
+        H = self.hidden_dim
+        params = self._flat_params()
+        grads = [torch.empty_like(p, memory_format=torch.contiguous_format) for p in params]
+        nq = 4 * self.num_layers * (2 if self.bidirectional else 1)
+        quads = [p.detach().contiguous() for p in params[:nq]]
+        wptr, gptr = _ptr_array(quads), _ptr_array(grads[:nq])
+        pw = params[nq].detach().contiguous() if self.projection is not None else None
+        pb = params[nq + 1].detach().contiguous() if self.projection is not None else None
+        with torch.cuda.device(ids.device):
+            _lib.check(L.tt_encoder_backward_f32(
+                ids.contiguous().data_ptr(), B, T, self.embedding.weight.detach().data_ptr(), V, E, H,
+                self.num_layers, int(self.bidirectional), wptr, pw.data_ptr() if pw is not None else None,
+                pb.data_ptr() if pb is not None else None, int(self.normalize_output), d_out.data_ptr(), gptr,
+                grads[nq].data_ptr() if pw is not None else None,
+                grads[nq + 1].data_ptr() if pb is not None else None, ws.data_ptr(), ws.numel(),
+                _stream(ids.device)))
+        return grads
+
+    # ---- public -----------------------------------------------------------------
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        self._check_device(x)
+        params = self._flat_params()
+        needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+        if needs_grad:
+            if self.embedding.weight.requires_grad:
+                raise NotImplementedError("training the embedding table is not supported by the HIP path: the "
+                                          "reference freezes it whenever GloVe vectors are loaded (model.py:25-27); "
+                                          "pass pretrained_embeddings or set embedding.weight.requires_grad=False")
+            if self.training and self.dropout > 0.0:
+                raise NotImplementedError("inter-layer dropout in train mode is not implemented yet (DROPOUT>0 with "
+                                          "NUM_LAYERS>1); use model.eval() or DROPOUT=0")
+            return _EncoderFn.apply(self, x, *params)
+        out, _, _ = self._run_forward(x, train=False)
+        return out
+
+
+class TwoTowerModel(nn.Module):
+    """Two independent RNNEncoder towers (no weight sharing; each owns its embedding table copy)."""
+
+    def __init__(self, config: Dict, pretrained_embeddings: Optional[np.ndarray] = None):
+        super().__init__()
+        encoder_args = {
+            "vocab_size": config["VOCAB_SIZE"],
+            "embed_dim": config["EMBED_DIM"],
+            "hidden_dim": config["HIDDEN_DIM"],
+            "pretrained_embeddings": pretrained_embeddings,
+            "rnn_type": config.get("RNN_TYPE", "GRU"),
+            "num_layers": config.get("NUM_LAYERS", 1),
+            "dropout": config.get("DROPOUT", 0.0),
+            "bidirectional": config.get("BIDIRECTIONAL", False),
+            "normalize_output": config.get("NORMALIZE_OUTPUT", True),
+        }
+        self.query_encoder = RNNEncoder(**encoder_args)
+        self.doc_encoder = RNNEncoder(**encoder_args)
+
+    def encode_query(self, query: torch.Tensor) -> torch.Tensor:
+        return self.query_encoder(query)
+
+    def encode_document(self, document: torch.Tensor) -> torch.Tensor:
+        return self.doc_encoder(document)
+
+    def forward(self, query: torch.Tensor, document: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        return self.encode_query(query), self.encode_document(document)
+
+
+class _TripletFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, p, n, margin: float):
+        L = _lib.lib()
+        q, p, n = q.contiguous(), p.contiguous(), n.contiguous()
+        B, H = q.shape
+        loss = torch.empty((), dtype=torch.float32, device=q.device)
+        dq, dp, dn = torch.empty_like(q), torch.empty_like(p), torch.empty_like(n)
+        with torch.cuda.device(q.device):
+            _lib.check(L.tt_triplet_loss_f32(q.data_ptr(), p.data_ptr(), n.data_ptr(), B, H, float(margin),
+                                             loss.data_ptr(), dq.data_ptr(), dp.data_ptr(), dn.data_ptr(),
+                                             _stream(q.device)))
+        ctx.save_for_backward(dq, dp, dn)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        dq, dp, dn = ctx.saved_tensors
+        return g * dq, g * dp, g * dn, None
+
+
+def triplet_loss_cosine(triplet: Tuple[torch.Tensor, torch.Tensor, torch.Tensor], margin: float = 0.2) -> torch.Tensor:
+    """mean(clamp(cos(q,n) - cos(q,p) + margin, min=0)), differentiable (fused forward+gradient kernel)."""
+    query, pos_doc, neg_doc = triplet
+    for t in (query, pos_doc, neg_doc):
+        if not t.is_cuda:
+            raise RuntimeError("triplet_loss_cosine runs only on an AMD GPU via libtt.so (no CPU fallback)")
+        if t.dtype != torch.float32 or t.dim() != 2 or t.shape != query.shape:
+            raise ValueError("triplet_loss_cosine wants three float32 [B,H] tensors of one shape")
+    return _TripletFn.apply(query, pos_doc, neg_doc, margin)
