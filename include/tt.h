@@ -126,6 +126,45 @@ int tt_encoder_forward_f32(const int64_t *ids, int B, int T, const float *table,
                            const float *proj_w, const float *proj_b, int normalize, int train, float *out,
                            void *workspace, size_t workspace_bytes, int32_t *status, tt_stream_t stream);
 
+/*
+ * Replaces loss.backward() through RNNEncoder.forward     backend/main.py:254 over model.py:48-75
+ * d_out [B,H] = gradient w.r.t. the forward's `out`.  `workspace` is the buffer a forward call with
+ * train=1 and the SAME ids/weights filled.  grads: HOST array of DEVICE pointers laid out like
+ * `weights`; every gradient buffer is OVERWRITTEN (the caller accumulates across calls, as autograd
+ * does).  The embedding table is frozen (model.py:25-27) and gets no gradient.
+ */
+int tt_encoder_backward_f32(const int64_t *ids, int B, int T, const float *table, int64_t V, int E, int H,
+                            int num_layers, int bidirectional, const float *const *weights /*host array*/,
+                            const float *proj_w, const float *proj_b, int normalize, const float *d_out,
+                            float *const *grads /*host array*/, float *g_proj_w, float *g_proj_b, void *workspace,
+                            size_t workspace_bytes, tt_stream_t stream);
+
+/* ------------------------------------------------------------------ */
+/* Training step pieces                                                */
+/* ------------------------------------------------------------------ */
+
+/*
+ * Replaces triplet_loss_cosine((q,p,n), margin)            backend/model.py:109-114
+ *   loss = mean(clamp(cos(q,n) - cos(q,p) + margin, min=0)), F.cosine_similarity eps 1e-8
+ * and its gradient: loss [1]; dq/dp/dn [B,H] = d loss / d{q,p,n} (all three or none, nullable);
+ * scratch_rows [B] f32.  Deterministic (fixed-order reduction).
+ */
+int tt_triplet_loss_f32(const float *q, const float *p, const float *n, int B, int H, float margin, float *loss,
+                        float *dq, float *dp, float *dn, float *scratch_rows, tt_stream_t stream);
+
+/*
+ * Replaces torch.nn.utils.clip_grad_norm_(params, max_norm) ; torch.optim.Adam(...).step()
+ *   backend/main.py:257,259 (optimizer built at :222; betas (0.9,0.999), eps 1e-8, no weight decay)
+ * over ONE flat fp32 buffer of n elements (params, grads, exp_avg, exp_avg_sq).  grads are first
+ * multiplied by grad_scale (1/world_size after a summing all-reduce: SURVEY 8e), then clipped by the
+ * global L2 norm (max_norm <= 0: no clipping) and left in place, then Adam step number `step` (1-based).
+ * total_norm_out (nullable, device) receives the pre-clip norm.  scratch: tt_clip_adam_scratch_bytes().
+ */
+size_t tt_clip_adam_scratch_bytes(void);
+int tt_clip_adam_step_f32(float *params, float *grads, float *exp_avg, float *exp_avg_sq, int64_t n, int64_t step,
+                          float lr, float beta1, float beta2, float eps, float max_norm, float grad_scale,
+                          float *total_norm_out, void *scratch, tt_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -31,6 +31,11 @@ SIGNATURES = {
     "tt_encoder_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i]),
     "tt_encoder_forward_f32": (_i, [_vp, _i, _i, _vp, _i64, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _vp, _sz,
                                     _vp, _vp]),
+    "tt_encoder_backward_f32": (_i, [_vp, _i, _i, _vp, _i64, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp,
+                                     _vp, _sz, _vp]),
+    "tt_triplet_loss_f32": (_i, [_vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "tt_clip_adam_scratch_bytes": (_sz, []),
+    "tt_clip_adam_step_f32": (_i, [_vp, _vp, _vp, _vp, _i64, _i64, _f, _f, _f, _f, _f, _f, _vp, _vp, _vp]),
 }
 
 _lib = None

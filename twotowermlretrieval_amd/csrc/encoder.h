@@ -21,6 +21,8 @@ struct EncLayout {
     size_t fwd_end;
     // backward scratch (train only)
     size_t d_hfin;                               // [ndir][B][H]
+    size_t d_hid;                                // [B][H] gradient w.r.t. the head output before normalisation
+    size_t prevmap[2];                           // [MT] int32: packed index of the token one step earlier (MT = none)
     size_t dgi[2];                               // [MT][3H] per direction
     size_t dghn[2];                              // [MT][H]: the n-gate column of dGh (= dn_pre * r)
     size_t dx[2];                                // ping-pong [MT][ndir*H]: gradient w.r.t. a layer's input
@@ -43,7 +45,8 @@ static inline EncLayout enc_layout(int B, int T, int E, int H, int L, int bidir,
     lo.perm = take(sizeof(int32_t) * B);
     lo.ids = take(sizeof(int32_t) * lo.MT);
     lo.flag = take(256);
-    const size_t seq = sizeof(float) * lo.MT * lo.ndir * H;
+    // train: one extra, all-zero row at index MT stands for "h before the first step"
+    const size_t seq = sizeof(float) * (lo.MT + (train ? 1 : 0)) * lo.ndir * H;
     lo.x[0] = 0;
     for (int l = 0; l < L; ++l) {
         if (train)
@@ -62,11 +65,14 @@ static inline EncLayout enc_layout(int B, int T, int E, int H, int L, int bidir,
         lo.wp[d] = d < lo.ndir ? take(sizeof(float) * 3 * H * H) : 0;
     }
     lo.fwd_end = off;
-    lo.d_hfin = lo.slabs = 0;
+    lo.d_hfin = lo.d_hid = lo.slabs = 0;
     for (int d = 0; d < 2; ++d)
-        lo.dgi[d] = lo.dghn[d] = lo.dx[d] = lo.wtp[d] = 0;
+        lo.dgi[d] = lo.dghn[d] = lo.dx[d] = lo.wtp[d] = lo.prevmap[d] = 0;
     if (train) {
         lo.d_hfin = take(sizeof(float) * lo.ndir * B * H);
+        lo.d_hid = take(sizeof(float) * B * H);
+        for (int d = 0; d < lo.ndir; ++d)
+            lo.prevmap[d] = take(sizeof(int32_t) * lo.MT);
         for (int d = 0; d < lo.ndir; ++d) {
             lo.dgi[d] = take(sizeof(float) * lo.MT * 3 * H);
             lo.dghn[d] = take(sizeof(float) * lo.MT * H);

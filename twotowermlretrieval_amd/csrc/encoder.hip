@@ -407,6 +407,8 @@ TT_EXPORT int tt_encoder_forward_f32(const int64_t *ids, int B, int T, const flo
         gp.out_ld = ndir * H;
         const bool last = l == num_layers - 1;
         float *xout = (last && !train) ? nullptr : (float *)(ws + lo.x[l + 1]);
+        if (train) // the all-zero row that stands for "h before the first step" in the backward GEMMs
+            TT_HIP_CHECK(hipMemsetAsync(xout + (size_t)lo.MT * ndir * H, 0, sizeof(float) * ndir * H, st));
         for (int d = 0; d < ndir; ++d) {
             const float *const *w = weights + ((size_t)l * ndir + d) * 4;
             SgemmParams g;

@@ -1,0 +1,422 @@
+// K7: gradient of RNNEncoder.forward w.r.t. every trainable tensor (what loss.backward() computes
+// through backend/model.py:48-75; backend/main.py:254).  The embedding table is frozen
+// (model.py:25-27) and receives no gradient.
+//
+//   head_bwd   F.normalize backward, then (bidirectional) the Linear(2H,H) backward as GEMMs
+//   gru_bwd    reverse-time recurrence: one workgroup = the same 16 batch rows as the forward; the
+//              gate derivatives are lane-local (they reuse the r,z,n,W_hn h stash the forward wrote),
+//              dh_{t-1} = dh_t z + dGh W_hh runs on v_mfma_f32_16x16x4_f32 with dGh staged in LDS and
+//              W_hh streamed from L2 in a pre-packed (transposed) B-operand order
+//   weights    dW_ih = dGi^T X, dW_hh = dGh^T H_prev over ALL tokens at once: split-K fp32 MFMA GEMMs
+//              with a deterministic slab reduction; X rows are gathered from the embedding table and
+//              H_prev rows are addressed through a "previous token" index map (no copies)
+#include "encoder.h"
+#include "sgemm.h"
+
+int enc_check_shape(const char *who, int B, int T, int E, int H, int L, int64_t V);
+
+namespace {
+
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+// d_hid = backward of y = hid / max(|hid|, 1e-12) (or identity)
+__global__ __launch_bounds__(256) void head_bwd_kernel(const float *__restrict__ hid, const float *__restrict__ d_out,
+                                                       int H, int normalize, float *__restrict__ d_hid)
+{
+    __shared__ float red[8];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float *x = hid + (size_t)b * H, *dy = d_out + (size_t)b * H;
+    if (!normalize) {
+        for (int u = tid; u < H; u += 256)
+            d_hid[(size_t)b * H + u] = dy[u];
+        return;
+    }
+    float ss = 0.0f, dt = 0.0f;
+    for (int u = tid; u < H; u += 256) {
+        ss += x[u] * x[u];
+        dt += x[u] * dy[u];
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        ss += __shfl_xor(ss, off);
+        dt += __shfl_xor(dt, off);
+    }
+    if ((tid & 63) == 0) {
+        red[tid >> 6] = ss;
+        red[4 + (tid >> 6)] = dt;
+    }
+    __syncthreads();
+    const float nrm = sqrtf(red[0] + red[1] + red[2] + red[3]);
+    const float dot = red[4] + red[5] + red[6] + red[7]; // x . dy
+    for (int u = tid; u < H; u += 256) {
+        float g;
+        if (nrm < 1e-12f)
+            g = dy[u] / 1e-12f;
+        else
+            g = (dy[u] - (x[u] / nrm) * (dot / nrm)) / nrm;
+        d_hid[(size_t)b * H + u] = g;
+    }
+}
+
+// column sums of X[m][n], m < *m_dyn, split over gridDim.y row slices -> slabs[y][n]
+__global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ X, int64_t ld, int N, int M,
+                                                     const int *__restrict__ m_dyn, float *__restrict__ slabs)
+{
+    const int Me = m_dyn ? min(M, *m_dyn) : M;
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    const int per = (Me + gridDim.y - 1) / gridDim.y;
+    const int m0 = blockIdx.y * per, m1 = min(m0 + per, Me);
+    if (n >= N)
+        return;
+    float s = 0.0f;
+    for (int m = m0; m < m1; ++m)
+        s += X[(size_t)m * ld + n];
+    slabs[(size_t)blockIdx.y * N + n] = s;
+}
+
+__global__ __launch_bounds__(256) void prevmap_kernel(const int32_t *__restrict__ len, const int32_t *__restrict__ tok_off,
+                                                      int none, int32_t *__restrict__ fwd, int32_t *__restrict__ rev)
+{
+    const int b = blockIdx.x;
+    const int L = len[b], o = tok_off[b];
+    for (int t = threadIdx.x; t < L; t += 256) {
+        fwd[o + t] = t > 0 ? o + t - 1 : none;
+        if (rev)
+            rev[o + t] = t < L - 1 ? o + t + 1 : none;
+    }
+}
+
+// wtp[((w*2 + ct)*(3H/16) + c)*256 + lane*4 + e] = W_hh[16c + 4(lane>>4) + e][32w + 16ct + (lane&15)]
+__global__ __launch_bounds__(256) void pack_whh_t_kernel(const float *__restrict__ W, int H, float *__restrict__ wtp)
+{
+    const int n = 3 * H * H / 4;
+    const int nc = 3 * H / 16;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const int lane = i & 63;
+        int r = i >> 6;
+        const int c = r % nc;
+        r /= nc;
+        const int ct = r & 1, w = r >> 1;
+        const int col = 32 * w + 16 * ct + (lane & 15);
+        const int row = 16 * c + 4 * (lane >> 4);
+        f32x4v v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            v[e] = W[(size_t)(row + e) * H + col];
+        *(f32x4v *)(wtp + (size_t)i * 4) = v;
+    }
+}
+
+struct GruBwdDir {
+    const float *gates;  // [M][4][H]
+    const float *hseq;   // this layer's output sequence, packed [M+1][ld]
+    const float *d_seq;  // nullable: gradient w.r.t. that sequence, [M][ld]
+    const float *d_hfin; // nullable: [B][H]
+    const float *wtp;
+    float *dgi;          // [M][3H]
+    float *dghn;         // [M][H]
+    int col0, reverse;
+};
+
+struct GruBwdParams {
+    GruBwdDir dir[2];
+    const int32_t *len, *tok_off, *perm;
+    int B, H, ld;
+};
+
+template <int MAXW>
+__global__ __launch_bounds__(MAXW * 64) void gru_bwd_seq_kernel(GruBwdParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) float gt[]; // [16][3H+4]
+    const GruBwdDir d = p.dir[blockIdx.y];
+    const int H = p.H, H3 = 3 * H, LDG = 3 * H + 4, nc = H3 / 16;
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 15, kq = lane >> 4;
+    const int row0 = blockIdx.x * ENC_RB;
+
+    int len_e[4], off_e[4], rid_e[4], unit[2];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int br = row0 + kq * 4 + e;
+        rid_e[e] = br < p.B ? p.perm[br] : -1;
+        len_e[e] = rid_e[e] >= 0 ? p.len[rid_e[e]] : 0;
+        off_e[e] = rid_e[e] >= 0 ? p.tok_off[rid_e[e]] : 0;
+    }
+    int steps = max(max(len_e[0], len_e[1]), max(len_e[2], len_e[3]));
+    steps = max(steps, __shfl_xor(steps, 16));
+    steps = max(steps, __shfl_xor(steps, 32));
+    float dh[2][4];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+        unit[ct] = 32 * w + 16 * ct + j;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            dh[ct][e] = (d.d_hfin && rid_e[e] >= 0) ? d.d_hfin[(size_t)rid_e[e] * H + unit[ct]] : 0.0f;
+    }
+    const float *wbase = d.wtp + (size_t)w * 2 * nc * 256 + lane * 4;
+
+    for (int s = steps - 1; s >= 0; --s) {
+        bool act[4];
+        float direct[2][4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            act[e] = s < len_e[e];
+            const int t = d.reverse ? len_e[e] - 1 - s : s;
+            const size_t tok = (size_t)(off_e[e] + (act[e] ? t : 0));
+            const size_t ptok = d.reverse ? tok + 1 : tok - 1;
+            float *grow = gt + (kq * 4 + e) * LDG;
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) {
+                const int u = unit[ct];
+                float dr_pre = 0.0f, dz_pre = 0.0f, dghn_v = 0.0f;
+                direct[ct][e] = 0.0f;
+                if (act[e]) {
+                    const float *gs = d.gates + tok * 4 * H + u;
+                    const float r = gs[0], z = gs[H], n = gs[2 * H], ghn = gs[3 * H];
+                    const float hp = s > 0 ? d.hseq[ptok * p.ld + d.col0 + u] : 0.0f;
+                    const float dhv = dh[ct][e] + (d.d_seq ? d.d_seq[tok * p.ld + d.col0 + u] : 0.0f);
+                    const float dn_pre = dhv * (1.0f - z) * (1.0f - n * n);
+                    dz_pre = dhv * (hp - n) * z * (1.0f - z);
+                    dr_pre = dn_pre * ghn * r * (1.0f - r);
+                    dghn_v = dn_pre * r;
+                    direct[ct][e] = dhv * z;
+                    float *go = d.dgi + tok * H3 + u;
+                    go[0] = dr_pre;
+                    go[H] = dz_pre;
+                    go[2 * H] = dn_pre;
+                    d.dghn[tok * H + u] = dghn_v;
+                }
+                grow[u] = dr_pre;
+                grow[H + u] = dz_pre;
+                grow[2 * H + u] = dghn_v;
+            }
+        }
+        __syncthreads();
+        f32x4v acc[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+        const float *gA = gt + j * LDG + 4 * kq;
+        for (int c = 0; c < nc; ++c) {
+            const f32x4v a = *(const f32x4v *)(gA + 16 * c);
+            const f32x4v b0 = *(const f32x4v *)(wbase + (size_t)c * 256);
+            const f32x4v b1 = *(const f32x4v *)(wbase + ((size_t)nc + c) * 256);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b0[e], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b1[e], acc[1], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (act[e])
+                    dh[ct][e] = direct[ct][e] + acc[ct][e];
+        __syncthreads();
+    }
+}
+
+int colsum(const float *X, int64_t ld, int N, int M, const int *m_dyn, float *slabs, float *out, hipStream_t st)
+{
+    hipLaunchKernelGGL(colsum_kernel, dim3((N + 255) / 256, ENC_SPLITK), dim3(256), 0, st, X, ld, N, M, m_dyn, slabs);
+    TT_LAUNCH_CHECK();
+    return tt_slab_reduce(slabs, ENC_SPLITK, N, out, 0, st);
+}
+
+// C[Mo][No] = A[:, a0:a0+Mo]^T * Bsrc (both summed over tokens), split-K + deterministic reduce
+int gemm_tn(const float *A, int64_t lda, int Mo, const float *Bsrc, int64_t ldb, const int32_t *b_map, int No,
+            int Ktok, const int *k_dyn, float *slabs, float *out, hipStream_t st)
+{
+    SgemmParams g;
+    g.A = A;
+    g.B = Bsrc;
+    g.C = slabs;
+    g.bias = nullptr;
+    g.a_map = nullptr;
+    g.b_map = b_map;
+    g.m_dyn = nullptr;
+    g.k_dyn = k_dyn;
+    g.M = Mo;
+    g.N = No;
+    g.K = Ktok;
+    g.lda = lda;
+    g.ldb = ldb;
+    g.ldc = No;
+    g.slab_stride = (int64_t)Mo * No;
+    g.accumulate = 0;
+    int rc = tt_sgemm(g, true, true, ENC_SPLITK, st);
+    if (rc != TT_OK)
+        return rc;
+    return tt_slab_reduce(slabs, ENC_SPLITK, (int64_t)Mo * No, out, 0, st);
+}
+
+} // namespace
+
+TT_EXPORT int tt_encoder_backward_f32(const int64_t *ids, int B, int T, const float *table, int64_t V, int E, int H,
+                                      int num_layers, int bidirectional, const float *const *weights,
+                                      const float *proj_w, const float *proj_b, int normalize, const float *d_out,
+                                      float *const *grads, float *g_proj_w, float *g_proj_b, void *workspace,
+                                      size_t workspace_bytes, tt_stream_t stream)
+{
+    (void)ids;
+    (void)proj_b;
+    hipStream_t st = (hipStream_t)stream;
+    int rc = enc_check_shape("tt_encoder_backward_f32", B, T, E, H, num_layers, V);
+    if (rc != TT_OK)
+        return rc;
+    if (!table || !weights || !d_out || !grads || (bidirectional && (!proj_w || !g_proj_w || !g_proj_b)))
+        return tt_fail(TT_ERR_BAD_SHAPE, "tt_encoder_backward_f32: null pointer");
+    const EncLayout lo = enc_layout(B, T, E, H, num_layers, bidirectional, 1);
+    if (!workspace || workspace_bytes < lo.total || ((uintptr_t)workspace & 255))
+        return tt_fail(TT_ERR_WORKSPACE, "tt_encoder_backward_f32: workspace %zu < %zu bytes: pass the buffer the "
+                                         "forward call (train=1) filled", workspace_bytes, lo.total);
+    char *ws = (char *)workspace;
+    const int ndir = lo.ndir, H3 = 3 * H;
+    const int32_t *len = (const int32_t *)(ws + lo.len), *tok_off = (const int32_t *)(ws + lo.tok_off);
+    const int32_t *perm = (const int32_t *)(ws + lo.perm), *idsp = (const int32_t *)(ws + lo.ids);
+    const int *m_valid = tok_off + B;
+    float *slabs = (float *)(ws + lo.slabs);
+    float *d_hfin = (float *)(ws + lo.d_hfin), *d_hid = (float *)(ws + lo.d_hid);
+    const float *hfin = (const float *)(ws + lo.hfin);
+    const int MT = (int)lo.MT;
+
+    // ---- head ------------------------------------------------------------------
+    hipLaunchKernelGGL(head_bwd_kernel, dim3(B), dim3(256), 0, st, (const float *)(ws + lo.hid), d_out, H, normalize,
+                       bidirectional ? d_hid : d_hfin);
+    TT_LAUNCH_CHECK();
+    if (bidirectional) {
+        rc = colsum(d_hid, H, H, B, nullptr, slabs, g_proj_b, st);
+        if (rc != TT_OK)
+            return rc;
+        for (int d = 0; d < 2; ++d) {
+            // g_proj_w[:, dH:(d+1)H] = d_hid^T * hfin[d]
+            SgemmParams g;
+            g.A = d_hid;
+            g.B = hfin + (size_t)d * B * H;
+            g.C = g_proj_w + (size_t)d * H;
+            g.bias = nullptr;
+            g.a_map = g.b_map = nullptr;
+            g.m_dyn = g.k_dyn = nullptr;
+            g.M = H;
+            g.N = H;
+            g.K = B;
+            g.lda = H;
+            g.ldb = H;
+            g.ldc = 2 * H;
+            g.slab_stride = 0;
+            g.accumulate = 0;
+            rc = tt_sgemm(g, true, true, 1, st);
+            if (rc != TT_OK)
+                return rc;
+            // d_hfin[d] = d_hid * proj_w[:, dH:(d+1)H]
+            g.A = d_hid;
+            g.B = proj_w + (size_t)d * H;
+            g.C = d_hfin + (size_t)d * B * H;
+            g.M = B;
+            g.N = H;
+            g.K = H;
+            g.lda = H;
+            g.ldb = 2 * H;
+            g.ldc = H;
+            rc = tt_sgemm(g, false, true, 1, st);
+            if (rc != TT_OK)
+                return rc;
+        }
+    }
+
+    // ---- "previous token" maps --------------------------------------------------
+    hipLaunchKernelGGL(prevmap_kernel, dim3(B), dim3(256), 0, st, len, tok_off, MT, (int32_t *)(ws + lo.prevmap[0]),
+                       ndir == 2 ? (int32_t *)(ws + lo.prevmap[1]) : (int32_t *)nullptr);
+    TT_LAUNCH_CHECK();
+
+    const size_t lds = sizeof(float) * ENC_RB * (H3 + 4);
+    for (int l = num_layers - 1; l >= 0; --l) {
+        const int I = l == 0 ? E : ndir * H;
+        const bool top = l == num_layers - 1;
+        const float *hseq = (const float *)(ws + lo.x[l + 1]);
+        const float *d_seq = top ? nullptr : (const float *)(ws + lo.dx[(l + 1) & 1]);
+        GruBwdParams bp;
+        bp.len = len;
+        bp.tok_off = tok_off;
+        bp.perm = perm;
+        bp.B = B;
+        bp.H = H;
+        bp.ld = ndir * H;
+        for (int d = 0; d < ndir; ++d) {
+            const float *const *w = weights + ((size_t)l * ndir + d) * 4;
+            hipLaunchKernelGGL(pack_whh_t_kernel, dim3(96), dim3(256), 0, st, w[1], H, (float *)(ws + lo.wtp[d]));
+            bp.dir[d].gates = (const float *)(ws + lo.gates[l][d]);
+            bp.dir[d].hseq = hseq;
+            bp.dir[d].d_seq = d_seq;
+            bp.dir[d].d_hfin = top ? d_hfin + (size_t)d * B * H : nullptr;
+            bp.dir[d].wtp = (const float *)(ws + lo.wtp[d]);
+            bp.dir[d].dgi = (float *)(ws + lo.dgi[d]);
+            bp.dir[d].dghn = (float *)(ws + lo.dghn[d]);
+            bp.dir[d].col0 = d * H;
+            bp.dir[d].reverse = d;
+        }
+        if (ndir == 1)
+            bp.dir[1] = bp.dir[0];
+        if (lds > 48 * 1024) {
+            TT_HIP_CHECK(hipFuncSetAttribute((const void *)gru_bwd_seq_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            TT_HIP_CHECK(hipFuncSetAttribute((const void *)gru_bwd_seq_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        }
+        if (H <= 256)
+            hipLaunchKernelGGL(gru_bwd_seq_kernel<8>, dim3((B + ENC_RB - 1) / ENC_RB, ndir), dim3(H / 32 * 64), lds, st, bp);
+        else
+            hipLaunchKernelGGL(gru_bwd_seq_kernel<16>, dim3((B + ENC_RB - 1) / ENC_RB, ndir), dim3(H / 32 * 64), lds, st, bp);
+        TT_LAUNCH_CHECK();
+
+        for (int d = 0; d < ndir; ++d) {
+            const float *const *w = weights + ((size_t)l * ndir + d) * 4;
+            float *const *g = grads + ((size_t)l * ndir + d) * 4;
+            const float *dgi = (const float *)(ws + lo.dgi[d]);
+            const float *dghn = (const float *)(ws + lo.dghn[d]);
+            // biases: b_ih <- colsum(dGi); b_hh <- [colsum(dGi)[0:2H], colsum(dghn)]
+            rc = colsum(dgi, H3, H3, MT, m_valid, slabs, g[2], st);
+            if (rc != TT_OK)
+                return rc;
+            TT_HIP_CHECK(hipMemcpyAsync(g[3], g[2], sizeof(float) * 2 * H, hipMemcpyDeviceToDevice, st));
+            rc = colsum(dghn, H, H, MT, m_valid, slabs, g[3] + 2 * H, st);
+            if (rc != TT_OK)
+                return rc;
+            // W_ih <- dGi^T X   (X = gathered table rows for layer 0, the layer below's output above)
+            if (l == 0)
+                rc = gemm_tn(dgi, H3, H3, table, E, idsp, E, MT, m_valid, slabs, g[0], st);
+            else
+                rc = gemm_tn(dgi, H3, H3, (const float *)(ws + lo.x[l]), I, nullptr, I, MT, m_valid, slabs, g[0], st);
+            if (rc != TT_OK)
+                return rc;
+            // W_hh <- dGh^T H_prev, H_prev rows through the previous-token map into this layer's own output
+            const int32_t *pm = (const int32_t *)(ws + lo.prevmap[d]);
+            rc = gemm_tn(dgi, H3, 2 * H, hseq + (size_t)d * H, ndir * H, pm, H, MT, m_valid, slabs, g[1], st);
+            if (rc != TT_OK)
+                return rc;
+            rc = gemm_tn(dghn, H, H, hseq + (size_t)d * H, ndir * H, pm, H, MT, m_valid, slabs, g[1] + (size_t)2 * H * H, st);
+            if (rc != TT_OK)
+                return rc;
+            // gradient w.r.t. this layer's input sequence (not needed below layer 0: frozen table)
+            if (l > 0) {
+                SgemmParams x;
+                x.A = dgi;
+                x.B = w[0];
+                x.C = (float *)(ws + lo.dx[l & 1]);
+                x.bias = nullptr;
+                x.a_map = x.b_map = nullptr;
+                x.m_dyn = m_valid;
+                x.k_dyn = nullptr;
+                x.M = MT;
+                x.N = I;
+                x.K = H3;
+                x.lda = H3;
+                x.ldb = I;
+                x.ldc = I;
+                x.slab_stride = 0;
+                x.accumulate = d;
+                rc = tt_sgemm(x, false, true, 1, st);
+                if (rc != TT_OK)
+                    return rc;
+            }
+        }
+    }
+    return TT_OK;
+}

@@ -133,7 +133,8 @@ int tt_sgemm(const SgemmParams &p, bool a_t, bool b_t, int splits, hipStream_t s
 {
     if (p.M <= 0 || p.N <= 0 || p.K <= 0)
         return TT_OK;
-    if ((p.K & 3) || (a_t && (p.M & 3)) || (b_t && (p.N & 3)) || (p.lda & 3) || (p.ldb & 3))
+    // vector loads run along K for a non-transposed operand and along M / N for a transposed one
+    if (((!a_t || !b_t) && (p.K & 3)) || (a_t && (p.M & 3)) || (b_t && (p.N & 3)) || (p.lda & 3) || (p.ldb & 3))
         return tt_fail(TT_ERR_UNSUPPORTED, "tt_sgemm: dims must be multiples of 4 (M=%d N=%d K=%d)", p.M, p.N, p.K);
     if (splits < 1)
         splits = 1;

@@ -1,0 +1,189 @@
+// K6 triplet loss (forward + gradient) and K8 fused clip_grad_norm_ + Adam (gfx950).
+#include "tt_common.h"
+
+namespace {
+
+// ------------------------------------------------------------------ K6
+// triplet_loss_cosine, backend/model.py:109-114:
+//   loss = mean_b max(0, cos(q,n) - cos(q,p) + margin), F.cosine_similarity eps 1e-8 (each norm
+//   clamped separately, as ATen does).  One wave per row; gradients are written already scaled by
+//   1/B so autograd only multiplies by the incoming scalar.  clamp(min=0) passes gradient where its
+//   argument is >= 0 (ATen's mask).
+__global__ __launch_bounds__(256) void triplet_rows_kernel(const float *__restrict__ q, const float *__restrict__ p,
+                                                           const float *__restrict__ n, int B, int H, float margin,
+                                                           float *__restrict__ row_loss, float *__restrict__ dq,
+                                                           float *__restrict__ dp, float *__restrict__ dn)
+{
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B)
+        return;
+    const float *qb = q + (size_t)b * H, *pb = p + (size_t)b * H, *nb = n + (size_t)b * H;
+    float sq = 0, sp = 0, sn = 0;
+    for (int u = lane; u < H; u += 64) {
+        sq += qb[u] * qb[u];
+        sp += pb[u] * pb[u];
+        sn += nb[u] * nb[u];
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        sq += __shfl_xor(sq, off);
+        sp += __shfl_xor(sp, off);
+        sn += __shfl_xor(sn, off);
+    }
+    const float nq = fmaxf(sqrtf(sq), 1e-8f), np_ = fmaxf(sqrtf(sp), 1e-8f), nn = fmaxf(sqrtf(sn), 1e-8f);
+    float cp = 0, cn = 0;
+    for (int u = lane; u < H; u += 64) {
+        const float qh = qb[u] / nq;
+        cp += qh * (pb[u] / np_);
+        cn += qh * (nb[u] / nn);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        cp += __shfl_xor(cp, off);
+        cn += __shfl_xor(cn, off);
+    }
+    const float v = cn - cp + margin;
+    if (lane == 0)
+        row_loss[b] = v > 0.0f ? v : 0.0f;
+    if (dq) {
+        const float g = (v >= 0.0f ? 1.0f : 0.0f) / (float)B;
+        for (int u = lane; u < H; u += 64) {
+            const float qh = qb[u] / nq, ph = pb[u] / np_, nh = nb[u] / nn;
+            dq[(size_t)b * H + u] = g * ((nh - cn * qh) / nq - (ph - cp * qh) / nq);
+            dp[(size_t)b * H + u] = -g * (qh - cp * ph) / np_;
+            dn[(size_t)b * H + u] = g * (qh - cn * nh) / nn;
+        }
+    }
+}
+
+// Fixed-order sum of x[0..n) by one block -> out[0] * scale (deterministic).
+__global__ __launch_bounds__(1024) void sum_fixed_kernel(const float *__restrict__ x, int n, float scale,
+                                                         float *__restrict__ out)
+{
+    __shared__ float red[16];
+    float s = 0.0f;
+    for (int i = threadIdx.x; i < n; i += 1024)
+        s += x[i];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1)
+        s += __shfl_xor(s, off);
+    if ((threadIdx.x & 63) == 0)
+        red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.0f;
+        for (int w = 0; w < 16; ++w)
+            t += red[w];
+        out[0] = t * scale;
+    }
+}
+
+// ------------------------------------------------------------------ K8
+constexpr int ADAM_BLOCKS = 512;
+
+// pass 1: per-block partial sum of (g*grad_scale)^2 in fp64 -> partial[ADAM_BLOCKS]
+__global__ __launch_bounds__(256) void sqnorm_partial_kernel(const float *__restrict__ g, int64_t n, float grad_scale,
+                                                             double *__restrict__ partial)
+{
+    __shared__ double red[4];
+    double s = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const double v = (double)(g[i] * grad_scale);
+        s += v * v;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1)
+        s += __shfl_xor(s, off);
+    if ((threadIdx.x & 63) == 0)
+        red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+// pass 2: every block re-derives the total norm from the partials in the same fixed order, then
+// applies clip + Adam to its slice.  clip_grad_norm_: coef = min(1, max_norm / (total + 1e-6)).
+// Adam (torch defaults wd=0, amsgrad=False): m = lerp(m, g, 1-b1); v = b2 v + (1-b2) g^2;
+// p -= (lr / (1-b1^t)) * m / (sqrt(v)/sqrt(1-b2^t) + eps).   backend/main.py:222,257,259
+__global__ __launch_bounds__(256) void clip_adam_kernel(float *__restrict__ p, float *__restrict__ g,
+                                                        float *__restrict__ m, float *__restrict__ v, int64_t n,
+                                                        float grad_scale, float max_norm, float lr, float b1,
+                                                        float b2, float eps, float bc1, float bc2_sqrt,
+                                                        const double *__restrict__ partial, int npartial,
+                                                        float *__restrict__ total_norm_out)
+{
+    __shared__ float s_coef;
+    if (threadIdx.x == 0) {
+        double ss = 0.0;
+        for (int i = 0; i < npartial; ++i)
+            ss += partial[i];
+        const float total = (float)sqrt(ss);
+        float coef = 1.0f;
+        if (max_norm > 0.0f) {
+            coef = max_norm / (total + 1e-6f);
+            coef = coef > 1.0f ? 1.0f : coef;
+        }
+        s_coef = coef * grad_scale;
+        if (blockIdx.x == 0 && total_norm_out)
+            *total_norm_out = total;
+    }
+    __syncthreads();
+    const float coef = s_coef;
+    const float step_size = lr / bc1;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float gi = g[i] * coef;
+        g[i] = gi; // the reference leaves clipped gradients in .grad
+        const float mi = m[i] + (gi - m[i]) * (1.0f - b1);
+        const float vi = v[i] * b2 + (1.0f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        p[i] -= step_size * (mi / (sqrtf(vi) / bc2_sqrt + eps));
+    }
+}
+
+} // namespace
+
+TT_EXPORT int tt_triplet_loss_f32(const float *q, const float *p, const float *n, int B, int H, float margin,
+                                  float *loss, float *dq, float *dp, float *dn, float *scratch_rows,
+                                  tt_stream_t stream)
+{
+    if (B <= 0 || H <= 0)
+        return tt_fail(TT_ERR_BAD_SHAPE, "tt_triplet_loss_f32: B=%d H=%d", B, H);
+    if (!q || !p || !n || !loss || !scratch_rows || ((dq || dp || dn) && !(dq && dp && dn)))
+        return tt_fail(TT_ERR_BAD_SHAPE, "tt_triplet_loss_f32: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(triplet_rows_kernel, dim3((B + 3) / 4), dim3(256), 0, st, q, p, n, B, H, margin, scratch_rows,
+                       dq, dp, dn);
+    hipLaunchKernelGGL(sum_fixed_kernel, dim3(1), dim3(1024), 0, st, (const float *)scratch_rows, B, 1.0f / (float)B,
+                       loss);
+    TT_LAUNCH_CHECK();
+    return TT_OK;
+}
+
+TT_EXPORT size_t tt_clip_adam_scratch_bytes(void) { return sizeof(double) * ADAM_BLOCKS + 256; }
+
+TT_EXPORT int tt_clip_adam_step_f32(float *params, float *grads, float *exp_avg, float *exp_avg_sq, int64_t n,
+                                    int64_t step, float lr, float beta1, float beta2, float eps, float max_norm,
+                                    float grad_scale, float *total_norm_out, void *scratch, tt_stream_t stream)
+{
+    if (n < 0 || step < 1)
+        return tt_fail(TT_ERR_BAD_SHAPE, "tt_clip_adam_step_f32: n=%lld step=%lld", (long long)n, (long long)step);
+    if (n == 0)
+        return TT_OK;
+    if (!params || !grads || !exp_avg || !exp_avg_sq || !scratch)
+        return tt_fail(TT_ERR_BAD_SHAPE, "tt_clip_adam_step_f32: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    int blocks = (int)((n + 255) / 256);
+    blocks = blocks > ADAM_BLOCKS ? ADAM_BLOCKS : blocks;
+    double *partial = (double *)scratch;
+    hipLaunchKernelGGL(sqnorm_partial_kernel, dim3(blocks), dim3(256), 0, st, (const float *)grads, n, grad_scale,
+                       partial);
+    const float bc1 = 1.0f - powf(beta1, (float)step);
+    const float bc2_sqrt = sqrtf(1.0f - powf(beta2, (float)step));
+    hipLaunchKernelGGL(clip_adam_kernel, dim3(blocks), dim3(256), 0, st, params, grads, exp_avg, exp_avg_sq, n,
+                       grad_scale, max_norm, lr, beta1, beta2, eps, bc1, bc2_sqrt, (const double *)partial, blocks,
+                       total_norm_out);
+    TT_LAUNCH_CHECK();
+    return TT_OK;
+}

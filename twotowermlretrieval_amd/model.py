@@ -256,10 +256,11 @@ class _TripletFn(torch.autograd.Function):
         B, H = q.shape
         loss = torch.empty((), dtype=torch.float32, device=q.device)
         dq, dp, dn = torch.empty_like(q), torch.empty_like(p), torch.empty_like(n)
+        rows = torch.empty(B, dtype=torch.float32, device=q.device)
         with torch.cuda.device(q.device):
             _lib.check(L.tt_triplet_loss_f32(q.data_ptr(), p.data_ptr(), n.data_ptr(), B, H, float(margin),
                                              loss.data_ptr(), dq.data_ptr(), dp.data_ptr(), dn.data_ptr(),
-                                             _stream(q.device)))
+                                             rows.data_ptr(), _stream(q.device)))
         ctx.save_for_backward(dq, dp, dn)
         return loss
 

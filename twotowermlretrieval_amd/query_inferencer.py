@@ -1,0 +1,66 @@
+"""Mirror of the reference's QueryInferencer (backend/query_inferencer.py:20-82): loads a run's
+artifacts directory (config.json, word_to_idx.pkl, model.pth -- the formats backend/main.py:92-106
+writes) and turns a query string into a unit vector with the HIP query tower.
+
+Differences from the reference, all deliberate:
+  * no module-level read of 'frontend/config.json' relative to the CWD (query_inferencer.py:15);
+  * device selection is "the AMD GPU" (no mps / cpu branch): this package has no CPU path;
+  * nothing is printed.
+Kept: EMBED_DIM fallback 200 (:47-48), HIDDEN_DIM fallback 128 for the zero vector (:68), a query that
+tokenises to [] returns zeros (:66-69), a query made only of id-0 tokens ("the the") raises the same
+RuntimeError the reference does (tests/golden/g9_inferencer.npz).
+"""
+from __future__ import annotations
+
+import json
+from pathlib import Path
+from typing import Optional
+
+import numpy as np
+import torch
+
+from .model import TwoTowerModel
+from .tokenizer import PretrainedTokenizer
+
+
+class QueryInferencer:
+    def __init__(self, artifacts_path: str, device: Optional[torch.device] = None):
+        self.artifacts_path = Path(artifacts_path)
+        self.device = device or self._get_best_device()
+        with open(self.artifacts_path / "config.json", "r") as f:
+            self.config = json.load(f)
+        self.tokenizer = PretrainedTokenizer(str(self.artifacts_path / "word_to_idx.pkl"))
+        self.config["VOCAB_SIZE"] = self.tokenizer.vocab_size()
+        if "EMBED_DIM" not in self.config:
+            self.config["EMBED_DIM"] = 200
+        self.model = TwoTowerModel(self.config, pretrained_embeddings=None).to(self.device)
+        state = torch.load(self.artifacts_path / "model.pth", map_location=self.device)
+        self.model.load_state_dict(state)
+        self.model.eval()
+
+    def get_query_embedding(self, query: str) -> np.ndarray:
+        with torch.no_grad():
+            token_ids = self.tokenizer.encode(query)
+            if not token_ids:
+                return np.zeros(self.config.get("HIDDEN_DIM", 128), dtype=np.float32)
+            tokens = torch.tensor(token_ids, dtype=torch.long).unsqueeze(0).to(self.device)
+            return self.model.encode_query(tokens).cpu().numpy().squeeze(0)
+
+    def get_query_embeddings(self, queries) -> torch.Tensor:
+        """Batched variant (new): [len(queries), H] on the device; un-tokenisable queries give zero rows."""
+        ids = self.tokenizer.encode_batch(queries)
+        B = ids.shape[0]
+        H = self.config["HIDDEN_DIM"]
+        out = torch.zeros((B, H), dtype=torch.float32, device=self.device)
+        if ids.shape[1] == 0:
+            return out
+        keep = torch.tensor([len(self.tokenizer.encode(q)) > 0 for q in queries])
+        if keep.any():
+            with torch.no_grad():
+                out[keep.to(self.device)] = self.model.encode_query(ids[keep].to(self.device))
+        return out
+
+    def _get_best_device(self) -> torch.device:
+        if torch.cuda.is_available():  # PyTorch-ROCm exposes the MI355X as "cuda"
+            return torch.device("cuda")
+        raise RuntimeError("QueryInferencer needs an AMD GPU: twotowermlretrieval_amd has no CPU path")

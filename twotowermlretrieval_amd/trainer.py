@@ -1,0 +1,139 @@
+"""Triplet-loss training step, data-parallel over RCCL.
+
+Mirrors the live train step of the reference (backend/main.py:244-259):
+
+    optimizer.zero_grad()
+    q, p, n = model.encode_query(queries), model.encode_document(pos), model.encode_document(neg)
+    loss = triplet_loss_cosine((q, p, n), margin)          # model.py:109-114
+    loss.backward()
+    torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=1.0)
+    optimizer.step()                                       # Adam(lr), main.py:222
+
+`FusedClipAdam` replaces the last two lines with ONE kernel pair over a single flat fp32 buffer
+(tt_clip_adam_step_f32) and, when a process group is given, ONE summing all-reduce of that buffer
+(RCCL over xGMI for the nccl backend) followed by the 1/world scale inside the kernel -- so every rank
+clips the SAME averaged gradient, exactly as the reference would on the global batch.
+The reference's own pair of torch calls also keeps working on this package's model (its gradients
+are ordinary tensors); the fused optimizer is the MI355X-native path.
+"""
+from __future__ import annotations
+
+from typing import Callable, Iterable, Optional, Tuple
+
+import torch
+
+from . import _lib
+from .model import TwoTowerModel, triplet_loss_cosine
+
+__all__ = ["FusedClipAdam", "train_step", "DataParallelTrainer"]
+
+
+def _hip_clip_adam(flat_p, flat_g, m, v, step, lr, betas, eps, max_norm, grad_scale, total_norm, scratch):
+    L = _lib.lib()
+    with torch.cuda.device(flat_p.device):
+        _lib.check(L.tt_clip_adam_step_f32(flat_p.data_ptr(), flat_g.data_ptr(), m.data_ptr(), v.data_ptr(),
+                                           flat_p.numel(), step, lr, betas[0], betas[1], eps, max_norm, grad_scale,
+                                           total_norm.data_ptr(), scratch.data_ptr(),
+                                           torch.cuda.current_stream(flat_p.device).cuda_stream))
+
+
+class FusedClipAdam:
+    """clip_grad_norm_(max_norm) + Adam(lr, betas, eps, weight_decay=0) over one flat buffer.
+
+    All trainable parameters are re-pointed at views of one contiguous fp32 buffer (`flat_params`), and
+    their .grad at views of `flat_grads`, so the optimizer (and the DP all-reduce) touch two pointers.
+    `step_fn` exists so the host logic can be exercised over gloo on CPU tensors by the tests (which
+    inject the oracle's step); the default is the HIP kernel.
+    """
+
+    def __init__(self, params: Iterable[torch.nn.Parameter], lr: float = 1e-4, betas: Tuple[float, float] = (0.9, 0.999),
+                 eps: float = 1e-8, max_norm: float = 1.0, group=None, step_fn: Optional[Callable] = None):
+        self.params = [p for p in params if p.requires_grad]
+        if not self.params:
+            raise ValueError("no trainable parameters")
+        dev = self.params[0].device
+        if step_fn is None and not dev.type == "cuda":
+            raise RuntimeError("FusedClipAdam runs only on an AMD GPU via libtt.so (no CPU fallback)")
+        self.lr, self.betas, self.eps, self.max_norm = float(lr), (float(betas[0]), float(betas[1])), float(eps), float(max_norm)
+        self.group = group
+        self._step_fn = step_fn or _hip_clip_adam
+        n = sum(p.numel() for p in self.params)
+        self.flat_params = torch.empty(n, dtype=torch.float32, device=dev)
+        self.flat_grads = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.total_norm = torch.zeros(1, dtype=torch.float32, device=dev)
+        nscratch = _lib.lib().tt_clip_adam_scratch_bytes() if step_fn is None else 4096
+        self._scratch = torch.empty(nscratch, dtype=torch.uint8, device=dev)
+        self._views = []
+        off = 0
+        with torch.no_grad():
+            for p in self.params:
+                k = p.numel()
+                self.flat_params[off:off + k].copy_(p.detach().reshape(-1))
+                p.data = self.flat_params[off:off + k].view_as(p)
+                gv = self.flat_grads[off:off + k].view_as(p)
+                p.grad = gv
+                self._views.append(gv)
+                off += k
+        self.step_count = 0
+
+    def zero_grad(self) -> None:
+        self.flat_grads.zero_()
+        for p, gv in zip(self.params, self._views):
+            p.grad = gv
+
+    def _collect(self) -> None:
+        """Tolerate callers that reset .grad to None / fresh tensors (model.zero_grad(set_to_none=True))."""
+        for p, gv in zip(self.params, self._views):
+            if p.grad is None:
+                gv.zero_()
+            elif p.grad.data_ptr() != gv.data_ptr():
+                gv.copy_(p.grad)
+            p.grad = gv
+
+    def step(self) -> torch.Tensor:
+        """Returns the pre-clip global gradient norm (device tensor, no sync)."""
+        import torch.distributed as dist
+        self._collect()
+        world = 1
+        if self.group is not None or (dist.is_available() and dist.is_initialized()):
+            world = dist.get_world_size(self.group)
+            if world > 1:
+                dist.all_reduce(self.flat_grads, op=dist.ReduceOp.SUM, group=self.group)  # one 3.4 MB bucket
+        self.step_count += 1
+        self._step_fn(self.flat_params, self.flat_grads, self.exp_avg, self.exp_avg_sq, self.step_count, self.lr,
+                      self.betas, self.eps, self.max_norm, 1.0 / world, self.total_norm, self._scratch)
+        return self.total_norm
+
+
+def train_step(model: TwoTowerModel, optimizer: FusedClipAdam, queries: torch.Tensor, pos_docs: torch.Tensor,
+               neg_docs: torch.Tensor, margin: float = 0.2) -> torch.Tensor:
+    """One step of backend/main.py:244-259 on this rank's (equal-sized) share of the global batch.
+    Returns the local loss as a 0-d device tensor (no .item(): the reference's per-step sync is dropped)."""
+    optimizer.zero_grad()
+    q = model.encode_query(queries)
+    p = model.encode_document(pos_docs)
+    n = model.encode_document(neg_docs)
+    loss = triplet_loss_cosine((q, p, n), margin=margin)
+    loss.backward()
+    optimizer.step()
+    return loss.detach()
+
+
+class DataParallelTrainer:
+    """Replicated model, per-rank batch shard, gradient all-reduce inside FusedClipAdam.step()."""
+
+    def __init__(self, model: TwoTowerModel, lr: float = 1e-4, margin: float = 0.2, max_norm: float = 1.0, group=None):
+        self.model = model
+        self.margin = margin
+        self.optimizer = FusedClipAdam(model.parameters(), lr=lr, max_norm=max_norm, group=group)
+
+    def broadcast_parameters(self, src: int = 0) -> None:
+        import torch.distributed as dist
+        if dist.is_initialized() and dist.get_world_size(self.optimizer.group) > 1:
+            dist.broadcast(self.optimizer.flat_params, src=src, group=self.optimizer.group)
+
+    def step(self, queries, pos_docs, neg_docs) -> torch.Tensor:
+        self.model.train()
+        return train_step(self.model, self.optimizer, queries, pos_docs, neg_docs, self.margin)
