@@ -1,0 +1,51 @@
+"""QueryInferencer drop-in (backend/query_inferencer.py:20-82) against the reference's recorded
+outputs on a synthetic artifacts directory (tests/golden/g9_inferencer.npz)."""
+import json
+import pickle
+
+import numpy as np
+import pytest
+import torch
+
+import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _artifacts(tmp_path, g):
+    from twotowermlretrieval_amd.model import TwoTowerModel
+    V, E, H, seed = [int(x) for x in g["dims"]]
+    vocab = json.loads(str(g["vocab_json"]))
+    with open(tmp_path / "word_to_idx.pkl", "wb") as f:
+        pickle.dump(vocab, f)
+    cfg = {"HIDDEN_DIM": H, "RNN_TYPE": "GRU", "NUM_LAYERS": 1, "BIDIRECTIONAL": False, "DROPOUT": 0.0,
+           "NORMALIZE_OUTPUT": True, "EMBED_DIM": E, "VOCAB_SIZE": V}
+    (tmp_path / "config.json").write_text(json.dumps(cfg))
+    table = synth.make_table(seed, V, E)
+    m = TwoTowerModel(dict(cfg), table)
+    sd = {}
+    for i, tower in enumerate(("query_encoder.", "doc_encoder.")):
+        sd[tower + "embedding.weight"] = torch.from_numpy(table)
+        sd.update({k: torch.from_numpy(v) for k, v in synth.make_encoder_state(seed + 10 + i, E, H, prefix=tower).items()})
+    m.load_state_dict(sd)
+    torch.save(m.state_dict(), tmp_path / "model.pth")  # the artifact format of backend/main.py:98
+    return tmp_path
+
+
+def test_query_inferencer_matches_reference(tmp_path, golden):
+    from twotowermlretrieval_amd.query_inferencer import QueryInferencer
+    g = golden("g9_inferencer.npz")
+    inf = QueryInferencer(str(_artifacts(tmp_path, g)))
+    for q, want in zip(g["queries"], g["embs"]):
+        e = inf.get_query_embedding(str(q))
+        assert e.shape == want.shape and e.dtype == np.float32
+        np.testing.assert_allclose(e, want, atol=1e-5, rtol=0)
+        assert abs(np.linalg.norm(e) - 1.0) < 1e-5          # the reference's own self-check (:98)
+    z = inf.get_query_embedding("")
+    assert z.shape == g["empty"].shape and not z.any()       # un-tokenisable query -> zero vector (:66-69)
+    assert str(g["the_the_error"]).startswith("RuntimeError")
+    with pytest.raises(RuntimeError, match="Length of all samples"):
+        inf.get_query_embedding("the the")                   # ids [0,0]: the reference raises too
+    batch = inf.get_query_embeddings([str(q) for q in g["queries"]] + [""])
+    np.testing.assert_allclose(batch[:-1].cpu().numpy(), g["embs"], atol=1e-5, rtol=0)
+    assert not batch[-1].any()
