@@ -77,6 +77,24 @@ int tt_score_topk_partials_f32(const float *Q, int B, int d, const float *D, int
                                int *part_m /*host out*/, tt_stream_t stream);
 
 /*
+ * Screened exact search for large query batches: SAME result as tt_score_topk_f32 (bit-exact
+ * scores, same tie order), computed as an fp16-MFMA screen over an fp16 shadow copy of the corpus
+ * with a rigorous error bound, followed by exact fp32 rescoring of the survivors
+ * (csrc/screen.hip header; DESIGN.md "K4s").  tt_index_build_f16 makes the shadow copy D16 [N,d]
+ * (2 bytes/element) and stats[2] = {largest row L2 norm, largest |element|} (device floats; the
+ * caller reads stats[0] once at index-build time and passes it as dmax_norm).  If the screen cannot
+ * guarantee exactness for some query (tie cluster too large, |q| beyond fp16) it sets
+ * fallback_flag[query / 32] (device int32 array of ceil(B/32) entries) and the exact kernel,
+ * predicated on those flags on the device, recomputes the flagged 32-query tiles -- no host
+ * synchronisation.  Supported: d = 256, k <= 16, dmax_norm < 6e4.
+ */
+int tt_index_build_f16(const float *D, int64_t N, int d, void *D16, float *stats, tt_stream_t stream);
+size_t tt_score_topk_screened_workspace_bytes(int B, int64_t N, int d, int k);
+int tt_score_topk_screened_f32(const float *Q, int B, int d, const float *D32, const void *D16, int64_t N, int k,
+                               float dmax_norm, int64_t idx_offset, float *out_val, int64_t *out_idx,
+                               int32_t *fallback_flag, void *workspace, size_t workspace_bytes, tt_stream_t stream);
+
+/*
  * Merge of partial top-k lists (per tile, per shard after the RCCL all-gather:
  * SURVEY 8e) into the global top-k: in_val/in_idx [B,M] candidates in any
  * order, idx < 0 = padding; out [B,k], (score desc, index asc), tail (-inf,-1).

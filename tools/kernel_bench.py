@@ -47,5 +47,29 @@ def main():
         print(json.dumps(dict(B=B, k=k, N=a.n, kernel_ms=round(ms, 4), full_ms=round(e0.elapsed_time(e1), 4), part_m=pm,
                               GBps=round(byts / ms / 1e6, 1), hbm_frac=round(byts / ms / 1e6 / 8000, 4),
                               TFLOPs_padded=round(fl / ms / 1e9, 2), qps=round(B / ms * 1e3, 1))), flush=True)
+def screened():
+    import twotowermlretrieval_amd as tt
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n", type=int, default=10_000_000)
+    a, _ = ap.parse_known_args()
+    g = torch.Generator(device="cuda").manual_seed(1)
+    D = torch.randn(a.n, 256, device="cuda", generator=g); D /= D.norm(dim=1, keepdim=True)
+    ix = tt.BruteForceIndex(D, screen=True)
+    for B in (128, 256, 512, 1024, 2048, 4096):
+        Q = torch.randn(B, 256, device="cuda", generator=g); Q /= Q.norm(dim=1, keepdim=True)
+        for _ in range(2): ix.search(Q, 10)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5): ix.search(Q, 10)
+        e1.record(); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 5
+        print(json.dumps(dict(path="screened", B=B, N=a.n, ms=round(ms, 4), qps=round(B / ms * 1e3, 1),
+                              TFLOPs=round(2.0 * B * a.n * 256 / ms / 1e9, 1), f16_GBps=round(a.n * 512 / ms / 1e6 * ((B + 511) // 512), 1),
+                              flags=int(ix.fallback_flags.ne(0).sum().item()))), flush=True)
+
 if __name__ == "__main__":
-    main()
+    if "--screened" in sys.argv:
+        sys.argv.remove("--screened"); screened()
+    else:
+        main()

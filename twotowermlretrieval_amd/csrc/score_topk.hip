@@ -58,6 +58,7 @@ struct ScoreParams {
     struct Cand *cand;  // [n_tasks][32][CAP] candidate buffers (workspace)
     const float *thr0;  // optional per-query lower bound of the final k-th score
     int thr0_stride, thr0_off;
+    const int *run_if;  // optional device predicate per 32-query tile: tile t is skipped while run_if[t] == 0
 };
 
 __device__ __forceinline__ int xcd_remap(int b, int nblk)
@@ -83,6 +84,14 @@ __device__ __forceinline__ Cand cand_load_l2(const Cand *p)
     c.v = __uint_as_float((unsigned)u);
     c.x = (int)(u >> 32);
     return c;
+}
+
+// Fire-and-forget 8-byte candidate store the compiler's waitcnt pass does not see (it still counts in
+// vmcnt: the counted waits of the DMA ring only get stricter, and every reader drains vmcnt(0) first).
+__device__ __forceinline__ void cand_store_async(Cand *dst, float v, int x)
+{
+    const unsigned long long bits = ((unsigned long long)(unsigned)x << 32) | (unsigned long long)__float_as_uint(v);
+    asm volatile("global_store_dwordx2 %0, %1, off\n\ts_nop 1" ::"v"(dst), "v"(bits) : "memory");
 }
 
 // Wave-cooperative compaction of one query's candidate buffer: keeps the k best of its n
@@ -153,6 +162,8 @@ __global__ __launch_bounds__(WPB * 64, 2) void score_topk_kernel(ScoreParams p)
     if (task >= p.n_tasks)
         return; // wave-uniform; the kernel has no block-level barrier
     const int qtile = task % p.n_qtiles;
+    if (p.run_if && p.run_if[qtile] == 0)
+        return;
     const int chunk = task / p.n_qtiles;
     const int t0 = chunk * p.tiles_per_chunk;
     const int t1 = min(t0 + p.tiles_per_chunk, p.n_tiles);
@@ -281,25 +292,25 @@ __global__ __launch_bounds__(WPB * 64, 2) void score_topk_kernel(ScoreParams p)
             for (int r = 1; r < 16; ++r)
                 m = fmaxf(m, acc[r]);
             if (__ballot(m >= thr) != 0ull) {
+                // Append pass.  The store is inline asm on purpose: a compiler-visible global store
+                // (or the compaction's loads) inside this loop makes hipcc emit s_waitcnt vmcnt(0) at
+                // every join, which drains the LDS-DMA ring on each tile that has a candidate.
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int doc = tile_base + (r & 3) + 8 * (r >> 2) + 4 * h;
                     const bool c = (!partial || doc < p.N) && acc[r] >= thr;
                     const unsigned long long mask = __ballot(c);
-                    if (mask) { // append: the two halves of the wave hold two documents of query j
-                        const int c_lo = (int)((mask >> j) & 1ull), c_hi = (int)((mask >> (j + 32)) & 1ull);
-                        if (c) {
-                            Cand e;
-                            e.v = acc[r];
-                            e.x = doc;
-                            cbase[cnt + (h ? c_lo : 0)] = e;
-                        }
-                        cnt += c_lo + c_hi;
-                        const unsigned long long full = __ballot(cnt > CAP - 2) & 0xffffffffull;
-                        if (full)
-                            compact_where(full);
-                    }
+                    if (mask == 0ull)
+                        continue;
+                    const int c_lo = (int)((mask >> j) & 1ull), c_hi = (int)((mask >> (j + 32)) & 1ull);
+                    if (c)
+                        cand_store_async(cbase + cnt + (h ? c_lo : 0), acc[r], doc);
+                    cnt += c_lo + c_hi;
                 }
+                // one tile adds at most 32 entries per query: compact while there is still room for that
+                const unsigned long long full = __ballot(cnt > CAP - 34) & 0xffffffffull;
+                if (full)
+                    compact_where(full);
             }
         }
     }
@@ -405,8 +416,10 @@ __device__ __forceinline__ void pool_next_best(const float *pool_v, const int64_
 __global__ __launch_bounds__(MERGE_THREADS) void topk_merge_kernel(const float *__restrict__ in_val,
                                                                    const int64_t *__restrict__ in_idx,
                                                                    int M, int k, float *out_val,
-                                                                   int64_t *out_idx)
+                                                                   int64_t *out_idx, const int *run_if)
 {
+    if (run_if && run_if[blockIdx.x >> 5] == 0)
+        return;
     __shared__ float pool_v[MERGE_POOL];
     __shared__ int64_t pool_i[MERGE_POOL];
     __shared__ float top_v[MERGE_KMAX];
@@ -645,11 +658,13 @@ ScoreParams pass_params(const Pass &ps, const float *Q, int B, const float *D, i
     sp.thr0 = nullptr;
     sp.thr0_stride = 0;
     sp.thr0_off = 0;
+    sp.run_if = nullptr;
     return sp;
 }
 
 int score_partials(const float *Q, int B, int d, const float *D, int64_t N, int k, int64_t idx_offset,
-                   void *workspace, size_t workspace_bytes, hipStream_t st, Plan *plan_out, const char *who)
+                   void *workspace, size_t workspace_bytes, hipStream_t st, Plan *plan_out, const char *who,
+                   const int *run_if = nullptr)
 {
     if (B <= 0 || N <= 0 || k <= 0)
         return tt_fail(TT_ERR_BAD_SHAPE, "%s: B=%d N=%lld k=%d", who, B, (long long)N, k);
@@ -673,12 +688,13 @@ int score_partials(const float *Q, int B, int d, const float *D, int64_t N, int 
         // sample pass over D[0:ns): per-(wave,query) maxima, then their k-th largest per query.
         // k distinct documents score at least that much, so it bounds the final k-th score from below.
         ScoreParams pp = pass_params(pl.pre, Q, B, D, k, 0, ws, pl);
+        pp.run_if = run_if;
         int rc = launch_score(d, pp, pl, st, true);
         if (rc != TT_OK)
             return rc;
         hipLaunchKernelGGL(topk_merge_kernel, dim3(B), dim3(MERGE_THREADS), 0, st, (const float *)pp.pval,
                            (const int64_t *)pp.pidx, pl.pre.n_chunks, k, (float *)(ws + pl.pre_val_off),
-                           (int64_t *)(ws + pl.pre_idx_off));
+                           (int64_t *)(ws + pl.pre_idx_off), run_if);
         TT_LAUNCH_CHECK();
         thr0 = (const float *)(ws + pl.pre_val_off);
     }
@@ -686,6 +702,7 @@ int score_partials(const float *Q, int B, int d, const float *D, int64_t N, int 
     sp.thr0 = thr0;
     sp.thr0_stride = k;
     sp.thr0_off = k - 1;
+    sp.run_if = run_if;
     return launch_score(d, sp, pl, st, false);
 }
 
@@ -718,11 +735,23 @@ TT_EXPORT int tt_score_topk_partials_f32(const float *Q, int B, int d, const flo
     return TT_OK;
 }
 
+// Exact path, optionally predicated on a device flag (the screened path's fallback).
+int tt_score_topk_f32_pred(const float *Q, int B, int d, const float *D, int64_t N, int k, int64_t idx_offset,
+                           float *out_val, int64_t *out_idx, void *workspace, size_t workspace_bytes,
+                           const int *run_if, hipStream_t st);
+
 TT_EXPORT int tt_score_topk_f32(const float *Q, int B, int d, const float *D, int64_t N, int k,
                                 int64_t idx_offset, float *out_val, int64_t *out_idx, void *workspace,
                                 size_t workspace_bytes, tt_stream_t stream)
 {
-    hipStream_t st = (hipStream_t)stream;
+    return tt_score_topk_f32_pred(Q, B, d, D, N, k, idx_offset, out_val, out_idx, workspace, workspace_bytes, nullptr,
+                                  (hipStream_t)stream);
+}
+
+int tt_score_topk_f32_pred(const float *Q, int B, int d, const float *D, int64_t N, int k, int64_t idx_offset,
+                           float *out_val, int64_t *out_idx, void *workspace, size_t workspace_bytes,
+                           const int *run_if, hipStream_t st)
+{
     if (B < 0 || N < 0 || k <= 0)
         return tt_fail(TT_ERR_BAD_SHAPE, "tt_score_topk_f32: B=%d N=%lld k=%d", B, (long long)N, k);
     if (B == 0)
@@ -735,17 +764,17 @@ TT_EXPORT int tt_score_topk_f32(const float *Q, int B, int d, const float *D, in
         return tt_fail(TT_ERR_BAD_SHAPE, "tt_score_topk_f32: null output pointer");
     if (N == 0) { // merge over zero candidates writes the (-inf,-1) tail
         hipLaunchKernelGGL(topk_merge_kernel, dim3(B), dim3(MERGE_THREADS), 0, st, (const float *)nullptr,
-                           (const int64_t *)nullptr, 0, k, out_val, out_idx);
+                           (const int64_t *)nullptr, 0, k, out_val, out_idx, (const int *)nullptr);
         TT_LAUNCH_CHECK();
         return TT_OK;
     }
     Plan pl;
-    int rc = score_partials(Q, B, d, D, N, k, idx_offset, workspace, workspace_bytes, st, &pl, "tt_score_topk_f32");
+    int rc = score_partials(Q, B, d, D, N, k, idx_offset, workspace, workspace_bytes, st, &pl, "tt_score_topk_f32", run_if);
     if (rc != TT_OK)
         return rc;
     const char *ws = (const char *)workspace;
     hipLaunchKernelGGL(topk_merge_kernel, dim3(B), dim3(MERGE_THREADS), 0, st, (const float *)(ws + pl.pval_off),
-                       (const int64_t *)(ws + pl.pidx_off), pl.main.n_chunks * k, k, out_val, out_idx);
+                       (const int64_t *)(ws + pl.pidx_off), pl.main.n_chunks * k, k, out_val, out_idx, run_if);
     TT_LAUNCH_CHECK();
     return TT_OK;
 }
@@ -758,7 +787,7 @@ TT_EXPORT int tt_topk_merge(const float *in_val, const int64_t *in_idx, int B, i
     if (B == 0)
         return TT_OK;
     hipLaunchKernelGGL(topk_merge_kernel, dim3(B), dim3(MERGE_THREADS), 0, (hipStream_t)stream, in_val, in_idx, M,
-                       k, out_val, out_idx);
+                       k, out_val, out_idx, (const int *)nullptr);
     TT_LAUNCH_CHECK();
     return TT_OK;
 }

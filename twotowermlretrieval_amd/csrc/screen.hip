@@ -1,0 +1,756 @@
+// Screened exact top-k for large query batches (gfx950).
+//
+// Exact fp32 scoring is bound by v_mfma_f32_32x32x2_f32 (157 TFLOP/s, 1/16 of the f16 MFMA rate).
+// This path gets the SAME bit-exact result (oracle/tt_oracle.c:o_score_topk order and scores)
+// through a rigorous filter:
+//
+//   1. screen   approximate scores s16 = <fp16(q), fp16(d)> with fp32 accumulation on
+//               v_mfma_f32_32x32x16_f16 against an fp16 shadow copy of the corpus.  For every pair
+//                   |s16 - s| <= eps_q  with  eps_q = 1.05e-3 |q| Dmax + 1e-6 (|q| + Dmax)
+//               (fp16 rounding 2^-11 per operand, exact products, fp32 summation of 256 terms on
+//               both sides, fp16 underflow; Dmax = largest document L2 norm; derivation in
+//               DESIGN.md).  A document can be in the exact top-k only if
+//               s16 >= A_k - 2 eps_q, where A_k is the k-th largest approximate score seen by
+//               ANY subset of the corpus, so each workgroup keeps, per query, every candidate
+//               within 2 eps_q of its running k-th best approximate score.
+//   2. finish   per query: pool all candidates, A_k over the whole corpus, survivors
+//               {s16 >= A_k - 2 eps_q}, EXACT fp32 FMA-chain rescoring of the survivors from the
+//               fp32 corpus, exact top-k with (score desc, index asc).
+//
+// Anything that would break the guarantee (candidate buffer or survivor list overflow -- e.g.
+// hundreds of near-duplicate documents around the k-th score --, |q| too large for fp16) raises a
+// device flag; the caller then runs the plain exact kernel, predicated on that flag, so no host
+// synchronisation is needed and the result is exact in every case.
+//
+// Work decomposition: one workgroup (8 waves, one per CU) = 512 queries x a contiguous chunk of
+// documents.  Each wave keeps 64 queries as f16 MFMA B-operands in 128 VGPRs; document tiles
+// (32 docs x 256 features f16 = 16 KiB) are DMA'd once per workgroup into a 4-deep LDS ring
+// (global_load_lds, XOR-swizzled source) and read by all 8 waves, so HBM/L2 traffic is
+// N*512 B per 512 queries.
+#include "tt_common.h"
+
+#include <hip/hip_fp16.h>
+#include <limits.h>
+#include <math.h>
+
+int tt_score_topk_f32_pred(const float *Q, int B, int d, const float *D, int64_t N, int k, int64_t idx_offset,
+                           float *out_val, int64_t *out_idx, void *workspace, size_t workspace_bytes,
+                           const int *run_if, hipStream_t st);
+
+namespace {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void gbl_void;
+
+constexpr int SW = 8;                 // waves per workgroup
+constexpr int SQ_PER_WAVE = 64;       // queries per wave (two 32-wide MFMA column tiles)
+constexpr int SQ_PER_BLOCK = SW * SQ_PER_WAVE;
+constexpr int STILE_BYTES = 32 * 512; // 32 docs x 256 f16
+constexpr int SRING = 4;
+constexpr int SCAP = 128;             // candidate entries per (workgroup, query)
+constexpr int SURV_MAX = 256;         // survivors per query the finish kernel can rescore
+constexpr int POOL_MAX = 8192;        // candidates per query the finish kernel can pool
+
+struct SCand {
+    float v;
+    int x;
+};
+
+__device__ __forceinline__ float screen_eps(float qnorm, float dmax)
+{
+    return 1.05e-3f * qnorm * dmax + 1e-6f * (qnorm + dmax);
+}
+
+__device__ __forceinline__ SCand scand_load_l2(const SCand *p)
+{
+    unsigned long long u = __hip_atomic_load((const unsigned long long *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    SCand c;
+    c.v = __uint_as_float((unsigned)u);
+    c.x = (int)(u >> 32);
+    return c;
+}
+
+struct ScreenParams {
+    const float *Q;
+    const _Float16 *D16;
+    int B, N, k;
+    int n_chunks, tiles_per_chunk, n_tiles;
+    float dmax;
+    SCand *cand;   // [n_blocks][512][SCAP]
+    int *pcnt;     // [rows_pad][n_chunks]
+    int *flag;     // overflow / unsupported -> exact fallback
+    // sample pass (MAXONLY): per-(workgroup, query) maximum approximate score
+    float *max_val;      // [rows_pad][n_chunks]
+    int64_t *max_idx;    // [rows_pad][n_chunks] = chunk id (so K5 can take the k-th largest)
+    const float *thr0;   // main pass: k-th largest sample maximum per query, stride thr0_stride (or null)
+    int thr0_stride;
+};
+
+__device__ __forceinline__ void scand_store_async(SCand *dst, float v, int x)
+{
+    const unsigned long long bits = ((unsigned long long)(unsigned)x << 32) | (unsigned long long)__float_as_uint(v);
+    asm volatile("global_store_dwordx2 %0, %1, off\n\ts_nop 1" ::"v"(dst), "v"(bits) : "memory");
+}
+
+// Keep, sorted, every entry within `slack` of the k-th best; returns new count and threshold.
+// Lane t owns entries t and t+64.
+__device__ __forceinline__ void screen_compact(SCand *base, int n, int k, float slack, int lane, int &n_new,
+                                               float &thr_new, bool &have, bool &overflow)
+{
+    constexpr int E = SCAP / 64;
+    float v[E];
+    int x[E], rank[E];
+#pragma unroll
+    for (int i = 0; i < E; ++i) {
+        v[i] = -INFINITY;
+        x[i] = INT_MAX;
+        rank[i] = 0;
+        if (lane + 64 * i < n) {
+            const SCand c = scand_load_l2(base + lane + 64 * i);
+            v[i] = c.v;
+            x[i] = c.x;
+        }
+    }
+#pragma unroll
+    for (int i2 = 0; i2 < E; ++i2) {
+        const int lim = min(n - 64 * i2, 64);
+        for (int l2 = 0; l2 < lim; ++l2) {
+            const float sv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v[i2]), l2));
+            const int sx = __builtin_amdgcn_readlane(x[i2], l2);
+#pragma unroll
+            for (int i = 0; i < E; ++i)
+                rank[i] += (sv > v[i] || (sv == v[i] && sx < x[i])) ? 1 : 0;
+        }
+    }
+    have = n >= k;
+    overflow = false;
+    n_new = n;
+    thr_new = -INFINITY;
+    if (have) {
+        float kth = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < E; ++i) {
+            const unsigned long long bk = __ballot(lane + 64 * i < n && rank[i] == k - 1);
+            if (bk)
+                kth = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v[i]), __ffsll((long long)bk) - 1));
+        }
+        thr_new = kth - slack;
+        n_new = 0;
+#pragma unroll
+        for (int i = 0; i < E; ++i)
+            n_new += __popcll(__ballot(lane + 64 * i < n && v[i] >= thr_new));
+        if (n_new > SCAP - 40) { // no room left for one more tile: exact fallback (this pass's result is discarded)
+            overflow = true;
+            n_new = k;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < E; ++i)
+        if (lane + 64 * i < n && rank[i] < n_new) {
+            SCand c;
+            c.v = v[i];
+            c.x = x[i];
+            base[rank[i]] = c;
+        }
+}
+
+template <bool MAXONLY>
+__global__ __launch_bounds__(SW * 64, 2) void screen_kernel(ScreenParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) char ring[]; // [SRING][STILE_BYTES]
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int chunk = blockIdx.x % p.n_chunks;
+    const int qgroup = blockIdx.x / p.n_chunks;
+    const int t0 = chunk * p.tiles_per_chunk;
+    const int t1 = min(t0 + p.tiles_per_chunk, p.n_tiles);
+    const int k = p.k;
+    const int h = lane >> 5, j = lane & 31;
+    const int qbase = qgroup * SQ_PER_BLOCK + w * SQ_PER_WAVE;
+    const bool wave_live = qbase < p.B;
+
+    // ---- query operands: set c holds queries qbase + 32c + j; lane (j,h) keeps k = 16s + 8h .. +7 ----
+    h8 qreg[2][16];
+    float eps2[2], thr[2];
+    int cnt[2] = {0, 0};
+    float runmax[2] = {-INFINITY, -INFINITY};
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        bool bad = false;
+        const int qrow = qbase + 32 * c + j;
+        const bool live = qrow < p.B;
+        const float *qp = p.Q + (size_t)min(qrow, p.B - 1) * 256 + 8 * h;
+        float ss = 0.0f;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const f32x4 a = *(const f32x4 *)(qp + 16 * s);
+            const f32x4 b = *(const f32x4 *)(qp + 16 * s + 4);
+            h8 hv;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float x0 = live ? a[e] : 0.0f, x1 = live ? b[e] : 0.0f;
+                ss += x0 * x0 + x1 * x1;
+                bad |= !(fabsf(x0) <= 60000.0f) || !(fabsf(x1) <= 60000.0f);
+                hv[e] = (_Float16)x0;
+                hv[4 + e] = (_Float16)x1;
+            }
+            qreg[c][s] = hv;
+        }
+        ss += __shfl_xor(ss, 32);
+        eps2[c] = 2.0f * screen_eps(sqrtf(ss), p.dmax);
+        // A_k over any subset of the corpus, minus 2 eps, never exceeds the approximate score of a
+        // true top-k document: the sample pass's k-th largest maximum seeds the threshold.
+        thr[c] = live ? ((!MAXONLY && p.thr0) ? p.thr0[(size_t)qrow * p.thr0_stride + p.thr0_stride - 1] - eps2[c] : -INFINITY)
+                      : INFINITY;
+        if (bad && live) // fp16 cannot hold this query: its 32-query tile goes to the exact kernel
+            atomicOr(p.flag + ((qbase + 32 * c) >> 5), 2);
+    }
+
+    SCand *const cwave = p.cand + ((size_t)blockIdx.x * SQ_PER_BLOCK + w * SQ_PER_WAVE) * SCAP;
+
+    auto compact_where = [&](int c, unsigned long long qmask) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        while (qmask) {
+            const int q = __ffsll((long long)qmask) - 1;
+            qmask &= qmask - 1;
+            const int n = __builtin_amdgcn_readlane(cnt[c], q);
+            const float slack = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, eps2[c]), q));
+            int n_new;
+            float tn;
+            bool have, ovf;
+            screen_compact(cwave + (size_t)(32 * c + q) * SCAP, n, k, slack, lane, n_new, tn, have, ovf);
+            if (ovf && lane == 0)
+                atomicOr(p.flag + ((qbase + 32 * c) >> 5), 1);
+            if (j == q) {
+                cnt[c] = n_new;
+                if (have)
+                    thr[c] = tn;
+            }
+        }
+    };
+
+    // ---- DMA: tile = 16 wave-instructions of 1 KiB (2 docs x 512 B); wave w issues 2w, 2w+1 ----
+    const char *D = (const char *)p.D16;
+    const char *rowp[2];
+    auto set_rows = [&](int tile) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = 2 * (2 * w + i) + h;            // doc within the tile
+            const int doc = min(tile * 32 + row, p.N - 1);
+            const int chunk16 = j ^ (row & 15);             // source swizzle: logical = physical ^ (row & 15)
+            rowp[i] = D + (size_t)doc * 512 + chunk16 * 16;
+        }
+    };
+    auto dma_issue = [&](int tile, int stage) {
+        set_rows(min(tile, t1 - 1));
+        char *dst = ring + stage * STILE_BYTES + (2 * w) * 1024;
+        __builtin_amdgcn_global_load_lds((gbl_void *)rowp[0], (lds_void *)dst, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_void *)rowp[1], (lds_void *)(dst + 1024), 16, 0, 0);
+    };
+
+    if (t0 < t1) {
+#pragma unroll
+        for (int g = 0; g < SRING - 1; ++g)
+            dma_issue(t0 + g, g);
+        int stage = 0;
+        const int rd_base = j * 512;
+        for (int tile = t0; tile < t1; ++tile) {
+            // own DMAs of this tile have landed; the barrier extends that to every wave's, and also
+            // guarantees every wave is done reading the tile consumed in the previous iteration
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (SRING - 2)) : "memory");
+            __builtin_amdgcn_s_barrier();
+            dma_issue(tile + SRING - 1, (stage + SRING - 1) % SRING);
+            if (wave_live) {
+                f32x16 acc0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+                f32x16 acc1 = acc0;
+                const char *buf = ring + stage * STILE_BYTES + rd_base;
+#pragma unroll
+                for (int s = 0; s < 16; ++s) {
+                    const h8 a = *(const h8 *)(buf + (((2 * s + h) ^ (j & 15)) << 4));
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, qreg[0][s], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, qreg[1][s], acc1, 0, 0, 0);
+                }
+                // ---- epilogue: accC[r] = s16(doc tile*32 + (r&3)+8(r>>2)+4h, query qbase+32C+j) ----
+                const int tile_base = tile * 32;
+                const bool partial = tile_base + 32 > p.N;
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const f32x16 &acc = c == 0 ? acc0 : acc1;
+                    if (MAXONLY) {
+                        float m = -INFINITY;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int doc = tile_base + (r & 3) + 8 * (r >> 2) + 4 * h;
+                            m = fmaxf(m, (!partial || doc < p.N) ? acc[r] : -INFINITY);
+                        }
+                        runmax[c] = fmaxf(runmax[c], m);
+                        continue;
+                    }
+                    float m = acc[0];
+#pragma unroll
+                    for (int r = 1; r < 16; ++r)
+                        m = fmaxf(m, acc[r]);
+                    if (__ballot(m >= thr[c]) == 0ull)
+                        continue;
+                    // append pass: inline-asm stores only (see score_topk.hip: a compiler-visible VMEM op
+                    // here would put s_waitcnt vmcnt(0) on the hot path and drain the DMA ring)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int doc = tile_base + (r & 3) + 8 * (r >> 2) + 4 * h;
+                        const bool cd = (!partial || doc < p.N) && acc[r] >= thr[c];
+                        const unsigned long long mask = __ballot(cd);
+                        if (mask == 0ull)
+                            continue;
+                        const int c_lo = (int)((mask >> j) & 1ull), c_hi = (int)((mask >> (j + 32)) & 1ull);
+                        if (cd)
+                            scand_store_async(cwave + (size_t)(32 * c + j) * SCAP + cnt[c] + (h ? c_lo : 0), acc[r], doc);
+                        cnt[c] += c_lo + c_hi;
+                    }
+                    const unsigned long long full = __ballot(cnt[c] > SCAP - 34) & 0xffffffffull;
+                    if (full)
+                        compact_where(c, full);
+                }
+            }
+            stage = (stage + 1) % SRING;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier(); // no wave may leave while a sibling's LDS-DMA could still be consumed
+
+    if (MAXONLY) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const float m = fmaxf(runmax[c], __shfl_xor(runmax[c], 32));
+            const int qrow = qbase + 32 * c + j;
+            if (h == 0 && qrow < p.B) {
+                p.max_val[(size_t)qrow * p.n_chunks + chunk] = m;
+                p.max_idx[(size_t)qrow * p.n_chunks + chunk] = t0 < t1 ? (int64_t)chunk : -1;
+            }
+        }
+        return;
+    }
+    // final compaction (bounds the pool the finish kernel sees) and counts out
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const unsigned long long over = __ballot(cnt[c] > k) & 0xffffffffull;
+        if (over)
+            compact_where(c, over);
+        const int qrow = qbase + 32 * c + j;
+        if (h == 0 && qrow < p.B)
+            p.pcnt[(size_t)qrow * p.n_chunks + chunk] = cnt[c];
+    }
+}
+
+// ------------------------------------------------------------------ finish
+struct FinishParams {
+    const float *Q;
+    const float *D32;
+    int B, N, k, n_chunks, blocks_per_group;
+    float dmax;
+    const SCand *cand;
+    const int *pcnt;
+    int *flag;
+    int64_t idx_offset;
+    float *out_val;
+    int64_t *out_idx;
+};
+
+__device__ __forceinline__ bool before_f(float sa, int ia, float sb, int ib) { return sa > sb || (sa == sb && ia < ib); }
+
+// block-wide arg-best over (v[i], x[i]), i < n, among entries ranking strictly after (pv, px)
+__device__ __forceinline__ void block_next_best(const float *v, const int *x, int n, float pv, int px, float *red_v,
+                                                int *red_x, float &bv, int &bx)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    bv = -INFINITY;
+    bx = INT_MAX;
+    bool any = false;
+    for (int m = tid; m < n; m += 256) {
+        const float cv = v[m];
+        const int cx = x[m];
+        if (!before_f(pv, px, cv, cx))
+            continue;
+        if (!any || before_f(cv, cx, bv, bx)) {
+            bv = cv;
+            bx = cx;
+            any = true;
+        }
+    }
+    if (!any)
+        bx = INT_MAX;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const float ov = __shfl_xor(bv, off);
+        const int ox = __shfl_xor(bx, off);
+        if (ox != INT_MAX && (bx == INT_MAX || before_f(ov, ox, bv, bx))) {
+            bv = ov;
+            bx = ox;
+        }
+    }
+    if (lane == 0) {
+        red_v[wave] = bv;
+        red_x[wave] = bx;
+    }
+    __syncthreads();
+    bv = red_v[0];
+    bx = red_x[0];
+#pragma unroll
+    for (int w2 = 1; w2 < 4; ++w2)
+        if (red_x[w2] != INT_MAX && (bx == INT_MAX || before_f(red_v[w2], red_x[w2], bv, bx))) {
+            bv = red_v[w2];
+            bx = red_x[w2];
+        }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void screen_finish_kernel(FinishParams p)
+{
+    __shared__ float pool_v[POOL_MAX];
+    __shared__ int pool_x[POOL_MAX];
+    __shared__ float qs[256];
+    __shared__ float sv_v[SURV_MAX];
+    __shared__ int sv_x[SURV_MAX];
+    __shared__ float red_v[4];
+    __shared__ int red_x[4];
+    __shared__ int n_pool, n_surv;
+    const int row = blockIdx.x, tid = threadIdx.x;
+    if (tid == 0)
+        n_pool = n_surv = 0;
+    qs[tid] = p.Q[(size_t)row * 256 + tid];
+    __syncthreads();
+    // |q| (fixed-order enough: any fp32 rounding is covered by the safety factor in screen_eps)
+    float ss = qs[tid] * qs[tid];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1)
+        ss += __shfl_xor(ss, off);
+    if ((tid & 63) == 0)
+        red_v[tid >> 6] = ss;
+    __syncthreads();
+    const float eps2 = 2.0f * screen_eps(sqrtf(red_v[0] + red_v[1] + red_v[2] + red_v[3]), p.dmax);
+    __syncthreads();
+
+    // ---- pool every workgroup's candidates for this query (counts -> prefix -> parallel copy) ----
+    const int qgroup = row / SQ_PER_BLOCK, qin = row % SQ_PER_BLOCK;
+    bool too_many = false;
+    int *pre = sv_x; // n_chunks + 1 <= 129 prefix entries, reused before the survivors are written
+    if (tid < p.n_chunks)
+        pool_x[tid] = p.pcnt[(size_t)row * p.n_chunks + tid];
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0;
+        for (int c = 0; c < p.n_chunks; ++c) {
+            pre[c] = run;
+            run += pool_x[c];
+        }
+        pre[p.n_chunks] = run;
+        n_pool = run;
+    }
+    __syncthreads();
+    const int total = n_pool;
+    if (total > POOL_MAX)
+        too_many = true;
+    __syncthreads(); // everyone has read the counts out of pool_x before it is overwritten
+    int my_c[POOL_MAX / 256], my_o[POOL_MAX / 256];
+#pragma unroll
+    for (int it = 0; it < POOL_MAX / 256; ++it) {
+        const int m = tid + 256 * it;
+        int lo = 0, hi = p.n_chunks; // largest c with pre[c] <= m
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (pre[mid] <= m)
+                lo = mid;
+            else
+                hi = mid;
+        }
+        my_c[it] = lo;
+        my_o[it] = m - pre[lo];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < POOL_MAX / 256; ++it) {
+        const int m = tid + 256 * it;
+        if (m < total && m < POOL_MAX) {
+            const SCand e = p.cand[((size_t)(qgroup * p.n_chunks + my_c[it]) * SQ_PER_BLOCK + qin) * SCAP + my_o[it]];
+            pool_v[m] = e.v;
+            pool_x[m] = e.x;
+        }
+    }
+    __syncthreads();
+    const int np = min(n_pool, POOL_MAX);
+    // ---- A_k = k-th best approximate score over the whole corpus ----
+    float pv = INFINITY, kth = -INFINITY;
+    int px = -1, found = 0;
+    for (int r = 0; r < p.k; ++r) {
+        float bv;
+        int bx;
+        block_next_best(pool_v, pool_x, np, pv, px, red_v, red_x, bv, bx);
+        if (bx == INT_MAX)
+            break;
+        pv = bv;
+        px = bx;
+        kth = bv;
+        ++found;
+    }
+    const float cut = found == p.k ? kth - eps2 : -INFINITY;
+    // ---- survivors, exact fp32 FMA-chain rescoring (the oracle's order: features ascending) ----
+    for (int m = tid; m < np; m += 256) {
+        if (pool_v[m] >= cut) {
+            const int slot = atomicAdd(&n_surv, 1);
+            if (slot < SURV_MAX)
+                sv_x[slot] = pool_x[m];
+            else
+                too_many = true;
+        }
+    }
+    __syncthreads();
+    const int ns = min(n_surv, SURV_MAX);
+    if (tid < ns) {
+        const float *drow = p.D32 + (size_t)sv_x[tid] * 256;
+        float acc = 0.0f;
+        for (int x = 0; x < 256; x += 4) {
+            const f32x4 dv = *(const f32x4 *)(drow + x);
+            acc = fmaf(qs[x], dv.x, acc);
+            acc = fmaf(qs[x + 1], dv.y, acc);
+            acc = fmaf(qs[x + 2], dv.z, acc);
+            acc = fmaf(qs[x + 3], dv.w, acc);
+        }
+        sv_v[tid] = acc;
+    }
+    if (__syncthreads_or(too_many) && tid == 0)
+        atomicOr(p.flag + (row >> 5), 4);
+    // ---- exact top-k of the survivors ----
+    pv = INFINITY;
+    px = -1;
+    for (int r = 0; r < p.k; ++r) {
+        float bv;
+        int bx;
+        block_next_best(sv_v, sv_x, ns, pv, px, red_v, red_x, bv, bx);
+        if (tid == 0) {
+            const bool ok = bx != INT_MAX;
+            p.out_val[(size_t)row * p.k + r] = ok ? bv : -INFINITY;
+            p.out_idx[(size_t)row * p.k + r] = ok ? p.idx_offset + bx : -1;
+        }
+        if (bx == INT_MAX) {
+            pv = -INFINITY;
+            px = INT_MAX;
+        } else {
+            pv = bv;
+            px = bx;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ fp16 shadow copy + corpus stats
+__global__ __launch_bounds__(256) void build_f16_kernel(const float *__restrict__ D, int64_t N, int d,
+                                                        _Float16 *__restrict__ out, unsigned *__restrict__ stats)
+{
+    __shared__ float red[8];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float nmax = 0.0f, amax = 0.0f;
+    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < N; row += (int64_t)gridDim.x * 4) {
+        float ss = 0.0f;
+        for (int x = lane * 4; x < d; x += 256) {
+            const f32x4 v = *(const f32x4 *)(D + row * d + x);
+            h4 hv;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                ss += v[e] * v[e];
+                amax = fmaxf(amax, fabsf(v[e]));
+                if (!(fabsf(v[e]) <= 3.0e38f))
+                    amax = INFINITY; // NaN / inf anywhere disables the screen
+                hv[e] = (_Float16)v[e];
+            }
+            *(h4 *)(out + row * d + x) = hv;
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1)
+            ss += __shfl_xor(ss, off);
+        nmax = fmaxf(nmax, sqrtf(ss));
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1)
+        amax = fmaxf(amax, __shfl_xor(amax, off));
+    if (lane == 0) {
+        red[wave] = nmax;
+        red[4 + wave] = amax;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) { // non-negative floats order like their bit patterns; inf is the largest
+        atomicMax(stats, __float_as_uint(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]))));
+        atomicMax(stats + 1, __float_as_uint(fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7]))));
+    }
+}
+
+struct SPlan {
+    int n_qgroups, n_tiles, n_chunks, tiles_per_chunk, n_blocks;
+    // sample pass
+    bool sample;
+    int s_tiles, s_chunks, s_tiles_per_chunk;
+    int64_t s_docs;
+    size_t cand_off, pcnt_off, smax_val_off, smax_idx_off, sthr_val_off, sthr_idx_off, ws_bytes, lds;
+};
+
+constexpr int SAMPLE_CHUNKS = 128;
+constexpr int64_t SAMPLE_MIN_N = 524288;
+
+int screen_cus()
+{
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) {
+        (void)hipGetLastError();
+        cus = 256;
+    }
+    return cus;
+}
+
+SPlan make_splan(int B, int64_t N)
+{
+    SPlan pl;
+    pl.n_qgroups = (B + SQ_PER_BLOCK - 1) / SQ_PER_BLOCK;
+    pl.n_tiles = (int)((N + 31) / 32);
+    int want = (2 * screen_cus() + pl.n_qgroups - 1) / pl.n_qgroups; // two waves of workgroups per CU
+    const int max_chunks = 255; // finish kernel: one thread per chunk count; pooled entries are checked at run time
+    want = want > max_chunks ? max_chunks : want;
+    want = want > pl.n_tiles ? pl.n_tiles : want;
+    want = want < 1 ? 1 : want;
+    pl.tiles_per_chunk = (pl.n_tiles + want - 1) / want;
+    pl.n_chunks = (pl.n_tiles + pl.tiles_per_chunk - 1) / pl.tiles_per_chunk;
+    pl.n_blocks = pl.n_qgroups * pl.n_chunks;
+    size_t off = 0;
+    pl.cand_off = off;
+    off = tt_align_up(off + (size_t)pl.n_blocks * SQ_PER_BLOCK * SCAP * sizeof(SCand), 256);
+    pl.pcnt_off = off;
+    off = tt_align_up(off + (size_t)pl.n_qgroups * SQ_PER_BLOCK * pl.n_chunks * sizeof(int), 256);
+    // sample pass: 1/64 of the corpus cut in SAMPLE_CHUNKS pieces (their maxima seed the thresholds)
+    pl.sample = N >= SAMPLE_MIN_N;
+    pl.s_docs = (N / 64 + 31) / 32 * 32;
+    pl.s_tiles = (int)(pl.s_docs / 32);
+    pl.s_tiles_per_chunk = (pl.s_tiles + SAMPLE_CHUNKS - 1) / SAMPLE_CHUNKS;
+    pl.s_chunks = pl.sample ? (pl.s_tiles + pl.s_tiles_per_chunk - 1) / pl.s_tiles_per_chunk : 0;
+    const size_t rows = (size_t)pl.n_qgroups * SQ_PER_BLOCK;
+    pl.smax_val_off = off;
+    off = tt_align_up(off + rows * SAMPLE_CHUNKS * sizeof(float), 256);
+    pl.smax_idx_off = off;
+    off = tt_align_up(off + rows * SAMPLE_CHUNKS * sizeof(int64_t), 256);
+    pl.sthr_val_off = off;
+    off = tt_align_up(off + rows * 16 * sizeof(float), 256);
+    pl.sthr_idx_off = off;
+    off = tt_align_up(off + rows * 16 * sizeof(int64_t), 256);
+    pl.ws_bytes = off;
+    pl.lds = (size_t)SRING * STILE_BYTES;
+    return pl;
+}
+
+} // namespace
+
+TT_EXPORT int tt_index_build_f16(const float *D, int64_t N, int d, void *D16, float *stats, tt_stream_t stream)
+{
+    if (N < 0 || d <= 0 || (d & 3))
+        return tt_fail(TT_ERR_BAD_SHAPE, "tt_index_build_f16: N=%lld d=%d", (long long)N, d);
+    if (!stats || (N > 0 && (!D || !D16)))
+        return tt_fail(TT_ERR_BAD_SHAPE, "tt_index_build_f16: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    TT_HIP_CHECK(hipMemsetAsync(stats, 0, 2 * sizeof(float), st));
+    if (N == 0)
+        return TT_OK;
+    const int64_t want_blocks = (N + 3) / 4;
+    hipLaunchKernelGGL(build_f16_kernel, dim3((unsigned)(want_blocks > 8192 ? 8192 : want_blocks)), dim3(256), 0, st, D,
+                       N, d, (_Float16 *)D16, (unsigned *)stats);
+    TT_LAUNCH_CHECK();
+    return TT_OK;
+}
+
+TT_EXPORT size_t tt_score_topk_screened_workspace_bytes(int B, int64_t N, int d, int k)
+{
+    if (B <= 0 || N <= 0)
+        return 0;
+    return make_splan(B, N).ws_bytes + tt_score_topk_workspace_bytes(B, N, d, k);
+}
+
+TT_EXPORT int tt_score_topk_screened_f32(const float *Q, int B, int d, const float *D32, const void *D16, int64_t N,
+                                         int k, float dmax_norm, int64_t idx_offset, float *out_val, int64_t *out_idx,
+                                         int32_t *fallback_flag, void *workspace, size_t workspace_bytes,
+                                         tt_stream_t stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    if (B <= 0 || N <= 0 || k <= 0)
+        return tt_fail(TT_ERR_BAD_SHAPE, "tt_score_topk_screened_f32: B=%d N=%lld k=%d", B, (long long)N, k);
+    if (d != 256)
+        return tt_fail(TT_ERR_UNSUPPORTED, "tt_score_topk_screened_f32: d=%d (supported: 256)", d);
+    if (k > 16)
+        return tt_fail(TT_ERR_UNSUPPORTED, "tt_score_topk_screened_f32: k=%d > 16", k);
+    if (N >= (int64_t)INT_MAX - 64)
+        return tt_fail(TT_ERR_UNSUPPORTED, "tt_score_topk_screened_f32: N too large; shard the corpus");
+    if (!(dmax_norm >= 0.0f) || !(dmax_norm < 60000.0f))
+        return tt_fail(TT_ERR_UNSUPPORTED, "tt_score_topk_screened_f32: corpus norm %g outside the fp16 range", dmax_norm);
+    if (!Q || !D32 || !D16 || !out_val || !out_idx || !fallback_flag)
+        return tt_fail(TT_ERR_BAD_SHAPE, "tt_score_topk_screened_f32: null pointer");
+    const SPlan pl = make_splan(B, N);
+    const size_t need = pl.ws_bytes + tt_score_topk_workspace_bytes(B, N, d, k);
+    if (!workspace || workspace_bytes < need || ((uintptr_t)workspace & 255))
+        return tt_fail(TT_ERR_WORKSPACE, "tt_score_topk_screened_f32: workspace %zu < %zu bytes", workspace_bytes, need);
+    char *ws = (char *)workspace;
+    TT_HIP_CHECK(hipMemsetAsync(fallback_flag, 0, sizeof(int32_t) * ((B + 31) / 32), st));
+
+    ScreenParams sp;
+    sp.Q = Q;
+    sp.D16 = (const _Float16 *)D16;
+    sp.B = B;
+    sp.N = (int)N;
+    sp.k = k;
+    sp.n_chunks = pl.n_chunks;
+    sp.tiles_per_chunk = pl.tiles_per_chunk;
+    sp.n_tiles = pl.n_tiles;
+    sp.dmax = dmax_norm;
+    sp.cand = (SCand *)(ws + pl.cand_off);
+    sp.pcnt = (int *)(ws + pl.pcnt_off);
+    sp.flag = fallback_flag;
+    sp.max_val = nullptr;
+    sp.max_idx = nullptr;
+    sp.thr0 = nullptr;
+    sp.thr0_stride = k;
+    TT_HIP_CHECK(hipFuncSetAttribute((const void *)screen_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds));
+    TT_HIP_CHECK(hipFuncSetAttribute((const void *)screen_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds));
+    if (pl.sample) {
+        ScreenParams ss = sp;
+        ss.N = (int)pl.s_docs;
+        ss.n_tiles = pl.s_tiles;
+        ss.n_chunks = pl.s_chunks;
+        ss.tiles_per_chunk = pl.s_tiles_per_chunk;
+        ss.max_val = (float *)(ws + pl.smax_val_off);
+        ss.max_idx = (int64_t *)(ws + pl.smax_idx_off);
+        hipLaunchKernelGGL(screen_kernel<true>, dim3(pl.n_qgroups * pl.s_chunks), dim3(SW * 64), pl.lds, st, ss);
+        TT_LAUNCH_CHECK();
+        int rc = tt_topk_merge(ss.max_val, ss.max_idx, B, pl.s_chunks, k, (float *)(ws + pl.sthr_val_off),
+                               (int64_t *)(ws + pl.sthr_idx_off), stream);
+        if (rc != TT_OK)
+            return rc;
+        sp.thr0 = (const float *)(ws + pl.sthr_val_off);
+    }
+    hipLaunchKernelGGL(screen_kernel<false>, dim3(pl.n_blocks), dim3(SW * 64), pl.lds, st, sp);
+    TT_LAUNCH_CHECK();
+
+    FinishParams fp;
+    fp.Q = Q;
+    fp.D32 = D32;
+    fp.B = B;
+    fp.N = (int)N;
+    fp.k = k;
+    fp.n_chunks = pl.n_chunks;
+    fp.blocks_per_group = pl.n_chunks;
+    fp.dmax = dmax_norm;
+    fp.cand = sp.cand;
+    fp.pcnt = sp.pcnt;
+    fp.flag = fallback_flag;
+    fp.idx_offset = idx_offset;
+    fp.out_val = out_val;
+    fp.out_idx = out_idx;
+    hipLaunchKernelGGL(screen_finish_kernel, dim3(B), dim3(256), 0, st, fp);
+    TT_LAUNCH_CHECK();
+    // exact kernel, a no-op unless a workgroup raised the flag; then it rewrites every output row
+    return tt_score_topk_f32_pred(Q, B, d, D32, N, k, idx_offset, out_val, out_idx, ws + pl.ws_bytes,
+                                  workspace_bytes - pl.ws_bytes, fallback_flag, st);
+}

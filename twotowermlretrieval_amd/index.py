@@ -95,15 +95,40 @@ def score_rank(q: torch.Tensor, docs: torch.Tensor, target: torch.Tensor) -> tor
     return rank
 
 
+SCREEN_MIN_BATCH = 96  # below this the exact fp32 kernel is HBM-bound and already at its roofline
+
+
 class BruteForceIndex:
     """A [N,d] fp32 document matrix resident in HBM (document_embeddings.npy layout,
-    backend/main.py:125-138: row i <-> documents[i]) with exact top-k search."""
+    backend/main.py:125-138: row i <-> documents[i]) with exact top-k search.
 
-    def __init__(self, doc_embeddings: torch.Tensor, idx_offset: int = 0):
+    screen=True additionally keeps an fp16 shadow copy (N*d*2 bytes) so that large query batches
+    run the screened path (fp16 MFMA filter + exact fp32 rescoring, tt_score_topk_screened_f32):
+    same bit-exact result, an order of magnitude more queries/s than the fp32-MFMA-bound kernel.
+    """
+
+    def __init__(self, doc_embeddings: torch.Tensor, idx_offset: int = 0, screen: bool = False):
         _need_cuda(doc_embeddings)
         self.docs = _f32c(doc_embeddings)
         self.idx_offset = int(idx_offset)
         self._ws: Optional[torch.Tensor] = None
+        self._ws_s: Optional[torch.Tensor] = None
+        self.docs16: Optional[torch.Tensor] = None
+        self.dmax_norm = float("nan")
+        self.fallback_flags = torch.zeros(1, dtype=torch.int32, device=self.docs.device)  # per 32-query tile
+        N, d = self.docs.shape
+        if screen and d == 256 and N > 0:
+            L = _lib.lib()
+            self.docs16 = torch.empty((N, d), dtype=torch.float16, device=self.docs.device)
+            stats = torch.zeros(2, dtype=torch.float32, device=self.docs.device)
+            with torch.cuda.device(self.docs.device):
+                _lib.check(L.tt_index_build_f16(self.docs.data_ptr(), N, d, self.docs16.data_ptr(), stats.data_ptr(),
+                                                _stream(self.docs)))
+            dmax, amax = (float(x) for x in stats.tolist())  # one sync, at index-build time
+            if dmax == dmax and amax < 6.0e4 and dmax < 6.0e4:
+                self.dmax_norm = dmax
+            else:
+                self.docs16 = None  # outside the fp16 range: exact kernel only
 
     @property
     def ntotal(self) -> int:
@@ -111,7 +136,27 @@ class BruteForceIndex:
 
     def search(self, q: torch.Tensor, k: int = 10) -> Tuple[torch.Tensor, torch.Tensor]:
         B = 1 if q.dim() == 1 else q.shape[0]
-        need = _lib.lib().tt_score_topk_workspace_bytes(B, self.docs.shape[0], self.docs.shape[1], k)
+        N, d = self.docs.shape
+        L = _lib.lib()
+        if self.docs16 is not None and q.dim() == 2 and B >= SCREEN_MIN_BATCH and k <= 16:
+            _need_cuda(q)
+            q = _f32c(q)
+            if q.shape[1] != d:
+                raise ValueError(f"shape mismatch: q {tuple(q.shape)} vs docs {tuple(self.docs.shape)}")
+            need = L.tt_score_topk_screened_workspace_bytes(B, N, d, k)
+            if self._ws_s is None or self._ws_s.numel() < need:
+                self._ws_s = torch.empty(need, dtype=torch.uint8, device=self.docs.device)
+            vals = torch.empty((B, k), dtype=torch.float32, device=q.device)
+            idx = torch.empty((B, k), dtype=torch.int64, device=q.device)
+            if self.fallback_flags.numel() < (B + 31) // 32:
+                self.fallback_flags = torch.zeros((B + 31) // 32, dtype=torch.int32, device=self.docs.device)
+            with torch.cuda.device(q.device):
+                _lib.check(L.tt_score_topk_screened_f32(q.data_ptr(), B, d, self.docs.data_ptr(), self.docs16.data_ptr(),
+                                                        N, k, self.dmax_norm, self.idx_offset, vals.data_ptr(),
+                                                        idx.data_ptr(), self.fallback_flags.data_ptr(),
+                                                        self._ws_s.data_ptr(), self._ws_s.numel(), _stream(q)))
+            return vals, idx
+        need = L.tt_score_topk_workspace_bytes(B, N, d, k)
         if self._ws is None or self._ws.numel() < need:
             self._ws = torch.empty(max(need, 16), dtype=torch.uint8, device=self.docs.device)
         return score_topk(q, self.docs, k, self.idx_offset, self._ws)
@@ -136,12 +181,12 @@ class ShardedIndex:
     """
 
     def __init__(self, local_docs: torch.Tensor, row_offset: int, group=None, shard_k: int = 50,
-                 local_search: Optional[Callable] = None, merge: Optional[Callable] = None):
+                 local_search: Optional[Callable] = None, merge: Optional[Callable] = None, screen: bool = False):
         self.group = group
         self.row_offset = int(row_offset)
         self.shard_k = int(shard_k)
         if local_search is None:
-            self._index = BruteForceIndex(local_docs, idx_offset=row_offset)
+            self._index = BruteForceIndex(local_docs, idx_offset=row_offset, screen=screen)
             self._search = self._index.search
         else:
             self._index = None
