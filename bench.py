@@ -5,14 +5,17 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 One step = one pass of the hot path over one batch of B=1024 synthetic queries: every rank scores
-the batch against its contiguous row shard of the SAME 10M-document corpus (fused fp32 MFMA
-score + top-k kernel, corpus resident in HBM), and for N > 1 the per-shard top-50 lists are
-all-gathered over RCCL and merged to the global top-10 on every rank (strong scaling: the corpus
-is fixed, the shard shrinks with N).  Rank 0 prints ONE JSON line.
+the batch against its contiguous row shard of the SAME 10M-document corpus, resident in HBM, with
+the screened exact search (fp16-MFMA filter over an fp16 shadow copy with a rigorous error bound,
+exact fp32 rescoring of the survivors: bit-identical to the plain fp32 kernel and to the CPU
+oracle), and for N > 1 the per-shard top-50 lists are all-gathered over RCCL and merged to the
+global top-10 on every rank (strong scaling: the corpus is fixed, the shard shrinks with N).
+Rank 0 prints ONE JSON line.
 
-Extra legs on rank 0 (untimed w.r.t. `value`): `roofline` (kernel-only HIP-event timing of the
-dominant kernel), `roofline_hbm` (same kernel in its HBM-bound regime, B=32), and at N=1
-`cpu_baseline` (the reference's torch CPU idiom on a bounded sample).
+Extra legs on rank 0 (untimed w.r.t. `value`): `roofline` (the step's dominant kernel,
+screen_kernel<false>, timed alone with HIP events recorded around its launch), `roofline_exact_f32`
+(the plain fp32-MFMA kernel on the same batch), `roofline_hbm` (the fp32 kernel in its HBM-bound
+regime, B=32), and at N=1 `cpu_baseline` (the reference's torch CPU idiom on a bounded sample).
 """
 from __future__ import annotations
 
@@ -38,6 +41,7 @@ SHARD_K = 50
 GEN_BLOCK = 1_000_000  # corpus is generated in seeded 1M-row blocks -> identical for every world size
 HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: HBM3E peak
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 MFMA peak
+MFMA_F16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16/f16 MFMA peak
 
 
 def gen_rows(lo: int, hi: int, device) -> torch.Tensor:
@@ -84,6 +88,30 @@ def kernel_only_ms(q, docs, k, iters=5, warm=2):
     e1.record()
     torch.cuda.synchronize()
     return e0.elapsed_time(e1) / iters
+
+
+def screen_kernel_ms(index, q, k, iters=5, warm=2):
+    """Average duration of screen_kernel<false> alone: HIP events recorded on the launch stream right
+    before and after that launch inside tt_score_topk_screened_f32 (prof_events)."""
+    from twotowermlretrieval_amd import _lib
+    L = _lib.lib()
+    evs = (C.c_void_p * 2)()
+    for i in range(2):
+        e = C.c_void_p()
+        _lib.check(L.tt_event_create(C.byref(e)))
+        evs[i] = e.value
+    for _ in range(warm):
+        index.search(q, k)
+    torch.cuda.synchronize()
+    tot = 0.0
+    for _ in range(iters):
+        index.search(q, k, _prof_events=evs)
+        ms = C.c_float()
+        _lib.check(L.tt_event_elapsed_ms(evs[0], evs[1], C.byref(ms)))
+        tot += ms.value
+    for i in range(2):
+        L.tt_event_destroy(evs[i])
+    return tot / iters
 
 
 def pmc_traffic(name: str):
@@ -138,11 +166,12 @@ def main():
     docs = gen_rows(lo, hi, dev)
     q = gen_queries(BATCH, dev)
     if world > 1:
-        index = tt.ShardedIndex(docs, lo, shard_k=SHARD_K)
-        step = lambda: index.search(q, TOPK)  # noqa: E731
+        index = tt.ShardedIndex(docs, lo, shard_k=SHARD_K, screen=True)
+        local_index = index._index
     else:
-        index = tt.BruteForceIndex(docs)
-        step = lambda: index.search(q, TOPK)  # noqa: E731
+        index = local_index = tt.BruteForceIndex(docs, screen=True)
+    assert local_index.docs16 is not None, "fp16 shadow copy was not built"
+    step = lambda: index.search(q, TOPK)  # noqa: E731
 
     def fence():
         torch.cuda.synchronize()
@@ -165,16 +194,24 @@ def main():
     vals, idx = out
     assert vals.shape == (BATCH, TOPK) and bool((vals[:, 1:] <= vals[:, :-1]).all()) and int(idx.min()) >= 0
 
+    flags = int(local_index.fallback_flags.ne(0).sum().item())
     if rank == 0:
         n_shard = hi - lo
         kp = TOPK if world == 1 else SHARD_K
-        ms = kernel_only_ms(q, docs, kp)
         flops = 2.0 * BATCH * n_shard * DIM
-        roof = {"bound": "mfma", "kernel": "score_topk_kernel<8,*,false> (fp32 MFMA 32x32x2)",
-                "achieved": round(flops / ms / 1e9, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(flops / ms / 1e9 / MFMA_F32_PEAK_TFLOPS, 4), "traffic": pmc_traffic("b1024"),
-                "kernel_ms": round(ms, 4), "batch": BATCH, "docs_per_gpu": n_shard,
-                "hbm_GBps_same_launch": round((n_shard * DIM * 4 + BATCH * DIM * 4 + BATCH * kp * 12) / ms / 1e6, 1)}
+        ms_s = screen_kernel_ms(local_index, q, kp)
+        roof = {"bound": "mfma", "kernel": "screen_kernel<false> (f16 MFMA 32x32x16, fp32 accumulate)",
+                "achieved": round(flops / ms_s / 1e9, 2), "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(flops / ms_s / 1e9 / MFMA_F16_PEAK_TFLOPS, 4), "traffic": pmc_traffic("screen_b1024"),
+                "kernel_ms": round(ms_s, 4), "batch": BATCH, "docs_per_gpu": n_shard,
+                "hbm_GBps_same_launch": round((-(-BATCH // 512) * n_shard * DIM * 2) / ms_s / 1e6, 1),
+                "exact_fallback_tiles": flags}
+        ms = kernel_only_ms(q, docs, kp, iters=3, warm=1)
+        roof_f32 = {"bound": "mfma", "kernel": "score_topk_kernel<8,*,false> (fp32 MFMA 32x32x2), same batch",
+                    "achieved": round(flops / ms / 1e9, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(flops / ms / 1e9 / MFMA_F32_PEAK_TFLOPS, 4), "traffic": pmc_traffic("b1024"),
+                    "kernel_ms": round(ms, 4), "batch": BATCH, "docs_per_gpu": n_shard,
+                    "qps": round(BATCH / ms * 1e3, 1)}
         qb = q[:32].contiguous()
         ms32 = kernel_only_ms(qb, docs, TOPK)
         byts = n_shard * DIM * 4 + 32 * DIM * 4 + 32 * TOPK * 12
@@ -190,9 +227,11 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"exact cosine top-{TOPK} of B={BATCH} queries over {N_DOCS} x {DIM} fp32 unit-norm "
                                    f"passages resident in HBM (BASELINE configs[3]; configs[1] batch), row-sharded "
-                                   f"over {world} GPU(s)" + (f", per-shard top-{SHARD_K} + RCCL all-gather + merge" if world > 1 else ""),
+                                   f"over {world} GPU(s), screened path (f16-MFMA filter + exact fp32 rescoring, "
+                                   f"bit-identical to the fp32 kernel)"
+                                   + (f", per-shard top-{SHARD_K} + RCCL all-gather + merge" if world > 1 else ""),
                        "n_docs": N_DOCS, "dim": DIM, "batch": BATCH, "k": TOPK, "parallelism": f"rowshard{world}"},
-            "roofline": roof, "roofline_hbm": roof_hbm,
+            "roofline": roof, "roofline_exact_f32": roof_f32, "roofline_hbm": roof_hbm,
         }
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(q, docs)

@@ -45,6 +45,12 @@ enum tt_status {
 const char *tt_version(void);
 const char *tt_last_error(void);
 
+/* hipEvent wrappers for hosts without HIP headers: used with the `prof_events` arguments (a HOST array
+ * of two events recorded on the stream right before / after an entry point's dominant kernel). */
+int tt_event_create(void **ev);
+int tt_event_destroy(void *ev);
+int tt_event_elapsed_ms(void *start, void *stop, float *ms); /* blocks until `stop` has happened */
+
 /* ------------------------------------------------------------------ */
 /* Brute-force scoring + top-k                                         */
 /* ------------------------------------------------------------------ */
@@ -86,13 +92,14 @@ int tt_score_topk_partials_f32(const float *Q, int B, int d, const float *D, int
  * guarantee exactness for some query (tie cluster too large, |q| beyond fp16) it sets
  * fallback_flag[query / 32] (device int32 array of ceil(B/32) entries) and the exact kernel,
  * predicated on those flags on the device, recomputes the flagged 32-query tiles -- no host
- * synchronisation.  Supported: d = 256, k <= 16, dmax_norm < 6e4.
+ * synchronisation.  Supported: d = 256, k <= 64, dmax_norm < 6e4.
  */
 int tt_index_build_f16(const float *D, int64_t N, int d, void *D16, float *stats, tt_stream_t stream);
 size_t tt_score_topk_screened_workspace_bytes(int B, int64_t N, int d, int k);
 int tt_score_topk_screened_f32(const float *Q, int B, int d, const float *D32, const void *D16, int64_t N, int k,
                                float dmax_norm, int64_t idx_offset, float *out_val, int64_t *out_idx,
-                               int32_t *fallback_flag, void *workspace, size_t workspace_bytes, tt_stream_t stream);
+                               int32_t *fallback_flag, void *workspace, size_t workspace_bytes,
+                               void *const *prof_events /*host, nullable*/, tt_stream_t stream);
 
 /*
  * Merge of partial top-k lists (per tile, per shard after the RCCL all-gather:

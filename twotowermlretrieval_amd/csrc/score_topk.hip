@@ -784,6 +784,8 @@ TT_EXPORT int tt_topk_merge(const float *in_val, const int64_t *in_idx, int B, i
 {
     if (B < 0 || M < 0 || k <= 0)
         return tt_fail(TT_ERR_BAD_SHAPE, "tt_topk_merge: B=%d M=%d k=%d", B, M, k);
+    if (k > MERGE_KMAX)
+        return tt_fail(TT_ERR_UNSUPPORTED, "tt_topk_merge: k=%d > %d", k, MERGE_KMAX);
     if (B == 0)
         return TT_OK;
     hipLaunchKernelGGL(topk_merge_kernel, dim3(B), dim3(MERGE_THREADS), 0, (hipStream_t)stream, in_val, in_idx, M,

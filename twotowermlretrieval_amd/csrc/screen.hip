@@ -592,7 +592,7 @@ struct SPlan {
     size_t cand_off, pcnt_off, smax_val_off, smax_idx_off, sthr_val_off, sthr_idx_off, ws_bytes, lds;
 };
 
-constexpr int SAMPLE_CHUNKS = 128;
+constexpr int SAMPLE_CHUNKS_MAX = 512; // maxima per query the sample pass can produce (>= 8k wanted)
 constexpr int64_t SAMPLE_MIN_N = 524288;
 
 int screen_cus()
@@ -606,13 +606,15 @@ int screen_cus()
     return cus;
 }
 
-SPlan make_splan(int B, int64_t N)
+SPlan make_splan(int B, int64_t N, int k)
 {
     SPlan pl;
     pl.n_qgroups = (B + SQ_PER_BLOCK - 1) / SQ_PER_BLOCK;
     pl.n_tiles = (int)((N + 31) / 32);
     int want = (2 * screen_cus() + pl.n_qgroups - 1) / pl.n_qgroups; // two waves of workgroups per CU
-    const int max_chunks = 255; // finish kernel: one thread per chunk count; pooled entries are checked at run time
+    // finish kernel: one thread per chunk count (<= 255), and room in its pool for k + slack entries per chunk
+    int max_chunks = POOL_MAX / (k + 16);
+    max_chunks = max_chunks > 255 ? 255 : max_chunks;
     want = want > max_chunks ? max_chunks : want;
     want = want > pl.n_tiles ? pl.n_tiles : want;
     want = want < 1 ? 1 : want;
@@ -628,17 +630,19 @@ SPlan make_splan(int B, int64_t N)
     pl.sample = N >= SAMPLE_MIN_N;
     pl.s_docs = (N / 64 + 31) / 32 * 32;
     pl.s_tiles = (int)(pl.s_docs / 32);
-    pl.s_tiles_per_chunk = (pl.s_tiles + SAMPLE_CHUNKS - 1) / SAMPLE_CHUNKS;
+    int s_want = 8 * k < 128 ? 128 : 8 * k;
+    s_want = s_want > SAMPLE_CHUNKS_MAX ? SAMPLE_CHUNKS_MAX : s_want;
+    pl.s_tiles_per_chunk = (pl.s_tiles + s_want - 1) / s_want;
     pl.s_chunks = pl.sample ? (pl.s_tiles + pl.s_tiles_per_chunk - 1) / pl.s_tiles_per_chunk : 0;
     const size_t rows = (size_t)pl.n_qgroups * SQ_PER_BLOCK;
     pl.smax_val_off = off;
-    off = tt_align_up(off + rows * SAMPLE_CHUNKS * sizeof(float), 256);
+    off = tt_align_up(off + rows * SAMPLE_CHUNKS_MAX * sizeof(float), 256);
     pl.smax_idx_off = off;
-    off = tt_align_up(off + rows * SAMPLE_CHUNKS * sizeof(int64_t), 256);
+    off = tt_align_up(off + rows * SAMPLE_CHUNKS_MAX * sizeof(int64_t), 256);
     pl.sthr_val_off = off;
-    off = tt_align_up(off + rows * 16 * sizeof(float), 256);
+    off = tt_align_up(off + rows * 64 * sizeof(float), 256);
     pl.sthr_idx_off = off;
-    off = tt_align_up(off + rows * 16 * sizeof(int64_t), 256);
+    off = tt_align_up(off + rows * 64 * sizeof(int64_t), 256);
     pl.ws_bytes = off;
     pl.lds = (size_t)SRING * STILE_BYTES;
     return pl;
@@ -667,28 +671,28 @@ TT_EXPORT size_t tt_score_topk_screened_workspace_bytes(int B, int64_t N, int d,
 {
     if (B <= 0 || N <= 0)
         return 0;
-    return make_splan(B, N).ws_bytes + tt_score_topk_workspace_bytes(B, N, d, k);
+    return make_splan(B, N, k).ws_bytes + tt_score_topk_workspace_bytes(B, N, d, k);
 }
 
 TT_EXPORT int tt_score_topk_screened_f32(const float *Q, int B, int d, const float *D32, const void *D16, int64_t N,
                                          int k, float dmax_norm, int64_t idx_offset, float *out_val, int64_t *out_idx,
                                          int32_t *fallback_flag, void *workspace, size_t workspace_bytes,
-                                         tt_stream_t stream)
+                                         void *const *prof_events, tt_stream_t stream)
 {
     hipStream_t st = (hipStream_t)stream;
     if (B <= 0 || N <= 0 || k <= 0)
         return tt_fail(TT_ERR_BAD_SHAPE, "tt_score_topk_screened_f32: B=%d N=%lld k=%d", B, (long long)N, k);
     if (d != 256)
         return tt_fail(TT_ERR_UNSUPPORTED, "tt_score_topk_screened_f32: d=%d (supported: 256)", d);
-    if (k > 16)
-        return tt_fail(TT_ERR_UNSUPPORTED, "tt_score_topk_screened_f32: k=%d > 16", k);
+    if (k > 64)
+        return tt_fail(TT_ERR_UNSUPPORTED, "tt_score_topk_screened_f32: k=%d > 64", k);
     if (N >= (int64_t)INT_MAX - 64)
         return tt_fail(TT_ERR_UNSUPPORTED, "tt_score_topk_screened_f32: N too large; shard the corpus");
     if (!(dmax_norm >= 0.0f) || !(dmax_norm < 60000.0f))
         return tt_fail(TT_ERR_UNSUPPORTED, "tt_score_topk_screened_f32: corpus norm %g outside the fp16 range", dmax_norm);
     if (!Q || !D32 || !D16 || !out_val || !out_idx || !fallback_flag)
         return tt_fail(TT_ERR_BAD_SHAPE, "tt_score_topk_screened_f32: null pointer");
-    const SPlan pl = make_splan(B, N);
+    const SPlan pl = make_splan(B, N, k);
     const size_t need = pl.ws_bytes + tt_score_topk_workspace_bytes(B, N, d, k);
     if (!workspace || workspace_bytes < need || ((uintptr_t)workspace & 255))
         return tt_fail(TT_ERR_WORKSPACE, "tt_score_topk_screened_f32: workspace %zu < %zu bytes", workspace_bytes, need);
@@ -730,8 +734,12 @@ TT_EXPORT int tt_score_topk_screened_f32(const float *Q, int B, int d, const flo
             return rc;
         sp.thr0 = (const float *)(ws + pl.sthr_val_off);
     }
+    if (prof_events)
+        TT_HIP_CHECK(hipEventRecord((hipEvent_t)prof_events[0], st));
     hipLaunchKernelGGL(screen_kernel<false>, dim3(pl.n_blocks), dim3(SW * 64), pl.lds, st, sp);
     TT_LAUNCH_CHECK();
+    if (prof_events)
+        TT_HIP_CHECK(hipEventRecord((hipEvent_t)prof_events[1], st));
 
     FinishParams fp;
     fp.Q = Q;

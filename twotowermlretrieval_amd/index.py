@@ -134,11 +134,11 @@ class BruteForceIndex:
     def ntotal(self) -> int:
         return self.docs.shape[0]
 
-    def search(self, q: torch.Tensor, k: int = 10) -> Tuple[torch.Tensor, torch.Tensor]:
+    def search(self, q: torch.Tensor, k: int = 10, _prof_events=None) -> Tuple[torch.Tensor, torch.Tensor]:
         B = 1 if q.dim() == 1 else q.shape[0]
         N, d = self.docs.shape
         L = _lib.lib()
-        if self.docs16 is not None and q.dim() == 2 and B >= SCREEN_MIN_BATCH and k <= 16:
+        if self.docs16 is not None and q.dim() == 2 and B >= SCREEN_MIN_BATCH and k <= 64:
             _need_cuda(q)
             q = _f32c(q)
             if q.shape[1] != d:
@@ -154,7 +154,8 @@ class BruteForceIndex:
                 _lib.check(L.tt_score_topk_screened_f32(q.data_ptr(), B, d, self.docs.data_ptr(), self.docs16.data_ptr(),
                                                         N, k, self.dmax_norm, self.idx_offset, vals.data_ptr(),
                                                         idx.data_ptr(), self.fallback_flags.data_ptr(),
-                                                        self._ws_s.data_ptr(), self._ws_s.numel(), _stream(q)))
+                                                        self._ws_s.data_ptr(), self._ws_s.numel(), _prof_events,
+                                                        _stream(q)))
             return vals, idx
         need = L.tt_score_topk_workspace_bytes(B, N, d, k)
         if self._ws is None or self._ws.numel() < need:
