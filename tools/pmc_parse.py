@@ -8,7 +8,7 @@ for d in sys.argv[1:]:
     for f in Path(d).rglob("*counter_collection.csv"):
         for row in csv.DictReader(open(f)):
             name = row.get("Kernel_Name", "")
-            if "score_topk" not in name and "merge" not in name and "gru" not in name:
+            if not any(t in name for t in ("score_topk", "merge", "gru", "screen", "sgemm")):
                 continue
             grid = row.get("Grid_Size", "")
             acc[(name[:70], grid, row["Counter_Name"])].append(float(row["Counter_Value"]))

@@ -48,7 +48,8 @@ constexpr int SW = 8;                 // waves per workgroup
 constexpr int SQ_PER_WAVE = 64;       // queries per wave (two 32-wide MFMA column tiles)
 constexpr int SQ_PER_BLOCK = SW * SQ_PER_WAVE;
 constexpr int STILE_BYTES = 32 * 512; // 32 docs x 256 f16
-constexpr int SRING = 4;
+constexpr int SRING = 8;              // ring depth in tiles
+constexpr int STPB = 2;               // tiles per barrier interval (waves drift freely inside one)
 constexpr int SCAP = 128;             // candidate entries per (workgroup, query)
 constexpr int SURV_MAX = 256;         // survivors per query the finish kernel can rescore
 constexpr int POOL_MAX = 8192;        // candidates per query the finish kernel can pool
@@ -251,17 +252,22 @@ __global__ __launch_bounds__(SW * 64, 2) void screen_kernel(ScreenParams p)
     };
 
     if (t0 < t1) {
+        // DMA runs SRING - STPB tiles ahead; one barrier per STPB tiles.
 #pragma unroll
-        for (int g = 0; g < SRING - 1; ++g)
+        for (int g = 0; g < SRING - STPB; ++g)
             dma_issue(t0 + g, g);
         int stage = 0;
         const int rd_base = j * 512;
         for (int tile = t0; tile < t1; ++tile) {
-            // own DMAs of this tile have landed; the barrier extends that to every wave's, and also
-            // guarantees every wave is done reading the tile consumed in the previous iteration
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (SRING - 2)) : "memory");
-            __builtin_amdgcn_s_barrier();
-            dma_issue(tile + SRING - 1, (stage + SRING - 1) % SRING);
+            if ((tile - t0) % STPB == 0) {
+                // own DMAs of this interval's tiles have landed; the barrier extends that to every wave's
+                // and guarantees every wave is done reading the tiles of the previous interval
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (SRING - 2 * STPB)) : "memory");
+                __builtin_amdgcn_s_barrier();
+#pragma unroll
+                for (int u = 0; u < STPB; ++u)
+                    dma_issue(tile + SRING - STPB + u, (stage + SRING - STPB + u) % SRING);
+            }
             if (wave_live) {
                 f32x16 acc0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
                 f32x16 acc1 = acc0;
