@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""Secondary metrics: encoder tokens/s and training triplets/s on synthetic MS-MARCO-shaped
+batches (V=400003, E=300, H=256, 1-layer GRU; queries ~Poisson(6), passages ~Poisson(70) clipped to [10,250])."""
+import argparse, json, sys, time
+from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+import numpy as np
+import torch
+import twotowermlretrieval_amd as tt
+
+def make_ids(rs, B, mean, lo, hi, V):
+    L = np.clip(rs.poisson(mean, B), lo, hi)
+    T = int(L.max())
+    ids = np.zeros((B, T), dtype=np.int64)
+    for b in range(B):
+        z = rs.zipf(1.07, L[b]) % V          # Zipf over [0,V): id 0 ("the") shows up inside sentences
+        z[0] = max(z[0], 1)
+        ids[b, :L[b]] = z
+    return torch.from_numpy(ids), int((ids != 0).sum())
+
+def timeit(fn, iters=10, warm=3):
+    for _ in range(warm): fn()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(iters): fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / iters
+
+def main():
+    ap = argparse.ArgumentParser(); ap.add_argument("--batch", type=int, default=512); a = ap.parse_args()
+    dev = torch.device("cuda"); rs = np.random.RandomState(0)
+    V, E, H = 400003, 300, 256
+    table = (rs.standard_normal((V, E)) * 0.3).astype(np.float32)
+    torch.manual_seed(0)
+    m = tt.TwoTowerModel({"VOCAB_SIZE": V, "EMBED_DIM": E, "HIDDEN_DIM": H}, table).to(dev)
+    for enc in (m.query_encoder, m.doc_encoder): enc.check_inputs = False
+    B = a.batch
+    q, qt = make_ids(rs, B, 6, 1, 30, V); p, pt = make_ids(rs, B, 70, 10, 250, V); n, nt = make_ids(rs, B, 70, 10, 250, V)
+    q, p, n = q.to(dev), p.to(dev), n.to(dev)
+    m.eval()
+    with torch.no_grad():
+        t_doc = timeit(lambda: m.encode_document(p))
+        t_q = timeit(lambda: m.encode_query(q))
+        big, bt = make_ids(rs, 8192, 70, 10, 250, V); big = big.to(dev)
+        t_big = timeit(lambda: m.encode_document(big), iters=3, warm=1)
+    print(json.dumps(dict(what="doc tower fwd", B=B, T=p.shape[1], tokens=pt, ms=round(t_doc*1e3, 3), tokens_per_s=round(pt/t_doc))), flush=True)
+    print(json.dumps(dict(what="query tower fwd", B=B, T=q.shape[1], tokens=qt, ms=round(t_q*1e3, 3), queries_per_s=round(B/t_q))), flush=True)
+    print(json.dumps(dict(what="index build fwd", B=8192, T=big.shape[1], tokens=bt, ms=round(t_big*1e3, 3), tokens_per_s=round(bt/t_big), docs_per_s=round(8192/t_big))), flush=True)
+    m.train()
+    opt = tt.FusedClipAdam(m.parameters(), lr=5e-5, max_norm=1.0)
+    t_tr = timeit(lambda: tt.train_step(m, opt, q, p, n, margin=0.5), iters=5, warm=2)
+    print(json.dumps(dict(what="train step (fwd+bwd+clip+adam)", triplets=B, tokens=qt+pt+nt, ms=round(t_tr*1e3, 3), triplets_per_s=round(B/t_tr))), flush=True)
+
+if __name__ == "__main__":
+    main()

@@ -206,9 +206,9 @@ class ShardedIndex:
         import torch.distributed as dist
         kp = max(k, self.shard_k)
         vals, idx = self._search(q, kp)
-        world = dist.get_world_size(self.group) if dist.is_initialized() else 1
-        if world == 1:
+        if not dist.is_initialized():
             return self._merge(vals, idx, k)
+        world = dist.get_world_size(self.group)  # a 1-rank group still takes the collective path
         B = vals.shape[0]
         # one collective: [vals bytes | idx bytes] per rank
         packed = torch.cat([vals.contiguous().view(torch.uint8).reshape(-1),
