@@ -172,14 +172,34 @@ __global__ __launch_bounds__(WPB * 64, 2) void score_topk_kernel(ScoreParams p)
     const int j = lane & 31;
 
     // ---- query operand: lane (j,h) keeps Q[qrow][2s+h] --------------------
+    // Staged through the (still idle) ring so the global reads are whole 512-B rows instead of
+    // 4-byte strided accesses: coalesced global_load_dwordx4 -> swizzled ds_write_b128 -> ds_read_b128.
     const int qrow = qtile * 32 + j;
     float qreg[NS * 16];
     {
-        const float *qp = p.Q + (size_t)min(qrow, p.B - 1) * (NS * 32) + h;
-        const bool live = qrow < p.B;
+        constexpr int F = NS >= 4 ? 128 : NS * 32; // features per pass (32 rows x F floats <= 16 KiB)
+        constexpr int NPASS = NS * 32 / F;
+        constexpr int CPR = F / 4;                 // 16-byte chunks per row
 #pragma unroll
-        for (int s = 0; s < NS * 16; ++s)
-            qreg[s] = live ? qp[2 * s] : 0.0f;
+        for (int pass = 0; pass < NPASS; ++pass) {
+#pragma unroll
+            for (int i = 0; i < F / 8; ++i) {
+                const int idx = i * 64 + lane;
+                const int row = idx / CPR, ch = idx % CPR;
+                const int gr = qtile * 32 + row;
+                f32x4 v = {0, 0, 0, 0};
+                if (gr < p.B)
+                    v = *(const f32x4 *)(p.Q + (size_t)gr * (NS * 32) + pass * F + ch * 4);
+                *(f32x4 *)(ring + row * (F * 4) + ((ch ^ (row & 15)) << 4)) = v;
+            }
+#pragma unroll
+            for (int t = 0; t < CPR; ++t) {
+                const f32x4 v = *(const f32x4 *)(ring + j * (F * 4) + ((t ^ (j & 15)) << 4));
+                qreg[pass * (F / 2) + 2 * t] = h ? v.y : v.x;
+                qreg[pass * (F / 2) + 2 * t + 1] = h ? v.w : v.z;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // reads done before the region is rewritten
+        }
     }
     // Selection state of query j, replicated in lanes j and j+32:
     //   thr = a proven lower bound of the query's final k-th score (documents below it are dropped),
@@ -469,12 +489,18 @@ __global__ __launch_bounds__(MERGE_THREADS) void topk_merge_kernel(const float *
         if (pool_n + MERGE_SEG > MERGE_POOL) // block-uniform (pool_n read after a barrier)
             reduce_pool();
         const int end = min(base + MERGE_SEG, M);
-        for (int m = base + tid; m < end; m += MERGE_THREADS) {
-            const int64_t ci = ix[m];
-            if (ci >= 0) {
+        int64_t ci[MERGE_SEG / MERGE_THREADS];
+#pragma unroll
+        for (int u = 0; u < MERGE_SEG / MERGE_THREADS; ++u) { // all index loads in flight together
+            const int m = base + tid + u * MERGE_THREADS;
+            ci[u] = m < end ? ix[m] : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < MERGE_SEG / MERGE_THREADS; ++u) {
+            if (ci[u] >= 0) {
                 const int slot = atomicAdd(&pool_n, 1);
-                pool_v[slot] = v[m];
-                pool_i[slot] = ci;
+                pool_v[slot] = v[base + tid + u * MERGE_THREADS];
+                pool_i[slot] = ci[u];
             }
         }
         __syncthreads();
