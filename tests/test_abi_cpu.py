@@ -49,9 +49,9 @@ def test_workspace_query_needs_no_gpu(libtt):
 
 def test_argument_validation_without_gpu(libtt):
     from twotowermlretrieval_amd import _lib
-    rc = libtt.tt_score_topk_f32(None, 4, 100, None, 10, 5, 0, None, None, None, 0, None)
+    rc = libtt.tt_score_topk_f32(None, 4, 100, None, 10, 5, 0, ctypes.c_void_p(16), ctypes.c_void_p(16), None, 0, None)
     assert rc == _lib.TT_ERR_UNSUPPORTED and b"d=100" in libtt.tt_last_error()
-    rc = libtt.tt_score_topk_f32(None, 4, 256, None, 10, 65, 0, None, None, None, 0, None)
+    rc = libtt.tt_score_topk_f32(None, 4, 256, None, 10, 65, 0, ctypes.c_void_p(16), ctypes.c_void_p(16), None, 0, None)
     assert rc == _lib.TT_ERR_UNSUPPORTED
     rc = libtt.tt_topk_merge(None, None, -1, 0, 5, None, None, None)
     assert rc == _lib.TT_ERR_BAD_SHAPE

@@ -1,0 +1,75 @@
+"""Evaluator shells and artifact export against the reference's recorded BatchEvaluator numbers
+(tests/golden/g7_batch_eval.npz) and the artifact formats of backend/main.py:92-138."""
+import json
+import pickle
+
+import numpy as np
+import pytest
+import torch
+
+import synth
+
+pytestmark = pytest.mark.gpu
+
+
+class _Stub:
+    """Stands in for a model: returns the recorded embeddings (same trick as the golden generator)."""
+
+    def __init__(self, g):
+        self.q, self.d, self.n = (torch.from_numpy(g[k]).cuda() for k in ("q", "d", "n"))
+
+    def eval(self):
+        pass
+
+    def encode_query(self, x):
+        return self.q[x[:, 0]]
+
+    def encode_document(self, x):
+        return torch.where((x[:, 1] == 0)[:, None], self.d[x[:, 0]], self.n[x[:, 0]])
+
+
+def test_batch_evaluator_matches_reference(golden):
+    from twotowermlretrieval_amd.evaluators import BatchEvaluator
+    g = golden("g7_batch_eval.npz")
+    loader = []
+    for s in range(0, 48, 16):
+        r = torch.arange(s, s + 16)
+        loader.append((torch.stack([r, torch.zeros_like(r)], 1), torch.stack([r, torch.zeros_like(r)], 1),
+                       torch.stack([r, torch.ones_like(r)], 1)))
+    metrics, val_loss = BatchEvaluator().evaluate(_Stub(g), loader, torch.device("cuda"), {"MARGIN": 0.5})
+    assert abs(metrics["MRR"] - float(g["mrr"])) < 1e-9
+    for k in (1, 5, 10):
+        assert abs(metrics[f"Recall@{k}"] - float(g[f"recall{k}"])) < 1e-12
+    assert abs(val_loss - float(g["val_loss"])) < 1e-6
+
+
+def test_artifact_export_round_trip(tmp_path, oracle):
+    import twotowermlretrieval_amd as tt
+    from twotowermlretrieval_amd.evaluators import corpus_recall_hit, save_inference_artifacts
+    vocab = {w: i for i, w in enumerate(["the", ",", ".", "of", "and"] + [f"w{i}" for i in range(5, 60)])}
+    tok = tt.PretrainedTokenizer(word2idx=vocab)
+    V, E, H = tok.vocab_size(), 20, 32
+    table = synth.make_table(5, V, E)
+    cfg = {"HIDDEN_DIM": H, "NUM_LAYERS": 1, "BIDIRECTIONAL": False, "BATCH_SIZE": 16, "VOCAB_SIZE": V, "EMBED_DIM": E}
+    m = tt.TwoTowerModel(cfg, table).cuda()
+    rs = np.random.RandomState(0)
+    docs = [" ".join(f"w{rs.randint(5, 60)}" for _ in range(rs.randint(3, 15))) for _ in range(70)]
+    emb = save_inference_artifacts(tmp_path, m, {k: v for k, v in cfg.items() if k not in ("VOCAB_SIZE", "EMBED_DIM")},
+                                   tok, docs, torch.device("cuda"))
+    loaded = np.load(tmp_path / "document_embeddings.npy")
+    assert loaded.shape == (70, H) and loaded.dtype == np.float32 and loaded.flags.c_contiguous
+    assert pickle.load(open(tmp_path / "documents.pkl", "rb")) == docs
+    saved_cfg = json.loads((tmp_path / "config.json").read_text())
+    assert saved_cfg["VOCAB_SIZE"] == V and saved_cfg["EMBED_DIM"] == E
+    # the exported rows are what the oracle computes for the same padded batches
+    quads = [tuple(p.detach().cpu().numpy() for p in quad) for quad in m.doc_encoder.rnn.quads()]
+    ids = tok.encode_batch(docs[:16]).numpy()
+    np.testing.assert_allclose(loaded[:16], oracle.encoder_forward(ids, table, quads, H), atol=1e-5)
+    # the inferencer loads the directory; a document's own text retrieves it
+    inf = tt.QueryInferencer(str(tmp_path))
+    D = torch.from_numpy(loaded).cuda()
+    sd = torch.load(tmp_path / "model.pth")
+    assert set(sd.keys()) == set(m.state_dict().keys())
+    qe = torch.from_numpy(inf.get_query_embedding(docs[3])).cuda()
+    res = corpus_recall_hit(qe, D, positives=[3], top_k=(1, 5))
+    assert set(res) == {"Recall@1", "Hit@1", "Recall@5", "Hit@5"} and 0.0 <= res["Recall@5"] <= 1.0

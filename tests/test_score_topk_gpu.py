@@ -47,7 +47,7 @@ def test_golden_reference_topk(tt, golden, k):
     (1, 1, 256, 1), (1, 31, 256, 5), (5, 32, 256, 10), (32, 33, 256, 10), (33, 1000, 256, 10),
     (70, 4103, 256, 16), (7, 2500, 256, 17), (40, 3000, 256, 50), (3, 5000, 256, 64),
     (9, 777, 128, 10), (64, 2049, 128, 50), (4, 600, 64, 7), (1, 100000, 256, 10),
-    (2, 3, 256, 10), (1, 9, 64, 64),
+    (2, 3, 256, 10), (1, 9, 64, 64), (11, 900, 32, 10), (40, 2000, 96, 5), (5, 1500, 192, 20),
 ])
 def test_bit_exact_vs_oracle(tt, oracle, B, N, d, k):
     Q = synth.unit_rows(11 + B, B, d)

@@ -177,9 +177,10 @@ __global__ __launch_bounds__(WPB * 64, 2) void score_topk_kernel(ScoreParams p)
     const int qrow = qtile * 32 + j;
     float qreg[NS * 16];
     {
-        constexpr int F = NS >= 4 ? 128 : NS * 32; // features per pass (32 rows x F floats <= 16 KiB)
+        constexpr int F = NS % 4 == 0 ? 128 : (NS % 2 == 0 ? 64 : 32); // features per pass (32 x F floats <= 16 KiB)
         constexpr int NPASS = NS * 32 / F;
         constexpr int CPR = F / 4;                 // 16-byte chunks per row
+        constexpr int SWZ = CPR >= 16 ? 15 : CPR - 1;
 #pragma unroll
         for (int pass = 0; pass < NPASS; ++pass) {
 #pragma unroll
@@ -190,11 +191,11 @@ __global__ __launch_bounds__(WPB * 64, 2) void score_topk_kernel(ScoreParams p)
                 f32x4 v = {0, 0, 0, 0};
                 if (gr < p.B)
                     v = *(const f32x4 *)(p.Q + (size_t)gr * (NS * 32) + pass * F + ch * 4);
-                *(f32x4 *)(ring + row * (F * 4) + ((ch ^ (row & 15)) << 4)) = v;
+                *(f32x4 *)(ring + row * (F * 4) + ((ch ^ (row & SWZ)) << 4)) = v;
             }
 #pragma unroll
             for (int t = 0; t < CPR; ++t) {
-                const f32x4 v = *(const f32x4 *)(ring + j * (F * 4) + ((t ^ (j & 15)) << 4));
+                const f32x4 v = *(const f32x4 *)(ring + j * (F * 4) + ((t ^ (j & SWZ)) << 4));
                 qreg[pass * (F / 2) + 2 * t] = h ? v.y : v.x;
                 qreg[pass * (F / 2) + 2 * t + 1] = h ? v.w : v.z;
             }
@@ -654,13 +655,26 @@ int launch_score_t(const ScoreParams &sp, const Plan &pl, hipStream_t st)
     return TT_OK;
 }
 
-int launch_score(int d, const ScoreParams &sp, const Plan &pl, hipStream_t st, bool maxonly)
+template <int NS>
+int launch_score_ns(const ScoreParams &sp, const Plan &pl, hipStream_t st, bool maxonly)
 {
     if (maxonly)
-        return d == 256 ? launch_score_t<8, 64, true>(sp, pl, st) : d == 128 ? launch_score_t<4, 64, true>(sp, pl, st) : launch_score_t<2, 64, true>(sp, pl, st);
-    if (pl.cap == 64)
-        return d == 256 ? launch_score_t<8, 64, false>(sp, pl, st) : d == 128 ? launch_score_t<4, 64, false>(sp, pl, st) : launch_score_t<2, 64, false>(sp, pl, st);
-    return d == 256 ? launch_score_t<8, 128, false>(sp, pl, st) : d == 128 ? launch_score_t<4, 128, false>(sp, pl, st) : launch_score_t<2, 128, false>(sp, pl, st);
+        return launch_score_t<NS, 64, true>(sp, pl, st);
+    return pl.cap == 64 ? launch_score_t<NS, 64, false>(sp, pl, st) : launch_score_t<NS, 128, false>(sp, pl, st);
+}
+
+constexpr bool score_dim_ok(int d) { return d == 32 || d == 64 || d == 96 || d == 128 || d == 192 || d == 256; }
+
+int launch_score(int d, const ScoreParams &sp, const Plan &pl, hipStream_t st, bool maxonly)
+{
+    switch (d) {
+    case 32: return launch_score_ns<1>(sp, pl, st, maxonly);
+    case 64: return launch_score_ns<2>(sp, pl, st, maxonly);
+    case 96: return launch_score_ns<3>(sp, pl, st, maxonly);
+    case 128: return launch_score_ns<4>(sp, pl, st, maxonly);
+    case 192: return launch_score_ns<6>(sp, pl, st, maxonly);
+    default: return launch_score_ns<8>(sp, pl, st, maxonly);
+    }
 }
 
 ScoreParams pass_params(const Pass &ps, const float *Q, int B, const float *D, int k, int64_t idx_offset, char *ws,
@@ -694,8 +708,8 @@ int score_partials(const float *Q, int B, int d, const float *D, int64_t N, int 
 {
     if (B <= 0 || N <= 0 || k <= 0)
         return tt_fail(TT_ERR_BAD_SHAPE, "%s: B=%d N=%lld k=%d", who, B, (long long)N, k);
-    if (d != 64 && d != 128 && d != 256)
-        return tt_fail(TT_ERR_UNSUPPORTED, "%s: d=%d (supported: 64, 128, 256)", who, d);
+    if (!score_dim_ok(d))
+        return tt_fail(TT_ERR_UNSUPPORTED, "%s: d=%d (supported: 32, 64, 96, 128, 192, 256)", who, d);
     if (k > 64)
         return tt_fail(TT_ERR_UNSUPPORTED, "%s: k=%d > 64", who, k);
     if (N >= (int64_t)INT_MAX - 64)
@@ -782,8 +796,8 @@ int tt_score_topk_f32_pred(const float *Q, int B, int d, const float *D, int64_t
         return tt_fail(TT_ERR_BAD_SHAPE, "tt_score_topk_f32: B=%d N=%lld k=%d", B, (long long)N, k);
     if (B == 0)
         return TT_OK;
-    if (d != 64 && d != 128 && d != 256)
-        return tt_fail(TT_ERR_UNSUPPORTED, "tt_score_topk_f32: d=%d (supported: 64, 128, 256)", d);
+    if (!score_dim_ok(d))
+        return tt_fail(TT_ERR_UNSUPPORTED, "tt_score_topk_f32: d=%d (supported: 32, 64, 96, 128, 192, 256)", d);
     if (k > 64)
         return tt_fail(TT_ERR_UNSUPPORTED, "tt_score_topk_f32: k=%d > 64", k);
     if (!out_val || !out_idx)

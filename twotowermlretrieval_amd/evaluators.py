@@ -1,0 +1,101 @@
+"""Metric shells of the reference's evaluators (backend/evaluators.py) on top of the HIP kernels.
+
+Only the arithmetic-heavy parts are reproduced -- the reference's Python bookkeeping around them
+(printing, random sampling of candidate documents) is out of scope:
+
+  * BatchEvaluator (evaluators.py:18-79): validation loss + Recall@{1,5,10} + MRR with the positive of
+    query i at index i.  The reference builds the full [Nq,Nq] score matrix (:50) and SORTS every row
+    (:62) to find one rank; here `score_rank` counts the documents ranking before the positive in one
+    streaming pass (ties: index ascending; the reference's torch.sort leaves tie order unspecified).
+  * corpus_recall_hit (evaluators.py:177-209): Recall@k / Hit@k of one query against a document-
+    embedding matrix, via the fused `score_topk`.
+  * embed_documents (evaluators.py:162-175, 240-250; main.py:125-138): batches of strings ->
+    [N,H] document embeddings through tokenizer.encode_batch + model.encode_document.
+"""
+from __future__ import annotations
+
+from typing import Dict, Iterable, List, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from .index import score_rank, score_topk
+from .model import triplet_loss_cosine
+
+
+class BatchEvaluator:
+    def __init__(self, top_k: List[int] = [1, 5, 10]):
+        self.top_k = top_k
+
+    def evaluate(self, model, val_loader: Iterable[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]],
+                 device: torch.device, config: Dict):
+        model.eval()
+        q_all, d_all, losses = [], [], []
+        with torch.no_grad():
+            for queries, pos_docs, neg_docs in val_loader:
+                queries, pos_docs, neg_docs = queries.to(device), pos_docs.to(device), neg_docs.to(device)
+                q = model.encode_query(queries)
+                d = model.encode_document(pos_docs)
+                n = model.encode_document(neg_docs)
+                losses.append(triplet_loss_cosine((q, d, n), margin=config.get("MARGIN", 0.2)))
+                q_all.append(q)
+                d_all.append(d)
+        if not q_all:
+            return {}, 0
+        q_embs, d_embs = torch.cat(q_all), torch.cat(d_all)
+        rank = score_rank(q_embs, d_embs, torch.arange(q_embs.shape[0], device=q_embs.device)).to(torch.float64)
+        metrics = {f"Recall@{k}": float((rank <= k).double().mean().item()) for k in self.top_k}
+        metrics["MRR"] = float((1.0 / rank).mean().item())
+        return metrics, float(torch.stack(losses).mean().item())
+
+
+def embed_documents(model, tokenizer, documents: Sequence[str], device: torch.device, batch_size: int = 64) -> torch.Tensor:
+    """[len(documents), H] fp32 on the device, row i <-> documents[i] (the document_embeddings.npy layout)."""
+    out = []
+    with torch.no_grad():
+        for i in range(0, len(documents), batch_size):
+            ids = tokenizer.encode_batch(documents[i:i + batch_size]).to(device)
+            out.append(model.encode_document(ids))
+    return torch.cat(out) if out else torch.empty((0, 0), device=device)
+
+
+def corpus_recall_hit(query_emb: torch.Tensor, doc_embeddings: torch.Tensor, positives: Sequence[int],
+                      top_k: Sequence[int] = (1, 5, 10)) -> Dict[str, float]:
+    """Recall@k = found positives / available positives, Hit@k = any positive found (evaluators.py:197-207).
+    `positives` are row indices of doc_embeddings."""
+    pos = set(int(p) for p in positives)
+    if not pos:
+        return {}
+    _, idx = score_topk(query_emb.reshape(1, -1), doc_embeddings, max(top_k))
+    top = [int(i) for i in idx[0].tolist()]
+    res = {}
+    for k in top_k:
+        found = len([i for i in top[:k] if i in pos])
+        res[f"Recall@{k}"] = found / len(pos)
+        res[f"Hit@{k}"] = 1 if found else 0
+    return res
+
+
+def save_inference_artifacts(output_dir, model, config: Dict, tokenizer, documents: Sequence[str], device) -> np.ndarray:
+    """The dense half of backend/main.py:92-138: model.pth, config.json (+VOCAB_SIZE, EMBED_DIM),
+    word_to_idx.pkl, documents.pkl and document_embeddings.npy ([N,H] fp32, C order, row i <-> documents[i]).
+    (The TF-IDF artifact of main.py:140-149 is CPU/sklearn work and out of scope.)"""
+    import json
+    import pickle
+    from pathlib import Path
+    out = Path(output_dir)
+    out.mkdir(parents=True, exist_ok=True)
+    torch.save(model.state_dict(), out / "model.pth")
+    cfg = dict(config)
+    cfg["VOCAB_SIZE"] = tokenizer.vocab_size()
+    cfg["EMBED_DIM"] = model.query_encoder.embedding.embedding_dim
+    (out / "config.json").write_text(json.dumps(cfg, indent=4))
+    with open(out / "word_to_idx.pkl", "wb") as f:
+        pickle.dump({w: i for w, i in tokenizer.word2idx.items()}, f)
+    docs = list(documents)
+    model.eval()
+    emb = embed_documents(model, tokenizer, docs, device, config.get("BATCH_SIZE", 64)).cpu().numpy()
+    with open(out / "documents.pkl", "wb") as f:
+        pickle.dump(docs, f)
+    np.save(out / "document_embeddings.npy", emb)
+    return emb
