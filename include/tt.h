@@ -135,8 +135,12 @@ int tt_score_rank_f32(const float *Q, int B, int d, const float *D, int64_t N, c
  * weights: HOST array of 4*num_layers*ndir DEVICE pointers, index (layer*ndir + dir)*4 +
  * {0: weight_ih [3H,I], 1: weight_hh [3H,H], 2: bias_ih [3H], 3: bias_hh [3H]} = the reference's
  * state_dict tensors rnn.{weight_ih,weight_hh,bias_ih,bias_hh}_l{layer}[_reverse]; I = E for
- * layer 0, ndir*H above.  proj_w [H,2H], proj_b [H] only when bidirectional.  Inter-layer
- * dropout is the identity (eval mode / DROPOUT 0).
+ * layer 0, ndir*H above.  proj_w [H,2H], proj_b [H] only when bidirectional.
+ * Inter-layer dropout (nn.GRU(dropout=p), config.json DROPOUT) is applied when train != 0,
+ * dropout_p > 0 and num_layers > 1: the output sequence of every layer but the last is multiplied by
+ * a Bernoulli(1-p) mask / (1-p).  torch's RNG stream cannot be matched, so the mask is DEFINED as a
+ * counter-based hash of (dropout_seed, layer, element) -- the same function in oracle/tt_oracle.c --
+ * which the backward pass regenerates (pass the same dropout_p / dropout_seed to it).
  * Lengths are computed on the device; nothing synchronises with the host.  Data errors cannot be
  * returned synchronously, so they are reported through `status` (device int32, nullable), written
  * on the stream: bit 0 = a row with no non-zero id (the reference raises RuntimeError), bit 1 = an
@@ -145,11 +149,13 @@ int tt_score_rank_f32(const float *Q, int B, int d, const float *D, int64_t N, c
  * (sized with train = 1) must then be passed, untouched, to tt_encoder_backward_f32.
  * Supported: H multiple of 32 in [32,512], E multiple of 4, 1 <= num_layers <= 4.
  */
-size_t tt_encoder_workspace_bytes(int B, int T, int E, int H, int num_layers, int bidirectional, int train);
+size_t tt_encoder_workspace_bytes(int B, int T, int E, int H, int num_layers, int bidirectional, int train,
+                                  int dropout /* train && dropout_p > 0 && num_layers > 1 */);
 int tt_encoder_forward_f32(const int64_t *ids, int B, int T, const float *table, int64_t V, int E, int H,
                            int num_layers, int bidirectional, const float *const *weights /*host array*/,
-                           const float *proj_w, const float *proj_b, int normalize, int train, float *out,
-                           void *workspace, size_t workspace_bytes, int32_t *status, tt_stream_t stream);
+                           const float *proj_w, const float *proj_b, int normalize, int train, float dropout_p,
+                           uint64_t dropout_seed, float *out, void *workspace, size_t workspace_bytes,
+                           int32_t *status, tt_stream_t stream);
 
 /*
  * Replaces loss.backward() through RNNEncoder.forward     backend/main.py:254 over model.py:48-75
@@ -160,9 +166,10 @@ int tt_encoder_forward_f32(const int64_t *ids, int B, int T, const float *table,
  */
 int tt_encoder_backward_f32(const int64_t *ids, int B, int T, const float *table, int64_t V, int E, int H,
                             int num_layers, int bidirectional, const float *const *weights /*host array*/,
-                            const float *proj_w, const float *proj_b, int normalize, const float *d_out,
-                            float *const *grads /*host array*/, float *g_proj_w, float *g_proj_b, void *workspace,
-                            size_t workspace_bytes, tt_stream_t stream);
+                            const float *proj_w, const float *proj_b, int normalize, float dropout_p,
+                            uint64_t dropout_seed, const float *d_out, float *const *grads /*host array*/,
+                            float *g_proj_w, float *g_proj_b, void *workspace, size_t workspace_bytes,
+                            tt_stream_t stream);
 
 /* ------------------------------------------------------------------ */
 /* Training step pieces                                                */

@@ -79,7 +79,7 @@ def _weight_ptrs(weights):
 
 
 def encoder_forward(ids, table, weights, hidden_dim, num_layers=1, bidirectional=False,
-                    proj_w=None, proj_b=None, normalize=True) -> np.ndarray:
+                    proj_w=None, proj_b=None, normalize=True, dropout_p=0.0, dropout_seed=0) -> np.ndarray:
     """RNNEncoder.forward (GRU).  weights: [(W_ih,W_hh,b_ih,b_hh)] per (layer,dir)."""
     ids = np.ascontiguousarray(ids, dtype=np.int64)
     table = _f32(table)
@@ -92,13 +92,13 @@ def encoder_forward(ids, table, weights, hidden_dim, num_layers=1, bidirectional
     out = np.zeros((B, H), dtype=np.float32)
     rc = lib().o_encoder_forward(_p(ids), B, T, _p(table), C.c_int64(V), E, H, int(num_layers),
                                  int(bool(bidirectional)), wp, _p(pw), _p(pb), int(bool(normalize)),
-                                 _p(out))
+                                 C.c_float(dropout_p), C.c_uint64(dropout_seed), _p(out))
     _check(rc, "o_encoder_forward")
     return out
 
 
 def encoder_backward(ids, table, weights, hidden_dim, d_out, num_layers=1, bidirectional=False,
-                     proj_w=None, proj_b=None, normalize=True):
+                     proj_w=None, proj_b=None, normalize=True, dropout_p=0.0, dropout_seed=0):
     """Returns (grads, g_proj_w, g_proj_b); grads mirrors `weights`."""
     ids = np.ascontiguousarray(ids, dtype=np.int64)
     table = _f32(table)
@@ -118,9 +118,16 @@ def encoder_backward(ids, table, weights, hidden_dim, d_out, num_layers=1, bidir
     d_out = _f32(d_out)
     rc = lib().o_encoder_backward(_p(ids), B, T, _p(table), C.c_int64(V), E, H, int(num_layers),
                                   int(bool(bidirectional)), wp, _p(pw), _p(pb),
-                                  int(bool(normalize)), _p(d_out), gp, _p(gpw), _p(gpb))
+                                  int(bool(normalize)), C.c_float(dropout_p), C.c_uint64(dropout_seed),
+                                  _p(d_out), gp, _p(gpw), _p(gpb))
     _check(rc, "o_encoder_backward")
     return grads, gpw, gpb
+
+
+def dropout_mask(seed, layer, n, p):
+    out = np.zeros(n, dtype=np.float32)
+    lib().o_dropout_mask(C.c_uint64(seed), int(layer), C.c_int64(n), C.c_float(p), _p(out))
+    return out
 
 
 def score_topk(Q, D, k, idx_offset=0):

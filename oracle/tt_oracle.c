@@ -159,6 +159,33 @@ void o_l2_normalize(const float *x, int B, int H, float *y)
 }
 
 /*
+ * Inter-layer dropout (nn.GRU(dropout=p), backend/model.py:31-37; config.json DROPOUT): in train mode
+ * the output sequence of every layer but the last is multiplied by a Bernoulli(1-p) mask / (1-p)
+ * before it feeds the next layer.  torch draws the mask from its own RNG stream, which cannot be
+ * matched; the build DEFINES the mask as a counter-based hash of (seed, layer, b, t, column) so the
+ * HIP kernels and this oracle agree bit for bit and the backward pass can regenerate it.
+ */
+static inline float o_dropout_scale(uint64_t seed, int layer, uint64_t idx, float p)
+{
+    uint64_t x = seed + 0x9E3779B97F4A7C15ull * (uint64_t)(layer + 1);
+    x ^= idx * 0xD1342543DE82EF95ull;
+    x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull;
+    x ^= x >> 27; x *= 0x94D049BB133111EBull;
+    x ^= x >> 31;
+    uint32_t u = (uint32_t)(x >> 32);
+    double t = (double)p * 4294967296.0;
+    uint32_t thresh = t >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)t;
+    return u >= thresh ? 1.0f / (1.0f - p) : 0.0f;
+}
+
+/* mask values for elements 0..n-1 of one layer boundary (test hook for the mask's statistics) */
+void o_dropout_mask(uint64_t seed, int layer, int64_t n, float p, float *out)
+{
+    for (int64_t i = 0; i < n; ++i)
+        out[i] = o_dropout_scale(seed, layer, (uint64_t)i, p);
+}
+
+/*
  * RNNEncoder.forward, GRU flavour.  backend/model.py:48-75
  * w holds 4 pointers per (layer, direction): index (layer*ndir + dir)*4 +
  * {0:W_ih [3H,I], 1:W_hh [3H,H], 2:b_ih [3H], 3:b_hh [3H]}; layer-0 I = E,
@@ -169,7 +196,8 @@ void o_l2_normalize(const float *x, int B, int H, float *y)
 int o_encoder_forward(const int64_t *ids, int B, int T, const float *table,
                       int64_t V, int E, int H, int num_layers, int bidir,
                       const float *const *w, const float *proj_w,
-                      const float *proj_b, int normalize, float *out)
+                      const float *proj_b, int normalize, float dropout_p,
+                      uint64_t dropout_seed, float *out)
 {
     if (B <= 0 || T <= 0 || num_layers < 1)
         return O_ERR_BAD_SHAPE;
@@ -208,6 +236,9 @@ int o_encoder_forward(const int64_t *ids, int B, int T, const float *table,
                        sizeof(float) * H);
         }
         I = ndir * H;
+        if (dropout_p > 0.0f && l + 1 < num_layers)
+            for (size_t i = 0; i < (size_t)B * T * I; ++i)
+                nxt[i] *= o_dropout_scale(dropout_seed, l, i, dropout_p);
         memcpy(cur, nxt, sizeof(float) * (size_t)B * T * I);
     }
     if (bidir) {
@@ -543,7 +574,8 @@ static int o_gru_layer_bwd(const float *x, int B, int T, int I,
 int o_encoder_backward(const int64_t *ids, int B, int T, const float *table,
                        int64_t V, int E, int H, int num_layers, int bidir,
                        const float *const *w, const float *proj_w,
-                       const float *proj_b, int normalize, const float *d_out,
+                       const float *proj_b, int normalize, float dropout_p,
+                       uint64_t dropout_seed, const float *d_out,
                        float *const *g, float *g_proj_w, float *g_proj_b)
 {
     int ndir = bidir ? 2 : 1;
@@ -593,6 +625,10 @@ int o_encoder_backward(const int64_t *ids, int B, int T, const float *table,
                        sizeof(float) * H);
         }
         I = ndir * H;
+        /* layer l+1 consumes the DROPPED sequence; the recurrence's own h (in the stash) is not dropped */
+        if (dropout_p > 0.0f && l + 1 < num_layers)
+            for (size_t i = 0; i < BT * I; ++i)
+                xin[l + 1][i] *= o_dropout_scale(dropout_seed, l, i, dropout_p);
     }
     /* head */
     if (bidir) {
@@ -651,8 +687,13 @@ int o_encoder_backward(const int64_t *ids, int B, int T, const float *table,
                 dtmp = (float *)malloc(sizeof(float) * BT * H);
                 if (!dtmp) { rc = O_ERR_NOMEM; goto done; }
                 for (size_t i = 0; i < BT; ++i)
-                    memcpy(dtmp + i * H, dseq + i * ndir * H + (size_t)d * H,
-                           sizeof(float) * H);
+                    for (int u = 0; u < H; ++u) {
+                        size_t ix = i * ndir * H + (size_t)d * H + u;
+                        float gv = dseq[ix]; /* gradient w.r.t. the dropped sequence */
+                        if (dropout_p > 0.0f)
+                            gv *= o_dropout_scale(dropout_seed, l, ix, dropout_p);
+                        dtmp[i * H + u] = gv;
+                    }
                 dos = dtmp;
             }
             float *zero_hf = NULL;

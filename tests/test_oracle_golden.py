@@ -188,3 +188,26 @@ def test_g10_error_cases(oracle):
     with pytest.raises(oracle.OracleError) as e:
         oracle.encoder_forward(np.array([[1, 64, 2]]), table, quads, 32)
     assert e.value.code == oracle.O_ERR_BAD_INDEX
+
+
+def test_dropout_mask_statistics_and_eval_identity(oracle):
+    """The build defines the inter-layer dropout mask (torch's RNG stream cannot be matched): check it
+    behaves like Bernoulli(1-p)/(1-p), differs per layer and per seed, and that p = 0 is the identity."""
+    for p in (0.2, 0.5):
+        m = oracle.dropout_mask(12345, 0, 400_000, p)
+        keep = m != 0
+        assert abs(keep.mean() - (1 - p)) < 4e-3
+        assert np.allclose(m[keep], 1.0 / (1.0 - p))
+        assert abs(m.mean() - 1.0) < 1e-2                       # expectation preserved
+        assert abs(np.corrcoef(keep[:-1], keep[1:])[0, 1]) < 1e-2  # no serial correlation
+    a, b, c = (oracle.dropout_mask(s, l, 10_000, 0.2) for s, l in ((1, 0), (1, 1), (2, 0)))
+    assert (a != b).mean() > 0.2 and (a != c).mean() > 0.2
+    V, E, H = 64, 16, 32
+    table = synth.make_table(1, V, E)
+    sd = synth.make_encoder_state(2, E, H, 2, True)
+    quads = synth.weight_quads(sd, 2, True)
+    ids = synth.make_ids(3, 6, 8, V)
+    y0 = oracle.encoder_forward(ids, table, quads, H, 2, True, sd["projection.weight"], sd["projection.bias"])
+    y1 = oracle.encoder_forward(ids, table, quads, H, 2, True, sd["projection.weight"], sd["projection.bias"],
+                                dropout_p=0.2, dropout_seed=7)
+    assert np.abs(y0 - y1).max() > 1e-3

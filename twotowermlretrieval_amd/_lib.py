@@ -17,7 +17,7 @@ class TTError(RuntimeError):
         self.code = code
 
 
-_vp, _i, _i64, _sz, _f = C.c_void_p, C.c_int, C.c_int64, C.c_size_t, C.c_float
+_vp, _i, _i64, _sz, _f, _u64 = C.c_void_p, C.c_int, C.c_int64, C.c_size_t, C.c_float, C.c_uint64
 
 # name -> (restype, argtypes); mirrors include/tt.h one to one
 SIGNATURES = {
@@ -34,11 +34,11 @@ SIGNATURES = {
     "tt_event_elapsed_ms": (_i, [_vp, _vp, _vp]),
     "tt_topk_merge": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "tt_score_rank_f32": (_i, [_vp, _i, _i, _vp, _i64, _vp, _vp, _vp]),
-    "tt_encoder_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i]),
-    "tt_encoder_forward_f32": (_i, [_vp, _i, _i, _vp, _i64, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _vp, _sz,
-                                    _vp, _vp]),
-    "tt_encoder_backward_f32": (_i, [_vp, _i, _i, _vp, _i64, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp,
-                                     _vp, _sz, _vp]),
+    "tt_encoder_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i, _i]),
+    "tt_encoder_forward_f32": (_i, [_vp, _i, _i, _vp, _i64, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _f, _u64, _vp, _vp,
+                                    _sz, _vp, _vp]),
+    "tt_encoder_backward_f32": (_i, [_vp, _i, _i, _vp, _i64, _i, _i, _i, _i, _vp, _vp, _vp, _i, _f, _u64, _vp, _vp,
+                                     _vp, _vp, _vp, _sz, _vp]),
     "tt_triplet_loss_f32": (_i, [_vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
     "tt_clip_adam_scratch_bytes": (_sz, []),
     "tt_clip_adam_step_f32": (_i, [_vp, _vp, _vp, _vp, _i64, _i64, _f, _f, _f, _f, _f, _f, _vp, _vp, _vp]),

@@ -13,6 +13,7 @@ struct EncLayout {
     int64_t MT;
     size_t len, tok_off, perm, ids, flag;        // int32 metadata (tok_off has B+1 entries)
     size_t x[ENC_MAX_LAYERS + 1];                // x[l+1] = output sequence of layer l: [MT][ndir*H]
+    size_t xd[ENC_MAX_LAYERS + 1];               // train + dropout: x[l+1] after the inter-layer dropout mask
     size_t gates[ENC_MAX_LAYERS][2];             // train: [MT][4][H] = r, z, n, W_hn h + b_hn
     size_t hfin;                                 // [ndir][B][H] final hidden of the LAST layer
     size_t hid;                                  // [B][H] head output before normalisation
@@ -33,7 +34,22 @@ struct EncLayout {
 
 constexpr int ENC_SPLITK = 32;
 
-static inline EncLayout enc_layout(int B, int T, int E, int H, int L, int bidir, int train)
+// The mask is a counter-based hash of (seed, layer, padded element index): no storage, the backward
+// pass regenerates it.  Identical to oracle/tt_oracle.c:o_dropout_scale.
+__host__ __device__ static inline float tt_dropout_scale(uint64_t seed, int layer, uint64_t idx, float p)
+{
+    uint64_t x = seed + 0x9E3779B97F4A7C15ull * (uint64_t)(layer + 1);
+    x ^= idx * 0xD1342543DE82EF95ull;
+    x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull;
+    x ^= x >> 27; x *= 0x94D049BB133111EBull;
+    x ^= x >> 31;
+    const uint32_t u = (uint32_t)(x >> 32);
+    const double t = (double)p * 4294967296.0;
+    const uint32_t thresh = t >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)t;
+    return u >= thresh ? 1.0f / (1.0f - p) : 0.0f;
+}
+
+static inline EncLayout enc_layout(int B, int T, int E, int H, int L, int bidir, int train, int dropout = 0)
 {
     EncLayout lo;
     lo.B = B; lo.T = T; lo.E = E; lo.H = H; lo.L = L; lo.ndir = bidir ? 2 : 1; lo.train = train;
@@ -48,7 +64,11 @@ static inline EncLayout enc_layout(int B, int T, int E, int H, int L, int bidir,
     // train: one extra, all-zero row at index MT stands for "h before the first step"
     const size_t seq = sizeof(float) * (lo.MT + (train ? 1 : 0)) * lo.ndir * H;
     lo.x[0] = 0;
+    for (int l = 0; l <= ENC_MAX_LAYERS; ++l)
+        lo.xd[l] = 0;
     for (int l = 0; l < L; ++l) {
+        if (train && dropout && l + 1 < L)
+            lo.xd[l + 1] = take(seq);
         if (train)
             lo.x[l + 1] = take(seq);
         else if (l + 1 < L)

@@ -303,6 +303,22 @@ __global__ __launch_bounds__(MAXW * 64) void gru_seq_kernel(GruParams p)
                 d.h_final[(size_t)rid_e[e] * H + unit[ct]] = hreg[ct][e];
 }
 
+// ------------------------------------------------------------------ inter-layer dropout (train mode)
+// xd = x * mask/(1-p) over the valid tokens of every row; mask = tt_dropout_scale(seed, layer, padded index)
+__global__ __launch_bounds__(256) void dropout_apply_kernel(const float *__restrict__ x, float *__restrict__ xd,
+                                                            const int32_t *__restrict__ len,
+                                                            const int32_t *__restrict__ tok_off, int T, int ld,
+                                                            int layer, float p, uint64_t seed)
+{
+    const int b = blockIdx.x;
+    const int L = len[b], o = tok_off[b];
+    for (int i = threadIdx.x; i < L * ld; i += 256) {
+        const int t = i / ld, c = i - t * ld;
+        const size_t tok = (size_t)(o + t);
+        xd[tok * ld + c] = x[tok * ld + c] * tt_dropout_scale(seed, layer, ((uint64_t)b * T + t) * ld + c, p);
+    }
+}
+
 // ------------------------------------------------------------------ K3 head
 __global__ __launch_bounds__(256) void head_kernel(const float *__restrict__ hfin, int B, int H, int ndir,
                                                    const float *__restrict__ proj_w,
@@ -360,17 +376,19 @@ int enc_check_shape(const char *who, int B, int T, int E, int H, int L, int64_t 
     return TT_OK;
 }
 
-TT_EXPORT size_t tt_encoder_workspace_bytes(int B, int T, int E, int H, int num_layers, int bidirectional, int train)
+TT_EXPORT size_t tt_encoder_workspace_bytes(int B, int T, int E, int H, int num_layers, int bidirectional, int train,
+                                            int dropout)
 {
     if (B <= 0 || T <= 0 || num_layers < 1 || num_layers > ENC_MAX_LAYERS)
         return 0;
-    return enc_layout(B, T, E, H, num_layers, bidirectional, train).total;
+    return enc_layout(B, T, E, H, num_layers, bidirectional, train, dropout).total;
 }
 
 TT_EXPORT int tt_encoder_forward_f32(const int64_t *ids, int B, int T, const float *table, int64_t V, int E, int H,
                                      int num_layers, int bidirectional, const float *const *weights,
-                                     const float *proj_w, const float *proj_b, int normalize, int train, float *out,
-                                     void *workspace, size_t workspace_bytes, int32_t *status, tt_stream_t stream)
+                                     const float *proj_w, const float *proj_b, int normalize, int train,
+                                     float dropout_p, uint64_t dropout_seed, float *out, void *workspace,
+                                     size_t workspace_bytes, int32_t *status, tt_stream_t stream)
 {
     hipStream_t st = (hipStream_t)stream;
     int rc = enc_check_shape("tt_encoder_forward_f32", B, T, E, H, num_layers, V);
@@ -378,7 +396,10 @@ TT_EXPORT int tt_encoder_forward_f32(const int64_t *ids, int B, int T, const flo
         return rc;
     if (!ids || !table || !weights || !out || (bidirectional && (!proj_w || !proj_b)))
         return tt_fail(TT_ERR_BAD_SHAPE, "tt_encoder_forward_f32: null pointer");
-    const EncLayout lo = enc_layout(B, T, E, H, num_layers, bidirectional, train);
+    if (!(dropout_p >= 0.0f && dropout_p < 1.0f))
+        return tt_fail(TT_ERR_BAD_SHAPE, "tt_encoder_forward_f32: dropout_p=%g", dropout_p);
+    const bool drop = train && dropout_p > 0.0f && num_layers > 1;
+    const EncLayout lo = enc_layout(B, T, E, H, num_layers, bidirectional, train, drop);
     if (!workspace || workspace_bytes < lo.total || ((uintptr_t)workspace & 255))
         return tt_fail(TT_ERR_WORKSPACE, "tt_encoder_forward_f32: workspace %zu < %zu bytes (or not 256-B aligned)",
                        workspace_bytes, lo.total);
@@ -412,7 +433,7 @@ TT_EXPORT int tt_encoder_forward_f32(const int64_t *ids, int B, int T, const flo
         for (int d = 0; d < ndir; ++d) {
             const float *const *w = weights + ((size_t)l * ndir + d) * 4;
             SgemmParams g;
-            g.A = l == 0 ? table : (const float *)(ws + lo.x[l]);
+            g.A = l == 0 ? table : (const float *)(ws + ((drop && l > 0) ? lo.xd[l] : lo.x[l]));
             g.a_map = l == 0 ? idsp : nullptr;
             g.B = w[0];
             g.b_map = nullptr;
@@ -449,6 +470,13 @@ TT_EXPORT int tt_encoder_forward_f32(const int64_t *ids, int B, int T, const flo
         else
             hipLaunchKernelGGL(gru_seq_kernel<16>, dim3((B + ENC_RB - 1) / ENC_RB, ndir), dim3(H / 32 * 64), lds, st, gp);
         TT_LAUNCH_CHECK();
+        if (drop && !last) { // nn.GRU's dropout sits on the outputs of every layer but the last
+            hipLaunchKernelGGL(dropout_apply_kernel, dim3(B), dim3(256), 0, st, (const float *)xout,
+                               (float *)(ws + lo.xd[l + 1]), len, tok_off, T, ndir * H, l, dropout_p, dropout_seed);
+            TT_HIP_CHECK(hipMemsetAsync((float *)(ws + lo.xd[l + 1]) + (size_t)lo.MT * ndir * H, 0,
+                                        sizeof(float) * ndir * H, st));
+            TT_LAUNCH_CHECK();
+        }
     }
     hipLaunchKernelGGL(head_kernel, dim3(B), dim3(256), 0, st, (const float *)(ws + lo.hfin), B, H, ndir, proj_w,
                        proj_b, normalize, train ? (float *)(ws + lo.hid) : (float *)nullptr, out);

@@ -122,6 +122,10 @@ struct GruBwdParams {
     GruBwdDir dir[2];
     const int32_t *len, *tok_off, *perm;
     int B, H, ld;
+    // inter-layer dropout on this layer's OUTPUT: d_seq is the gradient w.r.t. the dropped sequence
+    float drop_p;
+    uint64_t drop_seed;
+    int drop_layer, T;
 };
 
 template <int MAXW>
@@ -175,7 +179,14 @@ __global__ __launch_bounds__(MAXW * 64) void gru_bwd_seq_kernel(GruBwdParams p)
                     const float *gs = d.gates + tok * 4 * H + u;
                     const float r = gs[0], z = gs[H], n = gs[2 * H], ghn = gs[3 * H];
                     const float hp = s > 0 ? d.hseq[ptok * p.ld + d.col0 + u] : 0.0f;
-                    const float dhv = dh[ct][e] + (d.d_seq ? d.d_seq[tok * p.ld + d.col0 + u] : 0.0f);
+                    float dsv = 0.0f;
+                    if (d.d_seq) {
+                        dsv = d.d_seq[tok * p.ld + d.col0 + u];
+                        if (p.drop_p > 0.0f)
+                            dsv *= tt_dropout_scale(p.drop_seed, p.drop_layer,
+                                                    ((uint64_t)rid_e[e] * p.T + t) * p.ld + d.col0 + u, p.drop_p);
+                    }
+                    const float dhv = dh[ct][e] + dsv;
                     const float dn_pre = dhv * (1.0f - z) * (1.0f - n * n);
                     dz_pre = dhv * (hp - n) * z * (1.0f - z);
                     dr_pre = dn_pre * ghn * r * (1.0f - r);
@@ -253,9 +264,10 @@ int gemm_tn(const float *A, int64_t lda, int Mo, const float *Bsrc, int64_t ldb,
 
 TT_EXPORT int tt_encoder_backward_f32(const int64_t *ids, int B, int T, const float *table, int64_t V, int E, int H,
                                       int num_layers, int bidirectional, const float *const *weights,
-                                      const float *proj_w, const float *proj_b, int normalize, const float *d_out,
-                                      float *const *grads, float *g_proj_w, float *g_proj_b, void *workspace,
-                                      size_t workspace_bytes, tt_stream_t stream)
+                                      const float *proj_w, const float *proj_b, int normalize, float dropout_p,
+                                      uint64_t dropout_seed, const float *d_out, float *const *grads,
+                                      float *g_proj_w, float *g_proj_b, void *workspace, size_t workspace_bytes,
+                                      tt_stream_t stream)
 {
     (void)ids;
     (void)proj_b;
@@ -265,7 +277,8 @@ TT_EXPORT int tt_encoder_backward_f32(const int64_t *ids, int B, int T, const fl
         return rc;
     if (!table || !weights || !d_out || !grads || (bidirectional && (!proj_w || !g_proj_w || !g_proj_b)))
         return tt_fail(TT_ERR_BAD_SHAPE, "tt_encoder_backward_f32: null pointer");
-    const EncLayout lo = enc_layout(B, T, E, H, num_layers, bidirectional, 1);
+    const bool drop = dropout_p > 0.0f && num_layers > 1;
+    const EncLayout lo = enc_layout(B, T, E, H, num_layers, bidirectional, 1, drop);
     if (!workspace || workspace_bytes < lo.total || ((uintptr_t)workspace & 255))
         return tt_fail(TT_ERR_WORKSPACE, "tt_encoder_backward_f32: workspace %zu < %zu bytes: pass the buffer the "
                                          "forward call (train=1) filled", workspace_bytes, lo.total);
@@ -341,6 +354,10 @@ TT_EXPORT int tt_encoder_backward_f32(const int64_t *ids, int B, int T, const fl
         bp.B = B;
         bp.H = H;
         bp.ld = ndir * H;
+        bp.drop_p = (drop && !top) ? dropout_p : 0.0f;
+        bp.drop_seed = dropout_seed;
+        bp.drop_layer = l;
+        bp.T = T;
         for (int d = 0; d < ndir; ++d) {
             const float *const *w = weights + ((size_t)l * ndir + d) * 4;
             hipLaunchKernelGGL(pack_whh_t_kernel, dim3(96), dim3(256), 0, st, w[1], H, (float *)(ws + lo.wtp[d]));
@@ -383,7 +400,8 @@ TT_EXPORT int tt_encoder_backward_f32(const int64_t *ids, int B, int T, const fl
             if (l == 0)
                 rc = gemm_tn(dgi, H3, H3, table, E, idsp, E, MT, m_valid, slabs, g[0], st);
             else
-                rc = gemm_tn(dgi, H3, H3, (const float *)(ws + lo.x[l]), I, nullptr, I, MT, m_valid, slabs, g[0], st);
+                rc = gemm_tn(dgi, H3, H3, (const float *)(ws + (drop ? lo.xd[l] : lo.x[l])), I, nullptr, I, MT, m_valid,
+                             slabs, g[0], st);
             if (rc != TT_OK)
                 return rc;
             // W_hh <- dGh^T H_prev, H_prev rows through the previous-token map into this layer's own output

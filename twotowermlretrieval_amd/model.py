@@ -90,14 +90,18 @@ class _EncoderFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, enc: "RNNEncoder", ids: torch.Tensor, *params: torch.Tensor):
-        out, ws, status = enc._run_forward(ids, train=True)
+        p = enc.dropout if enc.training else 0.0
+        # the mask stream is seeded from torch's default CPU generator (torch.manual_seed reproduces it)
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if p > 0.0 else 0
+        out, ws, status = enc._run_forward(ids, train=True, dropout_p=p, dropout_seed=seed)
         ctx.enc, ctx.ids, ctx.ws, ctx.status = enc, ids, ws, status
+        ctx.dropout = (p, seed)
         ctx.n_params = len(params)
         return out
 
     @staticmethod
     def backward(ctx, d_out: torch.Tensor):
-        grads = ctx.enc._run_backward(ctx.ids, ctx.ws, d_out.contiguous())
+        grads = ctx.enc._run_backward(ctx.ids, ctx.ws, d_out.contiguous(), *ctx.dropout)
         ctx.ws = None
         return (None, None, *grads)
 
@@ -145,7 +149,7 @@ class RNNEncoder(nn.Module):
             if p.dtype != torch.float32:
                 raise TypeError("parameters must be float32")
 
-    def _run_forward(self, x: torch.Tensor, train: bool):
+    def _run_forward(self, x: torch.Tensor, train: bool, dropout_p: float = 0.0, dropout_seed: int = 0):
         L = _lib.lib()
         ids = x.contiguous()
         if ids.dtype != torch.int64:
@@ -155,7 +159,8 @@ class RNNEncoder(nn.Module):
         B, T = ids.shape
         V, E = self.embedding.weight.shape
         H = self.hidden_dim
-        need = L.tt_encoder_workspace_bytes(B, max(T, 1), E, H, self.num_layers, int(self.bidirectional), int(train))
+        drop = int(train and dropout_p > 0.0 and self.num_layers > 1)
+        need = L.tt_encoder_workspace_bytes(B, max(T, 1), E, H, self.num_layers, int(self.bidirectional), int(train), drop)
         if train:
             ws = torch.empty(max(need, 256), dtype=torch.uint8, device=ids.device)  # owned by the autograd node
         else:
@@ -173,13 +178,14 @@ class RNNEncoder(nn.Module):
             _lib.check(L.tt_encoder_forward_f32(
                 ids.data_ptr(), B, T, table.data_ptr(), V, E, H, self.num_layers, int(self.bidirectional), wptr,
                 pw.data_ptr() if pw is not None else None, pb.data_ptr() if pb is not None else None,
-                int(self.normalize_output), int(train), out.data_ptr(), ws.data_ptr(), ws.numel(),
-                status.data_ptr(), _stream(ids.device)))
+                int(self.normalize_output), int(train), float(dropout_p), int(dropout_seed), out.data_ptr(),
+                ws.data_ptr(), ws.numel(), status.data_ptr(), _stream(ids.device)))
         if self.check_inputs:
             _raise_status(int(status.item()))
         return out, ws, status
 
-    def _run_backward(self, ids: torch.Tensor, ws: torch.Tensor, d_out: torch.Tensor):
+    def _run_backward(self, ids: torch.Tensor, ws: torch.Tensor, d_out: torch.Tensor, dropout_p: float = 0.0,
+                      dropout_seed: int = 0):
         L = _lib.lib()
         B, T = ids.shape
         V, E = self.embedding.weight.shape
@@ -195,7 +201,8 @@ class RNNEncoder(nn.Module):
             _lib.check(L.tt_encoder_backward_f32(
                 ids.contiguous().data_ptr(), B, T, self.embedding.weight.detach().data_ptr(), V, E, H,
                 self.num_layers, int(self.bidirectional), wptr, pw.data_ptr() if pw is not None else None,
-                pb.data_ptr() if pb is not None else None, int(self.normalize_output), d_out.data_ptr(), gptr,
+                pb.data_ptr() if pb is not None else None, int(self.normalize_output), float(dropout_p),
+                int(dropout_seed), d_out.data_ptr(), gptr,
                 grads[nq].data_ptr() if pw is not None else None,
                 grads[nq + 1].data_ptr() if pb is not None else None, ws.data_ptr(), ws.numel(),
                 _stream(ids.device)))
@@ -211,9 +218,6 @@ class RNNEncoder(nn.Module):
                 raise NotImplementedError("training the embedding table is not supported by the HIP path: the "
                                           "reference freezes it whenever GloVe vectors are loaded (model.py:25-27); "
                                           "pass pretrained_embeddings or set embedding.weight.requires_grad=False")
-            if self.training and self.dropout > 0.0:
-                raise NotImplementedError("inter-layer dropout in train mode is not implemented yet (DROPOUT>0 with "
-                                          "NUM_LAYERS>1); use model.eval() or DROPOUT=0")
             return _EncoderFn.apply(self, x, *params)
         out, _, _ = self._run_forward(x, train=False)
         return out
