@@ -95,6 +95,11 @@ int tt_score_topk_partials_f32(const float *Q, int B, int d, const float *D, int
  * synchronisation.  Supported: d = 256, k <= 64, dmax_norm < 6e4.
  */
 int tt_index_build_f16(const float *D, int64_t N, int d, void *D16, float *stats, tt_stream_t stream);
+/* Same for a block of a bf16 corpus (BASELINE configs[4]: passages kept as bf16 in pinned host DRAM and
+ * streamed through the GPU): D_bf16 [N,d] -> D32 [N,d] fp32 (exact widening) and, when D16 is not NULL,
+ * the fp16 shadow; stats (nullable) accumulates the two maxima across calls unless reset_stats != 0. */
+int tt_index_build_from_bf16(const void *D_bf16, int64_t N, int d, float *D32, void *D16, float *stats,
+                             int reset_stats, tt_stream_t stream);
 size_t tt_score_topk_screened_workspace_bytes(int B, int64_t N, int d, int k);
 int tt_score_topk_screened_f32(const float *Q, int B, int d, const float *D32, const void *D16, int64_t N, int k,
                                float dmax_norm, int64_t idx_offset, float *out_val, int64_t *out_idx,

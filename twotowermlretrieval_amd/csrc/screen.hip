@@ -589,6 +589,55 @@ __global__ __launch_bounds__(256) void build_f16_kernel(const float *__restrict_
     }
 }
 
+// bf16 rows (streamed corpus blocks) -> fp32 rows (exact: bf16 is a truncated fp32) + fp16 shadow + stats
+__global__ __launch_bounds__(256) void build_from_bf16_kernel(const unsigned short *__restrict__ S, int64_t N, int d,
+                                                              float *__restrict__ out32, _Float16 *__restrict__ out16,
+                                                              unsigned *__restrict__ stats)
+{
+    __shared__ float red[8];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float nmax = 0.0f, amax = 0.0f;
+    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < N; row += (int64_t)gridDim.x * 4) {
+        float ss = 0.0f;
+        for (int x = lane * 4; x < d; x += 256) {
+            const uint2 raw = *(const uint2 *)(S + row * d + x);
+            f32x4 v;
+            v[0] = __uint_as_float(raw.x << 16);
+            v[1] = __uint_as_float(raw.x & 0xffff0000u);
+            v[2] = __uint_as_float(raw.y << 16);
+            v[3] = __uint_as_float(raw.y & 0xffff0000u);
+            h4 hv;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                ss += v[e] * v[e];
+                amax = fmaxf(amax, fabsf(v[e]));
+                if (!(fabsf(v[e]) <= 3.0e38f))
+                    amax = INFINITY;
+                hv[e] = (_Float16)v[e];
+            }
+            *(f32x4 *)(out32 + row * d + x) = v;
+            if (out16)
+                *(h4 *)(out16 + row * d + x) = hv;
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1)
+            ss += __shfl_xor(ss, off);
+        nmax = fmaxf(nmax, sqrtf(ss));
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1)
+        amax = fmaxf(amax, __shfl_xor(amax, off));
+    if (lane == 0) {
+        red[wave] = nmax;
+        red[4 + wave] = amax;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && stats) {
+        atomicMax(stats, __float_as_uint(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]))));
+        atomicMax(stats + 1, __float_as_uint(fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7]))));
+    }
+}
+
 struct SPlan {
     int n_qgroups, n_tiles, n_chunks, tiles_per_chunk, n_blocks;
     // sample pass
@@ -669,6 +718,25 @@ TT_EXPORT int tt_index_build_f16(const float *D, int64_t N, int d, void *D16, fl
     const int64_t want_blocks = (N + 3) / 4;
     hipLaunchKernelGGL(build_f16_kernel, dim3((unsigned)(want_blocks > 8192 ? 8192 : want_blocks)), dim3(256), 0, st, D,
                        N, d, (_Float16 *)D16, (unsigned *)stats);
+    TT_LAUNCH_CHECK();
+    return TT_OK;
+}
+
+TT_EXPORT int tt_index_build_from_bf16(const void *D_bf16, int64_t N, int d, float *D32, void *D16, float *stats,
+                                       int reset_stats, tt_stream_t stream)
+{
+    if (N < 0 || d <= 0 || (d & 3))
+        return tt_fail(TT_ERR_BAD_SHAPE, "tt_index_build_from_bf16: N=%lld d=%d", (long long)N, d);
+    if (N > 0 && (!D_bf16 || !D32))
+        return tt_fail(TT_ERR_BAD_SHAPE, "tt_index_build_from_bf16: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    if (stats && reset_stats)
+        TT_HIP_CHECK(hipMemsetAsync(stats, 0, 2 * sizeof(float), st));
+    if (N == 0)
+        return TT_OK;
+    const int64_t want_blocks = (N + 3) / 4;
+    hipLaunchKernelGGL(build_from_bf16_kernel, dim3((unsigned)(want_blocks > 8192 ? 8192 : want_blocks)), dim3(256), 0,
+                       st, (const unsigned short *)D_bf16, N, d, D32, (_Float16 *)D16, (unsigned *)stats);
     TT_LAUNCH_CHECK();
     return TT_OK;
 }
