@@ -514,6 +514,77 @@ __global__ __launch_bounds__(MERGE_THREADS) void topk_merge_kernel(const float *
 }
 
 // ---------------------------------------------------------------------------
+// k-th largest of M values per row (threshold seeding): 4-pass radix select on the order-preserving
+// integer image of the floats; one block per row, cost independent of k.  -inf when M < k.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ unsigned order_key(float f)
+{
+    const unsigned b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+
+__global__ __launch_bounds__(256) void kth_largest_kernel(const float *__restrict__ vals, int M, int k,
+                                                          float *__restrict__ out, const int *run_if)
+{
+    if (run_if && run_if[blockIdx.x >> 5] == 0)
+        return;
+    __shared__ int hist[256];
+    __shared__ int sel[2];
+    const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const float *v = vals + (size_t)row * M;
+    if (M < k) {
+        if (tid == 0)
+            out[row] = -INFINITY;
+        return;
+    }
+    unsigned prefix = 0u, mask = 0u;
+    int k_rem = k;
+#pragma unroll 1
+    for (int pass = 0; pass < 4; ++pass) {
+        const int shift = 24 - 8 * pass;
+        hist[tid] = 0;
+        __syncthreads();
+        for (int m = tid; m < M; m += 256) {
+            const unsigned key = order_key(v[m]);
+            if ((key & mask) == prefix)
+                atomicAdd(&hist[(key >> shift) & 255u], 1);
+        }
+        __syncthreads();
+        if (tid < 64) { // one wave: suffix sums over the 256 bins (4 bins per lane, high bins first)
+            int c[4], s = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                c[i] = hist[255 - (lane * 4 + i)];
+                s += c[i];
+            }
+            int incl = s; // inclusive scan over lanes
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int y = __shfl_up(incl, off);
+                if (lane >= off)
+                    incl += y;
+            }
+            int above = incl - s; // entries in strictly higher bins than this lane's first
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (above < k_rem && above + c[i] >= k_rem) {
+                    sel[0] = 255 - (lane * 4 + i);
+                    sel[1] = above;
+                }
+                above += c[i];
+            }
+        }
+        __syncthreads();
+        prefix |= (unsigned)sel[0] << shift;
+        mask |= 0xffu << shift;
+        k_rem -= sel[1];
+        __syncthreads();
+    }
+    if (tid == 0)
+        out[row] = __uint_as_float((prefix & 0x80000000u) ? (prefix & 0x7fffffffu) : ~prefix);
+}
+
+// ---------------------------------------------------------------------------
 // Rank of a designated document (BatchEvaluator, evaluators.py:58-65).
 // One block per query; scores are the same ascending-index FMA chain.
 // ---------------------------------------------------------------------------
@@ -732,16 +803,15 @@ int score_partials(const float *Q, int B, int d, const float *D, int64_t N, int 
         int rc = launch_score(d, pp, pl, st, true);
         if (rc != TT_OK)
             return rc;
-        hipLaunchKernelGGL(topk_merge_kernel, dim3(B), dim3(MERGE_THREADS), 0, st, (const float *)pp.pval,
-                           (const int64_t *)pp.pidx, pl.pre.n_chunks, k, (float *)(ws + pl.pre_val_off),
-                           (int64_t *)(ws + pl.pre_idx_off), run_if);
+        hipLaunchKernelGGL(kth_largest_kernel, dim3(B), dim3(256), 0, st, (const float *)pp.pval, pl.pre.n_chunks, k,
+                           (float *)(ws + pl.pre_val_off), run_if);
         TT_LAUNCH_CHECK();
         thr0 = (const float *)(ws + pl.pre_val_off);
     }
     ScoreParams sp = pass_params(pl.main, Q, B, D, k, idx_offset, ws, pl);
     sp.thr0 = thr0;
-    sp.thr0_stride = k;
-    sp.thr0_off = k - 1;
+    sp.thr0_stride = 1;
+    sp.thr0_off = 0;
     sp.run_if = run_if;
     return launch_score(d, sp, pl, st, false);
 }
@@ -815,6 +885,14 @@ int tt_score_topk_f32_pred(const float *Q, int B, int d, const float *D, int64_t
     const char *ws = (const char *)workspace;
     hipLaunchKernelGGL(topk_merge_kernel, dim3(B), dim3(MERGE_THREADS), 0, st, (const float *)(ws + pl.pval_off),
                        (const int64_t *)(ws + pl.pidx_off), pl.main.n_chunks * k, k, out_val, out_idx, run_if);
+    TT_LAUNCH_CHECK();
+    return TT_OK;
+}
+
+// k-th largest of each row of vals [B][M] -> out [B] (internal: threshold seeding of both search paths)
+int tt_kth_largest(const float *vals, int B, int M, int k, float *out, hipStream_t st)
+{
+    hipLaunchKernelGGL(kth_largest_kernel, dim3(B), dim3(256), 0, st, vals, M, k, out, (const int *)nullptr);
     TT_LAUNCH_CHECK();
     return TT_OK;
 }

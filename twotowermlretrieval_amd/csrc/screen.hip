@@ -37,6 +37,8 @@ int tt_score_topk_f32_pred(const float *Q, int B, int d, const float *D, int64_t
                            float *out_val, int64_t *out_idx, void *workspace, size_t workspace_bytes,
                            const int *run_if, hipStream_t st);
 
+int tt_kth_largest(const float *vals, int B, int M, int k, float *out, hipStream_t st);
+
 namespace {
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
@@ -184,6 +186,8 @@ __global__ __launch_bounds__(SW * 64, 2) void screen_kernel(ScreenParams p)
         const bool live = qrow < p.B;
         const float *qp = p.Q + (size_t)min(qrow, p.B - 1) * 256 + 8 * h;
         float ss = 0.0f;
+        // (staging the rows through LDS for coalesced reads was measured SLOWER here: four dependent
+        //  load->write->read rounds per wave instead of 64 independent loads in flight)
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
             const f32x4 a = *(const f32x4 *)(qp + 16 * s);
@@ -365,50 +369,15 @@ struct FinishParams {
 
 __device__ __forceinline__ bool before_f(float sa, int ia, float sb, int ib) { return sa > sb || (sa == sb && ia < ib); }
 
-// block-wide arg-best over (v[i], x[i]), i < n, among entries ranking strictly after (pv, px)
-__device__ __forceinline__ void block_next_best(const float *v, const int *x, int n, float pv, int px, float *red_v,
-                                                int *red_x, float &bv, int &bx)
+// float <-> unsigned with the same ordering (for the radix select)
+__device__ __forceinline__ unsigned f32_order_key(float f)
 {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    bv = -INFINITY;
-    bx = INT_MAX;
-    bool any = false;
-    for (int m = tid; m < n; m += 256) {
-        const float cv = v[m];
-        const int cx = x[m];
-        if (!before_f(pv, px, cv, cx))
-            continue;
-        if (!any || before_f(cv, cx, bv, bx)) {
-            bv = cv;
-            bx = cx;
-            any = true;
-        }
-    }
-    if (!any)
-        bx = INT_MAX;
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        const float ov = __shfl_xor(bv, off);
-        const int ox = __shfl_xor(bx, off);
-        if (ox != INT_MAX && (bx == INT_MAX || before_f(ov, ox, bv, bx))) {
-            bv = ov;
-            bx = ox;
-        }
-    }
-    if (lane == 0) {
-        red_v[wave] = bv;
-        red_x[wave] = bx;
-    }
-    __syncthreads();
-    bv = red_v[0];
-    bx = red_x[0];
-#pragma unroll
-    for (int w2 = 1; w2 < 4; ++w2)
-        if (red_x[w2] != INT_MAX && (bx == INT_MAX || before_f(red_v[w2], red_x[w2], bv, bx))) {
-            bv = red_v[w2];
-            bx = red_x[w2];
-        }
-    __syncthreads();
+    const unsigned b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float f32_from_order_key(unsigned k)
+{
+    return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
 }
 
 __global__ __launch_bounds__(256) void screen_finish_kernel(FinishParams p)
@@ -419,7 +388,8 @@ __global__ __launch_bounds__(256) void screen_finish_kernel(FinishParams p)
     __shared__ float sv_v[SURV_MAX];
     __shared__ int sv_x[SURV_MAX];
     __shared__ float red_v[4];
-    __shared__ int red_x[4];
+    __shared__ int hist[256];
+    __shared__ int sel[2];
     __shared__ int n_pool, n_surv;
     const int row = blockIdx.x, tid = threadIdx.x;
     if (tid == 0)
@@ -485,19 +455,56 @@ __global__ __launch_bounds__(256) void screen_finish_kernel(FinishParams p)
     }
     __syncthreads();
     const int np = min(n_pool, POOL_MAX);
-    // ---- A_k = k-th best approximate score over the whole corpus ----
-    float pv = INFINITY, kth = -INFINITY;
-    int px = -1, found = 0;
-    for (int r = 0; r < p.k; ++r) {
-        float bv;
-        int bx;
-        block_next_best(pool_v, pool_x, np, pv, px, red_v, red_x, bv, bx);
-        if (bx == INT_MAX)
-            break;
-        pv = bv;
-        px = bx;
-        kth = bv;
-        ++found;
+    // ---- A_k = k-th best approximate score over the whole corpus: 4-pass radix select on the
+    //      order-preserving integer image of the scores (cost independent of k) ----
+    float kth = -INFINITY;
+    const int found = np >= p.k ? p.k : np;
+    if (np >= p.k) {
+        unsigned prefix = 0u, mask = 0u;
+        int k_rem = p.k;
+#pragma unroll 1
+        for (int pass = 0; pass < 4; ++pass) {
+            const int shift = 24 - 8 * pass;
+            hist[tid] = 0;
+            __syncthreads();
+            for (int m = tid; m < np; m += 256) {
+                const unsigned key = f32_order_key(pool_v[m]);
+                if ((key & mask) == prefix)
+                    atomicAdd(&hist[(key >> shift) & 255u], 1);
+            }
+            __syncthreads();
+            if (tid < 64) { // one wave: suffix sums over the 256 bins (4 per lane, high bins first)
+                const int ln = tid;
+                int c[4], sm = 0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    c[i] = hist[255 - (ln * 4 + i)];
+                    sm += c[i];
+                }
+                int incl = sm;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const int y = __shfl_up(incl, off);
+                    if (ln >= off)
+                        incl += y;
+                }
+                int above = incl - sm;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (above < k_rem && above + c[i] >= k_rem) {
+                        sel[0] = 255 - (ln * 4 + i);
+                        sel[1] = above;
+                    }
+                    above += c[i];
+                }
+            }
+            __syncthreads();
+            prefix |= (unsigned)sel[0] << shift;
+            mask |= 0xffu << shift;
+            k_rem -= sel[1];
+            __syncthreads();
+        }
+        kth = f32_from_order_key(prefix);
     }
     const float cut = found == p.k ? kth - eps2 : -INFINITY;
     // ---- survivors, exact fp32 FMA-chain rescoring (the oracle's order: features ascending) ----
@@ -526,25 +533,22 @@ __global__ __launch_bounds__(256) void screen_finish_kernel(FinishParams p)
     }
     if (__syncthreads_or(too_many) && tid == 0)
         atomicOr(p.flag + (row >> 5), 4);
-    // ---- exact top-k of the survivors ----
-    pv = INFINITY;
-    px = -1;
-    for (int r = 0; r < p.k; ++r) {
-        float bv;
-        int bx;
-        block_next_best(sv_v, sv_x, ns, pv, px, red_v, red_x, bv, bx);
-        if (tid == 0) {
-            const bool ok = bx != INT_MAX;
-            p.out_val[(size_t)row * p.k + r] = ok ? bv : -INFINITY;
-            p.out_idx[(size_t)row * p.k + r] = ok ? p.idx_offset + bx : -1;
+    // ---- exact top-k of the survivors: every thread ranks its own survivor against all others ----
+    __syncthreads();
+    if (tid < ns) {
+        const float mv = sv_v[tid];
+        const int mx = sv_x[tid];
+        int rank = 0;
+        for (int u = 0; u < ns; ++u)
+            rank += before_f(sv_v[u], sv_x[u], mv, mx) ? 1 : 0;
+        if (rank < p.k) {
+            p.out_val[(size_t)row * p.k + rank] = mv;
+            p.out_idx[(size_t)row * p.k + rank] = p.idx_offset + mx;
         }
-        if (bx == INT_MAX) {
-            pv = -INFINITY;
-            px = INT_MAX;
-        } else {
-            pv = bv;
-            px = bx;
-        }
+    }
+    for (int r = ns + tid; r < p.k; r += 256) { // fewer survivors than k (tiny corpora)
+        p.out_val[(size_t)row * p.k + r] = -INFINITY;
+        p.out_idx[(size_t)row * p.k + r] = -1;
     }
 }
 
@@ -802,11 +806,11 @@ TT_EXPORT int tt_score_topk_screened_f32(const float *Q, int B, int d, const flo
         ss.max_idx = (int64_t *)(ws + pl.smax_idx_off);
         hipLaunchKernelGGL(screen_kernel<true>, dim3(pl.n_qgroups * pl.s_chunks), dim3(SW * 64), pl.lds, st, ss);
         TT_LAUNCH_CHECK();
-        int rc = tt_topk_merge(ss.max_val, ss.max_idx, B, pl.s_chunks, k, (float *)(ws + pl.sthr_val_off),
-                               (int64_t *)(ws + pl.sthr_idx_off), stream);
+        int rc = tt_kth_largest(ss.max_val, B, pl.s_chunks, k, (float *)(ws + pl.sthr_val_off), st);
         if (rc != TT_OK)
             return rc;
         sp.thr0 = (const float *)(ws + pl.sthr_val_off);
+        sp.thr0_stride = 1;
     }
     if (prof_events)
         TT_HIP_CHECK(hipEventRecord((hipEvent_t)prof_events[0], st));
