@@ -97,36 +97,40 @@ __device__ __forceinline__ void scand_store_async(SCand *dst, float v, int x)
     asm volatile("global_store_dwordx2 %0, %1, off\n\ts_nop 1" ::"v"(dst), "v"(bits) : "memory");
 }
 
-// Keep, sorted, every entry within `slack` of the k-th best; returns new count and threshold.
-// Lane t owns entries t and t+64.
-__device__ __forceinline__ void screen_compact(SCand *base, int n, int k, float slack, int lane, int &n_new,
+// A query's 128-entry buffer is two 64-entry halves, one per half-wave: lane (j,h) appends to half h
+// with its OWN counter, so the append pass needs no cross-lane traffic at all.
+// Compaction: keep every entry within `slack` of the k-th best of the union; rank r goes to half r&1,
+// slot r>>1 (keeps the halves balanced).  Lane t owns entry t of each half.
+__device__ __forceinline__ void screen_compact(SCand *base, int n0, int n1, int k, float slack, int lane, int &n_new,
                                                float &thr_new, bool &have, bool &overflow)
 {
-    constexpr int E = SCAP / 64;
-    float v[E];
-    int x[E], rank[E];
+    float v[2];
+    int x[2], rank[2];
+    bool live[2];
 #pragma unroll
-    for (int i = 0; i < E; ++i) {
+    for (int i = 0; i < 2; ++i) {
         v[i] = -INFINITY;
         x[i] = INT_MAX;
         rank[i] = 0;
-        if (lane + 64 * i < n) {
-            const SCand c = scand_load_l2(base + lane + 64 * i);
+        live[i] = lane < (i ? n1 : n0);
+        if (live[i]) {
+            const SCand c = scand_load_l2(base + 64 * i + lane);
             v[i] = c.v;
             x[i] = c.x;
         }
     }
 #pragma unroll
-    for (int i2 = 0; i2 < E; ++i2) {
-        const int lim = min(n - 64 * i2, 64);
+    for (int i2 = 0; i2 < 2; ++i2) {
+        const int lim = i2 ? n1 : n0;
         for (int l2 = 0; l2 < lim; ++l2) {
             const float sv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v[i2]), l2));
             const int sx = __builtin_amdgcn_readlane(x[i2], l2);
 #pragma unroll
-            for (int i = 0; i < E; ++i)
+            for (int i = 0; i < 2; ++i)
                 rank[i] += (sv > v[i] || (sv == v[i] && sx < x[i])) ? 1 : 0;
         }
     }
+    const int n = n0 + n1;
     have = n >= k;
     overflow = false;
     n_new = n;
@@ -134,28 +138,28 @@ __device__ __forceinline__ void screen_compact(SCand *base, int n, int k, float 
     if (have) {
         float kth = -INFINITY;
 #pragma unroll
-        for (int i = 0; i < E; ++i) {
-            const unsigned long long bk = __ballot(lane + 64 * i < n && rank[i] == k - 1);
+        for (int i = 0; i < 2; ++i) {
+            const unsigned long long bk = __ballot(live[i] && rank[i] == k - 1);
             if (bk)
                 kth = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v[i]), __ffsll((long long)bk) - 1));
         }
         thr_new = kth - slack;
         n_new = 0;
 #pragma unroll
-        for (int i = 0; i < E; ++i)
-            n_new += __popcll(__ballot(lane + 64 * i < n && v[i] >= thr_new));
-        if (n_new > SCAP - 40) { // no room left for one more tile: exact fallback (this pass's result is discarded)
+        for (int i = 0; i < 2; ++i)
+            n_new += __popcll(__ballot(live[i] && v[i] >= thr_new));
+        if (n_new > SCAP - 48) { // a half could not take one more tile: exact fallback (this pass's result is discarded)
             overflow = true;
             n_new = k;
         }
     }
 #pragma unroll
-    for (int i = 0; i < E; ++i)
-        if (lane + 64 * i < n && rank[i] < n_new) {
+    for (int i = 0; i < 2; ++i)
+        if (live[i] && rank[i] < n_new) {
             SCand c;
             c.v = v[i];
             c.x = x[i];
-            base[rank[i]] = c;
+            base[64 * (rank[i] & 1) + (rank[i] >> 1)] = c;
         }
 }
 
@@ -220,16 +224,16 @@ __global__ __launch_bounds__(SW * 64, 2) void screen_kernel(ScreenParams p)
         while (qmask) {
             const int q = __ffsll((long long)qmask) - 1;
             qmask &= qmask - 1;
-            const int n = __builtin_amdgcn_readlane(cnt[c], q);
+            const int n0 = __builtin_amdgcn_readlane(cnt[c], q), n1 = __builtin_amdgcn_readlane(cnt[c], q + 32);
             const float slack = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, eps2[c]), q));
             int n_new;
             float tn;
             bool have, ovf;
-            screen_compact(cwave + (size_t)(32 * c + q) * SCAP, n, k, slack, lane, n_new, tn, have, ovf);
+            screen_compact(cwave + (size_t)(32 * c + q) * SCAP, n0, n1, k, slack, lane, n_new, tn, have, ovf);
             if (ovf && lane == 0)
                 atomicOr(p.flag + ((qbase + 32 * c) >> 5), 1);
             if (j == q) {
-                cnt[c] = n_new;
+                cnt[c] = h ? (n_new >> 1) : ((n_new + 1) >> 1);
                 if (have)
                     thr[c] = tn;
             }
@@ -304,21 +308,21 @@ __global__ __launch_bounds__(SW * 64, 2) void screen_kernel(ScreenParams p)
                         m = fmaxf(m, acc[r]);
                     if (__ballot(m >= thr[c]) == 0ull)
                         continue;
-                    // append pass: inline-asm stores only (see score_topk.hip: a compiler-visible VMEM op
-                    // here would put s_waitcnt vmcnt(0) on the hot path and drain the DMA ring)
+                    // append pass: every lane appends to its own half of the query's buffer with its own
+                    // counter (no ballots), through inline-asm stores (a compiler-visible VMEM op here would put
+                    // s_waitcnt vmcnt(0) on the hot path and drain the DMA ring)
+                    SCand *const mine = cwave + (size_t)(32 * c + j) * SCAP + 64 * h;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int doc = tile_base + (r & 3) + 8 * (r >> 2) + 4 * h;
-                        const bool cd = (!partial || doc < p.N) && acc[r] >= thr[c];
-                        const unsigned long long mask = __ballot(cd);
-                        if (mask == 0ull)
-                            continue;
-                        const int c_lo = (int)((mask >> j) & 1ull), c_hi = (int)((mask >> (j + 32)) & 1ull);
-                        if (cd)
-                            scand_store_async(cwave + (size_t)(32 * c + j) * SCAP + cnt[c] + (h ? c_lo : 0), acc[r], doc);
-                        cnt[c] += c_lo + c_hi;
+                        if ((!partial || doc < p.N) && acc[r] >= thr[c]) {
+                            scand_store_async(mine + cnt[c], acc[r], doc);
+                            ++cnt[c];
+                        }
                     }
-                    const unsigned long long full = __ballot(cnt[c] > SCAP - 34) & 0xffffffffull;
+                    // a tile adds at most 16 entries per lane: compact while a half still has room for that
+                    unsigned long long full = __ballot(cnt[c] > 64 - 18);
+                    full = (full | (full >> 32)) & 0xffffffffull;
                     if (full)
                         compact_where(c, full);
                 }
@@ -341,15 +345,16 @@ __global__ __launch_bounds__(SW * 64, 2) void screen_kernel(ScreenParams p)
         }
         return;
     }
-    // final compaction (bounds the pool the finish kernel sees) and counts out
+    // final compaction (bounds the pool the finish kernel sees) and counts out: (half-0 count) | (half-1 count) << 16
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
-        const unsigned long long over = __ballot(cnt[c] > k) & 0xffffffffull;
+        const unsigned long long over = __ballot(cnt[c] + __shfl_xor(cnt[c], 32) > k) & 0xffffffffull;
         if (over)
             compact_where(c, over);
+        const int other = __shfl_xor(cnt[c], 32);
         const int qrow = qbase + 32 * c + j;
         if (h == 0 && qrow < p.B)
-            p.pcnt[(size_t)qrow * p.n_chunks + chunk] = cnt[c];
+            p.pcnt[(size_t)qrow * p.n_chunks + chunk] = cnt[c] | (other << 16);
     }
 }
 
@@ -412,13 +417,13 @@ __global__ __launch_bounds__(256) void screen_finish_kernel(FinishParams p)
     bool too_many = false;
     int *pre = sv_x; // n_chunks + 1 <= 129 prefix entries, reused before the survivors are written
     if (tid < p.n_chunks)
-        pool_x[tid] = p.pcnt[(size_t)row * p.n_chunks + tid];
+        hist[tid] = p.pcnt[(size_t)row * p.n_chunks + tid]; // packed (n0 | n1 << 16); hist is free until the select
     __syncthreads();
     if (tid == 0) {
         int run = 0;
         for (int c = 0; c < p.n_chunks; ++c) {
             pre[c] = run;
-            run += pool_x[c];
+            run += (hist[c] & 0xffff) + (hist[c] >> 16);
         }
         pre[p.n_chunks] = run;
         n_pool = run;
@@ -427,7 +432,6 @@ __global__ __launch_bounds__(256) void screen_finish_kernel(FinishParams p)
     const int total = n_pool;
     if (total > POOL_MAX)
         too_many = true;
-    __syncthreads(); // everyone has read the counts out of pool_x before it is overwritten
     int my_c[POOL_MAX / 256], my_o[POOL_MAX / 256];
 #pragma unroll
     for (int it = 0; it < POOL_MAX / 256; ++it) {
@@ -440,8 +444,9 @@ __global__ __launch_bounds__(256) void screen_finish_kernel(FinishParams p)
             else
                 hi = mid;
         }
+        const int o = m - pre[lo], n0 = hist[lo] & 0xffff;
         my_c[it] = lo;
-        my_o[it] = m - pre[lo];
+        my_o[it] = o < n0 ? o : 64 + (o - n0); // second half-buffer starts at entry 64
     }
     __syncthreads();
 #pragma unroll
@@ -670,7 +675,9 @@ SPlan make_splan(int B, int64_t N, int k)
     SPlan pl;
     pl.n_qgroups = (B + SQ_PER_BLOCK - 1) / SQ_PER_BLOCK;
     pl.n_tiles = (int)((N + 31) / 32);
-    int want = (2 * screen_cus() + pl.n_qgroups - 1) / pl.n_qgroups; // two waves of workgroups per CU
+    // one workgroup per CU is resident (8 waves x 256 VGPRs): aim at exactly one round, the per-workgroup
+    // set-up (query load + conversion, final compaction) is ~0.1 ms and would be paid once per round
+    int want = (screen_cus() + pl.n_qgroups - 1) / pl.n_qgroups;
     // finish kernel: one thread per chunk count (<= 255), and room in its pool for k + slack entries per chunk
     int max_chunks = POOL_MAX / (k + 16);
     max_chunks = max_chunks > 255 ? 255 : max_chunks;
