@@ -15,6 +15,8 @@ def dev(a):
 
 
 def screened(tt, Q, D, k, off=0):
+    from twotowermlretrieval_amd import index as _index
+    _index.SCREEN_MIN_DOCS = 0  # these tests exercise the screened kernels on small corpora too
     ix = tt.BruteForceIndex(dev(D), idx_offset=off, screen=True)
     assert ix.docs16 is not None
     v, i = ix.search(dev(Q), k)

@@ -84,9 +84,8 @@ struct ScreenParams {
     SCand *cand;   // [n_blocks][512][SCAP]
     int *pcnt;     // [rows_pad][n_chunks]
     int *flag;     // overflow / unsupported -> exact fallback
-    // sample pass (MAXONLY): per-(workgroup, query) maximum approximate score
-    float *max_val;      // [rows_pad][n_chunks]
-    int64_t *max_idx;    // [rows_pad][n_chunks] = chunk id (so K5 can take the k-th largest)
+    // sample pass (MAXONLY): per-(tile, query) maximum approximate score
+    float *max_val;      // [rows_pad][n_tiles]
     const float *thr0;   // main pass: k-th largest sample maximum per query, stride thr0_stride (or null)
     int thr0_stride;
 };
@@ -95,6 +94,11 @@ __device__ __forceinline__ void scand_store_async(SCand *dst, float v, int x)
 {
     const unsigned long long bits = ((unsigned long long)(unsigned)x << 32) | (unsigned long long)__float_as_uint(v);
     asm volatile("global_store_dwordx2 %0, %1, off\n\ts_nop 1" ::"v"(dst), "v"(bits) : "memory");
+}
+
+__device__ __forceinline__ void f32_store_async(float *dst, float v)
+{
+    asm volatile("global_store_dword %0, %1, off\n\ts_nop 0" ::"v"(dst), "v"(v) : "memory");
 }
 
 // A query's 128-entry buffer is two 64-entry halves, one per half-wave: lane (j,h) appends to half h
@@ -182,7 +186,6 @@ __global__ __launch_bounds__(SW * 64, 2) void screen_kernel(ScreenParams p)
     h8 qreg[2][16];
     float eps2[2], thr[2];
     int cnt[2] = {0, 0};
-    float runmax[2] = {-INFINITY, -INFINITY};
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
         bool bad = false;
@@ -292,14 +295,17 @@ __global__ __launch_bounds__(SW * 64, 2) void screen_kernel(ScreenParams p)
 #pragma unroll
                 for (int c = 0; c < 2; ++c) {
                     const f32x16 &acc = c == 0 ? acc0 : acc1;
-                    if (MAXONLY) {
+                    if (MAXONLY) { // one maximum per (tile, query): the k-th largest of them seeds the thresholds
                         float m = -INFINITY;
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
                             const int doc = tile_base + (r & 3) + 8 * (r >> 2) + 4 * h;
                             m = fmaxf(m, (!partial || doc < p.N) ? acc[r] : -INFINITY);
                         }
-                        runmax[c] = fmaxf(runmax[c], m);
+                        m = fmaxf(m, __shfl_xor(m, 32));
+                        const int qrow = qbase + 32 * c + j;
+                        if (h == 0 && qrow < p.B)
+                            f32_store_async(p.max_val + (size_t)qrow * p.n_tiles + tile, m);
                         continue;
                     }
                     float m = acc[0];
@@ -333,18 +339,8 @@ __global__ __launch_bounds__(SW * 64, 2) void screen_kernel(ScreenParams p)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier(); // no wave may leave while a sibling's LDS-DMA could still be consumed
 
-    if (MAXONLY) {
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            const float m = fmaxf(runmax[c], __shfl_xor(runmax[c], 32));
-            const int qrow = qbase + 32 * c + j;
-            if (h == 0 && qrow < p.B) {
-                p.max_val[(size_t)qrow * p.n_chunks + chunk] = m;
-                p.max_idx[(size_t)qrow * p.n_chunks + chunk] = t0 < t1 ? (int64_t)chunk : -1;
-            }
-        }
+    if (MAXONLY)
         return;
-    }
     // final compaction (bounds the pool the finish kernel sees) and counts out: (half-0 count) | (half-1 count) << 16
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
@@ -432,10 +428,7 @@ __global__ __launch_bounds__(256) void screen_finish_kernel(FinishParams p)
     const int total = n_pool;
     if (total > POOL_MAX)
         too_many = true;
-    int my_c[POOL_MAX / 256], my_o[POOL_MAX / 256];
-#pragma unroll
-    for (int it = 0; it < POOL_MAX / 256; ++it) {
-        const int m = tid + 256 * it;
+    for (int m = tid; m < total && m < POOL_MAX; m += 256) {
         int lo = 0, hi = p.n_chunks; // largest c with pre[c] <= m
         while (hi - lo > 1) {
             const int mid = (lo + hi) >> 1;
@@ -445,18 +438,10 @@ __global__ __launch_bounds__(256) void screen_finish_kernel(FinishParams p)
                 hi = mid;
         }
         const int o = m - pre[lo], n0 = hist[lo] & 0xffff;
-        my_c[it] = lo;
-        my_o[it] = o < n0 ? o : 64 + (o - n0); // second half-buffer starts at entry 64
-    }
-    __syncthreads();
-#pragma unroll
-    for (int it = 0; it < POOL_MAX / 256; ++it) {
-        const int m = tid + 256 * it;
-        if (m < total && m < POOL_MAX) {
-            const SCand e = p.cand[((size_t)(qgroup * p.n_chunks + my_c[it]) * SQ_PER_BLOCK + qin) * SCAP + my_o[it]];
-            pool_v[m] = e.v;
-            pool_x[m] = e.x;
-        }
+        const int slot = o < n0 ? o : 64 + (o - n0); // second half-buffer starts at entry 64
+        const SCand e = p.cand[((size_t)(qgroup * p.n_chunks + lo) * SQ_PER_BLOCK + qin) * SCAP + slot];
+        pool_v[m] = e.v;
+        pool_x[m] = e.x;
     }
     __syncthreads();
     const int np = min(n_pool, POOL_MAX);
@@ -656,8 +641,7 @@ struct SPlan {
     size_t cand_off, pcnt_off, smax_val_off, smax_idx_off, sthr_val_off, sthr_idx_off, ws_bytes, lds;
 };
 
-constexpr int SAMPLE_CHUNKS_MAX = 512; // maxima per query the sample pass can produce (>= 8k wanted)
-constexpr int64_t SAMPLE_MIN_N = 524288;
+constexpr int64_t SAMPLE_MIN_N = 65536;
 
 int screen_cus()
 {
@@ -696,15 +680,15 @@ SPlan make_splan(int B, int64_t N, int k)
     pl.sample = N >= SAMPLE_MIN_N;
     pl.s_docs = (N / 64 + 31) / 32 * 32;
     pl.s_tiles = (int)(pl.s_docs / 32);
-    int s_want = 8 * k < 128 ? 128 : 8 * k;
-    s_want = s_want > SAMPLE_CHUNKS_MAX ? SAMPLE_CHUNKS_MAX : s_want;
+    int s_want = (screen_cus() + pl.n_qgroups - 1) / pl.n_qgroups; // one round of workgroups, one maximum per TILE
+    s_want = s_want > pl.s_tiles ? pl.s_tiles : s_want;
+    s_want = s_want < 1 ? 1 : s_want;
     pl.s_tiles_per_chunk = (pl.s_tiles + s_want - 1) / s_want;
     pl.s_chunks = pl.sample ? (pl.s_tiles + pl.s_tiles_per_chunk - 1) / pl.s_tiles_per_chunk : 0;
     const size_t rows = (size_t)pl.n_qgroups * SQ_PER_BLOCK;
     pl.smax_val_off = off;
-    off = tt_align_up(off + rows * SAMPLE_CHUNKS_MAX * sizeof(float), 256);
+    off = tt_align_up(off + rows * (size_t)(pl.sample ? pl.s_tiles : 1) * sizeof(float), 256);
     pl.smax_idx_off = off;
-    off = tt_align_up(off + rows * SAMPLE_CHUNKS_MAX * sizeof(int64_t), 256);
     pl.sthr_val_off = off;
     off = tt_align_up(off + rows * 64 * sizeof(float), 256);
     pl.sthr_idx_off = off;
@@ -798,7 +782,6 @@ TT_EXPORT int tt_score_topk_screened_f32(const float *Q, int B, int d, const flo
     sp.pcnt = (int *)(ws + pl.pcnt_off);
     sp.flag = fallback_flag;
     sp.max_val = nullptr;
-    sp.max_idx = nullptr;
     sp.thr0 = nullptr;
     sp.thr0_stride = k;
     TT_HIP_CHECK(hipFuncSetAttribute((const void *)screen_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds));
@@ -810,10 +793,9 @@ TT_EXPORT int tt_score_topk_screened_f32(const float *Q, int B, int d, const flo
         ss.n_chunks = pl.s_chunks;
         ss.tiles_per_chunk = pl.s_tiles_per_chunk;
         ss.max_val = (float *)(ws + pl.smax_val_off);
-        ss.max_idx = (int64_t *)(ws + pl.smax_idx_off);
         hipLaunchKernelGGL(screen_kernel<true>, dim3(pl.n_qgroups * pl.s_chunks), dim3(SW * 64), pl.lds, st, ss);
         TT_LAUNCH_CHECK();
-        int rc = tt_kth_largest(ss.max_val, B, pl.s_chunks, k, (float *)(ws + pl.sthr_val_off), st);
+        int rc = tt_kth_largest(ss.max_val, B, pl.s_tiles, k, (float *)(ws + pl.sthr_val_off), st);
         if (rc != TT_OK)
             return rc;
         sp.thr0 = (const float *)(ws + pl.sthr_val_off);
