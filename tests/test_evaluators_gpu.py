@@ -73,3 +73,38 @@ def test_artifact_export_round_trip(tmp_path, oracle):
     qe = torch.from_numpy(inf.get_query_embedding(docs[3])).cuda()
     res = corpus_recall_hit(qe, D, positives=[3], top_k=(1, 5))
     assert set(res) == {"Recall@1", "Hit@1", "Recall@5", "Hit@5"} and 0.0 <= res["Recall@5"] <= 1.0
+
+
+def test_hybrid_rerank_blend_and_keyword_mode(tmp_path):
+    """frontend/main.py:102-210 with the Chroma top-50 replaced by the exact GPU top-50."""
+    import twotowermlretrieval_amd as tt
+    from twotowermlretrieval_amd.evaluators import save_inference_artifacts
+    from twotowermlretrieval_amd.hybrid import HybridSearcher
+    words = [f"w{i}" for i in range(5, 80)]
+    vocab = {w: i for i, w in enumerate(["the", ",", ".", "of", "and"] + words)}
+    tok = tt.PretrainedTokenizer(word2idx=vocab)
+    V, E, H = tok.vocab_size(), 20, 64
+    cfg = {"HIDDEN_DIM": H, "NUM_LAYERS": 1, "BIDIRECTIONAL": False, "BATCH_SIZE": 32}
+    m = tt.TwoTowerModel({**cfg, "VOCAB_SIZE": V, "EMBED_DIM": E}, synth.make_table(5, V, E)).cuda()
+    rs = np.random.RandomState(1)
+    docs = [" ".join(words[rs.randint(0, len(words))] for _ in range(rs.randint(4, 12))) for _ in range(120)]
+    emb = save_inference_artifacts(tmp_path, m, cfg, tok, docs, torch.device("cuda"))
+    inf = tt.QueryInferencer(str(tmp_path))
+    hs = HybridSearcher(inf, docs, torch.from_numpy(emb).cuda(), n_candidates=50)
+    query = docs[7]
+    res = hs.search(query, alpha=0.5)
+    assert len(res) == 10 and all(res[i]["score"] >= res[i + 1]["score"] for i in range(9))
+    for r in res:
+        assert abs(r["score"] - (0.5 * r["dense_score"] + 0.5 * r["tfidf_score"])) < 1e-6
+    assert res[0]["index"] == 7 and res[0]["tfidf_score"] > 0.99      # its own text wins the keyword half
+    # alpha = 1: pure dense order = the exact top-10 of the index
+    dense = hs.search(query, alpha=1.0)
+    v, i = hs.index.search(torch.from_numpy(inf.get_query_embedding(query)).cuda(), 10)
+    assert [r["index"] for r in dense] == i.cpu().tolist()
+    # the reference's Chroma-default score 1 - squared L2 = 2 cos - 1
+    hs2 = HybridSearcher(inf, docs, torch.from_numpy(emb).cuda(), hs.tfidf, hs.doc_tfidf, dense_score="chroma_l2")
+    d2 = hs2.search(query, alpha=1.0)
+    np.testing.assert_allclose([r["dense_score"] for r in d2], 2 * v.cpu().numpy() - 1, atol=1e-6)
+    # alpha = 0: corpus-wide keyword search, no GPU involved
+    kw = hs.search(query, alpha=0.0)
+    assert kw and kw[0]["index"] == 7 and all(r["dense_score"] == 0.0 for r in kw)

@@ -1,7 +1,7 @@
 """MI355X-native (gfx950) implementation of the two-tower retrieval hot path of
 jpe17/TwoTowerMLRetrieval: fused brute-force scoring + top-k, GRU encoder towers,
 triplet-loss training.  Python host over a C-ABI HIP library (libtt.so, include/tt.h)."""
-from . import evaluators, model, query_inferencer, tokenizer, trainer
+from . import evaluators, hybrid, model, query_inferencer, tokenizer, trainer
 from .index import BruteForceIndex, ShardedIndex, StreamedIndex, score_rank, score_topk, shard_bounds, topk_merge
 from .model import RNNEncoder, TwoTowerModel, triplet_loss_cosine
 from .query_inferencer import QueryInferencer
@@ -11,5 +11,5 @@ from .trainer import DataParallelTrainer, FusedClipAdam, train_step
 __all__ = ["BruteForceIndex", "ShardedIndex", "StreamedIndex", "score_topk", "topk_merge", "score_rank", "shard_bounds",
            "RNNEncoder", "TwoTowerModel", "triplet_loss_cosine", "QueryInferencer", "PretrainedTokenizer",
            "FusedClipAdam", "DataParallelTrainer", "train_step", "model", "trainer", "tokenizer", "query_inferencer",
-           "evaluators"]
+           "evaluators", "hybrid"]
 __version__ = "0.1.0"

@@ -638,7 +638,7 @@ struct SPlan {
     bool sample;
     int s_tiles, s_chunks, s_tiles_per_chunk;
     int64_t s_docs;
-    size_t cand_off, pcnt_off, smax_val_off, smax_idx_off, sthr_val_off, sthr_idx_off, ws_bytes, lds;
+    size_t cand_off, pcnt_off, smax_val_off, sthr_val_off, ws_bytes, lds;
 };
 
 constexpr int64_t SAMPLE_MIN_N = 65536;
@@ -688,11 +688,8 @@ SPlan make_splan(int B, int64_t N, int k)
     const size_t rows = (size_t)pl.n_qgroups * SQ_PER_BLOCK;
     pl.smax_val_off = off;
     off = tt_align_up(off + rows * (size_t)(pl.sample ? pl.s_tiles : 1) * sizeof(float), 256);
-    pl.smax_idx_off = off;
     pl.sthr_val_off = off;
-    off = tt_align_up(off + rows * 64 * sizeof(float), 256);
-    pl.sthr_idx_off = off;
-    off = tt_align_up(off + rows * 64 * sizeof(int64_t), 256);
+    off = tt_align_up(off + rows * sizeof(float), 256);
     pl.ws_bytes = off;
     pl.lds = (size_t)SRING * STILE_BYTES;
     return pl;
