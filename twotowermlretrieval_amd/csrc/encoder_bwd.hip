@@ -226,11 +226,13 @@ __global__ __launch_bounds__(MAXW * 64) void gru_bwd_seq_kernel(GruBwdParams p)
     }
 }
 
+constexpr int COLSUM_SLICES = 256; // N <= 3H <= 1536 columns: 256 x N floats fit the split-K slab buffer
+
 int colsum(const float *X, int64_t ld, int N, int M, const int *m_dyn, float *slabs, float *out, hipStream_t st)
 {
-    hipLaunchKernelGGL(colsum_kernel, dim3((N + 255) / 256, ENC_SPLITK), dim3(256), 0, st, X, ld, N, M, m_dyn, slabs);
+    hipLaunchKernelGGL(colsum_kernel, dim3((N + 255) / 256, COLSUM_SLICES), dim3(256), 0, st, X, ld, N, M, m_dyn, slabs);
     TT_LAUNCH_CHECK();
-    return tt_slab_reduce(slabs, ENC_SPLITK, N, out, 0, st);
+    return tt_slab_reduce(slabs, COLSUM_SLICES, N, out, 0, st);
 }
 
 // C[Mo][No] = A[:, a0:a0+Mo]^T * Bsrc (both summed over tokens), split-K + deterministic reduce

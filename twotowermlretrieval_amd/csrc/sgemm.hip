@@ -4,18 +4,20 @@ namespace {
 
 constexpr int BM = 128, BN = 128, BK = 16, LDT = 20; // LDS row stride 20 floats: conflict-free b128 reads
 
-// Stage one operand tile [128 rows][BK] (k contiguous in LDS) from global memory.
+// One operand tile [128 rows][BK] (k contiguous in LDS), staged in two halves so the global loads of
+// tile t+1 are in flight while tile t is multiplied: tile_fetch() -> registers, tile_commit() -> LDS.
 //  TR == false: source [rows][K]: thread -> (row t>>1, 8 consecutive k)
 //  TR == true : source [K][rows]: thread -> (k t>>4, 8 consecutive rows), scattered into LDS
 template <bool TR>
-__device__ __forceinline__ void stage_tile(float *__restrict__ tile, const float *__restrict__ src, int64_t ld,
-                                           const int32_t *__restrict__ map, int row0, int rows_eff, int k0,
-                                           int k_end, int tid)
+__device__ __forceinline__ void tile_fetch(f32x4 &v0, f32x4 &v1, const float *__restrict__ src, int64_t ld,
+                                           const int32_t *__restrict__ map, int row0, int rows_eff, int k0, int k_end,
+                                           int tid)
 {
+    v0 = (f32x4){0, 0, 0, 0};
+    v1 = (f32x4){0, 0, 0, 0};
     if (!TR) {
         const int r = tid >> 1, kc = (tid & 1) * 8;
         const int row = row0 + r;
-        f32x4 v0 = {0, 0, 0, 0}, v1 = {0, 0, 0, 0};
         if (row < rows_eff) {
             const int64_t srow = map ? (int64_t)map[row] : (int64_t)row;
             const float *p = src + srow * ld + k0 + kc;
@@ -24,12 +26,9 @@ __device__ __forceinline__ void stage_tile(float *__restrict__ tile, const float
             if (k0 + kc + 4 < k_end)
                 v1 = *(const f32x4 *)(p + 4);
         }
-        *(f32x4 *)(tile + r * LDT + kc) = v0;
-        *(f32x4 *)(tile + r * LDT + kc + 4) = v1;
     } else {
         const int kk = tid >> 4, rc = (tid & 15) * 8;
         const int k = k0 + kk;
-        f32x4 v0 = {0, 0, 0, 0}, v1 = {0, 0, 0, 0};
         if (k < k_end) {
             const int64_t srow = map ? (int64_t)map[k] : (int64_t)k;
             const float *p = src + srow * ld + row0 + rc;
@@ -38,6 +37,18 @@ __device__ __forceinline__ void stage_tile(float *__restrict__ tile, const float
             if (row0 + rc + 4 < rows_eff)
                 v1 = *(const f32x4 *)(p + 4);
         }
+    }
+}
+
+template <bool TR>
+__device__ __forceinline__ void tile_commit(float *__restrict__ tile, const f32x4 &v0, const f32x4 &v1, int tid)
+{
+    if (!TR) {
+        const int r = tid >> 1, kc = (tid & 1) * 8;
+        *(f32x4 *)(tile + r * LDT + kc) = v0;
+        *(f32x4 *)(tile + r * LDT + kc + 4) = v1;
+    } else {
+        const int kk = tid >> 4, rc = (tid & 15) * 8;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             tile[(rc + e) * LDT + kk] = v0[e];
@@ -74,10 +85,17 @@ __global__ __launch_bounds__(256) void sgemm_kernel(SgemmParams p)
             for (int r = 0; r < 16; ++r)
                 acc[a][b][r] = 0.0f;
 
+    f32x4 ra0, ra1, rb0, rb1;
+    tile_fetch<A_T>(ra0, ra1, p.A, p.lda, p.a_map, m0, M, kb, ke, tid);
+    tile_fetch<B_T>(rb0, rb1, p.B, p.ldb, p.b_map, n0, p.N, kb, ke, tid);
     for (int k0 = kb; k0 < ke; k0 += BK) {
-        stage_tile<A_T>(As, p.A, p.lda, p.a_map, m0, M, k0, ke, tid);
-        stage_tile<B_T>(Bs, p.B, p.ldb, p.b_map, n0, p.N, k0, ke, tid);
+        tile_commit<A_T>(As, ra0, ra1, tid);
+        tile_commit<B_T>(Bs, rb0, rb1, tid);
         __syncthreads();
+        if (k0 + BK < ke) { // next tile's global loads fly under this tile's MFMAs
+            tile_fetch<A_T>(ra0, ra1, p.A, p.lda, p.a_map, m0, M, k0 + BK, ke, tid);
+            tile_fetch<B_T>(rb0, rb1, p.B, p.ldb, p.b_map, n0, p.N, k0 + BK, ke, tid);
+        }
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             f32x4 a[2], b[2];
