@@ -153,7 +153,7 @@ def test_train_steps_reduce_loss_and_match_reference_loop_with_torch_optimizer()
         torch.nn.utils.clip_grad_norm_(ma.parameters(), max_norm=1.0)
         opt_t.step()
         la.append(loss.item())
-        lb.append(train_step(mb, opt_f, q, p, n, margin=0.5).item())
+        lb.append(train_step(mb, opt_f, q, p, n, margin=0.5, concurrent_towers=(_ % 2 == 0)).item())
     assert la[-1] < la[0]
     np.testing.assert_allclose(la, lb, atol=2e-5)
     for (na, pa), (nb, pb) in zip(ma.named_parameters(), mb.named_parameters()):

@@ -47,8 +47,10 @@ def main():
     print(json.dumps(dict(what="index build fwd", B=8192, T=big.shape[1], tokens=bt, ms=round(t_big*1e3, 3), tokens_per_s=round(bt/t_big), docs_per_s=round(8192/t_big))), flush=True)
     m.train()
     opt = tt.FusedClipAdam(m.parameters(), lr=5e-5, max_norm=1.0)
-    t_tr = timeit(lambda: tt.train_step(m, opt, q, p, n, margin=0.5), iters=5, warm=2)
-    print(json.dumps(dict(what="train step (fwd+bwd+clip+adam)", triplets=B, tokens=qt+pt+nt, ms=round(t_tr*1e3, 3), triplets_per_s=round(B/t_tr))), flush=True)
+    for conc in (False, True):
+        t_tr = timeit(lambda: tt.train_step(m, opt, q, p, n, margin=0.5, concurrent_towers=conc), iters=5, warm=2)
+        print(json.dumps(dict(what="train step (fwd+bwd+clip+adam)", concurrent_towers=conc, triplets=B, tokens=qt+pt+nt,
+                              ms=round(t_tr*1e3, 3), triplets_per_s=round(B/t_tr))), flush=True)
 
 if __name__ == "__main__":
     main()

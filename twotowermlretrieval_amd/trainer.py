@@ -107,14 +107,43 @@ class FusedClipAdam:
         return self.total_norm
 
 
+_TOWER_STREAMS = {}
+
+
+def _tower_streams(device):
+    key = (device.type, device.index)
+    if key not in _TOWER_STREAMS:
+        _TOWER_STREAMS[key] = [torch.cuda.Stream(device=device) for _ in range(3)]
+    return _TOWER_STREAMS[key]
+
+
 def train_step(model: TwoTowerModel, optimizer: FusedClipAdam, queries: torch.Tensor, pos_docs: torch.Tensor,
-               neg_docs: torch.Tensor, margin: float = 0.2) -> torch.Tensor:
+               neg_docs: torch.Tensor, margin: float = 0.2, concurrent_towers: bool = True) -> torch.Tensor:
     """One step of backend/main.py:244-259 on this rank's (equal-sized) share of the global batch.
-    Returns the local loss as a 0-d device tensor (no .item(): the reference's per-step sync is dropped)."""
+    Returns the local loss as a 0-d device tensor (no .item(): the reference's per-step sync is dropped).
+
+    concurrent_towers: the three encoder calls are independent and each recurrence kernel only occupies
+    ceil(B/16) CUs, so they are issued on three HIP streams (autograd replays each call's backward on the
+    stream its forward ran on); results are identical to the sequential order."""
     optimizer.zero_grad()
-    q = model.encode_query(queries)
-    p = model.encode_document(pos_docs)
-    n = model.encode_document(neg_docs)
+    if concurrent_towers and queries.is_cuda:
+        cur = torch.cuda.current_stream(queries.device)
+        outs = []
+        for s, (fn, ids) in zip(_tower_streams(queries.device),
+                                ((model.encode_query, queries), (model.encode_document, pos_docs),
+                                 (model.encode_document, neg_docs))):
+            s.wait_stream(cur)
+            with torch.cuda.stream(s):
+                ids.record_stream(s)
+                outs.append(fn(ids))
+        for s, o in zip(_tower_streams(queries.device), outs):
+            cur.wait_stream(s)
+            o.record_stream(cur)
+        q, p, n = outs
+    else:
+        q = model.encode_query(queries)
+        p = model.encode_document(pos_docs)
+        n = model.encode_document(neg_docs)
     loss = triplet_loss_cosine((q, p, n), margin=margin)
     loss.backward()
     optimizer.step()
