@@ -1,0 +1,26 @@
+#!/usr/bin/env python3
+"""Step time of one rank's share of the bench step for several shard sizes / k (single GPU, no collective)."""
+import sys, json
+from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+import torch
+import bench
+import twotowermlretrieval_amd as tt
+dev = torch.device("cuda:0")
+q = bench.gen_queries(1024, dev)
+for n in (1_250_000, 2_500_000, 5_000_000, 10_000_000):
+    docs = bench.gen_rows(0, n, dev)
+    ix = tt.BruteForceIndex(docs, screen=True)
+    for k in (10, 50):
+        for _ in range(3):
+            ix.search(q, k)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            ix.search(q, k)
+        e1.record()
+        torch.cuda.synchronize()
+        print(json.dumps(dict(docs=n, k=k, ms=round(e0.elapsed_time(e1) / 10, 4))), flush=True)
+    del ix, docs
+    torch.cuda.empty_cache()

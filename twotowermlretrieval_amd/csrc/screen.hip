@@ -28,6 +28,7 @@
 // (global_load_lds, XOR-swizzled source) and read by all 8 waves, so HBM/L2 traffic is
 // N*512 B per 512 queries.
 #include "tt_common.h"
+#include <cmath>
 
 #include <hip/hip_fp16.h>
 #include <limits.h>
@@ -90,10 +91,11 @@ struct ScreenParams {
     int thr0_stride;
 };
 
-__device__ __forceinline__ void scand_store_async(SCand *dst, float v, int x)
+// store (v, x) at wave-uniform base + per-lane 32-bit byte offset (SGPR-base addressing: no 64-bit VALU math)
+__device__ __forceinline__ void scand_store_async(const SCand *base, unsigned byte_off, float v, int x)
 {
     const unsigned long long bits = ((unsigned long long)(unsigned)x << 32) | (unsigned long long)__float_as_uint(v);
-    asm volatile("global_store_dwordx2 %0, %1, off\n\ts_nop 1" ::"v"(dst), "v"(bits) : "memory");
+    asm volatile("global_store_dwordx2 %0, %1, %2\n\ts_nop 1" ::"v"(byte_off), "v"(bits), "s"(base) : "memory");
 }
 
 __device__ __forceinline__ void f32_store_async(float *dst, float v)
@@ -292,6 +294,14 @@ __global__ __launch_bounds__(SW * 64, 2) void screen_kernel(ScreenParams p)
                 // ---- epilogue: accC[r] = s16(doc tile*32 + (r&3)+8(r>>2)+4h, query qbase+32C+j) ----
                 const int tile_base = tile * 32;
                 const bool partial = tile_base + 32 > p.N;
+                if (!MAXONLY && partial) { // rows past the corpus: NaN never passes `>= thr` and fmaxf drops it
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (tile_base + (r & 3) + 8 * (r >> 2) + 4 * h >= p.N) {
+                            acc0[r] = __builtin_nanf("");
+                            acc1[r] = __builtin_nanf("");
+                        }
+                }
 #pragma unroll
                 for (int c = 0; c < 2; ++c) {
                     const f32x16 &acc = c == 0 ? acc0 : acc1;
@@ -308,22 +318,29 @@ __global__ __launch_bounds__(SW * 64, 2) void screen_kernel(ScreenParams p)
                             f32_store_async(p.max_val + (size_t)qrow * p.n_tiles + tile, m);
                         continue;
                     }
-                    float m = acc[0];
+                    // group g = accumulator rows 4g..4g+3 (docs tile_base + 8g + 4h + 0..3)
+                    float mg[4];
 #pragma unroll
-                    for (int r = 1; r < 16; ++r)
-                        m = fmaxf(m, acc[r]);
+                    for (int g = 0; g < 4; ++g)
+                        mg[g] = fmaxf(fmaxf(acc[4 * g], acc[4 * g + 1]), fmaxf(acc[4 * g + 2], acc[4 * g + 3]));
+                    const float m = fmaxf(fmaxf(mg[0], mg[1]), fmaxf(mg[2], mg[3]));
                     if (__ballot(m >= thr[c]) == 0ull)
                         continue;
                     // append pass: every lane appends to its own half of the query's buffer with its own
                     // counter (no ballots), through inline-asm stores (a compiler-visible VMEM op here would put
-                    // s_waitcnt vmcnt(0) on the hot path and drain the DMA ring)
-                    SCand *const mine = cwave + (size_t)(32 * c + j) * SCAP + 64 * h;
+                    // s_waitcnt vmcnt(0) on the hot path and drain the DMA ring); groups without a hit are skipped
+                    const unsigned mine = (unsigned)(((32 * c + j) * SCAP + 64 * h) * sizeof(SCand));
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int doc = tile_base + (r & 3) + 8 * (r >> 2) + 4 * h;
-                        if ((!partial || doc < p.N) && acc[r] >= thr[c]) {
-                            scand_store_async(mine + cnt[c], acc[r], doc);
-                            ++cnt[c];
+                    for (int g = 0; g < 4; ++g) {
+                        if (__ballot(mg[g] >= thr[c]) == 0ull)
+                            continue;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            if (acc[4 * g + e] >= thr[c]) {
+                                scand_store_async(cwave, mine + (unsigned)cnt[c] * (unsigned)sizeof(SCand), acc[4 * g + e],
+                                                  tile_base + e + 8 * g + 4 * h);
+                                ++cnt[c];
+                            }
                         }
                     }
                     // a tile adds at most 16 entries per lane: compact while a half still has room for that
@@ -676,9 +693,16 @@ SPlan make_splan(int B, int64_t N, int k)
     off = tt_align_up(off + (size_t)pl.n_blocks * SQ_PER_BLOCK * SCAP * sizeof(SCand), 256);
     pl.pcnt_off = off;
     off = tt_align_up(off + (size_t)pl.n_qgroups * SQ_PER_BLOCK * pl.n_chunks * sizeof(int), 256);
-    // sample pass: 1/64 of the corpus cut in SAMPLE_CHUNKS pieces (their maxima seed the thresholds)
+    // sample pass: one maximum per 32-document tile of the sample; the k-th largest seeds the thresholds
     pl.sample = N >= SAMPLE_MIN_N;
-    pl.s_docs = (N / 64 + 31) / 32 * 32;
+    // Sample size: 1/64 of the corpus, or enough documents that the k-th sample maximum lets through about
+    // one candidate per 32x32 score tile or fewer (k / s_docs per score): matters for small shards, large k.
+    int64_t s_docs = N / 64;
+    constexpr int per_k = 2048; // measured optimum is broad (1024..4096) for k = 10..50 on 1.25M..10M documents
+    const int64_t s_min = (int64_t)k * per_k < N / 4 ? (int64_t)k * per_k : N / 4;
+    s_docs = s_docs < s_min ? s_min : s_docs;
+    s_docs = s_docs < 32 ? 32 : s_docs;
+    pl.s_docs = (s_docs + 31) / 32 * 32;
     pl.s_tiles = (int)(pl.s_docs / 32);
     int s_want = (screen_cus() + pl.n_qgroups - 1) / pl.n_qgroups; // one round of workgroups, one maximum per TILE
     s_want = s_want > pl.s_tiles ? pl.s_tiles : s_want;
