@@ -8,7 +8,8 @@ import bench
 import twotowermlretrieval_amd as tt
 dev = torch.device("cuda:0")
 q = bench.gen_queries(1024, dev)
-for n in (1_250_000, 2_500_000, 5_000_000, 10_000_000):
+sizes = [int(a) for a in sys.argv[1:]] or [1_250_000, 2_500_000, 5_000_000, 10_000_000]
+for n in sizes:
     docs = bench.gen_rows(0, n, dev)
     ix = tt.BruteForceIndex(docs, screen=True)
     for k in (10, 50):

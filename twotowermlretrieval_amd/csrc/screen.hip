@@ -5,7 +5,7 @@
 // through a rigorous filter:
 //
 //   1. screen   approximate scores s16 = <fp16(q), fp16(d)> with fp32 accumulation on
-//               v_mfma_f32_32x32x16_f16 against an fp16 shadow copy of the corpus.  For every pair
+//               v_mfma_f32_16x16x32_f16 against an fp16 shadow copy of the corpus.  For every pair
 //                   |s16 - s| <= eps_q  with  eps_q = 1.05e-3 |q| Dmax + 1e-6 (|q| + Dmax)
 //               (fp16 rounding 2^-11 per operand, exact products, fp32 summation of 256 terms on
 //               both sides, fp16 underflow; Dmax = largest document L2 norm; derivation in
@@ -48,7 +48,7 @@ typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void gbl_void;
 
 constexpr int SW = 8;                 // waves per workgroup
-constexpr int SQ_PER_WAVE = 64;       // queries per wave (two 32-wide MFMA column tiles)
+constexpr int SQ_PER_WAVE = 64;       // queries per wave (four 16-wide MFMA column tiles)
 constexpr int SQ_PER_BLOCK = SW * SQ_PER_WAVE;
 constexpr int STILE_BYTES = 32 * 512; // 32 docs x 256 f16
 constexpr int SRING = 8;              // ring depth in tiles
@@ -103,11 +103,16 @@ __device__ __forceinline__ void f32_store_async(float *dst, float v)
     asm volatile("global_store_dword %0, %1, off\n\ts_nop 0" ::"v"(dst), "v"(v) : "memory");
 }
 
-// A query's 128-entry buffer is two 64-entry halves, one per half-wave: lane (j,h) appends to half h
-// with its OWN counter, so the append pass needs no cross-lane traffic at all.
-// Compaction: keep every entry within `slack` of the k-th best of the union; rank r goes to half r&1,
-// slot r>>1 (keeps the halves balanced).  Lane t owns entry t of each half.
-__device__ __forceinline__ void screen_compact(SCand *base, int n0, int n1, int k, float slack, int lane, int &n_new,
+// A query's 128-entry buffer is four 32-entry quarters, one per lane that holds scores of that query
+// (16x16x32 MFMA: query n of a 16-query set sits in lanes n, n+16, n+32, n+48): lane (n,g) appends to
+// quarter g with its OWN counter, so the append pass needs no cross-lane traffic at all.
+// Compaction: keep every entry within `slack` of the k-th best of the union; rank r goes to quarter r&3,
+// slot r>>2 (keeps the quarters balanced).  Lane t owns entries t and 64+t of the buffer.
+constexpr int SQUART = SCAP / 4;                 // 32 entries per quarter
+constexpr int SQ_TRIGGER = SQUART - 10;          // a tile adds at most 8 entries per lane: compact above this
+constexpr int SQ_KEEP_MAX = 4 * SQ_TRIGGER - 4;  // more kept entries than this could not take another tile
+
+__device__ __forceinline__ void screen_compact(SCand *base, const int (&n)[4], int k, float slack, int lane, int &n_new,
                                                float &thr_new, bool &have, bool &overflow)
 {
     float v[2];
@@ -118,7 +123,7 @@ __device__ __forceinline__ void screen_compact(SCand *base, int n0, int n1, int 
         v[i] = -INFINITY;
         x[i] = INT_MAX;
         rank[i] = 0;
-        live[i] = lane < (i ? n1 : n0);
+        live[i] = (lane & 31) < ((lane >> 5) ? n[2 * i + 1] : n[2 * i]);
         if (live[i]) {
             const SCand c = scand_load_l2(base + 64 * i + lane);
             v[i] = c.v;
@@ -127,19 +132,22 @@ __device__ __forceinline__ void screen_compact(SCand *base, int n0, int n1, int 
     }
 #pragma unroll
     for (int i2 = 0; i2 < 2; ++i2) {
-        const int lim = i2 ? n1 : n0;
-        for (int l2 = 0; l2 < lim; ++l2) {
-            const float sv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v[i2]), l2));
-            const int sx = __builtin_amdgcn_readlane(x[i2], l2);
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
-                rank[i] += (sv > v[i] || (sv == v[i] && sx < x[i])) ? 1 : 0;
+        for (int sub = 0; sub < 2; ++sub) {
+            const int lim = n[2 * i2 + sub];
+            for (int l2 = 0; l2 < lim; ++l2) {
+                const float sv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v[i2]), 32 * sub + l2));
+                const int sx = __builtin_amdgcn_readlane(x[i2], 32 * sub + l2);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+                    rank[i] += (sv > v[i] || (sv == v[i] && sx < x[i])) ? 1 : 0;
+            }
         }
     }
-    const int n = n0 + n1;
-    have = n >= k;
+    const int total = n[0] + n[1] + n[2] + n[3];
+    have = total >= k;
     overflow = false;
-    n_new = n;
+    n_new = total;
     thr_new = -INFINITY;
     if (have) {
         float kth = -INFINITY;
@@ -154,7 +162,7 @@ __device__ __forceinline__ void screen_compact(SCand *base, int n0, int n1, int 
 #pragma unroll
         for (int i = 0; i < 2; ++i)
             n_new += __popcll(__ballot(live[i] && v[i] >= thr_new));
-        if (n_new > SCAP - 48) { // a half could not take one more tile: exact fallback (this pass's result is discarded)
+        if (n_new > SQ_KEEP_MAX) { // a quarter could not take one more tile: exact fallback (this pass's result is discarded)
             overflow = true;
             n_new = k;
         }
@@ -165,7 +173,7 @@ __device__ __forceinline__ void screen_compact(SCand *base, int n0, int n1, int 
             SCand c;
             c.v = v[i];
             c.x = x[i];
-            base[64 * (rank[i] & 1) + (rank[i] >> 1)] = c;
+            base[SQUART * (rank[i] & 3) + (rank[i] >> 2)] = c;
         }
 }
 
@@ -180,27 +188,28 @@ __global__ __launch_bounds__(SW * 64, 2) void screen_kernel(ScreenParams p)
     const int t0 = chunk * p.tiles_per_chunk;
     const int t1 = min(t0 + p.tiles_per_chunk, p.n_tiles);
     const int k = p.k;
-    const int h = lane >> 5, j = lane & 31;
+    const int g = lane >> 4, n = lane & 15;
     const int qbase = qgroup * SQ_PER_BLOCK + w * SQ_PER_WAVE;
     const bool wave_live = qbase < p.B;
 
-    // ---- query operands: set c holds queries qbase + 32c + j; lane (j,h) keeps k = 16s + 8h .. +7 ----
-    h8 qreg[2][16];
-    float eps2[2], thr[2];
-    int cnt[2] = {0, 0};
+    // ---- query operands (B of v_mfma_f32_16x16x32_f16): set c holds queries qbase + 16c + n;
+    //      lane (n,g) keeps features 32s + 8g .. +7 of k-step s ----
+    h8 qreg[4][8];
+    float eps2[4], thr[4];
+    int cnt[4] = {0, 0, 0, 0};
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
+    for (int c = 0; c < 4; ++c) {
         bool bad = false;
-        const int qrow = qbase + 32 * c + j;
+        const int qrow = qbase + 16 * c + n;
         const bool live = qrow < p.B;
-        const float *qp = p.Q + (size_t)min(qrow, p.B - 1) * 256 + 8 * h;
+        const float *qp = p.Q + (size_t)min(qrow, p.B - 1) * 256 + 8 * g;
         float ss = 0.0f;
-        // (staging the rows through LDS for coalesced reads was measured SLOWER here: four dependent
+        // (staging the rows through LDS for coalesced reads was measured SLOWER here: dependent
         //  load->write->read rounds per wave instead of 64 independent loads in flight)
 #pragma unroll
-        for (int s = 0; s < 16; ++s) {
-            const f32x4 a = *(const f32x4 *)(qp + 16 * s);
-            const f32x4 b = *(const f32x4 *)(qp + 16 * s + 4);
+        for (int s = 0; s < 8; ++s) {
+            const f32x4 a = *(const f32x4 *)(qp + 32 * s);
+            const f32x4 b = *(const f32x4 *)(qp + 32 * s + 4);
             h8 hv;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -212,6 +221,7 @@ __global__ __launch_bounds__(SW * 64, 2) void screen_kernel(ScreenParams p)
             }
             qreg[c][s] = hv;
         }
+        ss += __shfl_xor(ss, 16);
         ss += __shfl_xor(ss, 32);
         eps2[c] = 2.0f * screen_eps(sqrtf(ss), p.dmax);
         // A_k over any subset of the corpus, minus 2 eps, never exceeds the approximate score of a
@@ -219,26 +229,27 @@ __global__ __launch_bounds__(SW * 64, 2) void screen_kernel(ScreenParams p)
         thr[c] = live ? ((!MAXONLY && p.thr0) ? p.thr0[(size_t)qrow * p.thr0_stride + p.thr0_stride - 1] - eps2[c] : -INFINITY)
                       : INFINITY;
         if (bad && live) // fp16 cannot hold this query: its 32-query tile goes to the exact kernel
-            atomicOr(p.flag + ((qbase + 32 * c) >> 5), 2);
+            atomicOr(p.flag + ((qbase + 16 * c) >> 5), 2);
     }
 
     SCand *const cwave = p.cand + ((size_t)blockIdx.x * SQ_PER_BLOCK + w * SQ_PER_WAVE) * SCAP;
 
-    auto compact_where = [&](int c, unsigned long long qmask) {
+    auto compact_where = [&](int c, unsigned qmask) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         while (qmask) {
-            const int q = __ffsll((long long)qmask) - 1;
+            const int q = __ffs((int)qmask) - 1;
             qmask &= qmask - 1;
-            const int n0 = __builtin_amdgcn_readlane(cnt[c], q), n1 = __builtin_amdgcn_readlane(cnt[c], q + 32);
+            const int nq[4] = {__builtin_amdgcn_readlane(cnt[c], q), __builtin_amdgcn_readlane(cnt[c], q + 16),
+                               __builtin_amdgcn_readlane(cnt[c], q + 32), __builtin_amdgcn_readlane(cnt[c], q + 48)};
             const float slack = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, eps2[c]), q));
             int n_new;
             float tn;
             bool have, ovf;
-            screen_compact(cwave + (size_t)(32 * c + q) * SCAP, n0, n1, k, slack, lane, n_new, tn, have, ovf);
+            screen_compact(cwave + (size_t)(16 * c + q) * SCAP, nq, k, slack, lane, n_new, tn, have, ovf);
             if (ovf && lane == 0)
-                atomicOr(p.flag + ((qbase + 32 * c) >> 5), 1);
-            if (j == q) {
-                cnt[c] = h ? (n_new >> 1) : ((n_new + 1) >> 1);
+                atomicOr(p.flag + ((qbase + 16 * c) >> 5), 1);
+            if (n == q) {
+                cnt[c] = (n_new - g + 3) >> 2; // ranks r < n_new with r & 3 == g
                 if (have)
                     thr[c] = tn;
             }
@@ -251,9 +262,9 @@ __global__ __launch_bounds__(SW * 64, 2) void screen_kernel(ScreenParams p)
     auto set_rows = [&](int tile) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int row = 2 * (2 * w + i) + h;            // doc within the tile
+            const int row = 2 * (2 * w + i) + (lane >> 5);  // doc within the tile
             const int doc = min(tile * 32 + row, p.N - 1);
-            const int chunk16 = j ^ (row & 15);             // source swizzle: logical = physical ^ (row & 15)
+            const int chunk16 = (lane & 31) ^ (row & 15);   // source swizzle: logical = physical ^ (row & 15)
             rowp[i] = D + (size_t)doc * 512 + chunk16 * 16;
         }
     };
@@ -267,10 +278,10 @@ __global__ __launch_bounds__(SW * 64, 2) void screen_kernel(ScreenParams p)
     if (t0 < t1) {
         // DMA runs SRING - STPB tiles ahead; one barrier per STPB tiles.
 #pragma unroll
-        for (int g = 0; g < SRING - STPB; ++g)
-            dma_issue(t0 + g, g);
+        for (int gi = 0; gi < SRING - STPB; ++gi)
+            dma_issue(t0 + gi, gi);
         int stage = 0;
-        const int rd_base = j * 512;
+        const int rd_base = n * 512; // A row (document) n of sub-tile 0; sub-tile 1 is 16 rows = 8 KiB further
         for (int tile = t0; tile < t1; ++tile) {
             if ((tile - t0) % STPB == 0) {
                 // own DMAs of this interval's tiles have landed; the barrier extends that to every wave's
@@ -282,72 +293,95 @@ __global__ __launch_bounds__(SW * 64, 2) void screen_kernel(ScreenParams p)
                     dma_issue(tile + SRING - STPB + u, (stage + SRING - STPB + u) % SRING);
             }
             if (wave_live) {
-                f32x16 acc0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-                f32x16 acc1 = acc0;
-                const char *buf = ring + stage * STILE_BYTES + rd_base;
+                // acc[u][c][r] = s16(doc tile*32 + 16u + 4g + r, query qbase + 16c + n)
+                f32x4 acc[2][4];
 #pragma unroll
-                for (int s = 0; s < 16; ++s) {
-                    const h8 a = *(const h8 *)(buf + (((2 * s + h) ^ (j & 15)) << 4));
-                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, qreg[0][s], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, qreg[1][s], acc1, 0, 0, 0);
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        acc[u][c] = f32x4{0, 0, 0, 0};
+                const char *buf = ring + stage * STILE_BYTES + rd_base;
+                // A fragments run two k-steps ahead of the MFMAs that consume them (three register sets);
+                // the scheduling fences keep hipcc from sinking the reads back next to their use
+                h8 a0[3], a1[3];
+                auto a_read = [&](int s) {
+                    const int off = ((4 * s + g) ^ n) << 4;
+                    a0[s % 3] = *(const h8 *)(buf + off);
+                    a1[s % 3] = *(const h8 *)(buf + 16 * 512 + off);
+                };
+                a_read(0);
+                a_read(1);
+#pragma unroll
+                for (int s = 0; s < 8; ++s) {
+                    if (s + 2 < 8)
+                        a_read(s + 2);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        acc[0][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0[s % 3], qreg[c][s], acc[0][c], 0, 0, 0);
+                        acc[1][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[s % 3], qreg[c][s], acc[1][c], 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-                // ---- epilogue: accC[r] = s16(doc tile*32 + (r&3)+8(r>>2)+4h, query qbase+32C+j) ----
                 const int tile_base = tile * 32;
                 const bool partial = tile_base + 32 > p.N;
                 if (!MAXONLY && partial) { // rows past the corpus: NaN never passes `>= thr` and fmaxf drops it
 #pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        if (tile_base + (r & 3) + 8 * (r >> 2) + 4 * h >= p.N) {
-                            acc0[r] = __builtin_nanf("");
-                            acc1[r] = __builtin_nanf("");
-                        }
+                    for (int u = 0; u < 2; ++u)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (tile_base + 16 * u + 4 * g + r >= p.N) {
+#pragma unroll
+                                for (int c = 0; c < 4; ++c)
+                                    acc[u][c][r] = __builtin_nanf("");
+                            }
                 }
 #pragma unroll
-                for (int c = 0; c < 2; ++c) {
-                    const f32x16 &acc = c == 0 ? acc0 : acc1;
+                for (int c = 0; c < 4; ++c) {
                     if (MAXONLY) { // one maximum per (tile, query): the k-th largest of them seeds the thresholds
                         float m = -INFINITY;
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const int doc = tile_base + (r & 3) + 8 * (r >> 2) + 4 * h;
-                            m = fmaxf(m, (!partial || doc < p.N) ? acc[r] : -INFINITY);
-                        }
+                        for (int u = 0; u < 2; ++u)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const int doc = tile_base + 16 * u + 4 * g + r;
+                                m = fmaxf(m, (!partial || doc < p.N) ? acc[u][c][r] : -INFINITY);
+                            }
+                        m = fmaxf(m, __shfl_xor(m, 16));
                         m = fmaxf(m, __shfl_xor(m, 32));
-                        const int qrow = qbase + 32 * c + j;
-                        if (h == 0 && qrow < p.B)
+                        const int qrow = qbase + 16 * c + n;
+                        if (g == 0 && qrow < p.B)
                             f32_store_async(p.max_val + (size_t)qrow * p.n_tiles + tile, m);
                         continue;
                     }
-                    // group g = accumulator rows 4g..4g+3 (docs tile_base + 8g + 4h + 0..3)
-                    float mg[4];
+                    float mg[2];
 #pragma unroll
-                    for (int g = 0; g < 4; ++g)
-                        mg[g] = fmaxf(fmaxf(acc[4 * g], acc[4 * g + 1]), fmaxf(acc[4 * g + 2], acc[4 * g + 3]));
-                    const float m = fmaxf(fmaxf(mg[0], mg[1]), fmaxf(mg[2], mg[3]));
-                    if (__ballot(m >= thr[c]) == 0ull)
+                    for (int u = 0; u < 2; ++u)
+                        mg[u] = fmaxf(fmaxf(acc[u][c][0], acc[u][c][1]), fmaxf(acc[u][c][2], acc[u][c][3]));
+                    if (__ballot(fmaxf(mg[0], mg[1]) >= thr[c]) == 0ull)
                         continue;
-                    // append pass: every lane appends to its own half of the query's buffer with its own
+                    // append pass: every lane appends to its own quarter of the query's buffer with its own
                     // counter (no ballots), through inline-asm stores (a compiler-visible VMEM op here would put
-                    // s_waitcnt vmcnt(0) on the hot path and drain the DMA ring); groups without a hit are skipped
-                    const unsigned mine = (unsigned)(((32 * c + j) * SCAP + 64 * h) * sizeof(SCand));
+                    // s_waitcnt vmcnt(0) on the hot path and drain the DMA ring); sub-tiles without a hit are skipped
+                    const unsigned mine = (unsigned)(((16 * c + n) * SCAP + SQUART * g) * sizeof(SCand));
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        if (__ballot(mg[g] >= thr[c]) == 0ull)
+                    for (int u = 0; u < 2; ++u) {
+                        if (__ballot(mg[u] >= thr[c]) == 0ull)
                             continue;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            if (acc[4 * g + e] >= thr[c]) {
-                                scand_store_async(cwave, mine + (unsigned)cnt[c] * (unsigned)sizeof(SCand), acc[4 * g + e],
-                                                  tile_base + e + 8 * g + 4 * h);
+                        for (int r = 0; r < 4; ++r) {
+                            if (acc[u][c][r] >= thr[c]) {
+                                scand_store_async(cwave, mine + (unsigned)cnt[c] * (unsigned)sizeof(SCand), acc[u][c][r],
+                                                  tile_base + 16 * u + 4 * g + r);
                                 ++cnt[c];
                             }
                         }
                     }
-                    // a tile adds at most 16 entries per lane: compact while a half still has room for that
-                    unsigned long long full = __ballot(cnt[c] > 64 - 18);
-                    full = (full | (full >> 32)) & 0xffffffffull;
+                    unsigned long long full = __ballot(cnt[c] > SQ_TRIGGER);
+                    full = (full | (full >> 32));
+                    full = (full | (full >> 16)) & 0xffffull;
                     if (full)
-                        compact_where(c, full);
+                        compact_where(c, (unsigned)full);
                 }
             }
             stage = (stage + 1) % SRING;
@@ -358,16 +392,20 @@ __global__ __launch_bounds__(SW * 64, 2) void screen_kernel(ScreenParams p)
 
     if (MAXONLY)
         return;
-    // final compaction (bounds the pool the finish kernel sees) and counts out: (half-0 count) | (half-1 count) << 16
+    // final compaction (bounds the pool the finish kernel sees) and counts out: quarter g's count in byte g
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
-        const unsigned long long over = __ballot(cnt[c] + __shfl_xor(cnt[c], 32) > k) & 0xffffffffull;
+    for (int c = 0; c < 4; ++c) {
+        int tot = cnt[c] + __shfl_xor(cnt[c], 16);
+        tot += __shfl_xor(tot, 32);
+        const unsigned long long over = __ballot(tot > k) & 0xffffull;
         if (over)
-            compact_where(c, over);
-        const int other = __shfl_xor(cnt[c], 32);
-        const int qrow = qbase + 32 * c + j;
-        if (h == 0 && qrow < p.B)
-            p.pcnt[(size_t)qrow * p.n_chunks + chunk] = cnt[c] | (other << 16);
+            compact_where(c, (unsigned)over);
+        int packed = cnt[c] << (8 * g);
+        packed |= __shfl_xor(packed, 16);
+        packed |= __shfl_xor(packed, 32);
+        const int qrow = qbase + 16 * c + n;
+        if (g == 0 && qrow < p.B)
+            p.pcnt[(size_t)qrow * p.n_chunks + chunk] = packed;
     }
 }
 
@@ -430,13 +468,13 @@ __global__ __launch_bounds__(256) void screen_finish_kernel(FinishParams p)
     bool too_many = false;
     int *pre = sv_x; // n_chunks + 1 <= 129 prefix entries, reused before the survivors are written
     if (tid < p.n_chunks)
-        hist[tid] = p.pcnt[(size_t)row * p.n_chunks + tid]; // packed (n0 | n1 << 16); hist is free until the select
+        hist[tid] = p.pcnt[(size_t)row * p.n_chunks + tid]; // quarter counts, one per byte; hist is free until the select
     __syncthreads();
     if (tid == 0) {
         int run = 0;
         for (int c = 0; c < p.n_chunks; ++c) {
             pre[c] = run;
-            run += (hist[c] & 0xffff) + (hist[c] >> 16);
+            run += (hist[c] & 0xff) + ((hist[c] >> 8) & 0xff) + ((hist[c] >> 16) & 0xff) + ((hist[c] >> 24) & 0xff);
         }
         pre[p.n_chunks] = run;
         n_pool = run;
@@ -454,8 +492,16 @@ __global__ __launch_bounds__(256) void screen_finish_kernel(FinishParams p)
             else
                 hi = mid;
         }
-        const int o = m - pre[lo], n0 = hist[lo] & 0xffff;
-        const int slot = o < n0 ? o : 64 + (o - n0); // second half-buffer starts at entry 64
+        int o = m - pre[lo], slot = 0; // quarter g of the buffer starts at entry 32 g
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            const int ng = (hist[lo] >> (8 * gq)) & 0xff;
+            if (o >= 0 && o < ng)
+                slot = SQUART * gq + o;
+            o -= ng;
+            if (o < 0)
+                o = INT_MIN / 2;
+        }
         const SCand e = p.cand[((size_t)(qgroup * p.n_chunks + lo) * SQ_PER_BLOCK + qin) * SCAP + slot];
         pool_v[m] = e.v;
         pool_x[m] = e.x;
