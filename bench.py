@@ -200,16 +200,16 @@ def main():
         kp = TOPK if world == 1 else SHARD_K
         flops = 2.0 * BATCH * n_shard * DIM
         ms_s = screen_kernel_ms(local_index, q, kp)
-        roof = {"bound": "mfma", "kernel": "screen_kernel<false> (f16 MFMA 32x32x16, fp32 accumulate)",
+        roof = {"bound": "mfma", "kernel": "screen_kernel<false> (f16 MFMA 16x16x32, fp32 accumulate)",
                 "achieved": round(flops / ms_s / 1e9, 2), "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(flops / ms_s / 1e9 / MFMA_F16_PEAK_TFLOPS, 4), "traffic": pmc_traffic("screen_b1024"),
+                "frac": round(flops / ms_s / 1e9 / MFMA_F16_PEAK_TFLOPS, 4), "traffic": pmc_traffic("screen_b1024") if world == 1 else None,
                 "kernel_ms": round(ms_s, 4), "batch": BATCH, "docs_per_gpu": n_shard,
                 "hbm_GBps_same_launch": round((-(-BATCH // 512) * n_shard * DIM * 2) / ms_s / 1e6, 1),
                 "exact_fallback_tiles": flags}
         ms = kernel_only_ms(q, docs, kp, iters=3, warm=1)
         roof_f32 = {"bound": "mfma", "kernel": "score_topk_kernel<8,*,false> (fp32 MFMA 32x32x2), same batch",
                     "achieved": round(flops / ms / 1e9, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(flops / ms / 1e9 / MFMA_F32_PEAK_TFLOPS, 4), "traffic": pmc_traffic("b1024"),
+                    "frac": round(flops / ms / 1e9 / MFMA_F32_PEAK_TFLOPS, 4), "traffic": pmc_traffic("b1024") if world == 1 else None,
                     "kernel_ms": round(ms, 4), "batch": BATCH, "docs_per_gpu": n_shard,
                     "qps": round(BATCH / ms * 1e3, 1)}
         qb = q[:32].contiguous()
@@ -217,7 +217,7 @@ def main():
         byts = n_shard * DIM * 4 + 32 * DIM * 4 + 32 * TOPK * 12
         roof_hbm = {"bound": "hbm", "kernel": "score_topk_kernel<8,64,false> (+ sample pass, B=32)",
                     "achieved": round(byts / ms32 / 1e6, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                    "frac": round(byts / ms32 / 1e6 / HBM_PEAK_GBPS, 4), "traffic": pmc_traffic("b32"),
+                    "frac": round(byts / ms32 / 1e6 / HBM_PEAK_GBPS, 4), "traffic": pmc_traffic("b32") if world == 1 else None,
                     "kernel_ms": round(ms32, 4), "batch": 32, "docs_per_gpu": n_shard,
                     "qps": round(32 / ms32 * 1e3, 1)}
         line = {

@@ -194,8 +194,13 @@ __global__ __launch_bounds__(SW * 64, 2) void screen_kernel(ScreenParams p)
 
     // ---- query operands (B of v_mfma_f32_16x16x32_f16): set c holds queries qbase + 16c + n;
     //      lane (n,g) keeps features 32s + 8g .. +7 of k-step s ----
+    // Main pass: the accumulators start at -thr (the MFMA's C operand of the first k-step is negthr[c]), so a
+    // score passes its query's threshold iff its sign bit is clear and ONE integer max over a wave-tile's 32
+    // accumulator registers decides whether anything in the tile needs a second look.  thr is always finite:
+    // without a seed it is a lower bound of every possible score, -(1.01 |q| Dmax).
     h8 qreg[4][8];
-    float eps2[4], thr[4];
+    float eps2[4];
+    f32x4 negthr[4];
     int cnt[4] = {0, 0, 0, 0};
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -223,11 +228,15 @@ __global__ __launch_bounds__(SW * 64, 2) void screen_kernel(ScreenParams p)
         }
         ss += __shfl_xor(ss, 16);
         ss += __shfl_xor(ss, 32);
-        eps2[c] = 2.0f * screen_eps(sqrtf(ss), p.dmax);
+        const float qn = sqrtf(ss);
+        eps2[c] = 2.0f * screen_eps(qn, p.dmax);
         // A_k over any subset of the corpus, minus 2 eps, never exceeds the approximate score of a
         // true top-k document: the sample pass's k-th largest maximum seeds the threshold.
-        thr[c] = live ? ((!MAXONLY && p.thr0) ? p.thr0[(size_t)qrow * p.thr0_stride + p.thr0_stride - 1] - eps2[c] : -INFINITY)
-                      : INFINITY;
+        const float floor_thr = -(1.01f * qn * p.dmax + 1e-30f);
+        const float t_init = live ? ((!MAXONLY && p.thr0) ? fmaxf(p.thr0[(size_t)qrow * p.thr0_stride + p.thr0_stride - 1] - eps2[c], floor_thr)
+                                                          : floor_thr)
+                                  : INFINITY; // dead query rows: accumulators stay at -inf, never a candidate
+        negthr[c] = f32x4{-t_init, -t_init, -t_init, -t_init};
         if (bad && live) // fp16 cannot hold this query: its 32-query tile goes to the exact kernel
             atomicOr(p.flag + ((qbase + 16 * c) >> 5), 2);
     }
@@ -251,7 +260,7 @@ __global__ __launch_bounds__(SW * 64, 2) void screen_kernel(ScreenParams p)
             if (n == q) {
                 cnt[c] = (n_new - g + 3) >> 2; // ranks r < n_new with r & 3 == g
                 if (have)
-                    thr[c] = tn;
+                    negthr[c] = f32x4{-tn, -tn, -tn, -tn};
             }
         }
     };
@@ -294,12 +303,8 @@ __global__ __launch_bounds__(SW * 64, 2) void screen_kernel(ScreenParams p)
             }
             if (wave_live) {
                 // acc[u][c][r] = s16(doc tile*32 + 16u + 4g + r, query qbase + 16c + n)
+                // (main pass: minus the query's threshold, see negthr)
                 f32x4 acc[2][4];
-#pragma unroll
-                for (int u = 0; u < 2; ++u)
-#pragma unroll
-                    for (int c = 0; c < 4; ++c)
-                        acc[u][c] = f32x4{0, 0, 0, 0};
                 const char *buf = ring + stage * STILE_BYTES + rd_base;
                 // A fragments run two k-steps ahead of the MFMAs that consume them (three register sets);
                 // the scheduling fences keep hipcc from sinking the reads back next to their use
@@ -318,27 +323,76 @@ __global__ __launch_bounds__(SW * 64, 2) void screen_kernel(ScreenParams p)
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
-                        acc[0][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0[s % 3], qreg[c][s], acc[0][c], 0, 0, 0);
-                        acc[1][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[s % 3], qreg[c][s], acc[1][c], 0, 0, 0);
+                        const f32x4 zero = {0, 0, 0, 0};
+                        const f32x4 c0 = s == 0 ? (MAXONLY ? zero : negthr[c]) : acc[0][c];
+                        const f32x4 c1 = s == 0 ? (MAXONLY ? zero : negthr[c]) : acc[1][c];
+                        acc[0][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0[s % 3], qreg[c][s], c0, 0, 0, 0);
+                        acc[1][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[s % 3], qreg[c][s], c1, 0, 0, 0);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 const int tile_base = tile * 32;
                 const bool partial = tile_base + 32 > p.N;
-                if (!MAXONLY && partial) { // rows past the corpus: NaN never passes `>= thr` and fmaxf drops it
+                if (!MAXONLY) {
+                    if (partial) { // rows past the corpus never pass: -inf has its sign bit set
+#pragma unroll
+                        for (int u = 0; u < 2; ++u)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                                if (tile_base + 16 * u + 4 * g + r >= p.N) {
+#pragma unroll
+                                    for (int c = 0; c < 4; ++c)
+                                        acc[u][c][r] = -INFINITY;
+                                }
+                    }
+                    // any score at or above its threshold <=> some accumulator has a clear sign bit
+                    // <=> the signed-integer maximum of the raw registers is >= 0
+                    int mall = INT_MIN;
 #pragma unroll
                     for (int u = 0; u < 2; ++u)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            if (tile_base + 16 * u + 4 * g + r >= p.N) {
+                        for (int c = 0; c < 4; ++c)
 #pragma unroll
-                                for (int c = 0; c < 4; ++c)
-                                    acc[u][c][r] = __builtin_nanf("");
+                            for (int r = 0; r < 4; ++r)
+                                mall = max(mall, __float_as_int(acc[u][c][r]));
+                    if (__ballot(mall >= 0) != 0ull) {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            int mu[2];
+#pragma unroll
+                            for (int u = 0; u < 2; ++u)
+                                mu[u] = max(max(__float_as_int(acc[u][c][0]), __float_as_int(acc[u][c][1])),
+                                            max(__float_as_int(acc[u][c][2]), __float_as_int(acc[u][c][3])));
+                            if (__ballot(max(mu[0], mu[1]) >= 0) == 0ull)
+                                continue;
+                            // append pass: every lane appends to its own quarter of the query's buffer with its
+                            // own counter (no ballots), through inline-asm stores (a compiler-visible VMEM op here
+                            // would put s_waitcnt vmcnt(0) on the hot path and drain the DMA ring)
+                            const unsigned mine = (unsigned)(((16 * c + n) * SCAP + SQUART * g) * sizeof(SCand));
+                            const float thr_c = -negthr[c][0];
+#pragma unroll
+                            for (int u = 0; u < 2; ++u) {
+                                if (__ballot(mu[u] >= 0) == 0ull)
+                                    continue;
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) {
+                                    if (__float_as_int(acc[u][c][r]) >= 0) {
+                                        scand_store_async(cwave, mine + (unsigned)cnt[c] * (unsigned)sizeof(SCand),
+                                                          acc[u][c][r] + thr_c, tile_base + 16 * u + 4 * g + r);
+                                        ++cnt[c];
+                                    }
+                                }
                             }
-                }
+                            unsigned long long full = __ballot(cnt[c] > SQ_TRIGGER);
+                            full = (full | (full >> 32));
+                            full = (full | (full >> 16)) & 0xffffull;
+                            if (full)
+                                compact_where(c, (unsigned)full);
+                        }
+                    }
+                } else {
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    if (MAXONLY) { // one maximum per (tile, query): the k-th largest of them seeds the thresholds
+                    for (int c = 0; c < 4; ++c) { // one maximum per (tile, query): the k-th largest of them seeds the thresholds
                         float m = -INFINITY;
 #pragma unroll
                         for (int u = 0; u < 2; ++u)
@@ -352,36 +406,7 @@ __global__ __launch_bounds__(SW * 64, 2) void screen_kernel(ScreenParams p)
                         const int qrow = qbase + 16 * c + n;
                         if (g == 0 && qrow < p.B)
                             f32_store_async(p.max_val + (size_t)qrow * p.n_tiles + tile, m);
-                        continue;
                     }
-                    float mg[2];
-#pragma unroll
-                    for (int u = 0; u < 2; ++u)
-                        mg[u] = fmaxf(fmaxf(acc[u][c][0], acc[u][c][1]), fmaxf(acc[u][c][2], acc[u][c][3]));
-                    if (__ballot(fmaxf(mg[0], mg[1]) >= thr[c]) == 0ull)
-                        continue;
-                    // append pass: every lane appends to its own quarter of the query's buffer with its own
-                    // counter (no ballots), through inline-asm stores (a compiler-visible VMEM op here would put
-                    // s_waitcnt vmcnt(0) on the hot path and drain the DMA ring); sub-tiles without a hit are skipped
-                    const unsigned mine = (unsigned)(((16 * c + n) * SCAP + SQUART * g) * sizeof(SCand));
-#pragma unroll
-                    for (int u = 0; u < 2; ++u) {
-                        if (__ballot(mg[u] >= thr[c]) == 0ull)
-                            continue;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            if (acc[u][c][r] >= thr[c]) {
-                                scand_store_async(cwave, mine + (unsigned)cnt[c] * (unsigned)sizeof(SCand), acc[u][c][r],
-                                                  tile_base + 16 * u + 4 * g + r);
-                                ++cnt[c];
-                            }
-                        }
-                    }
-                    unsigned long long full = __ballot(cnt[c] > SQ_TRIGGER);
-                    full = (full | (full >> 32));
-                    full = (full | (full >> 16)) & 0xffffull;
-                    if (full)
-                        compact_where(c, (unsigned)full);
                 }
             }
             stage = (stage + 1) % SRING;
