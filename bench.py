@@ -64,9 +64,30 @@ def gen_queries(n: int, device, seed: int = 7) -> torch.Tensor:
     return q / q.norm(dim=1, keepdim=True)
 
 
+def _event_pair(L):
+    from twotowermlretrieval_amd import _lib
+    evs = (C.c_void_p * 2)()
+    for i in range(2):
+        e = C.c_void_p()
+        _lib.check(L.tt_event_create(C.byref(e)))
+        evs[i] = e.value
+    return evs
+
+
+def _pair_ms(L, evs):
+    """Elapsed time between the two events of a pair (synchronises on the second), then frees them."""
+    from twotowermlretrieval_amd import _lib
+    ms = C.c_float()
+    _lib.check(L.tt_event_elapsed_ms(evs[0], evs[1], C.byref(ms)))
+    for i in range(2):
+        L.tt_event_destroy(evs[i])
+    return ms.value
+
+
 def kernel_only_ms(q, docs, k, iters=5, warm=2):
-    """Average duration of the streaming score+top-k launch alone (HIP events on torch's current
-    stream, which is the stream the kernel is launched on)."""
+    """(main_ms, bracket_ms): average duration of the streaming score+top-k launch alone -- HIP events
+    recorded on the launch stream right before/after that launch (prof_events) -- and of the whole
+    partials call (sample pass + threshold select + main pass) bracketed on the same stream."""
     from twotowermlretrieval_amd import _lib
     L = _lib.lib()
     B, d = q.shape
@@ -74,20 +95,22 @@ def kernel_only_ms(q, docs, k, iters=5, warm=2):
     ws = torch.empty(L.tt_score_topk_workspace_bytes(B, N, d, k), dtype=torch.uint8, device=q.device)
     pv, pi, pm = C.c_void_p(), C.c_void_p(), C.c_int()
     st = torch.cuda.current_stream().cuda_stream
+    pairs = [_event_pair(L) for _ in range(iters)]
 
-    def call():
+    def call(prof=None):
         _lib.check(L.tt_score_topk_partials_f32(q.data_ptr(), B, d, docs.data_ptr(), N, k, 0, ws.data_ptr(),
-                                                ws.numel(), C.byref(pv), C.byref(pi), C.byref(pm), st))
+                                                ws.numel(), C.byref(pv), C.byref(pi), C.byref(pm), prof, st))
     for _ in range(warm):
         call()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(iters):
-        call()
+    for evs in pairs:  # back to back, no host synchronisation in between
+        call(evs)
     e1.record()
     torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / iters
+    main = sum(_pair_ms(L, evs) for evs in pairs)
+    return main / iters, e0.elapsed_time(e1) / iters
 
 
 def screen_kernel_ms(index, q, k, iters=5, warm=2):
@@ -95,23 +118,14 @@ def screen_kernel_ms(index, q, k, iters=5, warm=2):
     before and after that launch inside tt_score_topk_screened_f32 (prof_events)."""
     from twotowermlretrieval_amd import _lib
     L = _lib.lib()
-    evs = (C.c_void_p * 2)()
-    for i in range(2):
-        e = C.c_void_p()
-        _lib.check(L.tt_event_create(C.byref(e)))
-        evs[i] = e.value
+    pairs = [_event_pair(L) for _ in range(iters)]
     for _ in range(warm):
         index.search(q, k)
     torch.cuda.synchronize()
-    tot = 0.0
-    for _ in range(iters):
+    for evs in pairs:  # back to back, no host synchronisation in between
         index.search(q, k, _prof_events=evs)
-        ms = C.c_float()
-        _lib.check(L.tt_event_elapsed_ms(evs[0], evs[1], C.byref(ms)))
-        tot += ms.value
-    for i in range(2):
-        L.tt_event_destroy(evs[i])
-    return tot / iters
+    torch.cuda.synchronize()
+    return sum(_pair_ms(L, evs) for evs in pairs) / iters
 
 
 def pmc_traffic(name: str):
@@ -206,20 +220,20 @@ def main():
                 "kernel_ms": round(ms_s, 4), "batch": BATCH, "docs_per_gpu": n_shard,
                 "hbm_GBps_same_launch": round((-(-BATCH // 512) * n_shard * DIM * 2) / ms_s / 1e6, 1),
                 "exact_fallback_tiles": flags}
-        ms = kernel_only_ms(q, docs, kp, iters=3, warm=1)
+        ms, ms_br = kernel_only_ms(q, docs, kp, iters=3, warm=1)
         roof_f32 = {"bound": "mfma", "kernel": "score_topk_kernel<8,*,false> (fp32 MFMA 32x32x2), same batch",
                     "achieved": round(flops / ms / 1e9, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(flops / ms / 1e9 / MFMA_F32_PEAK_TFLOPS, 4), "traffic": pmc_traffic("b1024") if world == 1 else None,
-                    "kernel_ms": round(ms, 4), "batch": BATCH, "docs_per_gpu": n_shard,
-                    "qps": round(BATCH / ms * 1e3, 1)}
+                    "kernel_ms": round(ms, 4), "with_sample_pass_ms": round(ms_br, 4), "batch": BATCH,
+                    "docs_per_gpu": n_shard, "qps": round(BATCH / ms_br * 1e3, 1)}
         qb = q[:32].contiguous()
-        ms32 = kernel_only_ms(qb, docs, TOPK)
+        ms32, ms32_br = kernel_only_ms(qb, docs, TOPK)
         byts = n_shard * DIM * 4 + 32 * DIM * 4 + 32 * TOPK * 12
-        roof_hbm = {"bound": "hbm", "kernel": "score_topk_kernel<8,64,false> (+ sample pass, B=32)",
+        roof_hbm = {"bound": "hbm", "kernel": "score_topk_kernel<8,64,false> (fp32 MFMA 32x32x2, B=32)",
                     "achieved": round(byts / ms32 / 1e6, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": round(byts / ms32 / 1e6 / HBM_PEAK_GBPS, 4), "traffic": pmc_traffic("b32") if world == 1 else None,
-                    "kernel_ms": round(ms32, 4), "batch": 32, "docs_per_gpu": n_shard,
-                    "qps": round(32 / ms32 * 1e3, 1)}
+                    "kernel_ms": round(ms32, 4), "with_sample_pass_ms": round(ms32_br, 4), "batch": 32,
+                    "docs_per_gpu": n_shard, "qps": round(32 / ms32_br * 1e3, 1)}
         line = {
             "metric": "queries/sec top-k over 10M x 256-d docs", "value": round(BATCH * a.steps / dt, 2),
             "unit": "queries/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,

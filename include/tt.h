@@ -80,7 +80,9 @@ int tt_score_topk_f32(const float *Q, int B, int d, const float *D, int64_t N, i
 int tt_score_topk_partials_f32(const float *Q, int B, int d, const float *D, int64_t N, int k,
                                int64_t idx_offset, void *workspace, size_t workspace_bytes,
                                const float **part_val /*host out*/, const int64_t **part_idx /*host out*/,
-                               int *part_m /*host out*/, tt_stream_t stream);
+                               int *part_m /*host out*/, void *const *prof_events /*NULL, or 2 tt events
+                               recorded on `stream` right before/after the main-pass launch*/,
+                               tt_stream_t stream);
 
 /*
  * Screened exact search for large query batches: SAME result as tt_score_topk_f32 (bit-exact

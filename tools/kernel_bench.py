@@ -15,7 +15,7 @@ def time_partials(Q, D, k, iters=5, warm=2):
     st = torch.cuda.current_stream().cuda_stream
     def call():
         _lib.check(L.tt_score_topk_partials_f32(Q.data_ptr(), B, d, D.data_ptr(), N, k, 0, ws.data_ptr(), ws.numel(),
-                                                C.byref(pv), C.byref(pi), C.byref(pm), st))
+                                                C.byref(pv), C.byref(pi), C.byref(pm), None, st))
     for _ in range(warm): call()
     torch.cuda.synchronize()
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]

@@ -12,5 +12,5 @@ dev = torch.device("cuda:0")
 docs = bench.gen_rows(0, n, dev)
 q = bench.gen_queries(bench.BATCH, dev)
 for B, k, it in ((32, 10, 3), (1024, 10, 2)):
-    ms = bench.kernel_only_ms(q[:B].contiguous(), docs, k, iters=it, warm=1)
-    print(f"B={B} k={k} N={n} kernel_ms={ms:.4f}", flush=True)
+    ms, ms_br = bench.kernel_only_ms(q[:B].contiguous(), docs, k, iters=it, warm=1)
+    print(f"B={B} k={k} N={n} kernel_ms={ms:.4f} with_sample_pass_ms={ms_br:.4f}", flush=True)

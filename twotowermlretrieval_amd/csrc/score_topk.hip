@@ -775,7 +775,7 @@ ScoreParams pass_params(const Pass &ps, const float *Q, int B, const float *D, i
 
 int score_partials(const float *Q, int B, int d, const float *D, int64_t N, int k, int64_t idx_offset,
                    void *workspace, size_t workspace_bytes, hipStream_t st, Plan *plan_out, const char *who,
-                   const int *run_if = nullptr)
+                   const int *run_if = nullptr, void *const *prof_events = nullptr)
 {
     if (B <= 0 || N <= 0 || k <= 0)
         return tt_fail(TT_ERR_BAD_SHAPE, "%s: B=%d N=%lld k=%d", who, B, (long long)N, k);
@@ -813,7 +813,12 @@ int score_partials(const float *Q, int B, int d, const float *D, int64_t N, int 
     sp.thr0_stride = 1;
     sp.thr0_off = 0;
     sp.run_if = run_if;
-    return launch_score(d, sp, pl, st, false);
+    if (prof_events)
+        TT_HIP_CHECK(hipEventRecord((hipEvent_t)prof_events[0], st));
+    const int rc = launch_score(d, sp, pl, st, false);
+    if (prof_events && rc == TT_OK)
+        TT_HIP_CHECK(hipEventRecord((hipEvent_t)prof_events[1], st));
+    return rc;
 }
 
 } // namespace
@@ -829,11 +834,11 @@ TT_EXPORT size_t tt_score_topk_workspace_bytes(int B, int64_t N, int d, int k)
 TT_EXPORT int tt_score_topk_partials_f32(const float *Q, int B, int d, const float *D, int64_t N, int k,
                                          int64_t idx_offset, void *workspace, size_t workspace_bytes,
                                          const float **part_val, const int64_t **part_idx, int *part_m,
-                                         tt_stream_t stream)
+                                         void *const *prof_events, tt_stream_t stream)
 {
     Plan pl;
     int rc = score_partials(Q, B, d, D, N, k, idx_offset, workspace, workspace_bytes, (hipStream_t)stream, &pl,
-                            "tt_score_topk_partials_f32");
+                            "tt_score_topk_partials_f32", nullptr, prof_events);
     if (rc != TT_OK)
         return rc;
     if (part_val)

@@ -394,13 +394,24 @@ __global__ __launch_bounds__(SW * 64, 2) void screen_kernel(ScreenParams p)
 #pragma unroll
                     for (int c = 0; c < 4; ++c) { // one maximum per (tile, query): the k-th largest of them seeds the thresholds
                         float m = -INFINITY;
+                        if (!partial) {
+                            // signed-integer max of the raw bits = the float max when any value is >= 0, else the
+                            // smallest one: still the score of a real document of this tile, which is all the
+                            // threshold argument needs (v_max3_i32: no NaN canonicalisation, 4 instructions)
+                            int mi = INT_MIN;
 #pragma unroll
-                        for (int u = 0; u < 2; ++u)
+                            for (int u = 0; u < 2; ++u)
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                const int doc = tile_base + 16 * u + 4 * g + r;
-                                m = fmaxf(m, (!partial || doc < p.N) ? acc[u][c][r] : -INFINITY);
-                            }
+                                for (int r = 0; r < 4; ++r)
+                                    mi = max(mi, __float_as_int(acc[u][c][r]));
+                            m = __int_as_float(mi);
+                        } else {
+#pragma unroll
+                            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                                for (int r = 0; r < 4; ++r)
+                                    m = fmaxf(m, tile_base + 16 * u + 4 * g + r < p.N ? acc[u][c][r] : -INFINITY);
+                        }
                         m = fmaxf(m, __shfl_xor(m, 16));
                         m = fmaxf(m, __shfl_xor(m, 32));
                         const int qrow = qbase + 16 * c + n;
