@@ -41,6 +41,28 @@ def test_bit_exact_vs_oracle(tt, oracle, B, N, k):
     assert flag == 0
 
 
+@pytest.mark.parametrize("B,N,k", [(1, 5000, 10), (7, 33333, 10), (16, 20000, 16), (17, 1000, 1), (32, 4097, 5),
+                                   (33, 9000, 50), (64, 700000, 64), (1, 300000, 10), (32, 31, 8)])
+def test_small_batch_streaming_form_bit_exact_vs_oracle(tt, oracle, B, N, k):
+    """B <= 64 runs screen_stream_kernel (one wave per 32-query tile and document chunk)."""
+    Q = synth.unit_rows(300 + B, B, 256)
+    D = synth.unit_rows(400 + N, N, 256)
+    k = min(k, N)
+    v, i, flag = screened(tt, Q, D, k, off=11)
+    ov, oi = oracle.score_topk(Q, D, k, idx_offset=11)
+    assert np.array_equal(i, oi) and np.array_equal(v, ov)
+    assert flag == 0
+
+
+def test_single_query_vector_goes_through_the_screened_index(tt, oracle):
+    D = synth.unit_rows(77, 50000, 256)
+    q = synth.unit_rows(78, 1, 256)[0]
+    ix = tt.BruteForceIndex(torch.from_numpy(D).cuda(), screen=True)
+    v, i = ix.search(torch.from_numpy(q).cuda(), 10)
+    ov, oi = oracle.score_topk(q[None], D, 10)
+    assert v.shape == (10,) and np.array_equal(i.cpu().numpy(), oi[0]) and np.array_equal(v.cpu().numpy(), ov[0])
+
+
 def test_non_unit_norms_and_scaled_data(tt, oracle):
     rs = np.random.RandomState(3)
     Q = (synth.unit_rows(1, 130, 256) * rs.uniform(0.1, 5.0, (130, 1))).astype(np.float32)

@@ -56,6 +56,7 @@ constexpr int STPB = 2;               // tiles per barrier interval (waves drift
 constexpr int SCAP = 128;             // candidate entries per (workgroup, query)
 constexpr int SURV_MAX = 256;         // survivors per query the finish kernel can rescore
 constexpr int POOL_MAX = 8192;        // candidates per query the finish kernel can pool
+constexpr int FIN_MAX_CHUNKS = 4096;  // document chunks per query the finish kernel can pool
 
 struct SCand {
     float v;
@@ -445,6 +446,244 @@ __global__ __launch_bounds__(SW * 64, 2) void screen_kernel(ScreenParams p)
     }
 }
 
+// ------------------------------------------------------------------ small batches: streaming form
+// For B <= 32 the shared-tile kernel above would leave seven of a workgroup's eight waves without queries.  Here every
+// WAVE is an independent streaming engine (the organisation of the exact kernel, score_topk.hip): it keeps one
+// 32-query tile as B operands (64 VGPRs), walks its own range of documents through a private 4-slab LDS ring
+// (slab = 32 documents x 64 features f16 = 4 KiB, 4 global_load_lds per slab, 3 slabs in flight, no barriers)
+// and selects exactly like screen_kernel.  MFMA work is 1/16 of the exact kernel's, so the launch is bound by
+// HBM streaming of the fp16 shadow corpus (N x 512 B).
+constexpr int TW = 4;                    // waves per workgroup (2 workgroups per CU)
+constexpr int TSLAB_BYTES = 32 * 128;    // 32 docs x 64 f16
+constexpr int TSTAGE = 4;                // ring depth in slabs
+constexpr int TDMA = 4;                  // DMA instructions per slab
+
+template <bool MAXONLY>
+__global__ __launch_bounds__(TW * 64, 2) void screen_stream_kernel(ScreenParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) char ring_all[]; // [TW][TSTAGE][TSLAB_BYTES]
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    char *const ring = ring_all + w * (TSTAGE * TSLAB_BYTES);
+    const int task = blockIdx.x * TW + w;                 // = qtile * n_chunks + chunk
+    const int n_qtiles = (p.B + 31) / 32;
+    if (task >= n_qtiles * p.n_chunks)
+        return; // wave-uniform; this kernel has no workgroup barrier
+    const int qtile = task / p.n_chunks, chunk = task % p.n_chunks;
+    const int t0 = chunk * p.tiles_per_chunk;
+    const int t1 = min(t0 + p.tiles_per_chunk, p.n_tiles);
+    const int k = p.k;
+    const int g = lane >> 4, n = lane & 15;
+    const int qbase = qtile * 32;
+
+    // ---- query operands: set c holds queries qbase + 16c + n; lane (n,g) keeps features 32s + 8g .. +7 ----
+    h8 qreg[2][8];
+    float eps2[2];
+    f32x4 negthr[2];
+    int cnt[2] = {0, 0};
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        bool bad = false;
+        const int qrow = qbase + 16 * c + n;
+        const bool live = qrow < p.B;
+        const float *qp = p.Q + (size_t)min(qrow, p.B - 1) * 256 + 8 * g;
+        float ss = 0.0f;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const f32x4 a = *(const f32x4 *)(qp + 32 * s);
+            const f32x4 b = *(const f32x4 *)(qp + 32 * s + 4);
+            h8 hv;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float x0 = live ? a[e] : 0.0f, x1 = live ? b[e] : 0.0f;
+                ss += x0 * x0 + x1 * x1;
+                bad |= !(fabsf(x0) <= 60000.0f) || !(fabsf(x1) <= 60000.0f);
+                hv[e] = (_Float16)x0;
+                hv[4 + e] = (_Float16)x1;
+            }
+            qreg[c][s] = hv;
+        }
+        ss += __shfl_xor(ss, 16);
+        ss += __shfl_xor(ss, 32);
+        const float qn = sqrtf(ss);
+        eps2[c] = 2.0f * screen_eps(qn, p.dmax);
+        const float floor_thr = -(1.01f * qn * p.dmax + 1e-30f);
+        const float t_init = live ? ((!MAXONLY && p.thr0) ? fmaxf(p.thr0[(size_t)qrow * p.thr0_stride + p.thr0_stride - 1] - eps2[c], floor_thr)
+                                                          : floor_thr)
+                                  : INFINITY;
+        negthr[c] = f32x4{-t_init, -t_init, -t_init, -t_init};
+        if (bad && live)
+            atomicOr(p.flag + qtile, 2);
+    }
+
+    SCand *const cwave = p.cand + (size_t)task * 32 * SCAP;
+
+    auto compact_where = [&](int c, unsigned qmask) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        while (qmask) {
+            const int q = __ffs((int)qmask) - 1;
+            qmask &= qmask - 1;
+            const int nq[4] = {__builtin_amdgcn_readlane(cnt[c], q), __builtin_amdgcn_readlane(cnt[c], q + 16),
+                               __builtin_amdgcn_readlane(cnt[c], q + 32), __builtin_amdgcn_readlane(cnt[c], q + 48)};
+            const float slack = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, eps2[c]), q));
+            int n_new;
+            float tn;
+            bool have, ovf;
+            screen_compact(cwave + (size_t)(16 * c + q) * SCAP, nq, k, slack, lane, n_new, tn, have, ovf);
+            if (ovf && lane == 0)
+                atomicOr(p.flag + qtile, 1);
+            if (n == q) {
+                cnt[c] = (n_new - g + 3) >> 2;
+                if (have)
+                    negthr[c] = f32x4{-tn, -tn, -tn, -tn};
+            }
+        }
+    };
+
+    // ---- DMA: slab (tile, kq) = features 64kq..64kq+63 of the tile's 32 documents.  Instruction jj moves rows
+    //      8jj..8jj+7: lane -> (row 8jj + lane/8, physical 16-B chunk lane%8); logical chunk = physical ^ (row & 7).
+    const char *D = (const char *)p.D16;
+    int dma_tile = t0, dma_kq = 0;
+    const char *rowp[TDMA];
+    auto set_rows = [&](int tile) {
+#pragma unroll
+        for (int jj = 0; jj < TDMA; ++jj) {
+            const int row = 8 * jj + (lane >> 3);
+            const int doc = min(tile * 32 + row, p.N - 1);
+            rowp[jj] = D + (size_t)doc * 512 + (((lane & 7) ^ (row & 7)) << 4);
+        }
+    };
+    auto dma_issue = [&](int stage) {
+        char *dst = ring + stage * TSLAB_BYTES;
+#pragma unroll
+        for (int jj = 0; jj < TDMA; ++jj)
+            __builtin_amdgcn_global_load_lds((gbl_void *)(rowp[jj] + dma_kq * 128), (lds_void *)(dst + jj * 1024), 16, 0, 0);
+        if (++dma_kq == 4) {
+            dma_kq = 0;
+            dma_tile = min(dma_tile + 1, t1 - 1); // past the end: harmless re-read
+            set_rows(dma_tile);
+        }
+    };
+
+    if (t0 < t1) {
+        set_rows(t0);
+#pragma unroll
+        for (int i = 0; i < TSTAGE - 1; ++i)
+            dma_issue(i);
+        int stage = 0;
+        // A row (document) n of sub-tile 0 / 16 + n of sub-tile 1; both have row & 7 == n & 7
+        const char *rd_row = ring + n * 128;
+        const int rsw = n & 7;
+        for (int tile = t0; tile < t1; ++tile) {
+            f32x4 acc[2][2]; // acc[u][c][r] = s16(doc tile*32 + 16u + 4g + r, query qbase + 16c + n) - thr
+#pragma unroll
+            for (int kq = 0; kq < 4; ++kq) {
+                // slab (tile,kq) has landed once at most TSTAGE-2 younger slabs are pending (candidate stores
+                // also count in vmcnt: they only make this wait stricter)
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(TDMA * (TSTAGE - 2)) : "memory");
+                const char *buf = rd_row + stage * TSLAB_BYTES;
+                h8 a[2][2];
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+                        a[u][s2] = *(const h8 *)(buf + u * 2048 + (((4 * s2 + g) ^ rsw) << 4));
+                // the ring slot consumed one step ago is free once its reads have returned
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                dma_issue((stage + TSTAGE - 1) % TSTAGE);
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                    for (int c = 0; c < 2; ++c)
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            const f32x4 zero = {0, 0, 0, 0};
+                            const f32x4 cin = (kq == 0 && s2 == 0) ? (MAXONLY ? zero : negthr[c]) : acc[u][c];
+                            acc[u][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[u][s2], qreg[c][2 * kq + s2], cin, 0, 0, 0);
+                        }
+                stage = (stage + 1) % TSTAGE;
+            }
+            const int tile_base = tile * 32;
+            const bool partial = tile_base + 32 > p.N;
+            if (!MAXONLY) {
+                if (partial) {
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (tile_base + 16 * u + 4 * g + r >= p.N) {
+                                acc[u][0][r] = -INFINITY;
+                                acc[u][1][r] = -INFINITY;
+                            }
+                }
+                int mall = INT_MIN;
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int c = 0; c < 2; ++c)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            mall = max(mall, __float_as_int(acc[u][c][r]));
+                if (__ballot(mall >= 0) != 0ull) {
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) {
+                        const unsigned mine = (unsigned)(((16 * c + n) * SCAP + SQUART * g) * sizeof(SCand));
+                        const float thr_c = -negthr[c][0];
+#pragma unroll
+                        for (int u = 0; u < 2; ++u)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                if (__float_as_int(acc[u][c][r]) >= 0) {
+                                    scand_store_async(cwave, mine + (unsigned)cnt[c] * (unsigned)sizeof(SCand),
+                                                      acc[u][c][r] + thr_c, tile_base + 16 * u + 4 * g + r);
+                                    ++cnt[c];
+                                }
+                            }
+                        unsigned long long full = __ballot(cnt[c] > SQ_TRIGGER);
+                        full = (full | (full >> 32));
+                        full = (full | (full >> 16)) & 0xffffull;
+                        if (full)
+                            compact_where(c, (unsigned)full);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    float m = -INFINITY;
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            m = fmaxf(m, (!partial || tile_base + 16 * u + 4 * g + r < p.N) ? acc[u][c][r] : -INFINITY);
+                    m = fmaxf(m, __shfl_xor(m, 16));
+                    m = fmaxf(m, __shfl_xor(m, 32));
+                    const int qrow = qbase + 16 * c + n;
+                    if (g == 0 && qrow < p.B)
+                        f32_store_async(p.max_val + (size_t)qrow * p.n_tiles + tile, m);
+                }
+            }
+        }
+    }
+    // LDS-DMA still in flight would land after the wave has ended: drain it (and the stores)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (MAXONLY)
+        return;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        int tot = cnt[c] + __shfl_xor(cnt[c], 16);
+        tot += __shfl_xor(tot, 32);
+        const unsigned long long over = __ballot(tot > k) & 0xffffull;
+        if (over)
+            compact_where(c, (unsigned)over);
+        int packed = cnt[c] << (8 * g);
+        packed |= __shfl_xor(packed, 16);
+        packed |= __shfl_xor(packed, 32);
+        const int qrow = qbase + 16 * c + n;
+        if (g == 0 && qrow < p.B)
+            p.pcnt[(size_t)qrow * p.n_chunks + chunk] = packed;
+    }
+}
+
 // ------------------------------------------------------------------ finish
 struct FinishParams {
     const float *Q;
@@ -457,6 +696,7 @@ struct FinishParams {
     int64_t idx_offset;
     float *out_val;
     int64_t *out_idx;
+    int q_per_block; // candidate layout [query group][chunk][q_per_block][SCAP]: 512 (shared tiles) or 32 (streaming)
 };
 
 __device__ __forceinline__ bool before_f(float sa, int ia, float sb, int ib) { return sa > sb || (sa == sb && ia < ib); }
@@ -481,6 +721,8 @@ __global__ __launch_bounds__(256) void screen_finish_kernel(FinishParams p)
     __shared__ int sv_x[SURV_MAX];
     __shared__ float red_v[4];
     __shared__ int hist[256];
+    __shared__ int ccnt[FIN_MAX_CHUNKS];     // packed quarter counts per chunk
+    __shared__ int pre[FIN_MAX_CHUNKS + 1];  // exclusive prefix of the per-chunk totals
     __shared__ int sel[2];
     __shared__ int n_pool, n_surv;
     const int row = blockIdx.x, tid = threadIdx.x;
@@ -500,20 +742,39 @@ __global__ __launch_bounds__(256) void screen_finish_kernel(FinishParams p)
     __syncthreads();
 
     // ---- pool every workgroup's candidates for this query (counts -> prefix -> parallel copy) ----
-    const int qgroup = row / SQ_PER_BLOCK, qin = row % SQ_PER_BLOCK;
+    const int qgroup = row / p.q_per_block, qin = row % p.q_per_block;
     bool too_many = false;
-    int *pre = sv_x; // n_chunks + 1 <= 129 prefix entries, reused before the survivors are written
-    if (tid < p.n_chunks)
-        hist[tid] = p.pcnt[(size_t)row * p.n_chunks + tid]; // quarter counts, one per byte; hist is free until the select
+    // per-chunk totals: thread t owns chunks [t*per, t*per+per); its sum -> hist[t]; thread 0 scans the 256 sums
+    const int per = (p.n_chunks + 255) / 256;
+    {
+        int sum = 0;
+        for (int c = tid * per; c < min(tid * per + per, p.n_chunks); ++c) {
+            const int v = p.pcnt[(size_t)row * p.n_chunks + c]; // quarter counts, one per byte
+            ccnt[c] = v;
+            sum += (v & 0xff) + ((v >> 8) & 0xff) + ((v >> 16) & 0xff) + ((v >> 24) & 0xff);
+        }
+        hist[tid] = sum; // hist is free until the select
+    }
     __syncthreads();
     if (tid == 0) {
         int run = 0;
-        for (int c = 0; c < p.n_chunks; ++c) {
-            pre[c] = run;
-            run += (hist[c] & 0xff) + ((hist[c] >> 8) & 0xff) + ((hist[c] >> 16) & 0xff) + ((hist[c] >> 24) & 0xff);
+        for (int t = 0; t < 256; ++t) {
+            const int v = hist[t];
+            hist[t] = run;
+            run += v;
         }
-        pre[p.n_chunks] = run;
         n_pool = run;
+    }
+    __syncthreads();
+    {
+        int run = hist[tid];
+        for (int c = tid * per; c < min(tid * per + per, p.n_chunks); ++c) {
+            pre[c] = run;
+            const int v = ccnt[c];
+            run += (v & 0xff) + ((v >> 8) & 0xff) + ((v >> 16) & 0xff) + ((v >> 24) & 0xff);
+        }
+        if (tid == 255)
+            pre[p.n_chunks] = n_pool;
     }
     __syncthreads();
     const int total = n_pool;
@@ -531,14 +792,14 @@ __global__ __launch_bounds__(256) void screen_finish_kernel(FinishParams p)
         int o = m - pre[lo], slot = 0; // quarter g of the buffer starts at entry 32 g
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) {
-            const int ng = (hist[lo] >> (8 * gq)) & 0xff;
+            const int ng = (ccnt[lo] >> (8 * gq)) & 0xff;
             if (o >= 0 && o < ng)
                 slot = SQUART * gq + o;
             o -= ng;
             if (o < 0)
                 o = INT_MIN / 2;
         }
-        const SCand e = p.cand[((size_t)(qgroup * p.n_chunks + lo) * SQ_PER_BLOCK + qin) * SCAP + slot];
+        const SCand e = p.cand[((size_t)(qgroup * p.n_chunks + lo) * p.q_per_block + qin) * SCAP + slot];
         pool_v[m] = e.v;
         pool_x[m] = e.x;
     }
@@ -732,15 +993,19 @@ __global__ __launch_bounds__(256) void build_from_bf16_kernel(const unsigned sho
 }
 
 struct SPlan {
-    int n_qgroups, n_tiles, n_chunks, tiles_per_chunk, n_blocks;
+    bool stream;      // B <= STREAM_MAX_B: one independent streaming wave per (32-query tile, document chunk)
+    int n_qgroups;    // query groups of q_per_block rows (512-query workgroup rows, or 32-query tiles when streaming)
+    int q_per_block;
+    int n_tiles, n_chunks, tiles_per_chunk, n_blocks;
     // sample pass
     bool sample;
-    int s_tiles, s_chunks, s_tiles_per_chunk;
+    int s_tiles, s_chunks, s_tiles_per_chunk, s_blocks;
     int64_t s_docs;
     size_t cand_off, pcnt_off, smax_val_off, sthr_val_off, ws_bytes, lds;
 };
 
 constexpr int64_t SAMPLE_MIN_N = 65536;
+constexpr int STREAM_MAX_B = 32; // measured: at B = 64 the shared-tile kernel (1.48 ms) beats two streaming passes (1.59 ms)
 
 int screen_cus()
 {
@@ -756,25 +1021,38 @@ int screen_cus()
 SPlan make_splan(int B, int64_t N, int k)
 {
     SPlan pl;
-    pl.n_qgroups = (B + SQ_PER_BLOCK - 1) / SQ_PER_BLOCK;
+    pl.stream = B <= STREAM_MAX_B;
+    pl.q_per_block = pl.stream ? 32 : SQ_PER_BLOCK;
+    pl.n_qgroups = (B + pl.q_per_block - 1) / pl.q_per_block;
     pl.n_tiles = (int)((N + 31) / 32);
-    // one workgroup per CU is resident (8 waves x 256 VGPRs): aim at exactly one round, the per-workgroup
-    // set-up (query load + conversion, final compaction) is ~0.1 ms and would be paid once per round
-    int want = (screen_cus() + pl.n_qgroups - 1) / pl.n_qgroups;
-    // finish kernel: one thread per chunk count (<= 255), and room in its pool for k + slack entries per chunk
-    int max_chunks = POOL_MAX / (k + 16);
-    max_chunks = max_chunks > 255 ? 255 : max_chunks;
+    int want, max_chunks;
+    if (pl.stream) {
+        // 8 resident waves per CU (2 workgroups of 4), one round
+        want = (screen_cus() * 2 * TW + pl.n_qgroups - 1) / pl.n_qgroups;
+        // with seeded thresholds a chunk rarely keeps anything; without them every chunk ends with >= k entries
+        // and the finish kernel's pool bounds the number of chunks
+        max_chunks = N >= SAMPLE_MIN_N ? FIN_MAX_CHUNKS : POOL_MAX / (k + 16);
+    } else {
+        // one workgroup per CU is resident (8 waves x 256 VGPRs): aim at exactly one round, the per-workgroup
+        // set-up (query load + conversion, final compaction) is ~0.1 ms and would be paid once per round
+        want = (screen_cus() + pl.n_qgroups - 1) / pl.n_qgroups;
+        // room in the finish kernel's pool for k + slack entries per chunk
+        max_chunks = POOL_MAX / (k + 16);
+        max_chunks = max_chunks > 255 ? 255 : max_chunks;
+    }
     want = want > max_chunks ? max_chunks : want;
     want = want > pl.n_tiles ? pl.n_tiles : want;
     want = want < 1 ? 1 : want;
     pl.tiles_per_chunk = (pl.n_tiles + want - 1) / want;
     pl.n_chunks = (pl.n_tiles + pl.tiles_per_chunk - 1) / pl.tiles_per_chunk;
-    pl.n_blocks = pl.n_qgroups * pl.n_chunks;
+    const int n_tasks = pl.n_qgroups * pl.n_chunks;
+    pl.n_blocks = pl.stream ? (n_tasks + TW - 1) / TW : n_tasks;
+    const size_t rows = (size_t)pl.n_qgroups * pl.q_per_block;
     size_t off = 0;
     pl.cand_off = off;
-    off = tt_align_up(off + (size_t)pl.n_blocks * SQ_PER_BLOCK * SCAP * sizeof(SCand), 256);
+    off = tt_align_up(off + (size_t)n_tasks * pl.q_per_block * SCAP * sizeof(SCand), 256);
     pl.pcnt_off = off;
-    off = tt_align_up(off + (size_t)pl.n_qgroups * SQ_PER_BLOCK * pl.n_chunks * sizeof(int), 256);
+    off = tt_align_up(off + rows * pl.n_chunks * sizeof(int), 256);
     // sample pass: one maximum per 32-document tile of the sample; the k-th largest seeds the thresholds
     pl.sample = N >= SAMPLE_MIN_N;
     // Sample size: 1/64 of the corpus, or enough documents that the k-th sample maximum lets through about
@@ -786,18 +1064,19 @@ SPlan make_splan(int B, int64_t N, int k)
     s_docs = s_docs < 32 ? 32 : s_docs;
     pl.s_docs = (s_docs + 31) / 32 * 32;
     pl.s_tiles = (int)(pl.s_docs / 32);
-    int s_want = (screen_cus() + pl.n_qgroups - 1) / pl.n_qgroups; // one round of workgroups, one maximum per TILE
+    int s_want = pl.stream ? (screen_cus() * 2 * TW + pl.n_qgroups - 1) / pl.n_qgroups
+                           : (screen_cus() + pl.n_qgroups - 1) / pl.n_qgroups; // one round, one maximum per TILE
     s_want = s_want > pl.s_tiles ? pl.s_tiles : s_want;
     s_want = s_want < 1 ? 1 : s_want;
     pl.s_tiles_per_chunk = (pl.s_tiles + s_want - 1) / s_want;
     pl.s_chunks = pl.sample ? (pl.s_tiles + pl.s_tiles_per_chunk - 1) / pl.s_tiles_per_chunk : 0;
-    const size_t rows = (size_t)pl.n_qgroups * SQ_PER_BLOCK;
+    pl.s_blocks = pl.stream ? (pl.n_qgroups * pl.s_chunks + TW - 1) / TW : pl.n_qgroups * pl.s_chunks;
     pl.smax_val_off = off;
     off = tt_align_up(off + rows * (size_t)(pl.sample ? pl.s_tiles : 1) * sizeof(float), 256);
     pl.sthr_val_off = off;
     off = tt_align_up(off + rows * sizeof(float), 256);
     pl.ws_bytes = off;
-    pl.lds = (size_t)SRING * STILE_BYTES;
+    pl.lds = pl.stream ? (size_t)TW * TSTAGE * TSLAB_BYTES : (size_t)SRING * STILE_BYTES;
     return pl;
 }
 
@@ -887,8 +1166,28 @@ TT_EXPORT int tt_score_topk_screened_f32(const float *Q, int B, int d, const flo
     sp.max_val = nullptr;
     sp.thr0 = nullptr;
     sp.thr0_stride = k;
-    TT_HIP_CHECK(hipFuncSetAttribute((const void *)screen_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds));
-    TT_HIP_CHECK(hipFuncSetAttribute((const void *)screen_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds));
+    auto launch = [&](const ScreenParams &a, int blocks, bool maxonly) -> int {
+        if (pl.stream) {
+            if (maxonly)
+                hipLaunchKernelGGL(screen_stream_kernel<true>, dim3(blocks), dim3(TW * 64), pl.lds, st, a);
+            else
+                hipLaunchKernelGGL(screen_stream_kernel<false>, dim3(blocks), dim3(TW * 64), pl.lds, st, a);
+        } else {
+            if (maxonly)
+                hipLaunchKernelGGL(screen_kernel<true>, dim3(blocks), dim3(SW * 64), pl.lds, st, a);
+            else
+                hipLaunchKernelGGL(screen_kernel<false>, dim3(blocks), dim3(SW * 64), pl.lds, st, a);
+        }
+        TT_LAUNCH_CHECK();
+        return TT_OK;
+    };
+    if (pl.stream) {
+        TT_HIP_CHECK(hipFuncSetAttribute((const void *)screen_stream_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds));
+        TT_HIP_CHECK(hipFuncSetAttribute((const void *)screen_stream_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds));
+    } else {
+        TT_HIP_CHECK(hipFuncSetAttribute((const void *)screen_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds));
+        TT_HIP_CHECK(hipFuncSetAttribute((const void *)screen_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds));
+    }
     if (pl.sample) {
         ScreenParams ss = sp;
         ss.N = (int)pl.s_docs;
@@ -896,9 +1195,10 @@ TT_EXPORT int tt_score_topk_screened_f32(const float *Q, int B, int d, const flo
         ss.n_chunks = pl.s_chunks;
         ss.tiles_per_chunk = pl.s_tiles_per_chunk;
         ss.max_val = (float *)(ws + pl.smax_val_off);
-        hipLaunchKernelGGL(screen_kernel<true>, dim3(pl.n_qgroups * pl.s_chunks), dim3(SW * 64), pl.lds, st, ss);
-        TT_LAUNCH_CHECK();
-        int rc = tt_kth_largest(ss.max_val, B, pl.s_tiles, k, (float *)(ws + pl.sthr_val_off), st);
+        int rc = launch(ss, pl.s_blocks, true);
+        if (rc != TT_OK)
+            return rc;
+        rc = tt_kth_largest(ss.max_val, B, pl.s_tiles, k, (float *)(ws + pl.sthr_val_off), st);
         if (rc != TT_OK)
             return rc;
         sp.thr0 = (const float *)(ws + pl.sthr_val_off);
@@ -906,8 +1206,11 @@ TT_EXPORT int tt_score_topk_screened_f32(const float *Q, int B, int d, const flo
     }
     if (prof_events)
         TT_HIP_CHECK(hipEventRecord((hipEvent_t)prof_events[0], st));
-    hipLaunchKernelGGL(screen_kernel<false>, dim3(pl.n_blocks), dim3(SW * 64), pl.lds, st, sp);
-    TT_LAUNCH_CHECK();
+    {
+        const int rc = launch(sp, pl.n_blocks, false);
+        if (rc != TT_OK)
+            return rc;
+    }
     if (prof_events)
         TT_HIP_CHECK(hipEventRecord((hipEvent_t)prof_events[1], st));
 
@@ -919,6 +1222,7 @@ TT_EXPORT int tt_score_topk_screened_f32(const float *Q, int B, int d, const flo
     fp.k = k;
     fp.n_chunks = pl.n_chunks;
     fp.blocks_per_group = pl.n_chunks;
+    fp.q_per_block = pl.q_per_block;
     fp.dmax = dmax_norm;
     fp.cand = sp.cand;
     fp.pcnt = sp.pcnt;

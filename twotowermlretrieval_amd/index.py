@@ -95,7 +95,8 @@ def score_rank(q: torch.Tensor, docs: torch.Tensor, target: torch.Tensor) -> tor
     return rank
 
 
-SCREEN_MIN_BATCH = 96    # below this the exact fp32 kernel is HBM-bound and already at its roofline
+SCREEN_MIN_BATCH = 1     # the screened path wins at every batch size once the corpus is large enough to sample:
+                         # B <= 32 streaming form (half the bytes of the fp32 kernel), above it the shared-tile form
 SCREEN_MIN_DOCS = 65536  # below this there is no sample pass to seed thresholds and the exact kernel is faster
 
 
@@ -148,8 +149,12 @@ class BruteForceIndex:
         B = 1 if q.dim() == 1 else q.shape[0]
         N, d = self.docs.shape
         L = _lib.lib()
-        if self.docs16 is not None and q.dim() == 2 and B >= SCREEN_MIN_BATCH and N >= SCREEN_MIN_DOCS and k <= 64:
+        if (self.docs16 is not None and B >= SCREEN_MIN_BATCH
+                and N >= SCREEN_MIN_DOCS and k <= 64):
             _need_cuda(q)
+            if q.dim() == 1:  # single query (QueryInferencer / hybrid rerank): same path, squeezed result
+                vals, idx = self.search(q.unsqueeze(0), k, _prof_events)
+                return vals[0], idx[0]
             q = _f32c(q)
             if q.shape[1] != d:
                 raise ValueError(f"shape mismatch: q {tuple(q.shape)} vs docs {tuple(self.docs.shape)}")
