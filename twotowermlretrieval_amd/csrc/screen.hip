@@ -56,7 +56,7 @@ constexpr int STPB = 2;               // tiles per barrier interval (waves drift
 constexpr int SCAP = 128;             // candidate entries per (workgroup, query)
 constexpr int SURV_MAX = 256;         // survivors per query the finish kernel can rescore
 constexpr int POOL_MAX = 8192;        // candidates per query the finish kernel can pool
-constexpr int FIN_MAX_CHUNKS = 4096;  // document chunks per query the finish kernel can pool
+constexpr int FIN_MAX_CHUNKS = 2048;  // document chunks per query the finish kernel can pool
 
 struct SCand {
     float v;
@@ -715,7 +715,6 @@ __device__ __forceinline__ float f32_from_order_key(unsigned k)
 __global__ __launch_bounds__(256) void screen_finish_kernel(FinishParams p)
 {
     __shared__ float pool_v[POOL_MAX];
-    __shared__ int pool_x[POOL_MAX];
     __shared__ float qs[256];
     __shared__ float sv_v[SURV_MAX];
     __shared__ int sv_x[SURV_MAX];
@@ -753,17 +752,24 @@ __global__ __launch_bounds__(256) void screen_finish_kernel(FinishParams p)
             ccnt[c] = v;
             sum += (v & 0xff) + ((v >> 8) & 0xff) + ((v >> 16) & 0xff) + ((v >> 24) & 0xff);
         }
-        hist[tid] = sum; // hist is free until the select
-    }
-    __syncthreads();
-    if (tid == 0) {
-        int run = 0;
-        for (int t = 0; t < 256; ++t) {
-            const int v = hist[t];
-            hist[t] = run;
-            run += v;
+        // exclusive scan of the 256 per-thread sums: shuffles inside each wave, then the 4 wave totals
+        int inc = sum;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int v = __shfl_up(inc, off);
+            if ((tid & 63) >= off)
+                inc += v;
         }
-        n_pool = run;
+        if ((tid & 63) == 63)
+            hist[tid >> 6] = inc; // wave totals in hist[0..3] (hist is free until the select)
+        __syncthreads();
+        int base = 0;
+        for (int wv = 0; wv < (tid >> 6); ++wv)
+            base += hist[wv];
+        if (tid == 255)
+            n_pool = base + inc;
+        __syncthreads();
+        hist[tid] = base + inc - sum;
     }
     __syncthreads();
     {
@@ -780,7 +786,10 @@ __global__ __launch_bounds__(256) void screen_finish_kernel(FinishParams p)
     const int total = n_pool;
     if (total > POOL_MAX)
         too_many = true;
-    for (int m = tid; m < total && m < POOL_MAX; m += 256) {
+    // pooled position m -> its entry in the candidate buffers (chunk by binary search, then quarter and slot).
+    // Only the scores are pooled in LDS (52 KB per workgroup -> three workgroups per CU); the few survivors
+    // fetch their document index through the same mapping.
+    auto locate = [&](int m) -> const SCand * {
         int lo = 0, hi = p.n_chunks; // largest c with pre[c] <= m
         while (hi - lo > 1) {
             const int mid = (lo + hi) >> 1;
@@ -799,10 +808,10 @@ __global__ __launch_bounds__(256) void screen_finish_kernel(FinishParams p)
             if (o < 0)
                 o = INT_MIN / 2;
         }
-        const SCand e = p.cand[((size_t)(qgroup * p.n_chunks + lo) * p.q_per_block + qin) * SCAP + slot];
-        pool_v[m] = e.v;
-        pool_x[m] = e.x;
-    }
+        return p.cand + ((size_t)(qgroup * p.n_chunks + lo) * p.q_per_block + qin) * SCAP + slot;
+    };
+    for (int m = tid; m < total && m < POOL_MAX; m += 256)
+        pool_v[m] = locate(m)->v;
     __syncthreads();
     const int np = min(n_pool, POOL_MAX);
     // ---- A_k = k-th best approximate score over the whole corpus: 4-pass radix select on the
@@ -862,7 +871,7 @@ __global__ __launch_bounds__(256) void screen_finish_kernel(FinishParams p)
         if (pool_v[m] >= cut) {
             const int slot = atomicAdd(&n_surv, 1);
             if (slot < SURV_MAX)
-                sv_x[slot] = pool_x[m];
+                sv_x[slot] = locate(m)->x;
             else
                 too_many = true;
         }

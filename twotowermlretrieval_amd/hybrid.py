@@ -31,7 +31,7 @@ class HybridSearcher:
             raise ValueError("dense_score must be 'cosine' or 'chroma_l2'")
         self.inferencer = inferencer
         self.documents = list(documents)
-        self.index = BruteForceIndex(doc_embeddings)
+        self.index = BruteForceIndex(doc_embeddings, screen=True)  # single-query searches stream the fp16 shadow corpus
         self.n_candidates = int(n_candidates)
         self.dense_score = dense_score
         if tfidf_vectorizer is None:  # same construction as backend/main.py:142-143
