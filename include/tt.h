@@ -118,6 +118,15 @@ int tt_topk_merge(const float *in_val, const int64_t *in_idx, int B, int M, int 
                   int64_t *out_idx, tt_stream_t stream);
 
 /*
+ * The same merge over the per-shard lists of a row-sharded index, read IN PLACE from the all-gather's
+ * receive buffer (north_star: "per-shard top-k merged via RCCL all-gather"): rank r's block starts at
+ * gathered + r*rank_stride and holds vals f32 [B,kp] at byte 0 and idx int64 [B,kp] at byte
+ * idx_byte_offset (both 8-byte aligned).  Result: global top-k per row, same order rule.
+ */
+int tt_topk_merge_shards(const void *gathered, int world, size_t rank_stride, size_t idx_byte_offset,
+                         int B, int kp, int k, float *out_val, int64_t *out_idx, tt_stream_t stream);
+
+/*
  * Rank (1-based) of one designated document per query under (score desc,
  * index asc), what BatchEvaluator extracts from a full sort per row.
  *   backend/evaluators.py:50,58-65

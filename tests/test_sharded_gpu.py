@@ -53,3 +53,29 @@ def test_fused_optimizer_allreduce_through_rccl(nccl_group):
     torch.cuda.synchronize()
     assert all((a.detach() - b).abs().max() > 0 for a, b in zip(p, ref))
     assert abs(opt.total_norm.item() - (50 * 7 + 9) ** 0.5) < 1e-3
+
+
+@pytest.mark.parametrize("B,kp,k,world", [(37, 5, 3, 3), (64, 50, 10, 8), (1, 7, 7, 2)])
+def test_merge_reads_the_all_gather_buffer_in_place(oracle, B, kp, k, world):
+    """tt_topk_merge_shards over a hand-built receive buffer of `world` ranks (one GPU): equals the global top-k."""
+    import twotowermlretrieval_amd as tt
+    from twotowermlretrieval_amd import _lib
+    N = 9001
+    Q = synth.unit_rows(13, B, 256)
+    D = synth.unit_rows(14, N, 256)
+    q = torch.from_numpy(Q).cuda()
+    nv = (B * kp * 4 + 7) // 8 * 8
+    stride = nv + B * kp * 8
+    recv = torch.zeros(world * stride, dtype=torch.uint8, device="cuda")
+    for r in range(world):
+        lo, hi = tt.shard_bounds(N, r, world)
+        ix = tt.BruteForceIndex(torch.from_numpy(D[lo:hi]).cuda(), idx_offset=lo)
+        blk = recv[r * stride:(r + 1) * stride]
+        ix.search(q, kp, out=(blk[:B * kp * 4].view(torch.float32).view(B, kp), blk[nv:].view(torch.int64).view(B, kp)))
+    ov = torch.empty((B, k), dtype=torch.float32, device="cuda")
+    oi = torch.empty((B, k), dtype=torch.int64, device="cuda")
+    _lib.check(_lib.lib().tt_topk_merge_shards(recv.data_ptr(), world, stride, nv, B, kp, k, ov.data_ptr(), oi.data_ptr(),
+                                               torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    rv, ri = oracle.score_topk(Q, D, k)
+    assert np.array_equal(oi.cpu().numpy(), ri) and np.array_equal(ov.cpu().numpy(), rv)

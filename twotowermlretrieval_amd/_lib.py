@@ -34,6 +34,7 @@ SIGNATURES = {
     "tt_event_destroy": (_i, [_vp]),
     "tt_event_elapsed_ms": (_i, [_vp, _vp, _vp]),
     "tt_topk_merge": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "tt_topk_merge_shards": (_i, [_vp, _i, _sz, _sz, _i, _i, _i, _vp, _vp, _vp]),
     "tt_score_rank_f32": (_i, [_vp, _i, _i, _vp, _i64, _vp, _vp, _vp]),
     "tt_encoder_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i, _i]),
     "tt_encoder_forward_f32": (_i, [_vp, _i, _i, _vp, _i64, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _f, _u64, _vp, _vp,

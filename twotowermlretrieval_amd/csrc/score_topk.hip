@@ -434,10 +434,14 @@ __device__ __forceinline__ void pool_next_best(const float *pool_v, const int64_
     __syncthreads();
 }
 
+// Candidate m of row b lives in segment m / seg_len at [b][m % seg_len]; segment s starts seg_stride BYTES
+// after segment s-1 (one segment of length M = a plain [B,M] matrix; `world` segments of length k' = the
+// all-gathered per-shard lists of ShardedIndex, read in place).
 __global__ __launch_bounds__(MERGE_THREADS) void topk_merge_kernel(const float *__restrict__ in_val,
                                                                    const int64_t *__restrict__ in_idx,
                                                                    int M, int k, float *out_val,
-                                                                   int64_t *out_idx, const int *run_if)
+                                                                   int64_t *out_idx, const int *run_if,
+                                                                   int seg_len, size_t seg_stride)
 {
     if (run_if && run_if[blockIdx.x >> 5] == 0)
         return;
@@ -449,8 +453,14 @@ __global__ __launch_bounds__(MERGE_THREADS) void topk_merge_kernel(const float *
     __shared__ int64_t red_i[MERGE_THREADS / 64];
     __shared__ int pool_n;
     const int b = blockIdx.x, tid = threadIdx.x;
-    const float *v = in_val + (size_t)b * M;
-    const int64_t *ix = in_idx + (size_t)b * M;
+    auto v_at = [&](int m) -> float {
+        const int sg = m / seg_len, wi = m - sg * seg_len;
+        return ((const float *)((const char *)in_val + (size_t)sg * seg_stride))[(size_t)b * seg_len + wi];
+    };
+    auto ix_at = [&](int m) -> int64_t {
+        const int sg = m / seg_len, wi = m - sg * seg_len;
+        return ((const int64_t *)((const char *)in_idx + (size_t)sg * seg_stride))[(size_t)b * seg_len + wi];
+    };
     if (tid == 0)
         pool_n = 0;
     __syncthreads();
@@ -494,13 +504,13 @@ __global__ __launch_bounds__(MERGE_THREADS) void topk_merge_kernel(const float *
 #pragma unroll
         for (int u = 0; u < MERGE_SEG / MERGE_THREADS; ++u) { // all index loads in flight together
             const int m = base + tid + u * MERGE_THREADS;
-            ci[u] = m < end ? ix[m] : -1;
+            ci[u] = m < end ? ix_at(m) : -1;
         }
 #pragma unroll
         for (int u = 0; u < MERGE_SEG / MERGE_THREADS; ++u) {
             if (ci[u] >= 0) {
                 const int slot = atomicAdd(&pool_n, 1);
-                pool_v[slot] = v[base + tid + u * MERGE_THREADS];
+                pool_v[slot] = v_at(base + tid + u * MERGE_THREADS);
                 pool_i[slot] = ci[u];
             }
         }
@@ -879,7 +889,7 @@ int tt_score_topk_f32_pred(const float *Q, int B, int d, const float *D, int64_t
         return tt_fail(TT_ERR_BAD_SHAPE, "tt_score_topk_f32: null output pointer");
     if (N == 0) { // merge over zero candidates writes the (-inf,-1) tail
         hipLaunchKernelGGL(topk_merge_kernel, dim3(B), dim3(MERGE_THREADS), 0, st, (const float *)nullptr,
-                           (const int64_t *)nullptr, 0, k, out_val, out_idx, (const int *)nullptr);
+                           (const int64_t *)nullptr, 0, k, out_val, out_idx, (const int *)nullptr, 1, (size_t)0);
         TT_LAUNCH_CHECK();
         return TT_OK;
     }
@@ -889,7 +899,8 @@ int tt_score_topk_f32_pred(const float *Q, int B, int d, const float *D, int64_t
         return rc;
     const char *ws = (const char *)workspace;
     hipLaunchKernelGGL(topk_merge_kernel, dim3(B), dim3(MERGE_THREADS), 0, st, (const float *)(ws + pl.pval_off),
-                       (const int64_t *)(ws + pl.pidx_off), pl.main.n_chunks * k, k, out_val, out_idx, run_if);
+                       (const int64_t *)(ws + pl.pidx_off), pl.main.n_chunks * k, k, out_val, out_idx, run_if,
+                       pl.main.n_chunks * k, (size_t)0);
     TT_LAUNCH_CHECK();
     return TT_OK;
 }
@@ -912,7 +923,29 @@ TT_EXPORT int tt_topk_merge(const float *in_val, const int64_t *in_idx, int B, i
     if (B == 0)
         return TT_OK;
     hipLaunchKernelGGL(topk_merge_kernel, dim3(B), dim3(MERGE_THREADS), 0, (hipStream_t)stream, in_val, in_idx, M,
-                       k, out_val, out_idx, (const int *)nullptr);
+                       k, out_val, out_idx, (const int *)nullptr, M > 0 ? M : 1, (size_t)0);
+    TT_LAUNCH_CHECK();
+    return TT_OK;
+}
+
+TT_EXPORT int tt_topk_merge_shards(const void *gathered, int world, size_t rank_stride, size_t idx_byte_offset, int B,
+                                   int kp, int k, float *out_val, int64_t *out_idx, tt_stream_t stream)
+{
+    if (B < 0 || world <= 0 || kp <= 0 || k <= 0)
+        return tt_fail(TT_ERR_BAD_SHAPE, "tt_topk_merge_shards: world=%d B=%d kp=%d k=%d", world, B, kp, k);
+    if (k > MERGE_KMAX)
+        return tt_fail(TT_ERR_UNSUPPORTED, "tt_topk_merge_shards: k=%d > %d", k, MERGE_KMAX);
+    if ((int64_t)world * kp > INT_MAX)
+        return tt_fail(TT_ERR_UNSUPPORTED, "tt_topk_merge_shards: world*kp too large");
+    if (!gathered || !out_val || !out_idx || ((uintptr_t)gathered & 7) || (rank_stride & 7) || (idx_byte_offset & 7) ||
+        idx_byte_offset < (size_t)B * kp * sizeof(float) || rank_stride < idx_byte_offset + (size_t)B * kp * sizeof(int64_t))
+        return tt_fail(TT_ERR_BAD_SHAPE, "tt_topk_merge_shards: layout (stride %zu, idx offset %zu) does not hold [B,kp] f32 + i64, 8-byte aligned",
+                       rank_stride, idx_byte_offset);
+    if (B == 0)
+        return TT_OK;
+    hipLaunchKernelGGL(topk_merge_kernel, dim3(B), dim3(MERGE_THREADS), 0, (hipStream_t)stream, (const float *)gathered,
+                       (const int64_t *)((const char *)gathered + idx_byte_offset), world * kp, k, out_val, out_idx,
+                       (const int *)nullptr, kp, rank_stride);
     TT_LAUNCH_CHECK();
     return TT_OK;
 }

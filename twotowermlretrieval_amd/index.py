@@ -145,7 +145,8 @@ class BruteForceIndex:
     def ntotal(self) -> int:
         return self.docs.shape[0]
 
-    def search(self, q: torch.Tensor, k: int = 10, _prof_events=None) -> Tuple[torch.Tensor, torch.Tensor]:
+    def search(self, q: torch.Tensor, k: int = 10, _prof_events=None, out=None) -> Tuple[torch.Tensor, torch.Tensor]:
+        """out: optional (vals f32 [B,k], idx int64 [B,k]) contiguous device tensors to write into (2-D q only)."""
         B = 1 if q.dim() == 1 else q.shape[0]
         N, d = self.docs.shape
         L = _lib.lib()
@@ -161,8 +162,11 @@ class BruteForceIndex:
             need = L.tt_score_topk_screened_workspace_bytes(B, N, d, k)
             if self._ws_s is None or self._ws_s.numel() < need:
                 self._ws_s = torch.empty(need, dtype=torch.uint8, device=self.docs.device)
-            vals = torch.empty((B, k), dtype=torch.float32, device=q.device)
-            idx = torch.empty((B, k), dtype=torch.int64, device=q.device)
+            if out is not None:
+                vals, idx = out
+            else:
+                vals = torch.empty((B, k), dtype=torch.float32, device=q.device)
+                idx = torch.empty((B, k), dtype=torch.int64, device=q.device)
             if self.fallback_flags.numel() < (B + 31) // 32:
                 self.fallback_flags = torch.zeros((B + 31) // 32, dtype=torch.int32, device=self.docs.device)
             with torch.cuda.device(q.device):
@@ -175,7 +179,12 @@ class BruteForceIndex:
         need = L.tt_score_topk_workspace_bytes(B, N, d, k)
         if self._ws is None or self._ws.numel() < need:
             self._ws = torch.empty(max(need, 16), dtype=torch.uint8, device=self.docs.device)
-        return score_topk(q, self.docs, k, self.idx_offset, self._ws)
+        v, i = score_topk(q, self.docs, k, self.idx_offset, self._ws)
+        if out is not None:
+            out[0].copy_(v)
+            out[1].copy_(i)
+            return out
+        return v, i
 
 
 def shard_bounds(n_total: int, rank: int, world: int) -> Tuple[int, int]:
@@ -220,6 +229,8 @@ class ShardedIndex:
     def search(self, q: torch.Tensor, k: int = 10) -> Tuple[torch.Tensor, torch.Tensor]:
         import torch.distributed as dist
         kp = max(k, self.shard_k)
+        if self._index is not None and dist.is_initialized() and q.dim() == 2:
+            return self._search_in_place(q, k, kp)
         vals, idx = self._search(q, kp)
         if not dist.is_initialized():
             return self._merge(vals, idx, k)
@@ -237,6 +248,32 @@ class ShardedIndex:
         gv = gv.permute(1, 0, 2).reshape(B, world * kp).contiguous()
         gi = gi.permute(1, 0, 2).reshape(B, world * kp).contiguous()
         return self._merge(gv, gi, k)
+
+    def _search_in_place(self, q: torch.Tensor, k: int, kp: int) -> Tuple[torch.Tensor, torch.Tensor]:
+        """HIP path without glue kernels: the local search writes its [B,kp] lists straight into this rank's
+        send block, ONE all_gather_into_tensor, and the merge kernel reads the receive buffer in place
+        (tt_topk_merge_shards)."""
+        import torch.distributed as dist
+        world = dist.get_world_size(self.group)
+        B = q.shape[0]
+        nv = (B * kp * 4 + 7) // 8 * 8           # idx block 8-byte aligned
+        stride = nv + B * kp * 8
+        key = (B, kp, world)
+        if getattr(self, "_xchg_key", None) != key:
+            dev = self._index.docs.device
+            self._send = torch.empty(stride, dtype=torch.uint8, device=dev)
+            self._recv = torch.empty(world * stride, dtype=torch.uint8, device=dev)
+            self._send_v = self._send[:B * kp * 4].view(torch.float32).view(B, kp)
+            self._send_i = self._send[nv:].view(torch.int64).view(B, kp)
+            self._xchg_key = key
+        self._index.search(q, kp, out=(self._send_v, self._send_i))
+        dist.all_gather_into_tensor(self._recv, self._send, group=self.group)
+        ov = torch.empty((B, k), dtype=torch.float32, device=self._recv.device)
+        oi = torch.empty((B, k), dtype=torch.int64, device=self._recv.device)
+        with torch.cuda.device(self._recv.device):
+            _lib.check(_lib.lib().tt_topk_merge_shards(self._recv.data_ptr(), world, stride, nv, B, kp, k, ov.data_ptr(),
+                                                       oi.data_ptr(), _stream(self._recv)))
+        return ov, oi
 
 
 class StreamedIndex:
