@@ -126,3 +126,20 @@ def test_out_of_range_corpus_disables_screen(tt, oracle):
     v, i = ix.search(dev(Q), 10)
     ov, oi = oracle.score_topk(Q, D, 10)
     assert np.array_equal(i.cpu().numpy(), oi) and np.array_equal(v.cpu().numpy(), ov)
+
+
+def test_graphed_search_replays_bit_identically(tt, oracle):
+    """GraphedSearch: a whole screened search captured in a HIP graph; new queries through the static buffer."""
+    from twotowermlretrieval_amd import index as _index
+    _index.SCREEN_MIN_DOCS = 0
+    D = synth.unit_rows(91, 70000, 256)
+    ix = tt.BruteForceIndex(dev(D), screen=True)
+    gs = tt.GraphedSearch(ix, batch=4, k=10)
+    for seed in (92, 93):
+        Q = synth.unit_rows(seed, 4, 256)
+        v, i = gs(dev(Q))
+        torch.cuda.synchronize()
+        ov, oi = oracle.score_topk(Q, D, 10)
+        assert np.array_equal(i.cpu().numpy(), oi) and np.array_equal(v.cpu().numpy(), ov)
+    with pytest.raises(ValueError):
+        gs(dev(synth.unit_rows(1, 5, 256)))

@@ -1001,6 +1001,13 @@ __global__ __launch_bounds__(256) void build_from_bf16_kernel(const unsigned sho
     }
 }
 
+__global__ void zero_i32_kernel(int *p, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n)
+        p[i] = 0;
+}
+
 struct SPlan {
     bool stream;      // B <= STREAM_MAX_B: one independent streaming wave per (32-query tile, document chunk)
     int n_qgroups;    // query groups of q_per_block rows (512-query workgroup rows, or 32-query tiles when streaming)
@@ -1157,7 +1164,10 @@ TT_EXPORT int tt_score_topk_screened_f32(const float *Q, int B, int d, const flo
     if (!workspace || workspace_bytes < need || ((uintptr_t)workspace & 255))
         return tt_fail(TT_ERR_WORKSPACE, "tt_score_topk_screened_f32: workspace %zu < %zu bytes", workspace_bytes, need);
     char *ws = (char *)workspace;
-    TT_HIP_CHECK(hipMemsetAsync(fallback_flag, 0, sizeof(int32_t) * ((B + 31) / 32), st));
+    // (a kernel, not hipMemsetAsync: a 16-byte-multiple memset node captured in a HIP graph came back with
+    //  garbage from the second replay on -- ROCm 7.2, found with GraphedSearch at B=128)
+    hipLaunchKernelGGL(zero_i32_kernel, dim3(((B + 31) / 32 + 255) / 256), dim3(256), 0, st, fallback_flag, (B + 31) / 32);
+    TT_LAUNCH_CHECK();
 
     ScreenParams sp;
     sp.Q = Q;

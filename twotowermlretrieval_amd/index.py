@@ -20,7 +20,7 @@ import torch
 
 from . import _lib
 
-__all__ = ["score_topk", "topk_merge", "score_rank", "BruteForceIndex", "ShardedIndex", "StreamedIndex", "shard_bounds"]
+__all__ = ["GraphedSearch", "score_topk", "topk_merge", "score_rank", "BruteForceIndex", "ShardedIndex", "StreamedIndex", "shard_bounds"]
 
 
 def _stream(t: torch.Tensor) -> int:
@@ -185,6 +185,40 @@ class BruteForceIndex:
             out[1].copy_(i)
             return out
         return v, i
+
+
+class GraphedSearch:
+    """One search of a fixed shape (B, k) captured in a HIP graph and replayed: the nine launches of a
+    screened search (flag reset, sample pass, threshold select, screen, finish, predicated exact kernels)
+    become one graph launch, which matters at serving sizes where the whole search is < 1 ms.
+    Everything in the library is asynchronous on the caller's stream with caller-owned memory, so plain
+    stream capture works; queries are copied into a static buffer, results are returned in static buffers
+    (valid until the next call)."""
+
+    def __init__(self, index: "BruteForceIndex", batch: int, k: int = 10):
+        self.index, self.B, self.k = index, int(batch), int(k)
+        dev = index.docs.device
+        d = index.docs.shape[1]
+        self.q = torch.zeros((self.B, d), dtype=torch.float32, device=dev)
+        self.vals = torch.empty((self.B, self.k), dtype=torch.float32, device=dev)
+        self.idx = torch.empty((self.B, self.k), dtype=torch.int64, device=dev)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):  # warm-up outside capture: workspaces get allocated, kernels loaded
+            for _ in range(2):
+                index.search(self.q, self.k, out=(self.vals, self.idx))
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            index.search(self.q, self.k, out=(self.vals, self.idx))
+
+    def __call__(self, q: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        if tuple(q.shape) != tuple(self.q.shape):
+            raise ValueError(f"GraphedSearch was captured for queries of shape {tuple(self.q.shape)}, got {tuple(q.shape)}")
+        self.q.copy_(q)
+        self.graph.replay()
+        return self.vals, self.idx
 
 
 def shard_bounds(n_total: int, rank: int, world: int) -> Tuple[int, int]:
