@@ -213,6 +213,29 @@ int tt_clip_adam_step_f32(float *params, float *grads, float *exp_avg, float *ex
                           float lr, float beta1, float beta2, float eps, float max_norm, float grad_scale,
                           float *total_norm_out, void *scratch, tt_stream_t stream);
 
+/* ------------------------------------------------------------------ */
+/* Host-side text front end (no GPU): tokenise -> ids -> padded batch.  */
+/* ------------------------------------------------------------------ */
+
+/*
+ * PretrainedTokenizer.encode for a batch of texts, natively and on several threads, so that the index
+ * build (document tower at ~1e8 tokens/s) is not bound by a Python loop.
+ *   backend/tokenizer.py:41-43   re.findall(r"\w+|[.,!?;]", str(s).lower()) -> word2idx.get(tok, unk)
+ *   backend/main.py:50-56        pad_sequence(batch_first=True, padding_value=0)
+ * tt_tok_create copies the vocabulary (n_words UTF-8 keys back to back in words_blob, word_off[n_words+1],
+ * their ids).  tt_tok_encode tokenises text i = text_blob[text_off[i], text_off[i+1]) into
+ * ragged_ids[text_off[i] ...] (a text never has more tokens than bytes), lens[i] tokens; ASCII semantics only:
+ * a text with a byte >= 0x80 gets status[i] = 1, lens[i] = 0 and is left to the caller's Python path.
+ * tt_tok_pad writes the right-padded [n_texts, width] int64 batch (pad id 0).  All buffers are host memory.
+ */
+int tt_tok_create(const char *words_blob, const int64_t *word_off, const int64_t *word_ids, int64_t n_words,
+                  int64_t unk_id, void **handle);
+void tt_tok_destroy(void *handle);
+int tt_tok_encode(const void *handle, const char *text_blob, const int64_t *text_off, int64_t n_texts,
+                  int64_t *ragged_ids, int32_t *lens, int32_t *status, int n_threads);
+int tt_tok_pad(const int64_t *ragged_ids, const int64_t *text_off, const int32_t *lens, int64_t n_texts,
+               int64_t width, int64_t *out, int n_threads);
+
 #ifdef __cplusplus
 }
 #endif

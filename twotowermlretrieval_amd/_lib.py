@@ -36,6 +36,10 @@ SIGNATURES = {
     "tt_topk_merge": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "tt_topk_merge_shards": (_i, [_vp, _i, _sz, _sz, _i, _i, _i, _vp, _vp, _vp]),
     "tt_score_rank_f32": (_i, [_vp, _i, _i, _vp, _i64, _vp, _vp, _vp]),
+    "tt_tok_create": (_i, [_vp, _vp, _vp, _i64, _i64, _vp]),
+    "tt_tok_destroy": (None, [_vp]),
+    "tt_tok_encode": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _i]),
+    "tt_tok_pad": (_i, [_vp, _vp, _vp, _i64, _i64, _vp, _i]),
     "tt_encoder_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i, _i]),
     "tt_encoder_forward_f32": (_i, [_vp, _i, _i, _vp, _i64, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _f, _u64, _vp, _vp,
                                     _sz, _vp, _vp]),

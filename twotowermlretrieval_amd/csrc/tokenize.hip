@@ -1,0 +1,182 @@
+// Host-side text front end of the index build: tokenise -> ids -> right-padded int64 batch, so that
+// feeding the document tower (about 100 M tokens/s on one MI355X) is not bound by a Python loop.  No device code.
+//
+// Semantics: exactly PretrainedTokenizer.encode of the reference (backend/tokenizer.py:41-43) for ASCII text:
+//     tokens = re.findall(r"\w+|[.,!?;]", str(text).lower());  ids = word2idx.get(token, unk_id)
+// For ASCII, lower() maps A-Z to a-z and \w is [A-Za-z0-9_].  A text holding any byte >= 0x80 is NOT tokenised
+// here (Unicode \w and case mapping are Python's business): its status is set to 1 and the Python caller encodes
+// that one text itself, so results are identical by construction (tests/test_tokenize_native_cpu.py).
+#include "tt_common.h"
+
+#include <cstdint>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+namespace {
+
+struct TokTable {
+    std::vector<char> blob;          // all words, back to back
+    std::vector<int64_t> off;        // n_words + 1 offsets into blob
+    std::vector<int64_t> ids;        // id of word i
+    std::vector<int32_t> slots;      // open addressing, -1 = empty, else word number
+    uint64_t mask = 0;
+    int64_t unk = 0;
+};
+
+inline uint64_t fnv1a(const char *p, size_t n)
+{
+    uint64_t h = 1469598103934665603ull;
+    for (size_t i = 0; i < n; ++i) {
+        h ^= (unsigned char)p[i];
+        h *= 1099511628211ull;
+    }
+    return h ^ (h >> 29);
+}
+
+inline int64_t lookup(const TokTable &t, const char *p, size_t n)
+{
+    uint64_t s = fnv1a(p, n) & t.mask;
+    for (;;) {
+        const int32_t w = t.slots[s];
+        if (w < 0)
+            return t.unk;
+        const size_t len = (size_t)(t.off[w + 1] - t.off[w]);
+        if (len == n && std::memcmp(t.blob.data() + t.off[w], p, n) == 0)
+            return t.ids[w];
+        s = (s + 1) & t.mask;
+    }
+}
+
+inline bool is_word(unsigned char c)
+{
+    return (c >= 'a' && c <= 'z') || (c >= '0' && c <= '9') || c == '_' || (c >= 'A' && c <= 'Z');
+}
+inline bool is_punct(unsigned char c) { return c == '.' || c == ',' || c == '!' || c == '?' || c == ';'; }
+
+// one text -> ids at out[0..]; returns the token count, or -1 when the text is not pure ASCII
+int64_t encode_one(const TokTable &t, const char *s, size_t n, int64_t *out, std::vector<char> &lower)
+{
+    for (size_t i = 0; i < n; ++i)
+        if ((unsigned char)s[i] >= 0x80)
+            return -1;
+    int64_t cnt = 0;
+    size_t i = 0;
+    while (i < n) {
+        const unsigned char c = (unsigned char)s[i];
+        if (is_word(c)) {
+            size_t j = i;
+            lower.clear();
+            while (j < n && is_word((unsigned char)s[j])) {
+                const char ch = s[j];
+                lower.push_back((ch >= 'A' && ch <= 'Z') ? (char)(ch + 32) : ch);
+                ++j;
+            }
+            out[cnt++] = lookup(t, lower.data(), lower.size());
+            i = j;
+        } else if (is_punct(c)) {
+            out[cnt++] = lookup(t, s + i, 1);
+            ++i;
+        } else {
+            ++i;
+        }
+    }
+    return cnt;
+}
+
+template <class F>
+void parallel_for(int64_t n, int n_threads, F &&f)
+{
+    if (n_threads <= 1 || n < 2 * n_threads) {
+        f(0, n);
+        return;
+    }
+    std::vector<std::thread> th;
+    const int64_t per = (n + n_threads - 1) / n_threads;
+    for (int t = 0; t < n_threads; ++t) {
+        const int64_t lo = t * per, hi = lo + per < n ? lo + per : n;
+        if (lo >= hi)
+            break;
+        th.emplace_back([&f, lo, hi] { f(lo, hi); });
+    }
+    for (auto &x : th)
+        x.join();
+}
+
+} // namespace
+
+TT_EXPORT int tt_tok_create(const char *words_blob, const int64_t *word_off, const int64_t *word_ids, int64_t n_words,
+                            int64_t unk_id, void **handle)
+{
+    if (!handle || n_words < 0 || (n_words > 0 && (!words_blob || !word_off || !word_ids)) || n_words > (1ll << 30))
+        return tt_fail(TT_ERR_BAD_SHAPE, "tt_tok_create: n_words=%lld", (long long)n_words);
+    TokTable *t = new TokTable;
+    t->unk = unk_id;
+    t->off.assign(word_off, word_off + n_words + 1);
+    t->ids.assign(word_ids, word_ids + n_words);
+    t->blob.assign(words_blob, words_blob + (n_words ? word_off[n_words] : 0));
+    uint64_t cap = 16;
+    while (cap < (uint64_t)n_words * 2 + 1)
+        cap <<= 1;
+    t->mask = cap - 1;
+    t->slots.assign(cap, -1);
+    for (int64_t w = 0; w < n_words; ++w) {
+        const char *p = t->blob.data() + t->off[w];
+        const size_t n = (size_t)(t->off[w + 1] - t->off[w]);
+        uint64_t s = fnv1a(p, n) & t->mask;
+        bool dup = false;
+        while (t->slots[s] >= 0) {
+            const int32_t o = t->slots[s];
+            const size_t on = (size_t)(t->off[o + 1] - t->off[o]);
+            if (on == n && std::memcmp(t->blob.data() + t->off[o], p, n) == 0) {
+                dup = true; // the same key twice: the later entry wins, as in a dict built in order
+                t->slots[s] = (int32_t)w;
+                break;
+            }
+            s = (s + 1) & t->mask;
+        }
+        if (!dup)
+            t->slots[s] = (int32_t)w;
+    }
+    *handle = t;
+    return TT_OK;
+}
+
+TT_EXPORT void tt_tok_destroy(void *handle) { delete (TokTable *)handle; }
+
+TT_EXPORT int tt_tok_encode(const void *handle, const char *text_blob, const int64_t *text_off, int64_t n_texts,
+                            int64_t *ragged_ids, int32_t *lens, int32_t *status, int n_threads)
+{
+    if (!handle || n_texts < 0 || (n_texts > 0 && (!text_blob || !text_off || !ragged_ids || !lens || !status)))
+        return tt_fail(TT_ERR_BAD_SHAPE, "tt_tok_encode: n_texts=%lld", (long long)n_texts);
+    const TokTable &t = *(const TokTable *)handle;
+    parallel_for(n_texts, n_threads, [&](int64_t lo, int64_t hi) {
+        std::vector<char> lower;
+        lower.reserve(64);
+        for (int64_t i = lo; i < hi; ++i) {
+            const int64_t c = encode_one(t, text_blob + text_off[i], (size_t)(text_off[i + 1] - text_off[i]),
+                                         ragged_ids + text_off[i], lower);
+            status[i] = c < 0 ? 1 : 0;
+            lens[i] = c < 0 ? 0 : (int32_t)c;
+        }
+    });
+    return TT_OK;
+}
+
+TT_EXPORT int tt_tok_pad(const int64_t *ragged_ids, const int64_t *text_off, const int32_t *lens, int64_t n_texts,
+                         int64_t width, int64_t *out, int n_threads)
+{
+    if (n_texts < 0 || width < 0 || (n_texts > 0 && (!ragged_ids || !text_off || !lens || (width > 0 && !out))))
+        return tt_fail(TT_ERR_BAD_SHAPE, "tt_tok_pad: n_texts=%lld width=%lld", (long long)n_texts, (long long)width);
+    for (int64_t i = 0; i < n_texts; ++i)
+        if (lens[i] > width)
+            return tt_fail(TT_ERR_BAD_SHAPE, "tt_tok_pad: row %lld has %d tokens > width %lld", (long long)i, lens[i], (long long)width);
+    parallel_for(n_texts, n_threads, [&](int64_t lo, int64_t hi) {
+        for (int64_t i = lo; i < hi; ++i) {
+            int64_t *row = out + i * width;
+            std::memcpy(row, ragged_ids + text_off[i], sizeof(int64_t) * (size_t)lens[i]);
+            std::memset(row + lens[i], 0, sizeof(int64_t) * (size_t)(width - lens[i]));
+        }
+    });
+    return TT_OK;
+}

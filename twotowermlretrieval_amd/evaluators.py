@@ -50,13 +50,64 @@ class BatchEvaluator:
 
 
 def embed_documents(model, tokenizer, documents: Sequence[str], device: torch.device, batch_size: int = 64) -> torch.Tensor:
-    """[len(documents), H] fp32 on the device, row i <-> documents[i] (the document_embeddings.npy layout)."""
+    """[len(documents), H] fp32 on the device, row i <-> documents[i] (the document_embeddings.npy layout).
+    Same batching as the reference (backend/main.py:125-138, BATCH_SIZE documents per encoder call); for a large
+    corpus use embed_corpus, which pipelines the host front end against the GPU."""
     out = []
     with torch.no_grad():
         for i in range(0, len(documents), batch_size):
             ids = tokenizer.encode_batch(documents[i:i + batch_size]).to(device)
             out.append(model.encode_document(ids))
     return torch.cat(out) if out else torch.empty((0, 0), device=device)
+
+
+def embed_corpus(model, tokenizer, documents: Sequence[str], device: torch.device, batch_size: int = 8192,
+                 prefetch: int = 2, out: torch.Tensor = None) -> torch.Tensor:
+    """Index build: the same rows as embed_documents, with the host front end off the critical path.
+    A producer thread tokenises and pads batch i+1 natively (tt_tok_encode / tt_tok_pad release the GIL) into
+    pinned memory while the GPU encodes batch i; ids cross PCIe with a non-blocking copy on a side stream;
+    embeddings land in one preallocated [N, H] matrix.  Rows are independent, so the batch size does not change
+    the result."""
+    import queue
+    import threading
+    n = len(documents)
+    if n == 0:
+        return torch.empty((0, 0), device=device)
+    q: "queue.Queue" = queue.Queue(maxsize=max(1, prefetch))
+
+    def producer():
+        try:
+            for i in range(0, n, batch_size):
+                q.put((i, tokenizer.encode_batch(documents[i:i + batch_size], pin=True)))
+            q.put(None)
+        except BaseException as e:  # noqa: BLE001  (handed to the consumer)
+            q.put(e)
+
+    th = threading.Thread(target=producer, daemon=True)
+    th.start()
+    copy_stream = torch.cuda.Stream(device=device)
+    cur = torch.cuda.current_stream(device)
+    res = out
+    with torch.no_grad():
+        while True:
+            item = q.get()
+            if item is None:
+                break
+            if isinstance(item, BaseException):
+                raise item
+            i, ids_host = item
+            with torch.cuda.stream(copy_stream):
+                ids = ids_host.to(device, non_blocking=True)
+            cur.wait_stream(copy_stream)
+            ids.record_stream(cur)
+            emb = model.encode_document(ids)
+            if res is None:
+                res = torch.empty((n, emb.shape[1]), dtype=torch.float32, device=device)
+            res[i:i + emb.shape[0]].copy_(emb)
+            # the pinned batch must outlive its async copy: wait for this batch's encoder call before dropping it
+            torch.cuda.current_stream(device).synchronize()
+    th.join()
+    return res
 
 
 def corpus_recall_hit(query_emb: torch.Tensor, doc_embeddings: torch.Tensor, positives: Sequence[int],

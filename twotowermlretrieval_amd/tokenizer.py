@@ -1,6 +1,9 @@
 """Host-side text front end: the reference's PretrainedTokenizer semantics (backend/tokenizer.py:6-71)
 plus the pad-to-batch step of its collate_fn (backend/main.py:50-56), producing the right-padded
 int64 id batches the encoder kernels consume.  Plain CPU string work; no GPU code here.
+`encode_batch` runs natively (libtt.so: tt_tok_encode / tt_tok_pad, multi-threaded, GIL released) for ASCII
+texts and falls back to the Python `encode` for any text with a non-ASCII character, so the ids are identical
+to the reference's by construction (the index build must not be bound by a Python loop).
 
 Semantics kept exactly (tests/golden/g8_tokenizer.json):
   * tokens = re.findall(r"\\w+|[.,!?;]", str(text).lower())      -- str(None) == "none" is tokenised too
@@ -53,13 +56,70 @@ class PretrainedTokenizer:
         return word in self.word2idx
 
     # -- batch front end (pad_sequence(batch_first=True, padding_value=0), main.py:50-56) ---------
-    def encode_batch(self, texts: Sequence, pin: bool = False):
-        """texts -> right-padded int64 tensor [B, max_len] (at least one column)."""
+    def _native(self):
+        """Handle of the native vocabulary table (built once, on first use)."""
+        if getattr(self, "_tok_handle", None) is None:
+            import ctypes as C
+            from . import _lib
+            words = list(self.word2idx.keys())
+            enc = [w.encode("utf-8") if isinstance(w, str) else str(w).encode("utf-8") for w in words]
+            off = np.zeros(len(enc) + 1, dtype=np.int64)
+            np.cumsum([len(b) for b in enc], out=off[1:])
+            blob = b"".join(enc)
+            ids = np.asarray([self.word2idx[w] for w in words], dtype=np.int64)
+            h = C.c_void_p()
+            _lib.check(_lib.lib().tt_tok_create(blob, off.ctypes.data, ids.ctypes.data, len(enc), int(self.unk_token_id),
+                                                C.byref(h)))
+            self._tok_handle = h
+        return self._tok_handle
+
+    def __del__(self):
+        h = getattr(self, "_tok_handle", None)
+        if h is not None:
+            try:
+                from . import _lib
+                _lib.lib().tt_tok_destroy(h)
+            except Exception:  # noqa: BLE001  (interpreter shutdown)
+                pass
+
+    def encode_batch(self, texts: Sequence, pin: bool = False, native: bool = True, n_threads: int = 0):
+        """texts -> right-padded int64 tensor [B, max_len] (at least one column when B > 0 ... zero columns for
+        all-empty batches, like pad_sequence)."""
         import torch
-        rows = [self.encode(t) for t in texts]
-        width = max((len(r) for r in rows), default=0)
-        out = np.zeros((len(rows), width), dtype=np.int64)
-        for i, r in enumerate(rows):
-            out[i, :len(r)] = r
-        t = torch.from_numpy(out)
-        return t.pin_memory() if pin else t
+        if not native:
+            rows = [self.encode(t) for t in texts]
+            width = max((len(r) for r in rows), default=0)
+            out = np.zeros((len(rows), width), dtype=np.int64)
+            for i, r in enumerate(rows):
+                out[i, :len(r)] = r
+            t = torch.from_numpy(out)
+            return t.pin_memory() if pin else t
+        import os
+        from . import _lib
+        L = _lib.lib()
+        n = len(texts)
+        enc = [(t if isinstance(t, str) else str(t)).encode("utf-8") for t in texts]
+        off = np.zeros(n + 1, dtype=np.int64)
+        if n:
+            np.cumsum([len(b) for b in enc], out=off[1:])
+        blob = b"".join(enc)
+        total = int(off[-1])
+        ragged = np.empty(max(total, 1), dtype=np.int64)
+        lens = np.zeros(max(n, 1), dtype=np.int32)
+        status = np.zeros(max(n, 1), dtype=np.int32)
+        nt = n_threads or min(16, len(os.sched_getaffinity(0)))
+        _lib.check(L.tt_tok_encode(self._native(), blob, off.ctypes.data, n, ragged.ctypes.data, lens.ctypes.data,
+                                   status.ctypes.data, nt))
+        slow = np.flatnonzero(status[:n])
+        extra = {}
+        for i in slow:  # non-ASCII text: Python's Unicode \w and lower()
+            ids = self.encode(texts[i])
+            extra[int(i)] = ids
+            lens[i] = len(ids)
+        width = int(lens[:n].max()) if n else 0
+        for i, ids in extra.items():  # a text never has more tokens than UTF-8 bytes: its ragged slot is large enough
+            ragged[off[i]:off[i] + len(ids)] = ids
+        t = torch.empty((n, width), dtype=torch.int64, pin_memory=bool(pin) and n * width > 0)
+        if n and width:
+            _lib.check(L.tt_tok_pad(ragged.ctypes.data, off.ctypes.data, lens.ctypes.data, n, width, t.data_ptr(), nt))
+        return t
