@@ -284,6 +284,11 @@ __global__ __launch_bounds__(SW * 64, 2) void screen_kernel(ScreenParams p)
         __builtin_amdgcn_global_load_lds((gbl_void *)rowp[0], (lds_void *)dst, 16, 0, 0);
         __builtin_amdgcn_global_load_lds((gbl_void *)rowp[1], (lds_void *)(dst + 1024), 16, 0, 0);
     };
+    // one of a tile's two pieces (the addresses were prepared by set_rows)
+    auto dma_piece = [&](int i, int stage) {
+        char *dst = ring + stage * STILE_BYTES + (2 * w + i) * 1024;
+        __builtin_amdgcn_global_load_lds((gbl_void *)rowp[i], (lds_void *)dst, 16, 0, 0);
+    };
 
     if (t0 < t1) {
         // DMA runs SRING - STPB tiles ahead; one barrier per STPB tiles.
@@ -298,9 +303,15 @@ __global__ __launch_bounds__(SW * 64, 2) void screen_kernel(ScreenParams p)
                 // and guarantees every wave is done reading the tiles of the previous interval
                 asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (SRING - 2 * STPB)) : "memory");
                 __builtin_amdgcn_s_barrier();
-#pragma unroll
-                for (int u = 0; u < STPB; ++u)
-                    dma_issue(tile + SRING - STPB + u, (stage + SRING - STPB + u) % SRING);
+            }
+            // Every tile iteration refills the ring slot SRING - STPB tiles ahead (free since the last barrier);
+            // the two LDS-DMA pieces go out between k-steps of the MFMA loop rather than in one burst behind
+            // the barrier, where all eight waves would queue them at the same moment.
+            const int fill_stage = (stage + SRING - STPB) % SRING;
+            set_rows(min(tile + SRING - STPB, t1 - 1));
+            if (!wave_live) {
+                dma_piece(0, fill_stage);
+                dma_piece(1, fill_stage);
             }
             if (wave_live) {
                 // acc[u][c][r] = s16(doc tile*32 + 16u + 4g + r, query qbase + 16c + n)
@@ -321,6 +332,10 @@ __global__ __launch_bounds__(SW * 64, 2) void screen_kernel(ScreenParams p)
                 for (int s = 0; s < 8; ++s) {
                     if (s + 2 < 8)
                         a_read(s + 2);
+                    if (s == 2)
+                        dma_piece(0, fill_stage);
+                    if (s == 6)
+                        dma_piece(1, fill_stage);
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {

@@ -145,7 +145,11 @@ def save_inference_artifacts(output_dir, model, config: Dict, tokenizer, documen
         pickle.dump({w: i for w, i in tokenizer.word2idx.items()}, f)
     docs = list(documents)
     model.eval()
-    emb = embed_documents(model, tokenizer, docs, device, config.get("BATCH_SIZE", 64)).cpu().numpy()
+    # same rows either way (rows are independent); the pipelined build is the fast path for a real corpus
+    if len(docs) > 4096 and torch.device(device).type == "cuda":
+        emb = embed_corpus(model, tokenizer, docs, device).cpu().numpy()
+    else:
+        emb = embed_documents(model, tokenizer, docs, device, config.get("BATCH_SIZE", 64)).cpu().numpy()
     with open(out / "documents.pkl", "wb") as f:
         pickle.dump(docs, f)
     np.save(out / "document_embeddings.npy", emb)
