@@ -48,8 +48,6 @@ typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void gbl_void;
 
 constexpr int SW = 8;                 // waves per workgroup
-constexpr int SQ_PER_WAVE = 64;       // queries per wave (four 16-wide MFMA column tiles)
-constexpr int SQ_PER_BLOCK = SW * SQ_PER_WAVE;
 constexpr int STILE_BYTES = 32 * 512; // 32 docs x 256 f16
 constexpr int SRING = 8;              // ring depth in tiles
 constexpr int STPB = 2;               // tiles per barrier interval (waves drift freely inside one)
@@ -178,7 +176,9 @@ __device__ __forceinline__ void screen_compact(SCand *base, const int (&n)[4], i
         }
 }
 
-template <bool MAXONLY>
+// NSET = 16-query sets per wave: 4 (512 queries per workgroup) for large batches; 2 / 1 (256 / 128 queries per
+// workgroup) spread a mid-size batch over all eight waves instead of leaving most of them without queries.
+template <bool MAXONLY, int NSET>
 __global__ __launch_bounds__(SW * 64, 2) void screen_kernel(ScreenParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char ring[]; // [SRING][STILE_BYTES]
@@ -190,7 +190,8 @@ __global__ __launch_bounds__(SW * 64, 2) void screen_kernel(ScreenParams p)
     const int t1 = min(t0 + p.tiles_per_chunk, p.n_tiles);
     const int k = p.k;
     const int g = lane >> 4, n = lane & 15;
-    const int qbase = qgroup * SQ_PER_BLOCK + w * SQ_PER_WAVE;
+    constexpr int QW = 16 * NSET, QB = SW * QW; // queries per wave / per workgroup
+    const int qbase = qgroup * QB + w * QW;
     const bool wave_live = qbase < p.B;
 
     // ---- query operands (B of v_mfma_f32_16x16x32_f16): set c holds queries qbase + 16c + n;
@@ -199,12 +200,15 @@ __global__ __launch_bounds__(SW * 64, 2) void screen_kernel(ScreenParams p)
     // score passes its query's threshold iff its sign bit is clear and ONE integer max over a wave-tile's 32
     // accumulator registers decides whether anything in the tile needs a second look.  thr is always finite:
     // without a seed it is a lower bound of every possible score, -(1.01 |q| Dmax).
-    h8 qreg[4][8];
-    float eps2[4];
-    f32x4 negthr[4];
-    int cnt[4] = {0, 0, 0, 0};
+    h8 qreg[NSET][8];
+    float eps2[NSET];
+    f32x4 negthr[NSET];
+    int cnt[NSET];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
+    for (int c = 0; c < NSET; ++c)
+        cnt[c] = 0;
+#pragma unroll
+    for (int c = 0; c < NSET; ++c) {
         bool bad = false;
         const int qrow = qbase + 16 * c + n;
         const bool live = qrow < p.B;
@@ -242,7 +246,7 @@ __global__ __launch_bounds__(SW * 64, 2) void screen_kernel(ScreenParams p)
             atomicOr(p.flag + ((qbase + 16 * c) >> 5), 2);
     }
 
-    SCand *const cwave = p.cand + ((size_t)blockIdx.x * SQ_PER_BLOCK + w * SQ_PER_WAVE) * SCAP;
+    SCand *const cwave = p.cand + ((size_t)blockIdx.x * QB + w * QW) * SCAP;
 
     auto compact_where = [&](int c, unsigned qmask) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -316,7 +320,7 @@ __global__ __launch_bounds__(SW * 64, 2) void screen_kernel(ScreenParams p)
             if (wave_live) {
                 // acc[u][c][r] = s16(doc tile*32 + 16u + 4g + r, query qbase + 16c + n)
                 // (main pass: minus the query's threshold, see negthr)
-                f32x4 acc[2][4];
+                f32x4 acc[2][NSET];
                 const char *buf = ring + stage * STILE_BYTES + rd_base;
                 // A fragments run two k-steps ahead of the MFMAs that consume them (three register sets);
                 // the scheduling fences keep hipcc from sinking the reads back next to their use
@@ -338,7 +342,7 @@ __global__ __launch_bounds__(SW * 64, 2) void screen_kernel(ScreenParams p)
                         dma_piece(1, fill_stage);
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) {
+                    for (int c = 0; c < NSET; ++c) {
                         const f32x4 zero = {0, 0, 0, 0};
                         const f32x4 c0 = s == 0 ? (MAXONLY ? zero : negthr[c]) : acc[0][c];
                         const f32x4 c1 = s == 0 ? (MAXONLY ? zero : negthr[c]) : acc[1][c];
@@ -357,7 +361,7 @@ __global__ __launch_bounds__(SW * 64, 2) void screen_kernel(ScreenParams p)
                             for (int r = 0; r < 4; ++r)
                                 if (tile_base + 16 * u + 4 * g + r >= p.N) {
 #pragma unroll
-                                    for (int c = 0; c < 4; ++c)
+                                    for (int c = 0; c < NSET; ++c)
                                         acc[u][c][r] = -INFINITY;
                                 }
                     }
@@ -367,13 +371,13 @@ __global__ __launch_bounds__(SW * 64, 2) void screen_kernel(ScreenParams p)
 #pragma unroll
                     for (int u = 0; u < 2; ++u)
 #pragma unroll
-                        for (int c = 0; c < 4; ++c)
+                        for (int c = 0; c < NSET; ++c)
 #pragma unroll
                             for (int r = 0; r < 4; ++r)
                                 mall = max(mall, __float_as_int(acc[u][c][r]));
                     if (__ballot(mall >= 0) != 0ull) {
 #pragma unroll
-                        for (int c = 0; c < 4; ++c) {
+                        for (int c = 0; c < NSET; ++c) {
                             int mu[2];
 #pragma unroll
                             for (int u = 0; u < 2; ++u)
@@ -408,7 +412,7 @@ __global__ __launch_bounds__(SW * 64, 2) void screen_kernel(ScreenParams p)
                     }
                 } else {
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) { // one maximum per (tile, query): the k-th largest of them seeds the thresholds
+                    for (int c = 0; c < NSET; ++c) { // one maximum per (tile, query): the k-th largest of them seeds the thresholds
                         float m = -INFINITY;
                         if (!partial) {
                             // signed-integer max of the raw bits = the float max when any value is >= 0, else the
@@ -446,7 +450,7 @@ __global__ __launch_bounds__(SW * 64, 2) void screen_kernel(ScreenParams p)
         return;
     // final compaction (bounds the pool the finish kernel sees) and counts out: quarter g's count in byte g
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
+    for (int c = 0; c < NSET; ++c) {
         int tot = cnt[c] + __shfl_xor(cnt[c], 16);
         tot += __shfl_xor(tot, 32);
         const unsigned long long over = __ballot(tot > k) & 0xffffull;
@@ -1025,7 +1029,8 @@ __global__ void zero_i32_kernel(int *p, int n)
 
 struct SPlan {
     bool stream;      // B <= STREAM_MAX_B: one independent streaming wave per (32-query tile, document chunk)
-    int n_qgroups;    // query groups of q_per_block rows (512-query workgroup rows, or 32-query tiles when streaming)
+    int nset;         // shared-tile form: 16-query sets per wave (4, 2 or 1)
+    int n_qgroups;    // query groups of q_per_block rows (workgroup rows of 128 nset queries, or 32-query tiles when streaming)
     int q_per_block;
     int n_tiles, n_chunks, tiles_per_chunk, n_blocks;
     // sample pass
@@ -1053,7 +1058,8 @@ SPlan make_splan(int B, int64_t N, int k)
 {
     SPlan pl;
     pl.stream = B <= STREAM_MAX_B;
-    pl.q_per_block = pl.stream ? 32 : SQ_PER_BLOCK;
+    pl.nset = B <= SW * 16 ? 1 : (B <= SW * 32 ? 2 : 4);
+    pl.q_per_block = pl.stream ? 32 : SW * 16 * pl.nset;
     pl.n_qgroups = (B + pl.q_per_block - 1) / pl.q_per_block;
     pl.n_tiles = (int)((N + 31) / 32);
     int want, max_chunks;
@@ -1206,11 +1212,21 @@ TT_EXPORT int tt_score_topk_screened_f32(const float *Q, int B, int d, const flo
                 hipLaunchKernelGGL(screen_stream_kernel<true>, dim3(blocks), dim3(TW * 64), pl.lds, st, a);
             else
                 hipLaunchKernelGGL(screen_stream_kernel<false>, dim3(blocks), dim3(TW * 64), pl.lds, st, a);
+        } else if (pl.nset == 4) {
+            if (maxonly)
+                hipLaunchKernelGGL((screen_kernel<true, 4>), dim3(blocks), dim3(SW * 64), pl.lds, st, a);
+            else
+                hipLaunchKernelGGL((screen_kernel<false, 4>), dim3(blocks), dim3(SW * 64), pl.lds, st, a);
+        } else if (pl.nset == 2) {
+            if (maxonly)
+                hipLaunchKernelGGL((screen_kernel<true, 2>), dim3(blocks), dim3(SW * 64), pl.lds, st, a);
+            else
+                hipLaunchKernelGGL((screen_kernel<false, 2>), dim3(blocks), dim3(SW * 64), pl.lds, st, a);
         } else {
             if (maxonly)
-                hipLaunchKernelGGL(screen_kernel<true>, dim3(blocks), dim3(SW * 64), pl.lds, st, a);
+                hipLaunchKernelGGL((screen_kernel<true, 1>), dim3(blocks), dim3(SW * 64), pl.lds, st, a);
             else
-                hipLaunchKernelGGL(screen_kernel<false>, dim3(blocks), dim3(SW * 64), pl.lds, st, a);
+                hipLaunchKernelGGL((screen_kernel<false, 1>), dim3(blocks), dim3(SW * 64), pl.lds, st, a);
         }
         TT_LAUNCH_CHECK();
         return TT_OK;
@@ -1219,8 +1235,12 @@ TT_EXPORT int tt_score_topk_screened_f32(const float *Q, int B, int d, const flo
         TT_HIP_CHECK(hipFuncSetAttribute((const void *)screen_stream_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds));
         TT_HIP_CHECK(hipFuncSetAttribute((const void *)screen_stream_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds));
     } else {
-        TT_HIP_CHECK(hipFuncSetAttribute((const void *)screen_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds));
-        TT_HIP_CHECK(hipFuncSetAttribute((const void *)screen_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds));
+        const void *fns[6] = {(const void *)screen_kernel<false, 4>, (const void *)screen_kernel<true, 4>,
+                              (const void *)screen_kernel<false, 2>, (const void *)screen_kernel<true, 2>,
+                              (const void *)screen_kernel<false, 1>, (const void *)screen_kernel<true, 1>};
+        const int f0 = pl.nset == 4 ? 0 : (pl.nset == 2 ? 2 : 4);
+        TT_HIP_CHECK(hipFuncSetAttribute(fns[f0], hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds));
+        TT_HIP_CHECK(hipFuncSetAttribute(fns[f0 + 1], hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds));
     }
     if (pl.sample) {
         ScreenParams ss = sp;
