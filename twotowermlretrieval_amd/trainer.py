@@ -122,16 +122,25 @@ def train_step(model: TwoTowerModel, optimizer: FusedClipAdam, queries: torch.Te
     """One step of backend/main.py:244-259 on this rank's (equal-sized) share of the global batch.
     Returns the local loss as a 0-d device tensor (no .item(): the reference's per-step sync is dropped).
 
-    concurrent_towers: the three encoder calls are independent and each recurrence kernel only occupies
-    ceil(B/16) CUs, so they are issued on three HIP streams (autograd replays each call's backward on the
-    stream its forward ran on); results are identical to the sequential order."""
+    concurrent_towers: the encoder calls are independent and each recurrence kernel only occupies ceil(B/16)
+    CUs, so the query tower and the document tower (positives and negatives in one 2B-row call) are issued
+    on separate HIP streams (autograd replays each call's backward on the stream its forward ran on)."""
     optimizer.zero_grad()
     if concurrent_towers and queries.is_cuda:
         cur = torch.cuda.current_stream(queries.device)
+        B = pos_docs.shape[0]
+        if neg_docs.shape[0] == B:
+            # positives and negatives go through the SAME tower: one call over 2B rows (rows are independent),
+            # so the recurrence kernels fill twice the CUs and the weight-gradient GEMMs run once
+            T = max(pos_docs.shape[1], neg_docs.shape[1])
+            both = pos_docs.new_zeros((2 * B, T))
+            both[:B, :pos_docs.shape[1]] = pos_docs
+            both[B:, :neg_docs.shape[1]] = neg_docs
+            calls = ((model.encode_query, queries), (model.encode_document, both))
+        else:
+            calls = ((model.encode_query, queries), (model.encode_document, pos_docs), (model.encode_document, neg_docs))
         outs = []
-        for s, (fn, ids) in zip(_tower_streams(queries.device),
-                                ((model.encode_query, queries), (model.encode_document, pos_docs),
-                                 (model.encode_document, neg_docs))):
+        for s, (fn, ids) in zip(_tower_streams(queries.device), calls):
             s.wait_stream(cur)
             with torch.cuda.stream(s):
                 ids.record_stream(s)
@@ -139,7 +148,10 @@ def train_step(model: TwoTowerModel, optimizer: FusedClipAdam, queries: torch.Te
         for s, o in zip(_tower_streams(queries.device), outs):
             cur.wait_stream(s)
             o.record_stream(cur)
-        q, p, n = outs
+        if len(outs) == 2:
+            q, p, n = outs[0], outs[1][:B], outs[1][B:]
+        else:
+            q, p, n = outs
     else:
         q = model.encode_query(queries)
         p = model.encode_document(pos_docs)
