@@ -160,6 +160,39 @@ __global__ __launch_bounds__(MAXW * 64) void gru_bwd_seq_kernel(GruBwdParams p)
     }
     const float *wbase = d.wtp + (size_t)w * 2 * nc * 256 + lane * 4;
 
+    // The stash of a step (gates r,z,n,ghn, h_{t-1}, upstream d_seq) is loaded one step AHEAD, so the global
+    // latency hides under the previous step's MFMA loop instead of sitting on the serial path of every step.
+    struct Stash {
+        float r[2][4], z[2][4], n[2][4], ghn[2][4], hp[2][4], dsv[2][4];
+    };
+    auto load_stash = [&](int s, Stash &st) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const bool a = s >= 0 && s < len_e[e];
+            const int t = d.reverse ? len_e[e] - 1 - s : s;
+            const size_t tok = (size_t)(off_e[e] + (a ? t : 0));
+            const size_t ptok = d.reverse ? tok + 1 : tok - 1;
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) {
+                const int u = unit[ct];
+                st.r[ct][e] = st.z[ct][e] = st.n[ct][e] = st.ghn[ct][e] = st.hp[ct][e] = st.dsv[ct][e] = 0.0f;
+                if (a) {
+                    const float *gs = d.gates + tok * 4 * H + u;
+                    st.r[ct][e] = gs[0];
+                    st.z[ct][e] = gs[H];
+                    st.n[ct][e] = gs[2 * H];
+                    st.ghn[ct][e] = gs[3 * H];
+                    if (s > 0)
+                        st.hp[ct][e] = d.hseq[ptok * p.ld + d.col0 + u];
+                    if (d.d_seq)
+                        st.dsv[ct][e] = d.d_seq[tok * p.ld + d.col0 + u];
+                }
+            }
+        }
+    };
+    Stash cur_st, next_st;
+    load_stash(steps - 1, cur_st);
+
     for (int s = steps - 1; s >= 0; --s) {
         bool act[4];
         float direct[2][4];
@@ -168,7 +201,6 @@ __global__ __launch_bounds__(MAXW * 64) void gru_bwd_seq_kernel(GruBwdParams p)
             act[e] = s < len_e[e];
             const int t = d.reverse ? len_e[e] - 1 - s : s;
             const size_t tok = (size_t)(off_e[e] + (act[e] ? t : 0));
-            const size_t ptok = d.reverse ? tok + 1 : tok - 1;
             float *grow = gt + (kq * 4 + e) * LDG;
 #pragma unroll
             for (int ct = 0; ct < 2; ++ct) {
@@ -176,16 +208,12 @@ __global__ __launch_bounds__(MAXW * 64) void gru_bwd_seq_kernel(GruBwdParams p)
                 float dr_pre = 0.0f, dz_pre = 0.0f, dghn_v = 0.0f;
                 direct[ct][e] = 0.0f;
                 if (act[e]) {
-                    const float *gs = d.gates + tok * 4 * H + u;
-                    const float r = gs[0], z = gs[H], n = gs[2 * H], ghn = gs[3 * H];
-                    const float hp = s > 0 ? d.hseq[ptok * p.ld + d.col0 + u] : 0.0f;
-                    float dsv = 0.0f;
-                    if (d.d_seq) {
-                        dsv = d.d_seq[tok * p.ld + d.col0 + u];
-                        if (p.drop_p > 0.0f)
-                            dsv *= tt_dropout_scale(p.drop_seed, p.drop_layer,
-                                                    ((uint64_t)rid_e[e] * p.T + t) * p.ld + d.col0 + u, p.drop_p);
-                    }
+                    const float r = cur_st.r[ct][e], z = cur_st.z[ct][e], n = cur_st.n[ct][e], ghn = cur_st.ghn[ct][e];
+                    const float hp = cur_st.hp[ct][e];
+                    float dsv = cur_st.dsv[ct][e];
+                    if (d.d_seq && p.drop_p > 0.0f)
+                        dsv *= tt_dropout_scale(p.drop_seed, p.drop_layer,
+                                                ((uint64_t)rid_e[e] * p.T + t) * p.ld + d.col0 + u, p.drop_p);
                     const float dhv = dh[ct][e] + dsv;
                     const float dn_pre = dhv * (1.0f - z) * (1.0f - n * n);
                     dz_pre = dhv * (hp - n) * z * (1.0f - z);
@@ -203,6 +231,7 @@ __global__ __launch_bounds__(MAXW * 64) void gru_bwd_seq_kernel(GruBwdParams p)
                 grow[2 * H + u] = dghn_v;
             }
         }
+        load_stash(s - 1, next_st); // in flight during the MFMA loop below
         __syncthreads();
         f32x4v acc[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
         const float *gA = gt + j * LDG + 4 * kq;
@@ -222,6 +251,7 @@ __global__ __launch_bounds__(MAXW * 64) void gru_bwd_seq_kernel(GruBwdParams p)
             for (int e = 0; e < 4; ++e)
                 if (act[e])
                     dh[ct][e] = direct[ct][e] + acc[ct][e];
+        cur_st = next_st;
         __syncthreads();
     }
 }
