@@ -7,7 +7,7 @@ sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 import numpy as np, torch
 import twotowermlretrieval_amd as tt
 from twotowermlretrieval_amd.evaluators import embed_corpus
-n_docs = int(sys.argv[1]) if len(sys.argv) > 1 else 200_000
+n_docs = int(sys.argv[1]) if len(sys.argv) > 1 else 400_000
 V = 50_000
 words = ["the", ",", ".", "of", "and"] + [f"w{i}" for i in range(5, V)]
 tok = tt.PretrainedTokenizer(word2idx={w: i for i, w in enumerate(words)})
@@ -28,6 +28,6 @@ table = (np.random.RandomState(1).standard_normal((tok.vocab_size(), E)) * 0.3).
 m = tt.TwoTowerModel({"HIDDEN_DIM": H, "VOCAB_SIZE": tok.vocab_size(), "EMBED_DIM": E}, table).to(dev).eval()
 embed_corpus(m, tok, docs[:20000], dev)
 torch.cuda.synchronize()
-t = time.time(); emb = embed_corpus(m, tok, docs, dev, batch_size=8192); torch.cuda.synchronize(); dt = time.time() - t
+t = time.time(); emb = embed_corpus(m, tok, docs, dev); torch.cuda.synchronize(); dt = time.time() - t
 print(json.dumps(dict(what="pipelined index build from strings", docs=n_docs, tokens=n_tok, s=round(dt, 3), docs_per_s=round(n_docs / dt),
                       tok_per_s=round(n_tok / dt), shape=list(emb.shape))), flush=True)

@@ -61,7 +61,7 @@ def embed_documents(model, tokenizer, documents: Sequence[str], device: torch.de
     return torch.cat(out) if out else torch.empty((0, 0), device=device)
 
 
-def embed_corpus(model, tokenizer, documents: Sequence[str], device: torch.device, batch_size: int = 8192,
+def embed_corpus(model, tokenizer, documents: Sequence[str], device: torch.device, batch_size: int = 16384,
                  prefetch: int = 2, out: torch.Tensor = None) -> torch.Tensor:
     """Index build: the same rows as embed_documents, with the host front end off the critical path.
     A producer thread tokenises and pads batch i+1 natively (tt_tok_encode / tt_tok_pad release the GIL) into
