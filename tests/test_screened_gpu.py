@@ -143,3 +143,29 @@ def test_graphed_search_replays_bit_identically(tt, oracle):
         assert np.array_equal(i.cpu().numpy(), oi) and np.array_equal(v.cpu().numpy(), ov)
     with pytest.raises(ValueError):
         gs(dev(synth.unit_rows(1, 5, 256)))
+
+
+def test_full_baseline_size_10m_screened_equals_exact_kernel(tt):
+    """BASELINE configs[3] size (10M x 256): the screened index (shared-tile form at B=1024, streaming form at
+    B=32) returns exactly what the plain fp32 kernel returns, planted documents come back at rank 1, and nothing
+    falls back to the exact path."""
+    import sys
+    from pathlib import Path
+    sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+    import bench
+    devc = torch.device("cuda:0")
+    D = bench.gen_rows(0, bench.N_DOCS, devc)
+    Q = bench.gen_queries(1024, devc, seed=99)
+    planted = torch.tensor([0, 31, 4_999_999, 9_999_999], device=devc)
+    D[planted] = Q[:4]                      # queries 0..3 have an exact copy in the corpus
+    ix = tt.BruteForceIndex(D, screen=True)
+    for B in (1024, 32):
+        sv, si = ix.search(Q[:B].contiguous(), 10)
+        ev, ei = tt.score_topk(Q[:B].contiguous(), D, 10)
+        torch.cuda.synchronize()
+        assert int(ix.fallback_flags[:(B + 31) // 32].ne(0).sum().item()) == 0
+        assert torch.equal(si, ei) and torch.equal(sv, ev)
+        assert si[:4, 0].tolist() == planted.tolist() and bool((sv[:4, 0] - 1.0).abs().max() < 1e-5)
+        assert bool((sv[:, 1:] <= sv[:, :-1]).all())
+    del ix, D
+    torch.cuda.empty_cache()
