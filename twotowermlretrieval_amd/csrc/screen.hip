@@ -88,6 +88,10 @@ struct ScreenParams {
     float *max_val;      // [rows_pad][n_tiles]
     const float *thr0;   // main pass: k-th largest sample maximum per query, stride thr0_stride (or null)
     int thr0_stride;
+    // queries as MFMA B operands, prepared once per search by q_image_kernel:
+    // qimg[((S * 8 + s) * 64 + lane)] = 8 f16 of query 16 S + (lane & 15), features 32 s + 8 (lane >> 4) .. +7
+    const h8 *qimg;
+    const float *qnorm;  // |q| per (padded) query row
 };
 
 // store (v, x) at wave-uniform base + per-lane 32-bit byte offset (SGPR-base addressing: no 64-bit VALU math)
@@ -176,6 +180,43 @@ __device__ __forceinline__ void screen_compact(SCand *base, const int (&n)[4], i
         }
 }
 
+// Once per search: the queries in the register image the screen kernels keep as MFMA B operands (one coalesced
+// 1-KiB load per k-step and set instead of 64 scattered 16-byte row reads in every workgroup's prologue: the
+// per-workgroup set-up was ~40 us of a 0.7 ms shard step, paid in the sample pass and again in the main pass),
+// their norms, and the "fp16 cannot hold this query" flags.  One wave per 16-query set; rows >= B read as zeros.
+__global__ __launch_bounds__(64) void q_image_kernel(const float *__restrict__ Q, int B, h8 *__restrict__ img,
+                                                     float *__restrict__ qnorm, int *__restrict__ flag)
+{
+    const int S = blockIdx.x, lane = threadIdx.x;
+    const int g = lane >> 4, n = lane & 15;
+    const int qrow = 16 * S + n;
+    const bool live = qrow < B;
+    const float *qp = Q + (size_t)min(qrow, B - 1) * 256 + 8 * g;
+    float ss = 0.0f;
+    bool bad = false;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        const f32x4 a = *(const f32x4 *)(qp + 32 * s);
+        const f32x4 b = *(const f32x4 *)(qp + 32 * s + 4);
+        h8 hv;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float x0 = live ? a[e] : 0.0f, x1 = live ? b[e] : 0.0f;
+            ss += x0 * x0 + x1 * x1;
+            bad |= !(fabsf(x0) <= 60000.0f) || !(fabsf(x1) <= 60000.0f);
+            hv[e] = (_Float16)x0;
+            hv[4 + e] = (_Float16)x1;
+        }
+        img[((size_t)S * 8 + s) * 64 + lane] = hv;
+    }
+    ss += __shfl_xor(ss, 16);
+    ss += __shfl_xor(ss, 32);
+    if (g == 0)
+        qnorm[qrow] = sqrtf(ss);
+    if (bad && live) // its 32-query tile goes to the exact kernel
+        atomicOr(flag + (qrow >> 5), 2);
+}
+
 // NSET = 16-query sets per wave: 4 (512 queries per workgroup) for large batches; 2 / 1 (256 / 128 queries per
 // workgroup) spread a mid-size batch over all eight waves instead of leaving most of them without queries.
 template <bool MAXONLY, int NSET>
@@ -209,31 +250,16 @@ __global__ __launch_bounds__(SW * 64, 2) void screen_kernel(ScreenParams p)
         cnt[c] = 0;
 #pragma unroll
     for (int c = 0; c < NSET; ++c) {
-        bool bad = false;
         const int qrow = qbase + 16 * c + n;
         const bool live = qrow < p.B;
-        const float *qp = p.Q + (size_t)min(qrow, p.B - 1) * 256 + 8 * g;
-        float ss = 0.0f;
-        // (staging the rows through LDS for coalesced reads was measured SLOWER here: dependent
-        //  load->write->read rounds per wave instead of 64 independent loads in flight)
+        float qn = 0.0f;
+        if (wave_live) { // (a wave without queries only helps with the DMA)
+            const h8 *src = p.qimg + ((size_t)(qbase / 16 + c) * 8) * 64 + lane;
 #pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            const f32x4 a = *(const f32x4 *)(qp + 32 * s);
-            const f32x4 b = *(const f32x4 *)(qp + 32 * s + 4);
-            h8 hv;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float x0 = live ? a[e] : 0.0f, x1 = live ? b[e] : 0.0f;
-                ss += x0 * x0 + x1 * x1;
-                bad |= !(fabsf(x0) <= 60000.0f) || !(fabsf(x1) <= 60000.0f);
-                hv[e] = (_Float16)x0;
-                hv[4 + e] = (_Float16)x1;
-            }
-            qreg[c][s] = hv;
+            for (int s = 0; s < 8; ++s)
+                qreg[c][s] = src[s * 64];
+            qn = p.qnorm[qrow];
         }
-        ss += __shfl_xor(ss, 16);
-        ss += __shfl_xor(ss, 32);
-        const float qn = sqrtf(ss);
         eps2[c] = 2.0f * screen_eps(qn, p.dmax);
         // A_k over any subset of the corpus, minus 2 eps, never exceeds the approximate score of a
         // true top-k document: the sample pass's k-th largest maximum seeds the threshold.
@@ -242,8 +268,6 @@ __global__ __launch_bounds__(SW * 64, 2) void screen_kernel(ScreenParams p)
                                                           : floor_thr)
                                   : INFINITY; // dead query rows: accumulators stay at -inf, never a candidate
         negthr[c] = f32x4{-t_init, -t_init, -t_init, -t_init};
-        if (bad && live) // fp16 cannot hold this query: its 32-query tile goes to the exact kernel
-            atomicOr(p.flag + ((qbase + 16 * c) >> 5), 2);
     }
 
     SCand *const cwave = p.cand + ((size_t)blockIdx.x * QB + w * QW) * SCAP;
@@ -502,37 +526,19 @@ __global__ __launch_bounds__(TW * 64, 2) void screen_stream_kernel(ScreenParams 
     int cnt[2] = {0, 0};
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
-        bool bad = false;
         const int qrow = qbase + 16 * c + n;
         const bool live = qrow < p.B;
-        const float *qp = p.Q + (size_t)min(qrow, p.B - 1) * 256 + 8 * g;
-        float ss = 0.0f;
+        const h8 *src = p.qimg + ((size_t)(qbase / 16 + c) * 8) * 64 + lane;
 #pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            const f32x4 a = *(const f32x4 *)(qp + 32 * s);
-            const f32x4 b = *(const f32x4 *)(qp + 32 * s + 4);
-            h8 hv;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float x0 = live ? a[e] : 0.0f, x1 = live ? b[e] : 0.0f;
-                ss += x0 * x0 + x1 * x1;
-                bad |= !(fabsf(x0) <= 60000.0f) || !(fabsf(x1) <= 60000.0f);
-                hv[e] = (_Float16)x0;
-                hv[4 + e] = (_Float16)x1;
-            }
-            qreg[c][s] = hv;
-        }
-        ss += __shfl_xor(ss, 16);
-        ss += __shfl_xor(ss, 32);
-        const float qn = sqrtf(ss);
+        for (int s = 0; s < 8; ++s)
+            qreg[c][s] = src[s * 64];
+        const float qn = p.qnorm[qrow];
         eps2[c] = 2.0f * screen_eps(qn, p.dmax);
         const float floor_thr = -(1.01f * qn * p.dmax + 1e-30f);
         const float t_init = live ? ((!MAXONLY && p.thr0) ? fmaxf(p.thr0[(size_t)qrow * p.thr0_stride + p.thr0_stride - 1] - eps2[c], floor_thr)
                                                           : floor_thr)
                                   : INFINITY;
         negthr[c] = f32x4{-t_init, -t_init, -t_init, -t_init};
-        if (bad && live)
-            atomicOr(p.flag + qtile, 2);
     }
 
     SCand *const cwave = p.cand + (size_t)task * 32 * SCAP;
@@ -1037,7 +1043,8 @@ struct SPlan {
     bool sample;
     int s_tiles, s_chunks, s_tiles_per_chunk, s_blocks;
     int64_t s_docs;
-    size_t cand_off, pcnt_off, smax_val_off, sthr_val_off, ws_bytes, lds;
+    size_t cand_off, pcnt_off, smax_val_off, sthr_val_off, qimg_off, qnorm_off, ws_bytes, lds;
+    int rows_pad; // n_qgroups * q_per_block
 };
 
 constexpr int64_t SAMPLE_MIN_N = 65536;
@@ -1111,6 +1118,11 @@ SPlan make_splan(int B, int64_t N, int k)
     pl.smax_val_off = off;
     off = tt_align_up(off + rows * (size_t)(pl.sample ? pl.s_tiles : 1) * sizeof(float), 256);
     pl.sthr_val_off = off;
+    off = tt_align_up(off + rows * sizeof(float), 256);
+    pl.rows_pad = (int)rows;
+    pl.qimg_off = off;
+    off = tt_align_up(off + rows * 256 * sizeof(_Float16), 256);
+    pl.qnorm_off = off;
     off = tt_align_up(off + rows * sizeof(float), 256);
     pl.ws_bytes = off;
     pl.lds = pl.stream ? (size_t)TW * TSTAGE * TSLAB_BYTES : (size_t)SRING * STILE_BYTES;
@@ -1206,6 +1218,11 @@ TT_EXPORT int tt_score_topk_screened_f32(const float *Q, int B, int d, const flo
     sp.max_val = nullptr;
     sp.thr0 = nullptr;
     sp.thr0_stride = k;
+    sp.qimg = (const h8 *)(ws + pl.qimg_off);
+    sp.qnorm = (const float *)(ws + pl.qnorm_off);
+    hipLaunchKernelGGL(q_image_kernel, dim3(pl.rows_pad / 16), dim3(64), 0, st, Q, B, (h8 *)(ws + pl.qimg_off),
+                       (float *)(ws + pl.qnorm_off), fallback_flag);
+    TT_LAUNCH_CHECK();
     auto launch = [&](const ScreenParams &a, int blocks, bool maxonly) -> int {
         if (pl.stream) {
             if (maxonly)
