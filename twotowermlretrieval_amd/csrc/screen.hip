@@ -183,11 +183,14 @@ __device__ __forceinline__ void screen_compact(SCand *base, const int (&n)[4], i
 // Once per search: the queries in the register image the screen kernels keep as MFMA B operands (one coalesced
 // 1-KiB load per k-step and set instead of 64 scattered 16-byte row reads in every workgroup's prologue: the
 // per-workgroup set-up was ~40 us of a 0.7 ms shard step, paid in the sample pass and again in the main pass),
-// their norms, and the "fp16 cannot hold this query" flags.  One wave per 16-query set; rows >= B read as zeros.
-__global__ __launch_bounds__(64) void q_image_kernel(const float *__restrict__ Q, int B, h8 *__restrict__ img,
-                                                     float *__restrict__ qnorm, int *__restrict__ flag)
+// their norms, and the initial fallback flags (2 = fp16 cannot hold a query of this 32-query tile, else 0).
+// One workgroup of two waves per 32-query tile, one wave per 16-query set; rows >= B read as zeros.
+__global__ __launch_bounds__(128) void q_image_kernel(const float *__restrict__ Q, int B, h8 *__restrict__ img,
+                                                      float *__restrict__ qnorm, int *__restrict__ flag, int n_flags)
 {
-    const int S = blockIdx.x, lane = threadIdx.x;
+    __shared__ int any_bad[2];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int S = blockIdx.x * 2 + wv;
     const int g = lane >> 4, n = lane & 15;
     const int qrow = 16 * S + n;
     const bool live = qrow < B;
@@ -213,8 +216,12 @@ __global__ __launch_bounds__(64) void q_image_kernel(const float *__restrict__ Q
     ss += __shfl_xor(ss, 32);
     if (g == 0)
         qnorm[qrow] = sqrtf(ss);
-    if (bad && live) // its 32-query tile goes to the exact kernel
-        atomicOr(flag + (qrow >> 5), 2);
+    const bool wave_bad = __ballot(bad && live) != 0ull;
+    if (lane == 0)
+        any_bad[wv] = wave_bad ? 1 : 0;
+    __syncthreads();
+    if (threadIdx.x == 0 && (int)blockIdx.x < n_flags)
+        flag[blockIdx.x] = (any_bad[0] | any_bad[1]) ? 2 : 0;
 }
 
 // NSET = 16-query sets per wave: 4 (512 queries per workgroup) for large batches; 2 / 1 (256 / 128 queries per
@@ -1026,13 +1033,6 @@ __global__ __launch_bounds__(256) void build_from_bf16_kernel(const unsigned sho
     }
 }
 
-__global__ void zero_i32_kernel(int *p, int n)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n)
-        p[i] = 0;
-}
-
 struct SPlan {
     bool stream;      // B <= STREAM_MAX_B: one independent streaming wave per (32-query tile, document chunk)
     int nset;         // shared-tile form: 16-query sets per wave (4, 2 or 1)
@@ -1197,10 +1197,9 @@ TT_EXPORT int tt_score_topk_screened_f32(const float *Q, int B, int d, const flo
     if (!workspace || workspace_bytes < need || ((uintptr_t)workspace & 255))
         return tt_fail(TT_ERR_WORKSPACE, "tt_score_topk_screened_f32: workspace %zu < %zu bytes", workspace_bytes, need);
     char *ws = (char *)workspace;
-    // (a kernel, not hipMemsetAsync: a 16-byte-multiple memset node captured in a HIP graph came back with
-    //  garbage from the second replay on -- ROCm 7.2, found with GraphedSearch at B=128)
-    hipLaunchKernelGGL(zero_i32_kernel, dim3(((B + 31) / 32 + 255) / 256), dim3(256), 0, st, fallback_flag, (B + 31) / 32);
-    TT_LAUNCH_CHECK();
+    // (the fallback flags are initialised by q_image_kernel below -- a kernel, not hipMemsetAsync: a 16-byte-multiple
+    //  memset node captured in a HIP graph came back with garbage from the second replay on; ROCm 7.2, found with
+    //  GraphedSearch at B=128)
 
     ScreenParams sp;
     sp.Q = Q;
@@ -1220,8 +1219,8 @@ TT_EXPORT int tt_score_topk_screened_f32(const float *Q, int B, int d, const flo
     sp.thr0_stride = k;
     sp.qimg = (const h8 *)(ws + pl.qimg_off);
     sp.qnorm = (const float *)(ws + pl.qnorm_off);
-    hipLaunchKernelGGL(q_image_kernel, dim3(pl.rows_pad / 16), dim3(64), 0, st, Q, B, (h8 *)(ws + pl.qimg_off),
-                       (float *)(ws + pl.qnorm_off), fallback_flag);
+    hipLaunchKernelGGL(q_image_kernel, dim3(pl.rows_pad / 32), dim3(128), 0, st, Q, B, (h8 *)(ws + pl.qimg_off),
+                       (float *)(ws + pl.qnorm_off), fallback_flag, (B + 31) / 32);
     TT_LAUNCH_CHECK();
     auto launch = [&](const ScreenParams &a, int blocks, bool maxonly) -> int {
         if (pl.stream) {
