@@ -1,0 +1,91 @@
+"""Two ranks with the REAL HIP kernels: both processes share cuda:0 and talk over gloo (RCCL refuses two ranks
+on one device, and the dev box has one GPU), so the N > 1 code paths of ShardedIndex (send block -> all-gather ->
+in-place merge kernel) and of the data-parallel optimizer (flat all-reduce -> fused clip + Adam) run end to end
+on device tensors.  The RCCL transport itself is covered single-rank in tests/test_sharded_gpu.py."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import synth
+from conftest import GOLDEN, ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, tmp):
+    sys.path[:0] = [str(ROOT), str(GOLDEN)]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    import twotowermlretrieval_amd as tt
+    from twotowermlretrieval_amd import index as _index
+    _index.SCREEN_MIN_DOCS = 0
+    dev = torch.device("cuda", 0)
+    # ---- row-sharded search, both screen forms, per-shard top-50 -> global top-10
+    D = torch.from_numpy(synth.unit_rows(31, 70001, 256).copy())
+    D[60000] = D[17]                      # an exact tie across the two shards: the lower index must win
+    res = {}
+    for B in (5, 200):
+        Q = torch.from_numpy(synth.unit_rows(32 + B, B, 256).copy())
+        Q[0] = D[17]
+        ix = tt.ShardedIndex.from_global(D.to(dev), shard_k=50, screen=True)
+        v, i = ix.search(Q.to(dev), k=10)
+        torch.cuda.synchronize()
+        res[f"v{B}"], res[f"i{B}"] = v.cpu().numpy(), i.cpu().numpy()
+    # ---- data-parallel step: equal batch shards, one all-reduce, same update on both ranks
+    V, E, H = 60, 20, 32
+    table = synth.make_table(3, V, E)
+    torch.manual_seed(0)
+    m = tt.TwoTowerModel({"VOCAB_SIZE": V, "EMBED_DIM": E, "HIDDEN_DIM": H}, table).to(dev)
+    tr = tt.trainer.DataParallelTrainer(m, lr=1e-3, margin=0.5)
+    tr.broadcast_parameters()
+    ids = [torch.from_numpy(synth.make_ids(40 + s, 8, T, V)) for s, T in enumerate((5, 9, 7))]
+    lo, hi = rank * 4, rank * 4 + 4
+    loss = tr.step(*(x[lo:hi].to(dev) for x in ids))
+    torch.cuda.synchronize()
+    res["params"] = tr.optimizer.flat_params.detach().cpu().numpy()
+    res["loss"] = float(loss.item())
+    np.savez(os.path.join(tmp, f"rank{rank}.npz"), **res)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_on_one_gpu_sharded_search_and_dp_step(oracle, tmp_path):
+    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    D = synth.unit_rows(31, 70001, 256).copy()
+    D[60000] = D[17]
+    for B in (5, 200):
+        Q = synth.unit_rows(32 + B, B, 256).copy()
+        Q[0] = D[17]
+        ov, oi = oracle.score_topk(Q, D, 10)
+        for r in (r0, r1):                       # identical on every rank, identical to the unsharded oracle
+            assert np.array_equal(r[f"i{B}"], oi) and np.array_equal(r[f"v{B}"], ov)
+        assert list(oi[0][:2]) == [17, 60000]
+    assert np.array_equal(r0["params"], r1["params"])       # same averaged gradient, same clip, same Adam step
+    # single process on the full batch of 8 = the mean of the two rank means
+    import twotowermlretrieval_amd as tt
+    V, E, H = 60, 20, 32
+    torch.manual_seed(0)
+    m = tt.TwoTowerModel({"VOCAB_SIZE": V, "EMBED_DIM": E, "HIDDEN_DIM": H}, synth.make_table(3, V, E)).cuda()
+    opt = tt.FusedClipAdam(m.parameters(), lr=1e-3, max_norm=1.0)
+    ids = [torch.from_numpy(synth.make_ids(40 + s, 8, T, V)).cuda() for s, T in enumerate((5, 9, 7))]
+    m.train()
+    loss = tt.train_step(m, opt, *ids, margin=0.5)
+    torch.cuda.synchronize()
+    assert abs(float(loss.item()) - 0.5 * (float(r0["loss"]) + float(r1["loss"]))) < 1e-6
+    np.testing.assert_allclose(opt.flat_params.detach().cpu().numpy(), r0["params"], rtol=0, atol=2e-6)
