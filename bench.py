@@ -184,11 +184,18 @@ def main():
             sys.exit(f"--gpus {a.gpus} needs a launcher: python -m torch.distributed.run --nproc-per-node {a.gpus} "
                      f"--master-addr 127.0.0.1 bench.py --gpus {a.gpus} ...")
         sys.exit(f"--gpus {a.gpus} != WORLD_SIZE {world}")
+    # TT_BENCH_BACKEND=gloo rehearses the N > 1 code path on a box with fewer GPUs than ranks (ranks then share
+    # devices; the numbers mean nothing).  The default, and what the driver runs, is nccl = RCCL, one rank per GPU.
+    backend = os.environ.get("TT_BENCH_BACKEND", "nccl")
+    local = local if backend == "nccl" else local % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     import twotowermlretrieval_amd as tt
     lo, hi = tt.shard_bounds(N_DOCS, rank, world)
