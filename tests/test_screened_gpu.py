@@ -169,3 +169,16 @@ def test_full_baseline_size_10m_screened_equals_exact_kernel(tt):
         assert bool((sv[:, 1:] <= sv[:, :-1]).all())
     del ix, D
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("B", [4, 80])
+def test_query_beyond_fp16_range_goes_to_the_exact_kernel(tt, oracle, B):
+    """A query with an element fp16 cannot hold (|x| > 6e4) raises flag bit 2 for its 32-query tile in
+    q_image_kernel; the exact kernel recomputes that tile on the device; the other tiles stay screened."""
+    D = synth.unit_rows(51, 70000, 256)
+    Q = synth.unit_rows(52, B, 256).copy()
+    Q[1] *= 1.0e6
+    v, i, flag = screened(tt, Q, D, 10)
+    ov, oi = oracle.score_topk(Q, D, 10)
+    assert np.array_equal(i, oi) and np.array_equal(v, ov)
+    assert flag == 1     # exactly the tile holding query 1
