@@ -1,4 +1,4 @@
-// Screened exact top-k for large query batches (gfx950).
+// Screened exact top-k (gfx950): the path BruteForceIndex(screen=True) takes at every batch size.
 //
 // Exact fp32 scoring is bound by v_mfma_f32_32x32x2_f32 (157 TFLOP/s, 1/16 of the f16 MFMA rate).
 // This path gets the SAME bit-exact result (oracle/tt_oracle.c:o_score_topk order and scores)
@@ -22,11 +22,15 @@
 // device flag; the caller then runs the plain exact kernel, predicated on that flag, so no host
 // synchronisation is needed and the result is exact in every case.
 //
-// Work decomposition: one workgroup (8 waves, one per CU) = 512 queries x a contiguous chunk of
-// documents.  Each wave keeps 64 queries as f16 MFMA B-operands in 128 VGPRs; document tiles
-// (32 docs x 256 features f16 = 16 KiB) are DMA'd once per workgroup into a 4-deep LDS ring
-// (global_load_lds, XOR-swizzled source) and read by all 8 waves, so HBM/L2 traffic is
-// N*512 B per 512 queries.
+// Three kernels share that scheme and the finish kernel:
+//   q_image_kernel        once per search: queries -> f16 MFMA B-operand image, norms, initial flags
+//   screen_kernel<.,NSET> B > 32: one workgroup (8 waves, one per CU) = 128 NSET queries x a contiguous chunk of
+//                         documents; each wave keeps 16 NSET queries in registers; document tiles (32 docs x 256
+//                         features f16 = 16 KiB) are DMA'd once per workgroup into an 8-deep LDS ring
+//                         (global_load_lds, XOR-swizzled source) and read by all 8 waves
+//   screen_stream_kernel  B <= 32: every wave an independent streaming engine with a private 4-slab ring; bound by
+//                         HBM streaming of the fp16 copy (N * 512 B)
+// The accumulators start at minus the query's threshold, so "any candidate in this wave-tile?" is one integer max.
 #include "tt_common.h"
 #include <cmath>
 
