@@ -24,3 +24,5 @@ def test_streamed_equals_oracle_on_widened_corpus(oracle, B, N, block, k, screen
     v2, i2 = ix.search(torch.from_numpy(Q).cuda(), k)                               # buffers are reusable
     assert torch.equal(i2, i) and torch.equal(v2, v)
     assert abs(ix.dmax_norm - float(D.to(torch.float32).norm(dim=1).max())) < 1e-5
+    rv, ri = ix.resident().search(torch.from_numpy(Q).cuda(), k)                    # widened once into HBM: same answer
+    assert torch.equal(ri, i) and torch.equal(rv, v)

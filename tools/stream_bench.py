@@ -34,3 +34,16 @@ for B in (32, 1024):
     torch.cuda.synchronize()
     print(json.dumps(dict(what="streamed == resident on a 2M prefix", B=B, equal=bool(torch.equal(ri, si) and torch.equal(rv, sv)))), flush=True)
     del res
+
+t0 = time.perf_counter(); res = ix.resident(); torch.cuda.synchronize()
+print(json.dumps(dict(what="widen the shard into HBM (one streamed pass)", s=round(time.perf_counter() - t0, 3),
+                      hbm_GB=round(a.n * 256 * 6 / 1e9, 1))), flush=True)
+for B in (32, 1024):
+    q = torch.randn((B, 256), device=dev, generator=g); q /= q.norm(dim=1, keepdim=True)
+    sv, si = ix.search(q, 10)
+    rv, ri = res.search(q, 10); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5): res.search(q, 10)
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 5
+    print(json.dumps(dict(what="resident pass", B=B, N=a.n, ms=round(dt * 1e3, 3), qps=round(B / dt, 1),
+                          equals_streamed=bool(torch.equal(ri, si) and torch.equal(rv, sv)))), flush=True)

@@ -370,6 +370,20 @@ class StreamedIndex:
             self._free[s].record(cur)
             visit(s, lo, n)
 
+    def resident(self) -> "BruteForceIndex":
+        """The same corpus widened once into HBM (N*d*4 bytes fp32 + N*d*2 bytes fp16 shadow): configs[4]'s shard
+        of 12.5M passages is 19.2 GB of a 288 GB GPU, after which it is searched at the resident rates."""
+        d32 = torch.empty((self.N, self.d), dtype=torch.float32, device=self.device)
+        d16 = torch.empty((self.N, self.d), dtype=torch.float16, device=self.device) if self._d16[0] is not None else None
+
+        def visit(s, lo, n):
+            d32[lo:lo + n].copy_(self._d32[s][:n])
+            if d16 is not None:
+                d16[lo:lo + n].copy_(self._d16[s][:n])
+
+        self._walk(visit)
+        return BruteForceIndex._from_buffers(d32, d16, self.dmax_norm, self.idx_offset)
+
     def search(self, q: torch.Tensor, k: int = 10) -> Tuple[torch.Tensor, torch.Tensor]:
         _need_cuda(q)
         q = _f32c(q if q.dim() == 2 else q.unsqueeze(0))
