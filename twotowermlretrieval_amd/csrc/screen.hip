@@ -756,8 +756,11 @@ __global__ __launch_bounds__(256) void screen_finish_kernel(FinishParams p)
     __shared__ int sv_x[SURV_MAX];
     __shared__ float red_v[4];
     __shared__ int hist[256];
-    __shared__ int ccnt[FIN_MAX_CHUNKS];     // packed quarter counts per chunk
-    __shared__ int pre[FIN_MAX_CHUNKS + 1];  // exclusive prefix of the per-chunk totals
+    // per-chunk tables sized at launch (2 n_chunks + 1 ints): the shared-tile form has <= 255 chunks, which keeps
+    // the workgroup under 40 KB of LDS and four of them on a CU; the streaming form needs up to FIN_MAX_CHUNKS
+    extern __shared__ int fin_dyn[];
+    int *const ccnt = fin_dyn;                  // packed quarter counts per chunk
+    int *const pre = fin_dyn + p.n_chunks;      // exclusive prefix of the per-chunk totals (n_chunks + 1)
     __shared__ int sel[2];
     __shared__ int n_pool, n_surv;
     const int row = blockIdx.x, tid = threadIdx.x;
@@ -1304,7 +1307,7 @@ TT_EXPORT int tt_score_topk_screened_f32(const float *Q, int B, int d, const flo
     fp.idx_offset = idx_offset;
     fp.out_val = out_val;
     fp.out_idx = out_idx;
-    hipLaunchKernelGGL(screen_finish_kernel, dim3(B), dim3(256), 0, st, fp);
+    hipLaunchKernelGGL(screen_finish_kernel, dim3(B), dim3(256), (size_t)(2 * pl.n_chunks + 1) * sizeof(int), st, fp);
     TT_LAUNCH_CHECK();
     // exact kernel, a no-op unless a workgroup raised the flag; then it rewrites every output row
     return tt_score_topk_f32_pred(Q, B, d, D32, N, k, idx_offset, out_val, out_idx, ws + pl.ws_bytes,
