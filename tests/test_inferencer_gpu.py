@@ -49,3 +49,46 @@ def test_query_inferencer_matches_reference(tmp_path, golden):
     batch = inf.get_query_embeddings([str(q) for q in g["queries"]] + [""])
     np.testing.assert_allclose(batch[:-1].cpu().numpy(), g["embs"], atol=1e-5, rtol=0)
     assert not batch[-1].any()
+
+
+def test_concurrent_callers_share_an_encoder_and_an_index(tmp_path):
+    """The reference serves /search from a thread pool (frontend/main.py:103): eight threads, each on its own HIP
+    stream, hammer ONE query tower and ONE index; every answer must equal the single-threaded one."""
+    import threading
+    import twotowermlretrieval_amd as tt
+    from twotowermlretrieval_amd import index as _index
+    _index.SCREEN_MIN_DOCS = 0
+    V, E, H = 300, 20, 256
+    torch.manual_seed(0)
+    m = tt.TwoTowerModel({"HIDDEN_DIM": H, "VOCAB_SIZE": V, "EMBED_DIM": E}, synth.make_table(5, V, E)).cuda().eval()
+    D = torch.from_numpy(synth.unit_rows(7, 70000, 256)).cuda()
+    ix = tt.BruteForceIndex(D, screen=True)
+    ids = [torch.from_numpy(synth.make_ids(100 + t, 3, 4 + t, V)).cuda() for t in range(8)]
+    with torch.no_grad():
+        want = []
+        for x in ids:
+            q = m.encode_query(x)
+            want.append(tuple(t.clone() for t in ix.search(q, 10)))
+    torch.cuda.synchronize()
+    errs = []
+
+    def work(t):
+        try:
+            s = torch.cuda.Stream()
+            with torch.cuda.stream(s), torch.no_grad():
+                for _ in range(20):
+                    q = m.encode_query(ids[t])
+                    v, i = ix.search(q, 10)
+                    s.synchronize()
+                    if not (torch.equal(v, want[t][0]) and torch.equal(i, want[t][1])):
+                        errs.append(t)
+                        return
+        except Exception as e:  # noqa: BLE001
+            errs.append(repr(e))
+
+    th = [threading.Thread(target=work, args=(t,)) for t in range(8)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    assert not errs, errs

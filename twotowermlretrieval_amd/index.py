@@ -113,8 +113,6 @@ class BruteForceIndex:
         _need_cuda(doc_embeddings)
         self.docs = _f32c(doc_embeddings)
         self.idx_offset = int(idx_offset)
-        self._ws: Optional[torch.Tensor] = None
-        self._ws_s: Optional[torch.Tensor] = None
         self.docs16: Optional[torch.Tensor] = None
         self.dmax_norm = float("nan")
         self.fallback_flags = torch.zeros(1, dtype=torch.int32, device=self.docs.device)  # per 32-query tile
@@ -137,7 +135,6 @@ class BruteForceIndex:
         """An index over caller-managed device buffers (StreamedIndex's per-block view)."""
         self = cls.__new__(cls)
         self.docs, self.docs16, self.dmax_norm, self.idx_offset = docs32, docs16, float(dmax_norm), int(idx_offset)
-        self._ws = self._ws_s = None
         self.fallback_flags = torch.zeros(1, dtype=torch.int32, device=docs32.device)
         return self
 
@@ -159,27 +156,25 @@ class BruteForceIndex:
             q = _f32c(q)
             if q.shape[1] != d:
                 raise ValueError(f"shape mismatch: q {tuple(q.shape)} vs docs {tuple(self.docs.shape)}")
+            # per-call workspace and flags (cached allocator blocks): safe for concurrent callers and streams
             need = L.tt_score_topk_screened_workspace_bytes(B, N, d, k)
-            if self._ws_s is None or self._ws_s.numel() < need:
-                self._ws_s = torch.empty(need, dtype=torch.uint8, device=self.docs.device)
+            ws_s = torch.empty(need, dtype=torch.uint8, device=self.docs.device)
+            flags = torch.empty((B + 31) // 32, dtype=torch.int32, device=self.docs.device)
             if out is not None:
                 vals, idx = out
             else:
                 vals = torch.empty((B, k), dtype=torch.float32, device=q.device)
                 idx = torch.empty((B, k), dtype=torch.int64, device=q.device)
-            if self.fallback_flags.numel() < (B + 31) // 32:
-                self.fallback_flags = torch.zeros((B + 31) // 32, dtype=torch.int32, device=self.docs.device)
             with torch.cuda.device(q.device):
                 _lib.check(L.tt_score_topk_screened_f32(q.data_ptr(), B, d, self.docs.data_ptr(), self.docs16.data_ptr(),
                                                         N, k, self.dmax_norm, self.idx_offset, vals.data_ptr(),
-                                                        idx.data_ptr(), self.fallback_flags.data_ptr(),
-                                                        self._ws_s.data_ptr(), self._ws_s.numel(), _prof_events,
-                                                        _stream(q)))
+                                                        idx.data_ptr(), flags.data_ptr(), ws_s.data_ptr(), ws_s.numel(),
+                                                        _prof_events, _stream(q)))
+            self.fallback_flags = flags  # of the most recent search (per 32-query tile; non-zero = exact kernel took over)
             return vals, idx
         need = L.tt_score_topk_workspace_bytes(B, N, d, k)
-        if self._ws is None or self._ws.numel() < need:
-            self._ws = torch.empty(max(need, 16), dtype=torch.uint8, device=self.docs.device)
-        v, i = score_topk(q, self.docs, k, self.idx_offset, self._ws)
+        ws = torch.empty(max(need, 16), dtype=torch.uint8, device=self.docs.device)
+        v, i = score_topk(q, self.docs, k, self.idx_offset, ws)
         if out is not None:
             out[0].copy_(v)
             out[1].copy_(i)
@@ -338,7 +333,6 @@ class StreamedIndex:
         self._copy = torch.cuda.Stream(device=dev)
         self._ready = [torch.cuda.Event() for _ in range(2)]
         self._free = [torch.cuda.Event() for _ in range(2)]
-        self._slots = [None, None]
         # one streaming pass at build time: the corpus-wide largest row norm bounds the screen's error term
         stats = torch.zeros(2, dtype=torch.float32, device=dev)
         self._walk(lambda s, lo, n: None, stats=stats)
@@ -392,10 +386,7 @@ class StreamedIndex:
         def visit(s, lo, n):
             blk = BruteForceIndex._from_buffers(self._d32[s][:n], self._d16[s][:n] if self._d16[s] is not None else None,
                                                 self.dmax_norm, self.idx_offset + lo)
-            if self._slots[s] is not None:  # keep the workspaces of this slot alive across blocks
-                blk._ws, blk._ws_s, blk.fallback_flags = self._slots[s]
             v, i = blk.search(q, k)
-            self._slots[s] = (blk._ws, blk._ws_s, blk.fallback_flags)
             if run[0] is None:
                 run[0], run[1] = v, i
             else:

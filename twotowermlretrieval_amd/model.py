@@ -130,7 +130,6 @@ class RNNEncoder(nn.Module):
         self.normalize_output = normalize_output
         self.projection = _LinearParams(hidden_dim * 2, hidden_dim) if bidirectional else None
         self.check_inputs = True  # read the device status word after each call (one 4-byte D2H sync)
-        self._ws: Optional[torch.Tensor] = None
 
     # ---- plumbing ---------------------------------------------------------------
     def _flat_params(self):
@@ -161,12 +160,11 @@ class RNNEncoder(nn.Module):
         H = self.hidden_dim
         drop = int(train and dropout_p > 0.0 and self.num_layers > 1)
         need = L.tt_encoder_workspace_bytes(B, max(T, 1), E, H, self.num_layers, int(self.bidirectional), int(train), drop)
-        if train:
-            ws = torch.empty(max(need, 256), dtype=torch.uint8, device=ids.device)  # owned by the autograd node
-        else:
-            if self._ws is None or self._ws.numel() < need or self._ws.device != ids.device:
-                self._ws = torch.empty(max(need, 256), dtype=torch.uint8, device=ids.device)
-            ws = self._ws
+        # One workspace per call, from torch's caching allocator (a cached block: microseconds).  In train mode the
+        # autograd node owns it; in eval mode a per-call buffer keeps concurrent callers apart -- the reference serves
+        # queries from a thread pool (frontend/main.py:103), and a buffer shared across threads or streams would be
+        # overwritten by the next call's kernels while this call's are still queued.
+        ws = torch.empty(max(need, 256), dtype=torch.uint8, device=ids.device)
         out = torch.empty((B, H), dtype=torch.float32, device=ids.device)
         status = torch.zeros(1, dtype=torch.int32, device=ids.device)
         quads = [w.detach().contiguous() for quad in self.rnn.quads() for w in quad]
