@@ -97,6 +97,7 @@ def score_rank(q: torch.Tensor, docs: torch.Tensor, target: torch.Tensor) -> tor
 
 SCREEN_MIN_BATCH = 1     # the screened path wins at every batch size once the corpus is large enough to sample:
                          # B <= 32 streaming form (half the bytes of the fp32 kernel), above it the shared-tile form
+SCREEN_PADDED_MIN_BATCH = 33  # d < 256 (zero-padded screen copy): only where the exact kernel is MFMA-bound
 SCREEN_MIN_DOCS = 65536  # below this there is no sample pass to seed thresholds and the exact kernel is faster
 
 
@@ -117,12 +118,20 @@ class BruteForceIndex:
         self.dmax_norm = float("nan")
         self.fallback_flags = torch.zeros(1, dtype=torch.int32, device=self.docs.device)  # per 32-query tile
         N, d = self.docs.shape
-        if screen and d == 256 and N > 0:
+        self._sdocs = self.docs  # what the screened path scores against: [N,256] fp32
+        if screen and N > 0 and (d == 256 or (d < 256 and d % 4 == 0)):
             L = _lib.lib()
-            self.docs16 = torch.empty((N, d), dtype=torch.float16, device=self.docs.device)
+            if d < 256:
+                # narrower embeddings (HIDDEN_DIM 64, 128, ...): zero-padded to the screen kernels' 256 features.
+                # Padding adds fmaf(0, 0, acc) terms to the fp32 chain, which leave every score bit-identical; the
+                # padded copy costs N KiB and is used for batches above 32 queries (MFMA-bound), smaller batches
+                # stream the original rows through the exact kernel, which already moves only N*d*4 bytes.
+                self._sdocs = torch.zeros((N, 256), dtype=torch.float32, device=self.docs.device)
+                self._sdocs[:, :d] = self.docs
+            self.docs16 = torch.empty((N, 256), dtype=torch.float16, device=self.docs.device)
             stats = torch.zeros(2, dtype=torch.float32, device=self.docs.device)
             with torch.cuda.device(self.docs.device):
-                _lib.check(L.tt_index_build_f16(self.docs.data_ptr(), N, d, self.docs16.data_ptr(), stats.data_ptr(),
+                _lib.check(L.tt_index_build_f16(self._sdocs.data_ptr(), N, 256, self.docs16.data_ptr(), stats.data_ptr(),
                                                 _stream(self.docs)))
             dmax, amax = (float(x) for x in stats.tolist())  # one sync, at index-build time
             if dmax == dmax and amax < 6.0e4 and dmax < 6.0e4:
@@ -135,6 +144,7 @@ class BruteForceIndex:
         """An index over caller-managed device buffers (StreamedIndex's per-block view)."""
         self = cls.__new__(cls)
         self.docs, self.docs16, self.dmax_norm, self.idx_offset = docs32, docs16, float(dmax_norm), int(idx_offset)
+        self._sdocs = docs32
         self.fallback_flags = torch.zeros(1, dtype=torch.int32, device=docs32.device)
         return self
 
@@ -147,7 +157,7 @@ class BruteForceIndex:
         B = 1 if q.dim() == 1 else q.shape[0]
         N, d = self.docs.shape
         L = _lib.lib()
-        if (self.docs16 is not None and B >= SCREEN_MIN_BATCH
+        if (self.docs16 is not None and B >= (SCREEN_MIN_BATCH if d == 256 else SCREEN_PADDED_MIN_BATCH)
                 and N >= SCREEN_MIN_DOCS and k <= 64):
             _need_cuda(q)
             if q.dim() == 1:  # single query (QueryInferencer / hybrid rerank): same path, squeezed result
@@ -156,6 +166,10 @@ class BruteForceIndex:
             q = _f32c(q)
             if q.shape[1] != d:
                 raise ValueError(f"shape mismatch: q {tuple(q.shape)} vs docs {tuple(self.docs.shape)}")
+            if d < 256:
+                qp = torch.zeros((B, 256), dtype=torch.float32, device=q.device)
+                qp[:, :d] = q
+                q, d = qp, 256
             # per-call workspace and flags (cached allocator blocks): safe for concurrent callers and streams
             need = L.tt_score_topk_screened_workspace_bytes(B, N, d, k)
             ws_s = torch.empty(need, dtype=torch.uint8, device=self.docs.device)
@@ -166,7 +180,7 @@ class BruteForceIndex:
                 vals = torch.empty((B, k), dtype=torch.float32, device=q.device)
                 idx = torch.empty((B, k), dtype=torch.int64, device=q.device)
             with torch.cuda.device(q.device):
-                _lib.check(L.tt_score_topk_screened_f32(q.data_ptr(), B, d, self.docs.data_ptr(), self.docs16.data_ptr(),
+                _lib.check(L.tt_score_topk_screened_f32(q.data_ptr(), B, d, self._sdocs.data_ptr(), self.docs16.data_ptr(),
                                                         N, k, self.dmax_norm, self.idx_offset, vals.data_ptr(),
                                                         idx.data_ptr(), flags.data_ptr(), ws_s.data_ptr(), ws_s.numel(),
                                                         _prof_events, _stream(q)))
