@@ -39,6 +39,9 @@ def test_sharded_index_through_rccl(nccl_group, oracle, screen, B):
     torch.cuda.synchronize()
     ov, oi = oracle.score_topk(Q, D, 10)
     assert np.array_equal(i.cpu().numpy(), oi) and np.array_equal(v.cpu().numpy(), ov)
+    v1, i1 = idx.search(torch.from_numpy(Q[3]).cuda(), k=10)      # a single query vector
+    torch.cuda.synchronize()
+    assert v1.shape == (10,) and np.array_equal(i1.cpu().numpy(), oi[3]) and np.array_equal(v1.cpu().numpy(), ov[3])
 
 
 def test_fused_optimizer_allreduce_through_rccl(nccl_group):

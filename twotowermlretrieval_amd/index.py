@@ -271,8 +271,11 @@ class ShardedIndex:
 
     def search(self, q: torch.Tensor, k: int = 10) -> Tuple[torch.Tensor, torch.Tensor]:
         import torch.distributed as dist
+        if q.dim() == 1:  # a single query vector: same path, squeezed result
+            v, i = self.search(q.unsqueeze(0), k)
+            return v[0], i[0]
         kp = max(k, self.shard_k)
-        if self._index is not None and dist.is_initialized() and q.dim() == 2:
+        if self._index is not None and dist.is_initialized():
             return self._search_in_place(q, k, kp)
         vals, idx = self._search(q, kp)
         if not dist.is_initialized():
