@@ -397,7 +397,10 @@ class StreamedIndex:
 
     def search(self, q: torch.Tensor, k: int = 10) -> Tuple[torch.Tensor, torch.Tensor]:
         _need_cuda(q)
-        q = _f32c(q if q.dim() == 2 else q.unsqueeze(0))
+        if q.dim() == 1:  # a single query vector: squeezed result, like BruteForceIndex
+            v, i = self.search(q.unsqueeze(0), k)
+            return v[0], i[0]
+        q = _f32c(q)
         run = [None, None]
 
         def visit(s, lo, n):
