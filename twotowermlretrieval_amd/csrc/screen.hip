@@ -724,7 +724,7 @@ __global__ __launch_bounds__(TW * 64, 2) void screen_stream_kernel(ScreenParams 
 struct FinishParams {
     const float *Q;
     const float *D32;
-    int B, N, k, n_chunks, blocks_per_group;
+    int B, N, k, n_chunks;
     float dmax;
     const SCand *cand;
     const int *pcnt;
@@ -1298,7 +1298,6 @@ TT_EXPORT int tt_score_topk_screened_f32(const float *Q, int B, int d, const flo
     fp.N = (int)N;
     fp.k = k;
     fp.n_chunks = pl.n_chunks;
-    fp.blocks_per_group = pl.n_chunks;
     fp.q_per_block = pl.q_per_block;
     fp.dmax = dmax_norm;
     fp.cand = sp.cand;
