@@ -62,7 +62,8 @@ int tt_event_elapsed_ms(void *start, void *stop, float *ms); /* blocks until `st
  * int64 = idx_offset + row of D.  The [B,N] score matrix is never formed.
  * Score = fp32 FMA chain over the feature index in ascending order (exactly
  * oracle/tt_oracle.c:o_score_topk).  Ties: (score desc, index asc).  When
- * N < k the tail is (-inf, -1).  Supported: d in {32,64,96,128,192,256}, 1 <= k <= 64,
+ * N < k the tail is (-inf, -1).  Supported: d in {32,64,96,128,192,256} (32-query tiles, 32x32x2 MFMA) and
+ * {320,384,448,512} (16-query tiles, 16x16x4 MFMA: the same chain, bit for bit), 1 <= k <= 64,
  * N < 2^31 - 64 per call (shard larger corpora; idx_offset makes indices global).
  * Inputs must be finite (a NaN score is never selected).
  */

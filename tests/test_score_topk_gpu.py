@@ -189,3 +189,23 @@ def test_baseline_config2_size_properties(tt):
     b = tt.score_topk(Q, D[half:], 50, idx_offset=half)
     mv, mi = tt.topk_merge(torch.cat([a[0], b[0]], 1), torch.cat([a[1], b[1]], 1), 10)
     assert torch.equal(mi, i) and torch.equal(mv, v)
+
+
+@pytest.mark.parametrize("d,B,N,k", [(512, 5, 3000, 10), (512, 40, 20001, 10), (320, 16, 4097, 5), (384, 17, 9000, 50),
+                                     (448, 1, 700, 64), (512, 33, 300000, 10), (512, 3, 31, 8)])
+def test_wide_embeddings_16_query_tiles_bit_exact(oracle, d, B, N, k):
+    """256 < d <= 512 (score_topk16_kernel: 16-query tiles on v_mfma_f32_16x16x4_f32): still the oracle's fp32 FMA
+    chain, bit for bit, with the same tie order; N = 300000 exercises the sample pass."""
+    import twotowermlretrieval_amd as tt
+    Q = synth.unit_rows(500 + d + B, B, d)
+    D = synth.unit_rows(600 + N, N, d).copy()
+    if N > 1000:
+        D[N // 2] = D[7]                     # an exact tie: the lower index must come first
+        Q[0] = D[7]
+    k = min(k, N)
+    v, i = tt.score_topk(torch.from_numpy(Q).cuda(), torch.from_numpy(D).cuda(), k, 5)
+    torch.cuda.synchronize()
+    ov, oi = oracle.score_topk(Q, D, k, idx_offset=5)
+    assert np.array_equal(i.cpu().numpy(), oi) and np.array_equal(v.cpu().numpy(), ov)
+    if N > 1000:
+        assert list(oi[0][:2]) == [12, N // 2 + 5]

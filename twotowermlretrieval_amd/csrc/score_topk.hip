@@ -372,6 +372,203 @@ __global__ __launch_bounds__(WPB * 64, 2) void score_topk_kernel(ScoreParams p)
 }
 
 // ---------------------------------------------------------------------------
+// K4w: the same kernel for wide embeddings, 256 < d <= 512 (HIDDEN_DIM up to 512 is what the encoder supports).
+// 32 queries x 512 features do not fit a wave's registers as 32x32x2 B operands, so a task is a 16-QUERY tile on
+// v_mfma_f32_16x16x4_f32: lane (n = l&15, kq = l>>4) keeps Q[n][4s+kq], s < d/4 (128 VGPRs at d = 512) and its
+// 8 accumulator registers are 8 documents of query n (two 16-document sub-tiles x rows 4kq..4kq+3).  A chain of
+// 16x16x4 MFMAs with k ascending is bit-identical to the sequential fmaf chain, like the 32x32x2 form
+// (tools/experiments/mfma16_order.hip), so the oracle parity carries over.  Ring, DMA, thresholds, candidate
+// buffers, compaction, partial lists and merge are K4's; the launch is bound by HBM streaming (d * 4 bytes per doc).
+// ---------------------------------------------------------------------------
+template <int NS, int CAP, bool MAXONLY>
+__global__ __launch_bounds__(WPB * 64, 2) void score_topk16_kernel(ScoreParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int WAVE_LDS = NSTAGE * SLAB_BYTES;
+    constexpr int ROW_BYTES = NS * 128;
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    char *ring = smem + wid * WAVE_LDS;
+
+    const int task = xcd_remap(blockIdx.x, gridDim.x) * WPB + wid;
+    if (task >= p.n_tasks)
+        return; // wave-uniform; the kernel has no block-level barrier
+    const int qtile = task % p.n_qtiles; // 16 queries
+    if (p.run_if && p.run_if[qtile >> 1] == 0)
+        return;
+    const int chunk = task / p.n_qtiles;
+    const int t0 = chunk * p.tiles_per_chunk;
+    const int t1 = min(t0 + p.tiles_per_chunk, p.n_tiles);
+    const int k = p.k;
+    const int n = lane & 15, kq = lane >> 4;
+
+    const int qrow = qtile * 16 + n;
+    float qreg[NS * 8];
+    {
+        const float *qp = p.Q + (size_t)min(qrow, p.B - 1) * (NS * 32) + kq;
+#pragma unroll
+        for (int s = 0; s < NS * 8; ++s)
+            qreg[s] = qrow < p.B ? qp[4 * s] : 0.0f;
+    }
+    float thr = INFINITY; // padded queries never qualify
+    if (qrow < p.B)
+        thr = (!MAXONLY && p.thr0) ? p.thr0[(size_t)qrow * p.thr0_stride + p.thr0_off] : -INFINITY;
+    int cnt = 0; // the same value in the four lanes of a query
+    float runmax = -INFINITY;
+    Cand *const cbase = p.cand + ((size_t)task * 16 + n) * CAP;
+
+    auto compact_where = [&](unsigned qmask) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        while (qmask) {
+            const int q = __ffs((int)qmask) - 1;
+            qmask &= qmask - 1;
+            const int nn = __builtin_amdgcn_readlane(cnt, q);
+            int n_new;
+            float kth;
+            bool have;
+            compact_query<CAP>(p.cand + ((size_t)task * 16 + q) * CAP, nn, k, lane, n_new, kth, have);
+            if (n == q) {
+                cnt = n_new;
+                if (have)
+                    thr = kth;
+            }
+        }
+    };
+
+    // ---- DMA: K4's (slab = 32 docs x 32 features; instruction jj moves docs 8jj..8jj+7; lane -> (doc 8jj +
+    //      lane>>3, physical 16-B chunk lane&7); logical chunk = physical ^ ((doc>>1)&7)) ----
+    const char *Dbytes = (const char *)p.D;
+    int dma_tile = t0, dma_s = 0;
+    const char *rowp[DMA_PER_SLAB];
+    auto set_rows = [&](int tile) {
+#pragma unroll
+        for (int jj = 0; jj < DMA_PER_SLAB; ++jj) {
+            int di = 8 * jj + (lane >> 3);
+            int doc = min(tile * TILE_DOCS + di, p.N - 1);
+            int chunk16 = (lane & 7) ^ ((di >> 1) & 7);
+            rowp[jj] = Dbytes + (size_t)doc * ROW_BYTES + chunk16 * 16;
+        }
+    };
+    auto dma_issue = [&](int stage) {
+        char *dst = ring + stage * SLAB_BYTES;
+#pragma unroll
+        for (int jj = 0; jj < DMA_PER_SLAB; ++jj)
+            __builtin_amdgcn_global_load_lds((gbl_void *)(rowp[jj] + dma_s * 128),
+                                             (lds_void *)(dst + jj * 1024), 16, 0, 0);
+        if (++dma_s == NS) {
+            dma_s = 0;
+            dma_tile = min(dma_tile + 1, t1 - 1); // past the end: harmless re-read
+            set_rows(dma_tile);
+        }
+    };
+
+    if (t0 < t1) {
+        set_rows(t0);
+#pragma unroll
+        for (int gi = 0; gi < NSTAGE - 1; ++gi)
+            dma_issue(gi);
+        // A element (sub-tile u, k-step t of the slab): row 16u + n, logical chunk t, float kq of the chunk
+        const char *rd[2];
+        int rsw[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int r = 16 * u + n;
+            rd[u] = ring + r * 128 + 4 * kq;
+            rsw[u] = (r >> 1) & 7;
+        }
+        int stage = 0;
+        for (int tile = t0; tile < t1; ++tile) {
+            f32x4 acc[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_SLAB * (NSTAGE - 2)) : "memory");
+                float a[2][8];
+#pragma unroll
+                for (int t = 0; t < 8; ++t)
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+                        a[u][t] = *(const float *)(rd[u] + stage * SLAB_BYTES + ((t ^ rsw[u]) << 4));
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                dma_issue((stage + NSTAGE - 1) % NSTAGE);
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0][t], qreg[8 * s + t], acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1][t], qreg[8 * s + t], acc[1], 0, 0, 0);
+                }
+                stage = (stage + 1) % NSTAGE;
+            }
+            // ---- epilogue: acc[u][r] = score(doc tile*32 + 16u + 4kq + r, query n) ----
+            const int tile_base = tile * TILE_DOCS;
+            const bool partial = tile_base + TILE_DOCS > p.N;
+            float m = -INFINITY;
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    m = fmaxf(m, (!partial || tile_base + 16 * u + 4 * kq + r < p.N) ? acc[u][r] : -INFINITY);
+            if (MAXONLY) {
+                runmax = fmaxf(runmax, m);
+                continue;
+            }
+            if (__ballot(m >= thr) != 0ull) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int doc = tile_base + 16 * u + 4 * kq + r;
+                        const bool c = (!partial || doc < p.N) && acc[u][r] >= thr;
+                        const unsigned long long mask = __ballot(c);
+                        if (mask == 0ull)
+                            continue;
+                        // the four lanes of query n sit at n, n+16, n+32, n+48: slots in kq order
+                        const int b0 = (int)((mask >> n) & 1ull), b1 = (int)((mask >> (n + 16)) & 1ull);
+                        const int b2 = (int)((mask >> (n + 32)) & 1ull), b3 = (int)((mask >> (n + 48)) & 1ull);
+                        const int before = (kq > 0 ? b0 : 0) + (kq > 1 ? b1 : 0) + (kq > 2 ? b2 : 0);
+                        if (c)
+                            cand_store_async(cbase + cnt + before, acc[u][r], doc);
+                        cnt += b0 + b1 + b2 + b3;
+                    }
+                // one tile adds at most 32 entries per query: compact while there is still room for that
+                const unsigned long long full = __ballot(cnt > CAP - 34) & 0xffffull;
+                if (full)
+                    compact_where((unsigned)full);
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    if (MAXONLY) {
+        runmax = fmaxf(runmax, __shfl_xor(runmax, 16));
+        runmax = fmaxf(runmax, __shfl_xor(runmax, 32));
+        if (kq == 0 && qrow < p.B) {
+            const size_t o = (size_t)qrow * p.n_chunks + chunk;
+            p.pval[o] = runmax;
+            p.pidx[o] = t0 < t1 ? (int64_t)chunk : -1;
+        }
+        return;
+    }
+    {
+        const unsigned long long over = __ballot(cnt > k) & 0xffffull;
+        if (over)
+            compact_where((unsigned)over);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    const int rows_live = min(16, p.B - qtile * 16);
+    for (int it = lane; it < rows_live * k; it += 64) {
+        const int q = it / k, t = it - q * k;
+        const int nn = __shfl(cnt, q);
+        const size_t o = ((size_t)(qtile * 16 + q) * p.n_chunks + chunk) * k + t;
+        Cand c;
+        c.v = -INFINITY;
+        c.x = -1;
+        if (t < nn)
+            c = cand_load_l2(p.cand + ((size_t)task * 16 + q) * CAP + t);
+        p.pval[o] = c.v;
+        p.pidx[o] = t < nn ? p.idx_offset + c.x : -1;
+    }
+}
+
+// ---------------------------------------------------------------------------
 // K5: top-k of M unordered candidates per query, (score desc, index asc).
 // One block per query.  The candidates are scanned ONCE: valid entries (idx >= 0; most
 // partial-list slots are padding) are packed into an LDS pool; whenever the pool could overflow
@@ -663,11 +860,11 @@ int device_cus()
     return cus;
 }
 
-Pass make_pass(int B, int64_t N, int slots)
+Pass make_pass(int B, int64_t N, int slots, int qt)
 {
     Pass ps;
     ps.N = N;
-    ps.n_qtiles = (B + 31) / 32;
+    ps.n_qtiles = (B + qt - 1) / qt; // qt queries per task: 32, or 16 for wide embeddings (d > 256)
     ps.n_tiles = (int)((N + TILE_DOCS - 1) / TILE_DOCS);
     int want = (slots + ps.n_qtiles - 1) / ps.n_qtiles;
     want = want < 1 ? 1 : want;
@@ -688,31 +885,32 @@ constexpr int64_t PREPASS_MIN_N = 262144;
 constexpr int PREPASS_MAX_CHUNK_DOCS = 65536;
 constexpr int64_t PREPASS_MIN_SAMPLE = 16384;
 
-Plan make_plan(int B, int64_t N, int k)
+Plan make_plan(int B, int64_t N, int k, int d)
 {
     Plan pl;
+    const int qt = d > 256 ? 16 : 32;
     pl.cap = k <= 16 ? 64 : 128;
     pl.smem = (size_t)WPB * NSTAGE * SLAB_BYTES;
     const int slots = device_cus() * 8;
-    pl.main = make_pass(B, N, slots);
+    pl.main = make_pass(B, N, slots, qt);
     pl.prepass = N >= PREPASS_MIN_N && (int64_t)pl.main.tiles_per_chunk * TILE_DOCS < PREPASS_MAX_CHUNK_DOCS;
     int max_tasks = pl.main.n_tasks;
     if (pl.prepass) {
         int64_t ns = N / 256;
         ns = ns < PREPASS_MIN_SAMPLE ? PREPASS_MIN_SAMPLE : ns;
         ns = (ns + TILE_DOCS - 1) / TILE_DOCS * TILE_DOCS;
-        pl.pre = make_pass(B, ns, slots);
+        pl.pre = make_pass(B, ns, slots, qt);
         max_tasks = pl.pre.n_tasks > max_tasks ? pl.pre.n_tasks : max_tasks;
     } else {
-        pl.pre = make_pass(B, 0, slots);
+        pl.pre = make_pass(B, 0, slots, qt);
     }
-    const size_t rows = (size_t)pl.main.n_qtiles * 32;
+    const size_t rows = (size_t)pl.main.n_qtiles * qt;
     size_t max_chunks = pl.main.n_chunks;
     if (pl.prepass && (size_t)pl.pre.n_chunks > max_chunks)
         max_chunks = pl.pre.n_chunks;
     size_t off = 0;
     pl.cand_off = off;
-    off = tt_align_up(off + (size_t)max_tasks * 32 * pl.cap * 8, 256);
+    off = tt_align_up(off + (size_t)max_tasks * qt * pl.cap * 8, 256);
     pl.pval_off = off;
     off = tt_align_up(off + rows * max_chunks * k * sizeof(float), 256);
     pl.pidx_off = off;
@@ -744,11 +942,37 @@ int launch_score_ns(const ScoreParams &sp, const Plan &pl, hipStream_t st, bool 
     return pl.cap == 64 ? launch_score_t<NS, 64, false>(sp, pl, st) : launch_score_t<NS, 128, false>(sp, pl, st);
 }
 
-constexpr bool score_dim_ok(int d) { return d == 32 || d == 64 || d == 96 || d == 128 || d == 192 || d == 256; }
+constexpr bool score_dim_ok(int d)
+{
+    return d == 32 || d == 64 || d == 96 || d == 128 || d == 192 || d == 256 || d == 320 || d == 384 || d == 448 || d == 512;
+}
+
+template <int NS, int CAP, bool MAXONLY>
+int launch_score16_t(const ScoreParams &sp, const Plan &pl, hipStream_t st)
+{
+    auto kern = score_topk16_kernel<NS, CAP, MAXONLY>;
+    TT_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.smem));
+    const int grid = (sp.n_tasks + WPB - 1) / WPB;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(WPB * 64), pl.smem, st, sp);
+    TT_LAUNCH_CHECK();
+    return TT_OK;
+}
+
+template <int NS>
+int launch_score16_ns(const ScoreParams &sp, const Plan &pl, hipStream_t st, bool maxonly)
+{
+    if (maxonly)
+        return launch_score16_t<NS, 64, true>(sp, pl, st);
+    return pl.cap == 64 ? launch_score16_t<NS, 64, false>(sp, pl, st) : launch_score16_t<NS, 128, false>(sp, pl, st);
+}
 
 int launch_score(int d, const ScoreParams &sp, const Plan &pl, hipStream_t st, bool maxonly)
 {
     switch (d) {
+    case 320: return launch_score16_ns<10>(sp, pl, st, maxonly);
+    case 384: return launch_score16_ns<12>(sp, pl, st, maxonly);
+    case 448: return launch_score16_ns<14>(sp, pl, st, maxonly);
+    case 512: return launch_score16_ns<16>(sp, pl, st, maxonly);
     case 32: return launch_score_ns<1>(sp, pl, st, maxonly);
     case 64: return launch_score_ns<2>(sp, pl, st, maxonly);
     case 96: return launch_score_ns<3>(sp, pl, st, maxonly);
@@ -790,14 +1014,14 @@ int score_partials(const float *Q, int B, int d, const float *D, int64_t N, int 
     if (B <= 0 || N <= 0 || k <= 0)
         return tt_fail(TT_ERR_BAD_SHAPE, "%s: B=%d N=%lld k=%d", who, B, (long long)N, k);
     if (!score_dim_ok(d))
-        return tt_fail(TT_ERR_UNSUPPORTED, "%s: d=%d (supported: 32, 64, 96, 128, 192, 256)", who, d);
+        return tt_fail(TT_ERR_UNSUPPORTED, "%s: d=%d (supported: 32, 64, 96, 128, 192, 256, 320, 384, 448, 512)", who, d);
     if (k > 64)
         return tt_fail(TT_ERR_UNSUPPORTED, "%s: k=%d > 64", who, k);
     if (N >= (int64_t)INT_MAX - 64)
         return tt_fail(TT_ERR_UNSUPPORTED, "%s: N=%lld >= 2^31-64; shard the corpus", who, (long long)N);
     if (!Q || !D)
         return tt_fail(TT_ERR_BAD_SHAPE, "%s: null pointer", who);
-    const Plan pl = make_plan(B, N, k);
+    const Plan pl = make_plan(B, N, k, d);
     if (!workspace || workspace_bytes < pl.ws_bytes)
         return tt_fail(TT_ERR_WORKSPACE, "%s: workspace %zu < %zu bytes", who, workspace_bytes, pl.ws_bytes);
     if (((uintptr_t)D & 15) || ((uintptr_t)Q & 3) || ((uintptr_t)workspace & 255))
@@ -835,10 +1059,9 @@ int score_partials(const float *Q, int B, int d, const float *D, int64_t N, int 
 
 TT_EXPORT size_t tt_score_topk_workspace_bytes(int B, int64_t N, int d, int k)
 {
-    (void)d;
     if (B <= 0 || N < 0 || k <= 0)
         return 0;
-    return make_plan(B, N, k).ws_bytes;
+    return make_plan(B, N, k, d).ws_bytes;
 }
 
 TT_EXPORT int tt_score_topk_partials_f32(const float *Q, int B, int d, const float *D, int64_t N, int k,
@@ -882,7 +1105,7 @@ int tt_score_topk_f32_pred(const float *Q, int B, int d, const float *D, int64_t
     if (B == 0)
         return TT_OK;
     if (!score_dim_ok(d))
-        return tt_fail(TT_ERR_UNSUPPORTED, "tt_score_topk_f32: d=%d (supported: 32, 64, 96, 128, 192, 256)", d);
+        return tt_fail(TT_ERR_UNSUPPORTED, "tt_score_topk_f32: d=%d (supported: 32, 64, 96, 128, 192, 256, 320, 384, 448, 512)", d);
     if (k > 64)
         return tt_fail(TT_ERR_UNSUPPORTED, "tt_score_topk_f32: k=%d > 64", k);
     if (!out_val || !out_idx)
