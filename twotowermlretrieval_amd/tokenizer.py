@@ -98,11 +98,18 @@ class PretrainedTokenizer:
         from . import _lib
         L = _lib.lib()
         n = len(texts)
-        enc = [(t if isinstance(t, str) else str(t)).encode("utf-8") for t in texts]
+        strs = [t if type(t) is str else str(t) for t in texts]
         off = np.zeros(n + 1, dtype=np.int64)
-        if n:
-            np.cumsum([len(b) for b in enc], out=off[1:])
-        blob = b"".join(enc)
+        try:
+            # all-ASCII batch (the common case): ONE encode of the joined text, byte lengths = character lengths
+            blob = "".join(strs).encode("ascii")
+            if n:
+                np.cumsum(np.fromiter(map(len, strs), dtype=np.int64, count=n), out=off[1:])
+        except UnicodeEncodeError:
+            enc = [t.encode("utf-8") for t in strs]
+            if n:
+                np.cumsum([len(b) for b in enc], out=off[1:])
+            blob = b"".join(enc)
         total = int(off[-1])
         ragged = np.empty(max(total, 1), dtype=np.int64)
         lens = np.zeros(max(n, 1), dtype=np.int32)
