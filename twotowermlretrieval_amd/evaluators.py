@@ -85,6 +85,8 @@ def embed_corpus(model, tokenizer, documents: Sequence[str], device: torch.devic
 
     th = threading.Thread(target=producer, daemon=True)
     th.start()
+    import collections
+    inflight = collections.deque()
     copy_stream = torch.cuda.Stream(device=device)
     cur = torch.cuda.current_stream(device)
     res = out
@@ -104,8 +106,14 @@ def embed_corpus(model, tokenizer, documents: Sequence[str], device: torch.devic
             if res is None:
                 res = torch.empty((n, emb.shape[1]), dtype=torch.float32, device=device)
             res[i:i + emb.shape[0]].copy_(emb)
-            # the pinned batch must outlive its async copy: wait for this batch's encoder call before dropping it
-            torch.cuda.current_stream(device).synchronize()
+            # a pinned batch must outlive its async copy; keep two batches in flight so the GPU never waits for the host
+            ev = torch.cuda.Event()
+            ev.record(cur)
+            inflight.append((ids_host, ev))
+            if len(inflight) > 2:
+                inflight.popleft()[1].synchronize()
+    while inflight:
+        inflight.popleft()[1].synchronize()
     th.join()
     return res
 
