@@ -52,6 +52,17 @@ __global__ __launch_bounds__(256) void prep_len_kernel(const int64_t *__restrict
 
 constexpr int SORT_BINS = 4096;
 
+int enc_cus()
+{
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) {
+        (void)hipGetLastError();
+        cus = 256;
+    }
+    return cus;
+}
+
 // Single block: tok_off = exclusive scan of len; perm = rows sorted by length, longest first.
 __global__ __launch_bounds__(1024) void prep_scan_sort_kernel(const int32_t *__restrict__ len, int B, int T,
                                                               int32_t *__restrict__ tok_off, int32_t *__restrict__ perm)
@@ -176,6 +187,7 @@ struct GruParams {
     GruDir dir[2];
     const int32_t *len, *tok_off, *perm;
     int B, H, out_ld;
+    int slots; // workgroups resident at once (2 per CU): within one such round, long row groups pair with short ones
 };
 
 __device__ __forceinline__ float fast_sigmoid(float x)
@@ -198,7 +210,17 @@ __global__ __launch_bounds__(MAXW * 64) void gru_seq_kernel(GruParams p)
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 15, kq = lane >> 4;
-    const int row0 = blockIdx.x * ENC_RB;
+    // Rows are sorted longest first and two workgroups share a CU: with the plain order CU c would run groups c and
+    // c + slots/2 (long + medium) while the last CUs idle early.  Inside each round of `slots` workgroups the second
+    // half is taken in reverse, so the CU that got the longest group also gets the shortest (LPT pairing).
+    int grp = blockIdx.x;
+    {
+        const int base = grp / p.slots * p.slots, r = grp - base;
+        const int nr = min(p.slots, (int)gridDim.x - base), half = (nr + 1) / 2;
+        if (r >= half)
+            grp = base + nr - 1 - (r - half);
+    }
+    const int row0 = grp * ENC_RB;
 
     int len_e[4], off_e[4], rid_e[4];
 #pragma unroll
@@ -426,6 +448,7 @@ TT_EXPORT int tt_encoder_forward_f32(const int64_t *ids, int B, int T, const flo
         gp.B = B;
         gp.H = H;
         gp.out_ld = ndir * H;
+        gp.slots = 2 * enc_cus();
         const bool last = l == num_layers - 1;
         float *xout = (last && !train) ? nullptr : (float *)(ws + lo.x[l + 1]);
         if (train) // the all-zero row that stands for "h before the first step" in the backward GEMMs
