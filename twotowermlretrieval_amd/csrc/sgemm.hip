@@ -65,7 +65,22 @@ __global__ __launch_bounds__(256) void sgemm_kernel(SgemmParams p)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int M = p.m_dyn ? min(p.M, *p.m_dyn) : p.M;
     const int K = p.k_dyn ? min(p.K, *p.k_dyn) : p.K;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    // Workgroup -> tile.  Consecutive workgroup ids go round-robin over the 8 XCDs, each with its own L2; the
+    // n-blocks of one m-block re-read the same A rows (for K1: rows gathered from a 480 MB embedding table), so
+    // they are placed on ONE XCD, back to back: flat id L -> xcd = L % 8, slot = L / 8; the slots of an XCD walk
+    // (m-block, n-block) with n fastest and m-blocks dealt out 8 apart.
+    int bx = blockIdx.x, by = blockIdx.y;
+    {
+        const int nbx = gridDim.x, nby = gridDim.y;
+        const int L = by * nbx + bx, xcd = L & 7, slot = L >> 3;
+        const int mb = (slot / nbx) * 8 + xcd, nb = slot % nbx;
+        const int full = (nby / 8) * 8; // m-blocks beyond the last full group of 8 keep the plain mapping
+        if (by < full && mb < full) {
+            by = mb;
+            bx = nb;
+        }
+    }
+    const int m0 = by * BM, n0 = bx * BN;
     if (m0 >= M)
         return;
     // split-K range (multiples of BK)
