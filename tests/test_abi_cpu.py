@@ -70,3 +70,49 @@ def test_product_never_imports_oracle():
         src = f.read_text()
         assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
         assert "tt_oracle" not in src or f.suffix != ".py", f
+
+
+def test_header_is_plain_c_and_links_against_the_library(tmp_path):
+    """include/tt.h is the contract: it must compile as C99 (no C++ or torch types) and a C program that calls
+    through it must link against libtt.so and run (host-only entry points: version string, error string,
+    workspace queries, the tokenizer)."""
+    import shutil
+    import subprocess
+    from twotowermlretrieval_amd import build as b
+    lib = b.build()
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("gcc not available")
+    src = tmp_path / "abi.c"
+    src.write_text(r"""
+#include <stdio.h>
+#include <string.h>
+#include "tt.h"
+int main(void)
+{
+    const char *words = "theofw5";
+    const int64_t off[4] = {0, 3, 5, 7}, ids[3] = {0, 3, 5};
+    void *h = 0;
+    if (tt_tok_create(words, off, ids, 3, 9, &h) != 0) return 2;
+    const char *text = "The w5, of zzz";
+    const int64_t toff[2] = {0, (int64_t)strlen(text)};
+    int64_t ragged[32]; int32_t len = 0, status = 0;
+    if (tt_tok_encode(h, text, toff, 1, ragged, &len, &status, 1) != 0) return 3;
+    tt_tok_destroy(h);
+    /* "The w5, of zzz" -> the w5 , of zzz -> 0 5 <unk=9> 3 9 */
+    if (status != 0 || len != 5 || ragged[0] != 0 || ragged[1] != 5 || ragged[2] != 9 || ragged[3] != 3 || ragged[4] != 9) return 4;
+    if (tt_score_topk_workspace_bytes(1024, 10000000, 256, 10) == 0) return 5;
+    if (tt_score_topk_f32(0, 1, 7, 0, 1, 10, 0, 0, 0, 0, 0, 0) == 0) return 6;      /* d = 7 is refused ... */
+    if (strstr(tt_last_error(), "d=7") == 0) return 7;                               /* ... with a message */
+    printf("%s\n", tt_version());
+    return 0;
+}
+""")
+    exe = tmp_path / "abi"
+    inc = b.PKG.parent / "include"
+    r = subprocess.run([gcc, "-std=c99", "-Wall", "-Werror", f"-I{inc}", str(src), "-o", str(exe), str(lib),
+                        f"-Wl,-rpath,{lib.parent}"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
+    assert r.stdout.strip()
