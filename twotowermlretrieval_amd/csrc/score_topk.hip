@@ -888,7 +888,7 @@ constexpr int64_t PREPASS_MIN_SAMPLE = 16384;
 Plan make_plan(int B, int64_t N, int k, int d)
 {
     Plan pl;
-    const int qt = d > 256 ? 16 : 32;
+    const int qt = (d > 256 || B <= 16) ? 16 : 32; // 16-query tiles: wide embeddings, and batches that fit one such tile
     pl.cap = k <= 16 ? 64 : 128;
     pl.smem = (size_t)WPB * NSTAGE * SLAB_BYTES;
     const int slots = device_cus() * 8;
@@ -968,6 +968,16 @@ int launch_score16_ns(const ScoreParams &sp, const Plan &pl, hipStream_t st, boo
 
 int launch_score(int d, const ScoreParams &sp, const Plan &pl, hipStream_t st, bool maxonly)
 {
+    if (d <= 256 && sp.B <= 16) { // half the MFMA work of a 32-query tile: the launch stays on the HBM roofline
+        switch (d) {
+        case 32: return launch_score16_ns<1>(sp, pl, st, maxonly);
+        case 64: return launch_score16_ns<2>(sp, pl, st, maxonly);
+        case 96: return launch_score16_ns<3>(sp, pl, st, maxonly);
+        case 128: return launch_score16_ns<4>(sp, pl, st, maxonly);
+        case 192: return launch_score16_ns<6>(sp, pl, st, maxonly);
+        default: return launch_score16_ns<8>(sp, pl, st, maxonly);
+        }
+    }
     switch (d) {
     case 320: return launch_score16_ns<10>(sp, pl, st, maxonly);
     case 384: return launch_score16_ns<12>(sp, pl, st, maxonly);
