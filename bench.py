@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: queries/sec of exact top-10 over a 10M x 256-d fp32 corpus (BASELINE.json).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W        (N > 1 without a launcher: starts N rank processes itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 One step = one pass of the hot path over one batch of B=1024 synthetic queries: every rank scores
@@ -16,7 +16,10 @@ Extra legs on rank 0 (untimed w.r.t. `value`): `roofline` (the step's dominant k
 screen_kernel<false>, timed alone with HIP events recorded around its launch), `roofline_exact_f32`
 (the plain fp32-MFMA kernel on the same batch), `roofline_hbm` (a serving-size batch, B=32: the
 streaming form of the screen, bound by HBM streaming of the fp16 shadow corpus),
-`roofline_hbm_exact_f32` (the fp32 kernel at B=32), and at N=1 `cpu_baseline` (the reference's torch CPU idiom on a bounded sample).
+`roofline_hbm_exact_f32` (the fp32 kernel at B=32), `encoder` / `train` (SURVEY 8d's secondary metrics: tower
+tokens/s, index-build tokens/s, training triplets/s on synthetic MS-MARCO-shaped batches, each with its fp32-MFMA
+fraction), and at N=1 `cpu_baseline` (the reference's torch CPU idiom on a bounded sample; `cpu_baseline.legs` holds
+the other rows of BASELINE.md section 2: B=64 scoring, doc-tower forward, train step).
 """
 from __future__ import annotations
 
@@ -24,6 +27,8 @@ import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -154,7 +159,8 @@ def pmc_traffic(name: str):
     return None
 
 
-def cpu_baseline(q_gpu, docs_gpu):
+def cpu_baseline(q_gpu, docs_gpu, enc_inputs=None):
+    """The reference's torch CPU idioms (oracle/torch_ref.py) on this box's host cores, bounded samples."""
     from oracle import torch_ref
     n_s = 1_000_000
     cores = min(len(os.sched_getaffinity(0)), 64)
@@ -163,9 +169,133 @@ def cpu_baseline(q_gpu, docs_gpu):
     ds = docs_gpu[:n_s].cpu()
     t = torch_ref.time_scoring_idiom(qs, ds, TOPK, warmup=1, reps=3)
     scale = N_DOCS / n_s
-    return {"value": round(BATCH / (t * scale), 2), "unit": "queries/s", "cores": cores, "kind": "port",
-            "sample": f"B={BATCH} queries x first {n_s} of the {N_DOCS} docs, torch.matmul+torch.topk on CPU "
-                      f"(reference idiom evaluators.py:185-186), median of 3 = {t:.3f} s, time scaled x{scale:.0f}"}
+    out = {"value": round(BATCH / (t * scale), 2), "unit": "queries/s", "cores": cores, "kind": "port",
+           "sample": f"B={BATCH} queries x first {n_s} of the {N_DOCS} docs, torch.matmul+torch.topk on CPU "
+                     f"(reference idiom evaluators.py:185-186), median of 3 = {t:.3f} s, time scaled x{scale:.0f}"}
+    legs = {}
+    t64 = torch_ref.time_scoring_idiom(qs[:64].contiguous(), ds, TOPK, warmup=1, reps=3)
+    legs["scoring_b64"] = {"value": round(64 / (t64 * scale), 2), "unit": "queries/s",
+                           "sample": f"B=64 x first {n_s} docs, median of 3 = {t64:.3f} s, time scaled x{scale:.0f}"}
+    if enc_inputs is not None:
+        table, q_ids, p_ids, n_ids = enc_inputs
+        nb = 64  # bounded sample: 64 rows of each 512-row batch (the reference's BATCH_SIZE)
+        qt, dt = torch_ref.TorchTower(table, ENC_H, seed=0), torch_ref.TorchTower(table, ENC_H, seed=1)
+        qc, pc, nc = q_ids[:nb].cpu(), p_ids[:nb].cpu(), n_ids[:nb].cpu()
+        tf = torch_ref.time_tower_forward(dt, pc, warmup=1, reps=3)
+        ptok = int((pc != 0).sum())
+        legs["doc_tower_forward"] = {"value": round(ptok / tf), "unit": "tokens/s",
+                                     "sample": f"{nb} passages ({ptok} tokens), nn.Embedding + nn.GRU + F.normalize "
+                                               f"(model.py:48-75), median of 3 = {tf:.3f} s"}
+        tt_ = torch_ref.time_train_step(qt, dt, qc, pc, nc, margin=0.5, lr=5e-5, warmup=1, reps=3)
+        legs["train_step"] = {"value": round(nb / tt_, 1), "unit": "triplets/s",
+                              "sample": f"{nb} triplets per step (main.py:244-259: 3 forwards, loss, backward, "
+                                        f"clip_grad_norm_, Adam), median of 3 = {tt_:.3f} s"}
+    out["legs"] = legs
+    return out
+
+
+# ---- secondary metrics: synthetic MS-MARCO-shaped token batches, north-star model shape ----
+ENC_V, ENC_E, ENC_H = 400_003, 300, 256
+FLOP_PER_TOKEN_FWD = 2.0 * 3 * ENC_H * (ENC_E + ENC_H)             # input projection + recurrence
+FLOP_PER_TOKEN_TRAIN = FLOP_PER_TOKEN_FWD + 2.0 * 3 * ENC_H * (ENC_E + 2 * ENC_H)  # + dW_ih, dW_hh, dh (table frozen)
+
+
+def make_ids(rs, B, mean, lo, hi, V):
+    """ids ~ Zipf(1.07) over [0,V) (id 0, "the", also occurs inside sentences), lengths ~ clip(Poisson(mean), lo, hi),
+    first token non-zero, right-padded with 0 to the batch maximum."""
+    import numpy as np
+    L = np.clip(rs.poisson(mean, B), lo, hi)
+    T = int(L.max())
+    ids = np.zeros((B, T), dtype=np.int64)
+    for b in range(B):
+        z = rs.zipf(1.07, L[b]) % V
+        z[0] = max(z[0], 1)
+        ids[b, :L[b]] = z
+    return torch.from_numpy(ids), int((ids != 0).sum())
+
+
+def _time_gpu(fn, iters, warm):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / iters
+
+
+def encoder_legs(dev):
+    """Tower forward (B=512), index build (B=8192) and the train step (512 triplets) on this rank's GPU.
+    Returns (encoder dict, train dict, inputs for the CPU legs)."""
+    import numpy as np
+    import twotowermlretrieval_amd as tt
+    rs = np.random.RandomState(0)
+    g = torch.Generator(device=dev).manual_seed(5)
+    table = (torch.randn((ENC_V, ENC_E), dtype=torch.float32, device=dev, generator=g) * 0.3).cpu()
+    torch.manual_seed(0)
+    m = tt.TwoTowerModel({"VOCAB_SIZE": ENC_V, "EMBED_DIM": ENC_E, "HIDDEN_DIM": ENC_H}, table.numpy()).to(dev)
+    B = 512
+    q, qt = make_ids(rs, B, 6, 1, 30, ENC_V)
+    p, pt = make_ids(rs, B, 70, 10, 250, ENC_V)
+    n, nt = make_ids(rs, B, 70, 10, 250, ENC_V)
+    big, bt = make_ids(rs, 8192, 70, 10, 250, ENC_V)
+    qd, pd, nd, bigd = q.to(dev), p.to(dev), n.to(dev), big.to(dev)
+    m.eval()
+    with torch.no_grad():
+        t_doc = _time_gpu(lambda: m.encode_document(pd), 10, 3)
+        t_q = _time_gpu(lambda: m.encode_query(qd), 10, 3)
+        t_big = _time_gpu(lambda: m.encode_document(bigd), 3, 1)
+
+    def leg(tokens, t, extra):
+        tf = tokens * FLOP_PER_TOKEN_FWD / t / 1e12
+        return {"tokens_per_s": round(tokens / t), "ms": round(t * 1e3, 3), "tokens": tokens,
+                "TFLOPs": round(tf, 2), "frac_f32_mfma": round(tf / MFMA_F32_PEAK_TFLOPS, 4), **extra}
+    enc = {"model": f"1-layer GRU, V={ENC_V}, E={ENC_E}, H={ENC_H}, fp32 (model.py:48-75)",
+           "doc_tower_b512": leg(pt, t_doc, {"batch": B, "T": int(p.shape[1])}),
+           "query_tower_b512": leg(qt, t_q, {"batch": B, "T": int(q.shape[1]), "queries_per_s": round(B / t_q)}),
+           "index_build_b8192": leg(bt, t_big, {"batch": 8192, "T": int(big.shape[1]), "docs_per_s": round(8192 / t_big)})}
+    m.train()
+    opt = tt.FusedClipAdam(m.parameters(), lr=5e-5, max_norm=1.0)
+    t_tr = _time_gpu(lambda: tt.train_step(m, opt, qd, pd, nd, margin=0.5), 5, 2)
+    tok = qt + pt + nt
+    tf = tok * FLOP_PER_TOKEN_TRAIN / t_tr / 1e12
+    train = {"triplets_per_s": round(B / t_tr), "ms_per_step": round(t_tr * 1e3, 3), "triplets": B, "tokens": tok,
+             "step": "3 tower forwards + triplet loss + backward + clip_grad_norm_(1.0) + Adam (main.py:244-259), default "
+                     "input checking",
+             "TFLOPs": round(tf, 2), "frac_f32_mfma": round(tf / MFMA_F32_PEAK_TFLOPS, 4)}
+    del m, opt
+    torch.cuda.empty_cache()
+    return enc, train, (table, q, p, n)
+
+
+def launch_ranks(n: int) -> int:
+    """`python bench.py --gpus N` from a bare shell: this parent makes NO GPU call; it starts N fresh rank processes
+    (never an exec of itself), relays rank 0's JSON line and fails if any rank fails."""
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve()), *sys.argv[1:]], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    rc = 0
+    try:
+        out0, _ = procs[0].communicate()
+        for pr in procs:
+            rc = rc or pr.wait()
+    finally:
+        for pr in procs:
+            if pr.poll() is None:
+                pr.kill()
+    line = [l for l in (out0 or "").splitlines() if l.startswith("{")]
+    if rc == 0 and line:
+        print(line[-1], flush=True)
+        return 0
+    sys.stderr.write(f"bench.py: a rank failed (rc={rc}); rank 0 stdout was:\n{out0}\n")
+    return rc or 1
 
 
 def main():
@@ -174,15 +304,15 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the encoder / train legs")
     a = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        sys.exit(launch_ranks(a.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if a.gpus != world:
-        if world == 1 and a.gpus > 1:
-            sys.exit(f"--gpus {a.gpus} needs a launcher: python -m torch.distributed.run --nproc-per-node {a.gpus} "
-                     f"--master-addr 127.0.0.1 bench.py --gpus {a.gpus} ...")
         sys.exit(f"--gpus {a.gpus} != WORLD_SIZE {world}")
     # TT_BENCH_BACKEND=gloo rehearses the N > 1 code path on a box with fewer GPUs than ranks (ranks then share
     # devices; the numbers mean nothing).  The default, and what the driver runs, is nccl = RCCL, one rank per GPU.
@@ -239,6 +369,7 @@ def main():
         roof = {"bound": "mfma", "kernel": "screen_kernel<false> (f16 MFMA 16x16x32, fp32 accumulate)",
                 "achieved": round(flops / ms_s / 1e9, 2), "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(flops / ms_s / 1e9 / MFMA_F16_PEAK_TFLOPS, 4), "traffic": pmc_traffic("screen_b1024") if world == 1 else None,
+                "traffic_source": "static: committed rocprofv3 PMC pass (profiles/pmc_traffic.json), not this run",
                 "kernel_ms": round(ms_s, 4), "batch": BATCH, "docs_per_gpu": n_shard,
                 "hbm_GBps_same_launch": round((-(-BATCH // 512) * n_shard * DIM * 2) / ms_s / 1e6, 1),
                 "exact_fallback_tiles": flags}
@@ -271,7 +402,8 @@ def main():
             "metric": "queries/sec top-k over 10M x 256-d docs", "value": round(BATCH * a.steps / dt, 2),
             "unit": "queries/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32 results (bit-identical to the fp32 FMA chain); f16-MFMA screen + fp32 rescoring",
+            "data": "synthetic",
             "config": {"workload": f"exact cosine top-{TOPK} of B={BATCH} queries over {N_DOCS} x {DIM} fp32 unit-norm "
                                    f"passages resident in HBM (BASELINE configs[3]; configs[1] batch), row-sharded "
                                    f"over {world} GPU(s), screened path (f16-MFMA filter + exact fp32 rescoring, "
@@ -281,8 +413,13 @@ def main():
             "roofline": roof, "roofline_exact_f32": roof_f32, "roofline_hbm": roof_hbm,
             "roofline_hbm_exact_f32": roof_hbm_f32,
         }
+        enc_inputs = None
+        if not a.no_secondary:
+            del index, local_index
+            torch.cuda.empty_cache()
+            line["encoder"], line["train"], enc_inputs = encoder_legs(dev)
         if world == 1 and not a.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(q, docs)
+            line["cpu_baseline"] = cpu_baseline(q, docs, enc_inputs)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -8,8 +8,8 @@ import pytest
 from conftest import ROOT
 
 
-def _declared():
-    text = (ROOT / "include" / "tt.h").read_text()
+def _declared(header="tt.h"):
+    text = (ROOT / "include" / header).read_text()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(tt_[a-z0-9_]+)\s*\(", text)))
 
@@ -27,8 +27,19 @@ def test_header_declares_functions():
 
 
 def test_library_exports_every_declared_symbol(libtt):
-    for name in _declared():
-        assert hasattr(libtt, name), f"libtt.so does not export {name}"
+    for header in sorted(p.name for p in (ROOT / "include").glob("*.h")):
+        for name in _declared(header):
+            assert hasattr(libtt, name), f"libtt.so does not export {name} ({header})"
+
+
+def test_debug_exports_are_not_part_of_the_product_surface():
+    """include/tt_debug.h is test infrastructure: the package binds none of it."""
+    from twotowermlretrieval_amd import _lib
+    dbg = _declared("tt_debug.h")
+    assert dbg and all(n.startswith("tt_debug_") for n in dbg)
+    assert not set(dbg) & set(_lib.SIGNATURES)
+    for f in (ROOT / "twotowermlretrieval_amd").glob("*.py"):
+        assert "tt_debug_" not in f.read_text(), f
 
 
 def test_binding_table_matches_header():

@@ -145,10 +145,12 @@ def test_graphed_search_replays_bit_identically(tt, oracle):
         gs(dev(synth.unit_rows(1, 5, 256)))
 
 
-def test_full_baseline_size_10m_screened_equals_exact_kernel(tt):
+def test_full_baseline_size_10m_screened_equals_exact_kernel(tt, oracle):
     """BASELINE configs[3] size (10M x 256): the screened index (shared-tile form at B=1024, streaming form at
     B=32) returns exactly what the plain fp32 kernel returns, planted documents come back at rank 1, and nothing
-    falls back to the exact path."""
+    falls back to the exact path.  Six queries per form -- planted and not, first and last of the batch, both
+    512-query groups -- are also checked against the CPU oracle over all 10M rows, which pins the bench-size launch
+    geometry (255 chunks, sample pass, two query groups) to the oracle directly, not only to the other HIP kernel."""
     import sys
     from pathlib import Path
     sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
@@ -159,6 +161,7 @@ def test_full_baseline_size_10m_screened_equals_exact_kernel(tt):
     planted = torch.tensor([0, 31, 4_999_999, 9_999_999], device=devc)
     D[planted] = Q[:4]                      # queries 0..3 have an exact copy in the corpus
     ix = tt.BruteForceIndex(D, screen=True)
+    results = {}
     for B in (1024, 32):
         sv, si = ix.search(Q[:B].contiguous(), 10)
         ev, ei = tt.score_topk(Q[:B].contiguous(), D, 10)
@@ -167,7 +170,16 @@ def test_full_baseline_size_10m_screened_equals_exact_kernel(tt):
         assert torch.equal(si, ei) and torch.equal(sv, ev)
         assert si[:4, 0].tolist() == planted.tolist() and bool((sv[:4, 0] - 1.0).abs().max() < 1e-5)
         assert bool((sv[:, 1:] <= sv[:, :-1]).all())
-    del ix, D
+        results[B] = (sv.cpu().numpy(), si.cpu().numpy())
+    Dh = D.cpu().numpy()
+    Qh = Q.cpu().numpy()
+    from concurrent.futures import ThreadPoolExecutor
+    checks = [(B, r) for B, rows in ((1024, [0, 3, 5, 511, 512, 1023]), (32, [0, 2, 4, 15, 16, 31])) for r in rows]
+    with ThreadPoolExecutor(max_workers=12) as pool:  # one scalar fmaf chain per (query, document): ~3 s per query
+        outs = list(pool.map(lambda br: oracle.score_topk(Qh[br[1]:br[1] + 1], Dh, 10), checks))
+    for (B, r), (ov, oi) in zip(checks, outs):
+        assert np.array_equal(results[B][1][r], oi[0]) and np.array_equal(results[B][0][r], ov[0]), f"B={B} query {r} vs oracle"
+    del ix, D, Dh
     torch.cuda.empty_cache()
 
 

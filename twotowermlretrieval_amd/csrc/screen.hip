@@ -96,6 +96,9 @@ struct ScreenParams {
     // qimg[((S * 8 + s) * 64 + lane)] = 8 f16 of query 16 S + (lane & 15), features 32 s + 8 (lane >> 4) .. +7
     const h8 *qimg;
     const float *qnorm;  // |q| per (padded) query row
+    // test-only (tt_debug_screen_s16): MAXONLY pass whose accumulators start at -dbg_thr[query] like the main
+    // pass's, so the raw value t = fl(sum - thr) the filter compares with +0 can be observed; null in the product
+    const float *dbg_thr;
 };
 
 // store (v, x) at wave-uniform base + per-lane 32-bit byte offset (SGPR-base addressing: no 64-bit VALU math)
@@ -276,9 +279,12 @@ __global__ __launch_bounds__(SW * 64, 2) void screen_kernel(ScreenParams p)
         // true top-k document: the sample pass's k-th largest maximum seeds the threshold.
         const float floor_thr = -(1.01f * qn * p.dmax + 1e-30f);
         const float t_init = live ? ((!MAXONLY && p.thr0) ? fmaxf(p.thr0[(size_t)qrow * p.thr0_stride + p.thr0_stride - 1] - eps2[c], floor_thr)
-                                                          : floor_thr)
-                                  : INFINITY; // dead query rows: accumulators stay at -inf, never a candidate
-        negthr[c] = f32x4{-t_init, -t_init, -t_init, -t_init};
+                                                    : floor_thr)
+                            : INFINITY; // dead query rows: accumulators stay at -inf, never a candidate
+        float c_init = -t_init;
+        if (MAXONLY) // sample pass: plain scores (C = +0); the debug export may plant a threshold instead
+            c_init = (p.dbg_thr && live) ? -p.dbg_thr[qrow] : 0.0f;
+        negthr[c] = f32x4{c_init, c_init, c_init, c_init};
     }
 
     SCand *const cwave = p.cand + ((size_t)blockIdx.x * QB + w * QW) * SCAP;
@@ -378,9 +384,8 @@ __global__ __launch_bounds__(SW * 64, 2) void screen_kernel(ScreenParams p)
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int c = 0; c < NSET; ++c) {
-                        const f32x4 zero = {0, 0, 0, 0};
-                        const f32x4 c0 = s == 0 ? (MAXONLY ? zero : negthr[c]) : acc[0][c];
-                        const f32x4 c1 = s == 0 ? (MAXONLY ? zero : negthr[c]) : acc[1][c];
+                        const f32x4 c0 = s == 0 ? negthr[c] : acc[0][c];
+                        const f32x4 c1 = s == 0 ? negthr[c] : acc[1][c];
                         acc[0][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0[s % 3], qreg[c][s], c0, 0, 0, 0);
                         acc[1][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[s % 3], qreg[c][s], c1, 0, 0, 0);
                     }
@@ -547,9 +552,12 @@ __global__ __launch_bounds__(TW * 64, 2) void screen_stream_kernel(ScreenParams 
         eps2[c] = 2.0f * screen_eps(qn, p.dmax);
         const float floor_thr = -(1.01f * qn * p.dmax + 1e-30f);
         const float t_init = live ? ((!MAXONLY && p.thr0) ? fmaxf(p.thr0[(size_t)qrow * p.thr0_stride + p.thr0_stride - 1] - eps2[c], floor_thr)
-                                                          : floor_thr)
-                                  : INFINITY;
-        negthr[c] = f32x4{-t_init, -t_init, -t_init, -t_init};
+                                                    : floor_thr)
+                            : INFINITY;
+        float c_init = -t_init;
+        if (MAXONLY)
+            c_init = (p.dbg_thr && live) ? -p.dbg_thr[qrow] : 0.0f;
+        negthr[c] = f32x4{c_init, c_init, c_init, c_init};
     }
 
     SCand *const cwave = p.cand + (size_t)task * 32 * SCAP;
@@ -633,8 +641,7 @@ __global__ __launch_bounds__(TW * 64, 2) void screen_stream_kernel(ScreenParams 
                     for (int c = 0; c < 2; ++c)
 #pragma unroll
                         for (int u = 0; u < 2; ++u) {
-                            const f32x4 zero = {0, 0, 0, 0};
-                            const f32x4 cin = (kq == 0 && s2 == 0) ? (MAXONLY ? zero : negthr[c]) : acc[u][c];
+                            const f32x4 cin = (kq == 0 && s2 == 0) ? negthr[c] : acc[u][c];
                             acc[u][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[u][s2], qreg[c][2 * kq + s2], cin, 0, 0, 0);
                         }
                 stage = (stage + 1) % TSTAGE;
@@ -1226,6 +1233,7 @@ TT_EXPORT int tt_score_topk_screened_f32(const float *Q, int B, int d, const flo
     sp.thr0_stride = k;
     sp.qimg = (const h8 *)(ws + pl.qimg_off);
     sp.qnorm = (const float *)(ws + pl.qnorm_off);
+    sp.dbg_thr = nullptr;
     hipLaunchKernelGGL(q_image_kernel, dim3(pl.rows_pad / 32), dim3(128), 0, st, Q, B, (h8 *)(ws + pl.qimg_off),
                        (float *)(ws + pl.qnorm_off), fallback_flag, (B + 31) / 32);
     TT_LAUNCH_CHECK();
@@ -1311,4 +1319,105 @@ TT_EXPORT int tt_score_topk_screened_f32(const float *Q, int B, int d, const flo
     // exact kernel, a no-op unless a workgroup raised the flag; then it rewrites every output row
     return tt_score_topk_f32_pred(Q, B, d, D32, N, k, idx_offset, out_val, out_idx, ws + pl.ws_bytes,
                                   workspace_bytes - pl.ws_bytes, fallback_flag, st);
+}
+
+// ------------------------------------------------------------------ test-only: observe the screen's raw scores
+// include/tt_debug.h.  Runs the REAL screen kernels (q_image_kernel + the MAXONLY form of screen_stream_kernel /
+// screen_kernel<.,NSET>) over the whole corpus and returns one value per (query, 32-document tile): the tile
+// maximum of s16 (thr == NULL: accumulators start at +0, the sample pass's arithmetic) or of
+// t = fl(sum - thr[query]) (accumulators start at -thr, the main pass's arithmetic).  A test that fills every tile
+// with 32 copies of one document reads that document's value.  Not bound by the Python package.
+namespace {
+struct DbgPlan {
+    int q_per_block, n_qgroups, rows_pad, n_tiles, n_chunks, tiles_per_chunk, n_blocks;
+    size_t qimg_off, qnorm_off, flag_off, total;
+};
+bool make_dbg_plan(int B, int64_t N, int form, DbgPlan &pl)
+{
+    if (form != 0 && form != 1 && form != 2 && form != 4)
+        return false;
+    pl.q_per_block = form == 0 ? 32 : SW * 16 * form;
+    pl.n_qgroups = (B + pl.q_per_block - 1) / pl.q_per_block;
+    pl.rows_pad = pl.n_qgroups * pl.q_per_block;
+    pl.n_tiles = (int)((N + 31) / 32);
+    int want = form == 0 ? (screen_cus() * 2 * TW + pl.n_qgroups - 1) / pl.n_qgroups
+                         : (screen_cus() + pl.n_qgroups - 1) / pl.n_qgroups;
+    want = want > pl.n_tiles ? pl.n_tiles : want;
+    want = want < 1 ? 1 : want;
+    pl.tiles_per_chunk = (pl.n_tiles + want - 1) / want;
+    pl.n_chunks = (pl.n_tiles + pl.tiles_per_chunk - 1) / pl.tiles_per_chunk;
+    const int n_tasks = pl.n_qgroups * pl.n_chunks;
+    pl.n_blocks = form == 0 ? (n_tasks + TW - 1) / TW : n_tasks;
+    size_t off = 0;
+    pl.qimg_off = off;
+    off = tt_align_up(off + (size_t)pl.rows_pad * 256 * sizeof(_Float16), 256);
+    pl.qnorm_off = off;
+    off = tt_align_up(off + (size_t)pl.rows_pad * sizeof(float), 256);
+    pl.flag_off = off;
+    off = tt_align_up(off + (size_t)(pl.rows_pad / 32 + 1) * sizeof(int), 256);
+    pl.total = off;
+    return true;
+}
+} // namespace
+
+TT_EXPORT size_t tt_debug_screen_s16_workspace_bytes(int B, int64_t N, int form)
+{
+    DbgPlan pl;
+    if (B <= 0 || N <= 0 || !make_dbg_plan(B, N, form, pl))
+        return 0;
+    return pl.total;
+}
+
+TT_EXPORT int tt_debug_screen_s16(const float *Q, int B, const void *D16, int64_t N, float dmax_norm, const float *thr,
+                                  int form, float *out_t, void *workspace, size_t workspace_bytes, tt_stream_t stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    DbgPlan pl;
+    if (B <= 0 || N <= 0 || N >= (int64_t)INT_MAX - 64 || !make_dbg_plan(B, N, form, pl))
+        return tt_fail(TT_ERR_BAD_SHAPE, "tt_debug_screen_s16: B=%d N=%lld form=%d", B, (long long)N, form);
+    if (!Q || !D16 || !out_t)
+        return tt_fail(TT_ERR_BAD_SHAPE, "tt_debug_screen_s16: null pointer");
+    if (!workspace || workspace_bytes < pl.total || ((uintptr_t)workspace & 255))
+        return tt_fail(TT_ERR_WORKSPACE, "tt_debug_screen_s16: workspace %zu < %zu bytes", workspace_bytes, pl.total);
+    char *ws = (char *)workspace;
+    ScreenParams sp;
+    sp.Q = Q;
+    sp.D16 = (const _Float16 *)D16;
+    sp.B = B;
+    sp.N = (int)N;
+    sp.k = 1;
+    sp.n_chunks = pl.n_chunks;
+    sp.tiles_per_chunk = pl.tiles_per_chunk;
+    sp.n_tiles = pl.n_tiles;
+    sp.dmax = dmax_norm;
+    sp.cand = nullptr;
+    sp.pcnt = nullptr;
+    sp.flag = (int *)(ws + pl.flag_off);
+    sp.max_val = out_t; // [B][n_tiles]
+    sp.thr0 = nullptr;
+    sp.thr0_stride = 1;
+    sp.qimg = (const h8 *)(ws + pl.qimg_off);
+    sp.qnorm = (const float *)(ws + pl.qnorm_off);
+    sp.dbg_thr = thr;
+    hipLaunchKernelGGL(q_image_kernel, dim3(pl.rows_pad / 32), dim3(128), 0, st, Q, B, (h8 *)(ws + pl.qimg_off),
+                       (float *)(ws + pl.qnorm_off), sp.flag, pl.rows_pad / 32);
+    TT_LAUNCH_CHECK();
+    if (form == 0) {
+        const size_t lds = (size_t)TW * TSTAGE * TSLAB_BYTES;
+        TT_HIP_CHECK(hipFuncSetAttribute((const void *)screen_stream_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(screen_stream_kernel<true>, dim3(pl.n_blocks), dim3(TW * 64), lds, st, sp);
+    } else {
+        const size_t lds = (size_t)SRING * STILE_BYTES;
+        const void *fn = form == 4 ? (const void *)screen_kernel<true, 4>
+                                   : (form == 2 ? (const void *)screen_kernel<true, 2> : (const void *)screen_kernel<true, 1>);
+        TT_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        if (form == 4)
+            hipLaunchKernelGGL((screen_kernel<true, 4>), dim3(pl.n_blocks), dim3(SW * 64), lds, st, sp);
+        else if (form == 2)
+            hipLaunchKernelGGL((screen_kernel<true, 2>), dim3(pl.n_blocks), dim3(SW * 64), lds, st, sp);
+        else
+            hipLaunchKernelGGL((screen_kernel<true, 1>), dim3(pl.n_blocks), dim3(SW * 64), lds, st, sp);
+    }
+    TT_LAUNCH_CHECK();
+    return TT_OK;
 }
