@@ -19,6 +19,7 @@ Fixtures:
   g7_batch_eval.npz       BatchEvaluator metrics for fixed embeddings (evaluators.py:48-76)
   g8_tokenizer.json       PretrainedTokenizer.encode (tokenizer.py:41-43)
   g9_inferencer.npz       QueryInferencer.get_query_embedding (query_inferencer.py:59-75)
+  g11_hybrid.npz          SimpleHybridRetriever.fit/search blend alpha*dense + (1-alpha)*tfidf (simple_hybrid.py:28-67)
   g10_errors.json         error behaviour (all-zero row, empty row, interior zeros)
 """
 from __future__ import annotations
@@ -302,6 +303,77 @@ def g9():
                         vocab_json=np.array(json.dumps(_vocab())))
 
 
+def _hybrid_docs():
+    """40 short passages over the synthetic vocabulary (none empty, none all-"the": both would raise or zero out)."""
+    rs = np.random.RandomState(1109)
+    words = [w for w in _vocab() if w.isalnum()]
+    docs = []
+    for i in range(40):
+        n = int(rs.randint(3, 12))
+        toks = [words[int(j)] for j in rs.randint(0, len(words), n)]
+        if all(t == "the" for t in toks):
+            toks[0] = "w5"
+        docs.append(" ".join(toks) + (" ." if i % 3 == 0 else ""))
+    return docs
+
+
+def g11():
+    """backend/simple_hybrid.py on the g9 artifacts: documents embedded with the SAME (query) encoder (:37-41),
+    TfidfVectorizer(stop_words='english', max_features=10000) (:24), combined = alpha*dense + (1-alpha)*tfidf (:56),
+    argsort descending (:59)."""
+    V0, E, H, seed = len(_vocab()), 20, 32, 909
+    docs = _hybrid_docs()
+    queries = ["what is machine learning", "w5 of w6 , w7 .", "e mail w7 w7", "learning machine w6"]
+    alphas = [0.3, 0.5, 1.0]
+    with tempfile.TemporaryDirectory() as td:
+        td = Path(td)
+        (td / "frontend").mkdir()
+        art = td / "artifacts" / "run-x"
+        art.mkdir(parents=True)
+        (td / "frontend" / "config.json").write_text(json.dumps({"ARTIFACTS_PATH": str(art)}))
+        with open(art / "word_to_idx.pkl", "wb") as f:
+            pickle.dump(_vocab(), f)
+        V = V0 + 1
+        m, cfg, table = _two_tower(V, E, H, seed)
+        torch.save(m.state_dict(), art / "model.pth")
+        cfg_saved = {"HIDDEN_DIM": H, "RNN_TYPE": "GRU", "NUM_LAYERS": 1, "BIDIRECTIONAL": False,
+                     "DROPOUT": 0.0, "NORMALIZE_OUTPUT": True, "EMBED_DIM": E, "VOCAB_SIZE": V}
+        (art / "config.json").write_text(json.dumps(cfg_saved))
+        cwd = os.getcwd()
+        os.chdir(td)
+        try:
+            import simple_hybrid as refsh  # imports query_inferencer, which reads frontend/config.json at import
+            combined, top = [], []
+            doc_emb = None
+            for a in alphas:
+                r = refsh.SimpleHybridRetriever(str(art), alpha=a)
+                r.fit(list(docs))
+                doc_emb = np.asarray(r.doc_embeddings, dtype=np.float32)
+                per_q, per_top = [], []
+                for q in queries:
+                    # the reference's search() returns only (doc, score) pairs; its intermediate arithmetic is
+                    # re-run here through the SAME objects to record the full score vector as well
+                    q_tfidf = r.tfidf.transform([q])
+                    from sklearn.metrics.pairwise import cosine_similarity
+                    tfidf_scores = cosine_similarity(q_tfidf, r.tfidf_matrix)[0]
+                    q_emb = r.dense_retriever.get_query_embedding(q)
+                    dense = cosine_similarity([q_emb], r.doc_embeddings)[0]
+                    comb = r.alpha * dense + (1 - r.alpha) * tfidf_scores
+                    res = r.search(q, top_k=10)
+                    order = [docs.index(d) for d, _ in res]
+                    assert np.allclose([sc for _, sc in res], comb[order])
+                    per_q.append(comb)
+                    per_top.append(order)
+                combined.append(per_q)
+                top.append(per_top)
+        finally:
+            os.chdir(cwd)
+    np.savez_compressed(HERE / "g11_hybrid.npz", docs=np.array(docs), queries=np.array(queries),
+                        alphas=np.array(alphas, dtype=np.float64), combined=np.array(combined, dtype=np.float64),
+                        top10=np.array(top, dtype=np.int64), doc_emb=doc_emb, dims=np.array([V, E, H, seed]),
+                        vocab_json=np.array(json.dumps(_vocab())))
+
+
 def g10():
     V, E, H, seed = 64, 16, 32, 101
     table = synth.make_table(seed, V, E)
@@ -321,6 +393,9 @@ def g10():
 
 
 if __name__ == "__main__":
-    for fn in (g1, g2, g3, g4, g5, g6, g7, g8, g9, g10):
+    only = set(sys.argv[1:])
+    for fn in (g1, g2, g3, g4, g5, g6, g7, g8, g9, g10, g11):
+        if only and fn.__name__ not in only:
+            continue
         fn()
         print("wrote", fn.__name__)

@@ -1,0 +1,46 @@
+"""Hybrid rerank (twotowermlretrieval_amd.hybrid.HybridSearcher) pinned to the reference's own blend:
+tests/golden/g11_hybrid.npz holds backend/simple_hybrid.py:28-67 run on a synthetic artifacts directory --
+documents embedded with the query tower, TfidfVectorizer(stop_words='english', max_features=10000),
+combined = alpha * dense + (1 - alpha) * tfidf, descending argsort -- for alpha in {0.3, 0.5, 1.0}."""
+import numpy as np
+import pytest
+import torch
+
+from test_inferencer_gpu import _artifacts
+
+pytestmark = pytest.mark.gpu
+
+
+def test_hybrid_blend_matches_reference_simple_hybrid(tmp_path, golden):
+    from sklearn.feature_extraction.text import TfidfVectorizer
+    from twotowermlretrieval_amd.hybrid import HybridSearcher
+    from twotowermlretrieval_amd.query_inferencer import QueryInferencer
+    g = golden("g11_hybrid.npz")
+    docs = [str(d) for d in g["docs"]]
+    inf = QueryInferencer(str(_artifacts(tmp_path, g)))
+    # the reference embeds the corpus with the SAME (query) encoder (simple_hybrid.py:37-41)
+    emb = inf.get_query_embeddings(docs)
+    np.testing.assert_allclose(emb.cpu().numpy(), g["doc_emb"], atol=1e-5, rtol=0)
+    tfidf = TfidfVectorizer(stop_words="english", max_features=10000)  # simple_hybrid.py:24
+    mat = tfidf.fit_transform(docs)
+    hs = HybridSearcher(inf, docs, emb, tfidf_vectorizer=tfidf, doc_tfidf_matrix=mat, n_candidates=len(docs),
+                        dense_score="cosine")
+    for ai, alpha in enumerate(g["alphas"]):
+        for qi, q in enumerate(g["queries"]):
+            want = g["combined"][ai, qi]                 # the reference's score of EVERY document
+            res = hs.search(str(q), alpha=float(alpha), n_results=10)
+            assert len(res) == 10
+            for r in res:                                 # every returned score is the reference's score of that document
+                assert abs(r["score"] - want[r["index"]]) < 1e-5, (alpha, q, r)
+            # same ranking wherever the reference's own adjacent gap exceeds the tolerance
+            ref_order = g["top10"][ai, qi]
+            ref_sorted = np.sort(want)[::-1]
+            for pos in range(10):
+                lo_gap = ref_sorted[pos] - ref_sorted[pos + 1]
+                hi_gap = ref_sorted[pos - 1] - ref_sorted[pos] if pos else np.inf
+                if lo_gap > 2e-5 and hi_gap > 2e-5:
+                    assert res[pos]["index"] == int(ref_order[pos]), (alpha, q, pos)
+            # and the returned set is a valid top-10: nothing outside it beats the 10th score by more than the tolerance
+            tenth = min(r["score"] for r in res)
+            outside = np.delete(want, [r["index"] for r in res])
+            assert outside.max() <= tenth + 2e-5
