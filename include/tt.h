@@ -216,6 +216,37 @@ int tt_clip_adam_step_f32(float *params, float *grads, float *exp_avg, float *ex
                           float *total_norm_out, void *scratch, tt_stream_t stream);
 
 /* ------------------------------------------------------------------ */
+/* Collectives of the sharded path (RCCL over xGMI), SURVEY 8e          */
+/* ------------------------------------------------------------------ */
+
+/*
+ * New in the build (the reference is single-device).  `comm` is an ncclComm_t CREATED BY THE HOST (one per rank and
+ * GPU; e.g. torch.distributed's NCCL process group, or tt_comm_init_rank below) and passed as an opaque handle;
+ * libtt.so does not link RCCL but binds, at first use, to the RCCL instance already mapped into the process
+ * (tt_comm_library() names it), so the handle and the calls belong to the same library.  Both calls are
+ * asynchronous on `stream`; as with any NCCL collective, every rank must issue them in the same order.
+ *
+ * tt_allgather_topk -- the ONE exchange of a row-sharded search, after the per-shard
+ *   torch.matmul + torch.topk (backend/evaluators.py:185-186) that tt_score_topk*_f32 replaces:
+ *   every rank contributes its block (vals f32 [B,kp] | idx int64 [B,kp], block_bytes bytes, written in place by
+ *   the local search) and receives all `world` blocks in rank order in recv_blocks (world * block_bytes bytes) --
+ *   exactly the layout tt_topk_merge_shards reads in place.
+ * tt_allreduce_grads -- data-parallel training: the summing all-reduce of the flat fp32 gradient buffer, in place,
+ *   between loss.backward() and clip_grad_norm_ (backend/main.py:254 -> :257); tt_clip_adam_step_f32 then
+ *   applies grad_scale = 1/world before the norm, so every rank clips the same averaged gradient.
+ */
+int tt_allgather_topk(void *comm, const void *send_block, void *recv_blocks, size_t block_bytes, tt_stream_t stream);
+int tt_allreduce_grads(void *comm, float *flat_grads, int64_t n, tt_stream_t stream);
+
+/* Helpers for hosts without an RCCL binding of their own: rank 0 obtains a 128-byte id (HOST buffer), ships it to the
+ * other ranks by any means, then every rank calls tt_comm_init_rank on its GPU (hipSetDevice first). */
+const char *tt_comm_library(void);                 /* path of the RCCL libtt.so bound to ("" if none) */
+int tt_comm_unique_id(void *id_bytes /*host, 128 bytes*/);
+int tt_comm_init_rank(void **comm /*host out*/, int world, const void *id_bytes /*host*/, int rank);
+int tt_comm_info(void *comm, int *world /*host out*/, int *rank /*host out*/);
+int tt_comm_destroy(void *comm);
+
+/* ------------------------------------------------------------------ */
 /* Host-side text front end (no GPU): tokenise -> ids -> padded batch.  */
 /* ------------------------------------------------------------------ */
 

@@ -1,7 +1,8 @@
 """CPU tests of the host logic: tokenizer front end vs the reference's recorded behaviour, shard
-arithmetic, and the multi-process (world_size 2, gloo) paths of ShardedIndex and FusedClipAdam with the
-oracle injected in place of the HIP kernels (the product defaults are the HIP kernels; nothing in the
-package imports the oracle)."""
+arithmetic, and the multi-process (world_size 2, gloo) host logic of the sharded search and of the data-parallel
+optimizer -- the package's PRIVATE helpers index._exchange_and_merge and trainer._FlatClipAdam, driven with the
+oracle's search / merge / step on CPU tensors (the public classes take no such hooks: they run the HIP kernels and
+refuse CPU tensors; nothing in the package imports the oracle)."""
 import json
 import os
 import socket
@@ -63,7 +64,7 @@ def _sharded_worker(rank, world, port, out):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from oracle import oracle as o
-    from twotowermlretrieval_amd.index import ShardedIndex
+    from twotowermlretrieval_amd.index import _exchange_and_merge, shard_bounds
 
     def local_search(q, docs, k, off):
         v, i = o.score_topk(q.numpy(), docs.numpy(), k, idx_offset=off)
@@ -77,8 +78,9 @@ def _sharded_worker(rank, world, port, out):
     D[2500] = D[17]  # an exact tie across the two shards: lower index must win
     Q = torch.from_numpy(synth.unit_rows(6, 9, 64))
     Q[0] = D[17]
-    idx = ShardedIndex.from_global(D, shard_k=20, local_search=local_search, merge=merge)
-    v, i = idx.search(Q, k=10)
+    lo, hi = shard_bounds(D.shape[0], rank, world)
+    lv, li = local_search(Q, D[lo:hi], 20, lo)          # per-shard top-20 with global indices
+    v, i = _exchange_and_merge(lv, li, 10, merge)
     out[rank] = (v.numpy(), i.numpy())
     dist.destroy_process_group()
 
@@ -103,7 +105,7 @@ def _dp_worker(rank, world, port, out):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from oracle import oracle as o
-    from twotowermlretrieval_amd.trainer import FusedClipAdam
+    from twotowermlretrieval_amd.trainer import _FlatClipAdam
 
     def step_fn(p, g, m, v, step, lr, betas, eps, max_norm, grad_scale, total_norm, scratch):
         gn = g.numpy()
@@ -113,7 +115,8 @@ def _dp_worker(rank, world, port, out):
     rs = np.random.RandomState(3)
     shapes = [(12, 5), (7,), (4, 4)]
     params = [torch.nn.Parameter(torch.from_numpy(rs.standard_normal(s).astype(np.float32))) for s in shapes]
-    opt = FusedClipAdam(params, lr=1e-2, max_norm=1.0, step_fn=step_fn)
+    opt = _FlatClipAdam(params, step_fn, lambda g: dist.all_reduce(g, op=dist.ReduceOp.SUM), world, lr=1e-2,
+                        betas=(0.9, 0.999), eps=1e-8, max_norm=1.0, scratch_bytes=64)
     norms = []
     for step in range(3):
         opt.zero_grad()

@@ -42,6 +42,12 @@ def test_sharded_index_through_rccl(nccl_group, oracle, screen, B):
     v1, i1 = idx.search(torch.from_numpy(Q[3]).cuda(), k=10)      # a single query vector
     torch.cuda.synchronize()
     assert v1.shape == (10,) and np.array_equal(i1.cpu().numpy(), oi[3]) and np.array_equal(v1.cpu().numpy(), ov[3])
+    # the exchange went through the C ABI (tt_allgather_topk) on torch.distributed's own RCCL communicator
+    assert idx.collective.startswith("rccl-c-abi"), idx.collective
+    pend = [idx.submit(torch.from_numpy(Q).cuda(), k=10) for _ in range(3)]   # pipelined form, second stream
+    pv, pi = pend[-1].result()
+    torch.cuda.synchronize()
+    assert np.array_equal(pi.cpu().numpy(), oi) and np.array_equal(pv.cpu().numpy(), ov)
 
 
 def test_fused_optimizer_allreduce_through_rccl(nccl_group):
@@ -56,6 +62,38 @@ def test_fused_optimizer_allreduce_through_rccl(nccl_group):
     torch.cuda.synchronize()
     assert all((a.detach() - b).abs().max() > 0 for a, b in zip(p, ref))
     assert abs(opt.total_norm.item() - (50 * 7 + 9) ** 0.5) < 1e-3
+    assert opt._coll.via.startswith("rccl-c-abi"), opt._coll.via
+
+
+def test_c_abi_collectives_on_a_communicator_made_by_the_library():
+    """tt_comm_unique_id / tt_comm_init_rank (hosts without an RCCL binding) + tt_allgather_topk /
+    tt_allreduce_grads on that communicator; one rank: the gather returns the block, the sum returns the buffer."""
+    import ctypes as C
+    from twotowermlretrieval_amd import _lib
+    from twotowermlretrieval_amd.collective import Collective, RcclComm
+    L = _lib.lib()
+    assert b"rccl" in L.tt_comm_library()
+    comm = RcclComm(1, 0, torch.device("cuda", 0))
+    try:
+        w, r = C.c_int(), C.c_int()
+        _lib.check(L.tt_comm_info(C.c_void_p(comm.ptr), C.byref(w), C.byref(r)))
+        assert (w.value, r.value) == (1, 0)
+        coll = Collective(comm=comm)
+        send = torch.arange(4096, dtype=torch.int32, device="cuda").view(torch.uint8)
+        recv = torch.zeros_like(send)
+        g = torch.randn(857088, device="cuda")
+        want = g.clone()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):        # asynchronous on the caller's stream, whichever it is
+            coll.all_gather_blocks(send, recv)
+            coll.all_reduce_sum(g)
+        side.synchronize()
+        assert torch.equal(recv, send) and torch.equal(g, want)
+        rc = L.tt_allgather_topk(None, send.data_ptr(), recv.data_ptr(), 16, None)
+        assert rc == _lib.TT_ERR_BAD_SHAPE
+    finally:
+        comm.close()
 
 
 @pytest.mark.parametrize("B,kp,k,world", [(37, 5, 3, 3), (64, 50, 10, 8), (1, 7, 7, 2)])

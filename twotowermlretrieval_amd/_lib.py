@@ -46,6 +46,13 @@ SIGNATURES = {
     "tt_encoder_backward_f32": (_i, [_vp, _i, _i, _vp, _i64, _i, _i, _i, _i, _vp, _vp, _vp, _i, _f, _u64, _vp, _vp,
                                      _vp, _vp, _vp, _sz, _vp]),
     "tt_triplet_loss_f32": (_i, [_vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "tt_allgather_topk": (_i, [_vp, _vp, _vp, _sz, _vp]),
+    "tt_allreduce_grads": (_i, [_vp, _vp, _i64, _vp]),
+    "tt_comm_library": (C.c_char_p, []),
+    "tt_comm_unique_id": (_i, [_vp]),
+    "tt_comm_init_rank": (_i, [_vp, _i, _vp, _i]),
+    "tt_comm_info": (_i, [_vp, _vp, _vp]),
+    "tt_comm_destroy": (_i, [_vp]),
     "tt_clip_adam_scratch_bytes": (_sz, []),
     "tt_clip_adam_step_f32": (_i, [_vp, _vp, _vp, _vp, _i64, _i64, _f, _f, _f, _f, _f, _f, _vp, _vp, _vp]),
 }

@@ -20,7 +20,8 @@ import torch
 
 from . import _lib
 
-__all__ = ["GraphedSearch", "score_topk", "topk_merge", "score_rank", "BruteForceIndex", "ShardedIndex", "StreamedIndex", "shard_bounds"]
+__all__ = ["GraphedSearch", "score_topk", "topk_merge", "score_rank", "BruteForceIndex", "ShardedIndex", "PendingSearch", "StreamedIndex",
+           "shard_bounds"]
 
 
 def _stream(t: torch.Tensor) -> int:
@@ -157,6 +158,11 @@ class BruteForceIndex:
         B = 1 if q.dim() == 1 else q.shape[0]
         N, d = self.docs.shape
         L = _lib.lib()
+        _need_cuda(q)
+        if q.device != self.docs.device:
+            raise ValueError(f"queries on {q.device} but the index lives on {self.docs.device}")
+        if q.shape[-1] != d:
+            raise ValueError(f"shape mismatch: q {tuple(q.shape)} vs docs {tuple(self.docs.shape)}")
         if (self.docs16 is not None and B >= (SCREEN_MIN_BATCH if d == 256 else SCREEN_PADDED_MIN_BATCH)
                 and N >= SCREEN_MIN_DOCS and k <= 64):
             _need_cuda(q)
@@ -164,29 +170,28 @@ class BruteForceIndex:
                 vals, idx = self.search(q.unsqueeze(0), k, _prof_events)
                 return vals[0], idx[0]
             q = _f32c(q)
-            if q.shape[1] != d:
-                raise ValueError(f"shape mismatch: q {tuple(q.shape)} vs docs {tuple(self.docs.shape)}")
             if d < 256:
                 qp = torch.zeros((B, 256), dtype=torch.float32, device=q.device)
                 qp[:, :d] = q
                 q, d = qp, 256
-            # per-call workspace and flags (cached allocator blocks): safe for concurrent callers and streams
-            need = L.tt_score_topk_screened_workspace_bytes(B, N, d, k)
-            ws_s = torch.empty(need, dtype=torch.uint8, device=self.docs.device)
-            flags = torch.empty((B + 31) // 32, dtype=torch.int32, device=self.docs.device)
             if out is not None:
                 vals, idx = out
             else:
                 vals = torch.empty((B, k), dtype=torch.float32, device=q.device)
                 idx = torch.empty((B, k), dtype=torch.int64, device=q.device)
-            with torch.cuda.device(q.device):
+            with torch.cuda.device(self.docs.device):  # workspace sizing depends on the device's CU count
+                # per-call workspace and flags (cached allocator blocks): safe for concurrent callers and streams
+                need = L.tt_score_topk_screened_workspace_bytes(B, N, d, k)
+                ws_s = torch.empty(need, dtype=torch.uint8, device=self.docs.device)
+                flags = torch.empty((B + 31) // 32, dtype=torch.int32, device=self.docs.device)
                 _lib.check(L.tt_score_topk_screened_f32(q.data_ptr(), B, d, self._sdocs.data_ptr(), self.docs16.data_ptr(),
                                                         N, k, self.dmax_norm, self.idx_offset, vals.data_ptr(),
                                                         idx.data_ptr(), flags.data_ptr(), ws_s.data_ptr(), ws_s.numel(),
                                                         _prof_events, _stream(q)))
             self.fallback_flags = flags  # of the most recent search (per 32-query tile; non-zero = exact kernel took over)
             return vals, idx
-        need = L.tt_score_topk_workspace_bytes(B, N, d, k)
+        with torch.cuda.device(self.docs.device):
+            need = L.tt_score_topk_workspace_bytes(B, N, d, k)
         ws = torch.empty(max(need, 16), dtype=torch.uint8, device=self.docs.device)
         v, i = score_topk(q, self.docs, k, self.idx_offset, ws)
         if out is not None:
@@ -238,28 +243,83 @@ def shard_bounds(n_total: int, rank: int, world: int) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def _exchange_and_merge(vals: torch.Tensor, idx: torch.Tensor, k: int, merge: Callable, group=None):
+    """Host logic of the sharded search on ordinary tensors: pack this rank's [B,kp] lists into one byte block,
+    ONE all_gather_into_tensor, unpack to [B, world*kp] candidates, merge.  Private: the CPU tests drive it over
+    gloo with the oracle's search and merge; the product path is ShardedIndex below, which exchanges in place."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    B, kp = vals.shape
+    packed = torch.cat([vals.contiguous().view(torch.uint8).reshape(-1), idx.contiguous().view(torch.uint8).reshape(-1)])
+    out = torch.empty(world * packed.numel(), dtype=torch.uint8, device=packed.device)
+    dist.all_gather_into_tensor(out, packed, group=group)
+    out = out.view(world, -1)
+    nv = B * kp * 4
+    gv = out[:, :nv].contiguous().view(torch.float32).view(world, B, kp)
+    gi = out[:, nv:].contiguous().view(torch.int64).view(world, B, kp)
+    gv = gv.permute(1, 0, 2).reshape(B, world * kp).contiguous()
+    gi = gi.permute(1, 0, 2).reshape(B, world * kp).contiguous()
+    return merge(gv, gi, k)
+
+
+class _Slot:
+    """One set of exchange buffers of a ShardedIndex (two of them: a step's all-gather + merge overlaps the next
+    step's search): send block [vals f32 [B,kp] | idx int64 [B,kp]], receive buffer of `world` such blocks, outputs."""
+
+    def __init__(self, B: int, kp: int, k: int, world: int, dev):
+        self.nv = (B * kp * 4 + 7) // 8 * 8           # idx block 8-byte aligned
+        self.stride = self.nv + B * kp * 8
+        self.send = torch.empty(self.stride, dtype=torch.uint8, device=dev)
+        self.recv = torch.empty(world * self.stride, dtype=torch.uint8, device=dev)
+        self.send_v = self.send[:B * kp * 4].view(torch.float32).view(B, kp)
+        self.send_i = self.send[self.nv:].view(torch.int64).view(B, kp)
+        self.out_v = torch.empty((B, k), dtype=torch.float32, device=dev)
+        self.out_i = torch.empty((B, k), dtype=torch.int64, device=dev)
+        self.searched = torch.cuda.Event()
+        self.merged = torch.cuda.Event()
+
+
+class PendingSearch:
+    """Result of ShardedIndex.submit(): result() makes the CURRENT stream wait for the exchange + merge (no host
+    synchronisation) and returns (values, indices) views valid until two more submits on the same index."""
+
+    def __init__(self, slot: _Slot):
+        self._slot = slot
+
+    def result(self) -> Tuple[torch.Tensor, torch.Tensor]:
+        torch.cuda.current_stream(self._slot.out_v.device).wait_event(self._slot.merged)
+        return self._slot.out_v, self._slot.out_i
+
+
 class ShardedIndex:
     """Row-sharded corpus: every rank holds rows [lo,hi) and the SAME queries; search =
-    local top-k' (global indices) -> one all-gather (RCCL over xGMI when the group's backend
-    is nccl) -> merge on every rank.  Result is identical on all ranks and identical to the
-    single-GPU search for any world size (global top-k is a subset of the union of shard top-k).
+    local top-k' (global indices) -> one all-gather (RCCL over xGMI) -> merge on every rank.  Result is identical on
+    all ranks and identical to the single-GPU search for any world size (the global top-k is a subset of the union of
+    the shard top-k's).
 
-    `local_search` / `merge` exist so the host logic can be exercised over gloo on CPU tensors
-    by the tests (which inject the oracle); the defaults are the HIP kernels.
-    """
+    No glue kernels: the local search writes its [B,k'] lists straight into this rank's send block, ONE all-gather
+    (tt_allgather_topk on torch.distributed's RCCL communicator; torch.distributed's own call for other backends),
+    and the merge kernel reads the receive buffer in place (tt_topk_merge_shards).
 
-    def __init__(self, local_docs: torch.Tensor, row_offset: int, group=None, shard_k: int = 50,
-                 local_search: Optional[Callable] = None, merge: Optional[Callable] = None, screen: bool = False):
+    submit() pipelines consecutive searches: step i's all-gather + merge run on a second HIP stream with their own
+    buffers while step i+1's search runs on the caller's stream."""
+
+    def __init__(self, local_docs: torch.Tensor, row_offset: int, group=None, shard_k: int = 50, screen: bool = False,
+                 comm=None):
+        from .collective import Collective
         self.group = group
         self.row_offset = int(row_offset)
         self.shard_k = int(shard_k)
-        if local_search is None:
-            self._index = BruteForceIndex(local_docs, idx_offset=row_offset, screen=screen)
-            self._search = self._index.search
-        else:
-            self._index = None
-            self._search = lambda q, k: local_search(q, local_docs, k, row_offset)
-        self._merge = merge or topk_merge
+        self._index = BruteForceIndex(local_docs, idx_offset=row_offset, screen=screen)
+        self._coll = Collective(group, self._index.docs.device, comm=comm)
+        self._slots = {}
+        self._n_submitted = 0
+        self._xs: Optional[torch.cuda.Stream] = None
+
+    @property
+    def collective(self) -> str:
+        """Which transport the exchange uses (reported by bench.py)."""
+        return self._coll.via
 
     @classmethod
     def from_global(cls, docs: torch.Tensor, group=None, **kw) -> "ShardedIndex":
@@ -269,57 +329,54 @@ class ShardedIndex:
         lo, hi = shard_bounds(docs.shape[0], rank, world)
         return cls(docs[lo:hi], lo, group=group, **kw)
 
+    def _slot(self, B: int, kp: int, k: int, which: int) -> _Slot:
+        key = (B, kp, k, self._coll.world)
+        if key not in self._slots:
+            self._slots = {key: [_Slot(B, kp, k, self._coll.world, self._index.docs.device) for _ in range(2)]}
+        return self._slots[key][which]
+
+    def _exchange_merge(self, sl: _Slot, B: int, kp: int, k: int) -> None:
+        """all-gather + in-place merge of one slot on the CURRENT stream."""
+        self._coll.all_gather_blocks(sl.send, sl.recv)
+        with torch.cuda.device(sl.recv.device):
+            _lib.check(_lib.lib().tt_topk_merge_shards(sl.recv.data_ptr(), self._coll.world, sl.stride, sl.nv, B, kp, k,
+                                                       sl.out_v.data_ptr(), sl.out_i.data_ptr(), _stream(sl.recv)))
+
     def search(self, q: torch.Tensor, k: int = 10) -> Tuple[torch.Tensor, torch.Tensor]:
-        import torch.distributed as dist
+        """One search, everything on the caller's stream; fresh result tensors."""
         if q.dim() == 1:  # a single query vector: same path, squeezed result
             v, i = self.search(q.unsqueeze(0), k)
             return v[0], i[0]
         kp = max(k, self.shard_k)
-        if self._index is not None and dist.is_initialized():
-            return self._search_in_place(q, k, kp)
-        vals, idx = self._search(q, kp)
-        if not dist.is_initialized():
-            return self._merge(vals, idx, k)
-        world = dist.get_world_size(self.group)  # a 1-rank group still takes the collective path
-        B = vals.shape[0]
-        # one collective: [vals bytes | idx bytes] per rank
-        packed = torch.cat([vals.contiguous().view(torch.uint8).reshape(-1),
-                            idx.contiguous().view(torch.uint8).reshape(-1)])
-        out = torch.empty(world * packed.numel(), dtype=torch.uint8, device=packed.device)
-        dist.all_gather_into_tensor(out, packed, group=self.group)
-        out = out.view(world, -1)
-        nv = B * kp * 4
-        gv = out[:, :nv].contiguous().view(torch.float32).view(world, B, kp)
-        gi = out[:, nv:].contiguous().view(torch.int64).view(world, B, kp)
-        gv = gv.permute(1, 0, 2).reshape(B, world * kp).contiguous()
-        gi = gi.permute(1, 0, 2).reshape(B, world * kp).contiguous()
-        return self._merge(gv, gi, k)
+        sl = self._slot(q.shape[0], kp, k, 0)
+        cur = torch.cuda.current_stream(sl.send.device)
+        cur.wait_event(sl.merged)  # a pipelined step may still own this slot
+        self._index.search(q, kp, out=(sl.send_v, sl.send_i))
+        self._exchange_merge(sl, q.shape[0], kp, k)
+        sl.merged.record(cur)
+        return sl.out_v.clone(), sl.out_i.clone()
 
-    def _search_in_place(self, q: torch.Tensor, k: int, kp: int) -> Tuple[torch.Tensor, torch.Tensor]:
-        """HIP path without glue kernels: the local search writes its [B,kp] lists straight into this rank's
-        send block, ONE all_gather_into_tensor, and the merge kernel reads the receive buffer in place
-        (tt_topk_merge_shards)."""
-        import torch.distributed as dist
-        world = dist.get_world_size(self.group)
+    def submit(self, q: torch.Tensor, k: int = 10) -> PendingSearch:
+        """Pipelined search of a [B,d] batch: the local search is enqueued on the caller's stream now, the exchange
+        and the merge on this index's second stream; call .result() when the answer is needed."""
+        if q.dim() != 2:
+            raise ValueError("submit wants a [B,d] batch")
+        kp = max(k, self.shard_k)
         B = q.shape[0]
-        nv = (B * kp * 4 + 7) // 8 * 8           # idx block 8-byte aligned
-        stride = nv + B * kp * 8
-        key = (B, kp, world)
-        if getattr(self, "_xchg_key", None) != key:
-            dev = self._index.docs.device
-            self._send = torch.empty(stride, dtype=torch.uint8, device=dev)
-            self._recv = torch.empty(world * stride, dtype=torch.uint8, device=dev)
-            self._send_v = self._send[:B * kp * 4].view(torch.float32).view(B, kp)
-            self._send_i = self._send[nv:].view(torch.int64).view(B, kp)
-            self._xchg_key = key
-        self._index.search(q, kp, out=(self._send_v, self._send_i))
-        dist.all_gather_into_tensor(self._recv, self._send, group=self.group)
-        ov = torch.empty((B, k), dtype=torch.float32, device=self._recv.device)
-        oi = torch.empty((B, k), dtype=torch.int64, device=self._recv.device)
-        with torch.cuda.device(self._recv.device):
-            _lib.check(_lib.lib().tt_topk_merge_shards(self._recv.data_ptr(), world, stride, nv, B, kp, k, ov.data_ptr(),
-                                                       oi.data_ptr(), _stream(self._recv)))
-        return ov, oi
+        sl = self._slot(B, kp, k, self._n_submitted % 2)
+        self._n_submitted += 1
+        dev = sl.send.device
+        if self._xs is None:
+            self._xs = torch.cuda.Stream(device=dev)
+        cur = torch.cuda.current_stream(dev)
+        cur.wait_event(sl.merged)            # the slot's previous exchange has read its send block
+        self._index.search(q, kp, out=(sl.send_v, sl.send_i))
+        sl.searched.record(cur)
+        with torch.cuda.stream(self._xs):
+            self._xs.wait_event(sl.searched)
+            self._exchange_merge(sl, B, kp, k)
+            sl.merged.record(self._xs)
+        return PendingSearch(sl)
 
 
 class StreamedIndex:

@@ -77,6 +77,35 @@ def _ptr_array(tensors):
     return arr
 
 
+class deferred_input_checks:
+    """Context manager: the encoders' per-call status reads (one D2H sync each) are collected instead and checked
+    ONCE on exit, so independent tower calls can be enqueued back to back on several streams.  The same exceptions
+    are raised, only later: after all the towers of a step have been launched, before anything consumes them."""
+
+    def __init__(self, *encoders: "RNNEncoder"):
+        self.encoders = encoders
+
+    def __enter__(self):
+        self._box = []
+        for e in self.encoders:
+            e._deferred_status = self._box
+        return self
+
+    def __exit__(self, exc_type, exc, tb):
+        for e in self.encoders:
+            e._deferred_status = None
+        if exc_type is None and self._box:
+            _raise_status(_or_all(self._box))
+        return False
+
+
+def _or_all(status_tensors) -> int:
+    acc = 0
+    for v in torch.cat([s.reshape(1) for s in status_tensors]).tolist():  # one D2H copy for all of them
+        acc |= int(v)
+    return acc
+
+
 def _raise_status(status: int) -> None:
     if status & 2:
         raise IndexError("index out of range in self")  # nn.Embedding's message (tests/golden/g10_errors.json)
@@ -130,6 +159,7 @@ class RNNEncoder(nn.Module):
         self.normalize_output = normalize_output
         self.projection = _LinearParams(hidden_dim * 2, hidden_dim) if bidirectional else None
         self.check_inputs = True  # read the device status word after each call (one 4-byte D2H sync)
+        self._deferred_status = None  # a list while a caller (trainer.train_step) batches the status reads
 
     # ---- plumbing ---------------------------------------------------------------
     def _flat_params(self):
@@ -179,7 +209,10 @@ class RNNEncoder(nn.Module):
                 int(self.normalize_output), int(train), float(dropout_p), int(dropout_seed), out.data_ptr(),
                 ws.data_ptr(), ws.numel(), status.data_ptr(), _stream(ids.device)))
         if self.check_inputs:
-            _raise_status(int(status.item()))
+            if self._deferred_status is not None:
+                self._deferred_status.append(status)  # the caller reads them once, after enqueuing its other calls
+            else:
+                _raise_status(int(status.item()))
         return out, ws, status
 
     def _run_backward(self, ids: torch.Tensor, ws: torch.Tensor, d_out: torch.Tensor, dropout_p: float = 0.0,

@@ -18,12 +18,12 @@ are ordinary tensors); the fused optimizer is the MI355X-native path.
 """
 from __future__ import annotations
 
-from typing import Callable, Iterable, Optional, Tuple
+from typing import Callable, Iterable, Tuple
 
 import torch
 
 from . import _lib
-from .model import TwoTowerModel, triplet_loss_cosine
+from .model import TwoTowerModel, deferred_input_checks, triplet_loss_cosine
 
 __all__ = ["FusedClipAdam", "train_step", "DataParallelTrainer"]
 
@@ -37,34 +37,27 @@ def _hip_clip_adam(flat_p, flat_g, m, v, step, lr, betas, eps, max_norm, grad_sc
                                            torch.cuda.current_stream(flat_p.device).cuda_stream))
 
 
-class FusedClipAdam:
-    """clip_grad_norm_(max_norm) + Adam(lr, betas, eps, weight_decay=0) over one flat buffer.
+class _FlatClipAdam:
+    """Host logic of the fused optimizer on ordinary tensors: all trainable parameters are re-pointed at views of one
+    contiguous fp32 buffer (`flat_params`) and their .grad at views of `flat_grads`, so the optimizer and the
+    data-parallel all-reduce touch two pointers; step() = summing all-reduce -> step_fn(..., grad_scale = 1/world).
+    Private: the CPU tests drive it over gloo with the oracle's step; the product class is FusedClipAdam."""
 
-    All trainable parameters are re-pointed at views of one contiguous fp32 buffer (`flat_params`), and
-    their .grad at views of `flat_grads`, so the optimizer (and the DP all-reduce) touch two pointers.
-    `step_fn` exists so the host logic can be exercised over gloo on CPU tensors by the tests (which
-    inject the oracle's step); the default is the HIP kernel.
-    """
-
-    def __init__(self, params: Iterable[torch.nn.Parameter], lr: float = 1e-4, betas: Tuple[float, float] = (0.9, 0.999),
-                 eps: float = 1e-8, max_norm: float = 1.0, group=None, step_fn: Optional[Callable] = None):
+    def __init__(self, params: Iterable[torch.nn.Parameter], step_fn: Callable, all_reduce: Callable, world: int,
+                 lr: float, betas: Tuple[float, float], eps: float, max_norm: float, scratch_bytes: int):
         self.params = [p for p in params if p.requires_grad]
         if not self.params:
             raise ValueError("no trainable parameters")
         dev = self.params[0].device
-        if step_fn is None and not dev.type == "cuda":
-            raise RuntimeError("FusedClipAdam runs only on an AMD GPU via libtt.so (no CPU fallback)")
         self.lr, self.betas, self.eps, self.max_norm = float(lr), (float(betas[0]), float(betas[1])), float(eps), float(max_norm)
-        self.group = group
-        self._step_fn = step_fn or _hip_clip_adam
+        self._step_fn, self._all_reduce, self.world = step_fn, all_reduce, int(world)
         n = sum(p.numel() for p in self.params)
         self.flat_params = torch.empty(n, dtype=torch.float32, device=dev)
         self.flat_grads = torch.zeros(n, dtype=torch.float32, device=dev)
         self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
         self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
         self.total_norm = torch.zeros(1, dtype=torch.float32, device=dev)
-        nscratch = _lib.lib().tt_clip_adam_scratch_bytes() if step_fn is None else 4096
-        self._scratch = torch.empty(nscratch, dtype=torch.uint8, device=dev)
+        self._scratch = torch.empty(scratch_bytes, dtype=torch.uint8, device=dev)
         self._views = []
         off = 0
         with torch.no_grad():
@@ -94,17 +87,30 @@ class FusedClipAdam:
 
     def step(self) -> torch.Tensor:
         """Returns the pre-clip global gradient norm (device tensor, no sync)."""
-        import torch.distributed as dist
         self._collect()
-        world = 1
-        if self.group is not None or (dist.is_available() and dist.is_initialized()):
-            world = dist.get_world_size(self.group)
-            if world > 1:
-                dist.all_reduce(self.flat_grads, op=dist.ReduceOp.SUM, group=self.group)  # one 3.4 MB bucket
+        if self.world > 1:
+            self._all_reduce(self.flat_grads)  # one 3.4 MB bucket
         self.step_count += 1
         self._step_fn(self.flat_params, self.flat_grads, self.exp_avg, self.exp_avg_sq, self.step_count, self.lr,
-                      self.betas, self.eps, self.max_norm, 1.0 / world, self.total_norm, self._scratch)
+                      self.betas, self.eps, self.max_norm, 1.0 / self.world, self.total_norm, self._scratch)
         return self.total_norm
+
+
+class FusedClipAdam(_FlatClipAdam):
+    """clip_grad_norm_(max_norm) + Adam(lr, betas, eps, weight_decay=0) over one flat buffer in ONE kernel pair
+    (tt_clip_adam_step_f32); with a process group, ONE summing all-reduce of that buffer first (tt_allreduce_grads on
+    torch.distributed's RCCL communicator; torch.distributed's own call for other backends)."""
+
+    def __init__(self, params: Iterable[torch.nn.Parameter], lr: float = 1e-4, betas: Tuple[float, float] = (0.9, 0.999),
+                 eps: float = 1e-8, max_norm: float = 1.0, group=None, comm=None):
+        from .collective import Collective
+        params = [p for p in params if p.requires_grad]
+        if params and params[0].device.type != "cuda":
+            raise RuntimeError("FusedClipAdam runs only on an AMD GPU via libtt.so (no CPU fallback)")
+        self.group = group
+        self._coll = Collective(group, params[0].device if params else None, comm=comm)
+        super().__init__(params, _hip_clip_adam, self._coll.all_reduce_sum, self._coll.world, lr, betas, eps, max_norm,
+                         _lib.lib().tt_clip_adam_scratch_bytes())
 
 
 _TOWER_STREAMS = {}
@@ -140,14 +146,18 @@ def train_step(model: TwoTowerModel, optimizer: FusedClipAdam, queries: torch.Te
         else:
             calls = ((model.encode_query, queries), (model.encode_document, pos_docs), (model.encode_document, neg_docs))
         outs = []
-        for s, (fn, ids) in zip(_tower_streams(queries.device), calls):
-            s.wait_stream(cur)
-            with torch.cuda.stream(s):
-                ids.record_stream(s)
-                outs.append(fn(ids))
-        for s, o in zip(_tower_streams(queries.device), outs):
-            cur.wait_stream(s)
-            o.record_stream(cur)
+        # input checking stays on (zero-length rows / out-of-range ids raise as in the reference), but the status
+        # words of the towers are read ONCE, after all of them have been enqueued: a per-call read would make the
+        # host wait for the query tower before it could launch the document tower
+        with deferred_input_checks(model.query_encoder, model.doc_encoder):
+            for s, (fn, ids) in zip(_tower_streams(queries.device), calls):
+                s.wait_stream(cur)
+                with torch.cuda.stream(s):
+                    ids.record_stream(s)
+                    outs.append(fn(ids))
+            for s, o in zip(_tower_streams(queries.device), outs):
+                cur.wait_stream(s)
+                o.record_stream(cur)
         if len(outs) == 2:
             q, p, n = outs[0], outs[1][:B], outs[1][B:]
         else:
