@@ -148,3 +148,35 @@ def test_unsupported_tower_types_fail_loudly():
     from twotowermlretrieval_amd.model import RNNEncoder
     with pytest.raises(NotImplementedError):
         RNNEncoder(10, 8, 32, rnn_type="LSTM")
+
+
+def test_encoder_forward_replays_from_a_hip_graph():
+    import twotowermlretrieval_amd as tt
+    """The forward issues hipMemsetAsync (status block, zero rows) besides its kernels; captured in a HIP graph and
+    replayed with new ids in the static input buffer, every replay must equal the eager call bit for bit
+    (check_inputs off: the status read is a host synchronisation, which a capture cannot contain)."""
+    V, E, H = 500, 52, 64
+    torch.manual_seed(0)
+    m = tt.TwoTowerModel({"VOCAB_SIZE": V, "EMBED_DIM": E, "HIDDEN_DIM": H, "NUM_LAYERS": 2, "BIDIRECTIONAL": True},
+                         synth.make_table(9, V, E)).cuda().eval()
+    enc = m.query_encoder
+    enc.check_inputs = False
+    ids = [torch.from_numpy(synth.make_ids(70 + s, 6, 11, V)).cuda() for s in range(4)]
+    static = ids[0].clone()
+    with torch.no_grad():
+        want = [enc(x).clone() for x in ids]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            enc(static)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            out = enc(static)
+        for rep in range(2):
+            for x, w in zip(ids, want):
+                static.copy_(x)
+                g.replay()
+                torch.cuda.synchronize()
+                assert torch.equal(out, w), rep
