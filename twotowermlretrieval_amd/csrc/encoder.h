@@ -107,3 +107,28 @@ static inline EncLayout enc_layout(int B, int T, int E, int H, int L, int bidir,
     lo.total = off;
     return lo;
 }
+
+// ------------------------------------------------------------------ K2 recurrence: shared launch parameters
+struct GruDir {
+    const float *gi;      // [M][3H] packed tokens
+    const float *wp;      // packed W_hh (fp32 MFMA order, or fp16 hi/lo fragments for the f16-split kernel)
+    const unsigned *wmax; // f16-split kernel: bit pattern of max|W_hh| (the scale exponent derives from it)
+    const float *b_hh;    // [3H]
+    float *out_seq;       // nullable, [M][out_ld]
+    float *gates;         // nullable, [M][4][H]
+    float *h_final;       // [B][H]
+    int out_col0;
+    int reverse;
+};
+
+struct GruParams {
+    GruDir dir[2];
+    const int32_t *len, *tok_off, *perm;
+    int B, H, out_ld;
+    int slots; // workgroups resident at once (2 per CU): within one such round, long row groups pair with short ones
+};
+
+// csrc/gru16.hip: the recurrence on the f16 matrix pipes (fp16 hi/lo split of both operands, fp32 accuracy)
+bool gru16_supported(int H);
+int gru16_pack(const float *W_hh, int H, unsigned *absmax, void *wp16, hipStream_t st);
+int gru16_launch(const GruParams &gp, int ndir, hipStream_t st);

@@ -19,6 +19,7 @@
 #include "sgemm.h"
 
 #include <limits.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -171,25 +172,7 @@ __global__ __launch_bounds__(256) void pack_whh_kernel(const float *__restrict__
     }
 }
 
-// ------------------------------------------------------------------ K2 recurrence
-struct GruDir {
-    const float *gi;   // [M][3H] packed tokens
-    const float *wp;   // packed W_hh
-    const float *b_hh; // [3H]
-    float *out_seq;    // nullable, [M][out_ld]
-    float *gates;      // nullable, [M][4][H]
-    float *h_final;    // [B][H]
-    int out_col0;
-    int reverse;
-};
-
-struct GruParams {
-    GruDir dir[2];
-    const int32_t *len, *tok_off, *perm;
-    int B, H, out_ld;
-    int slots; // workgroups resident at once (2 per CU): within one such round, long row groups pair with short ones
-};
-
+// ------------------------------------------------------------------ K2 recurrence (GruDir / GruParams: encoder.h)
 __device__ __forceinline__ float fast_sigmoid(float x)
 {
     return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
@@ -439,6 +422,10 @@ TT_EXPORT int tt_encoder_forward_f32(const int64_t *ids, int B, int T, const flo
         TT_HIP_CHECK(hipMemcpyAsync(status, flag, sizeof(int32_t), hipMemcpyDeviceToDevice, st));
 
     const size_t lds = sizeof(float) * 2 * ENC_RB * (H + 4);
+    // H = 128 / 256: the recurrence runs on the f16 matrix pipes with both operands split into fp16 hi + lo parts
+    // (gru16.hip; fp32-grade accuracy at 3/16 of the fp32 MFMA time).  TT_GRU_F32=1 keeps the fp32-MFMA kernel.
+    static const bool force_f32 = [] { const char *e = getenv("TT_GRU_F32"); return e && e[0] == '1'; }();
+    const bool use16 = gru16_supported(H) && !force_f32;
     for (int l = 0; l < num_layers; ++l) {
         const int I = l == 0 ? E : ndir * H;
         GruParams gp;
@@ -475,9 +462,17 @@ TT_EXPORT int tt_encoder_forward_f32(const int64_t *ids, int B, int T, const flo
             rc = tt_sgemm(g, false, false, 1, st);
             if (rc != TT_OK)
                 return rc;
-            hipLaunchKernelGGL(pack_whh_kernel, dim3(96), dim3(256), 0, st, w[1], H, (float *)(ws + lo.wp[d]));
+            unsigned *wmax = (unsigned *)flag + 16 + 2 * l + d; // in the status block cleared above
+            if (use16) {
+                rc = gru16_pack(w[1], H, wmax, ws + lo.wp[d], st);
+                if (rc != TT_OK)
+                    return rc;
+            } else {
+                hipLaunchKernelGGL(pack_whh_kernel, dim3(96), dim3(256), 0, st, w[1], H, (float *)(ws + lo.wp[d]));
+            }
             gp.dir[d].gi = (const float *)(ws + lo.gi[d]);
             gp.dir[d].wp = (const float *)(ws + lo.wp[d]);
+            gp.dir[d].wmax = wmax;
             gp.dir[d].b_hh = w[3];
             gp.dir[d].out_seq = xout;
             gp.dir[d].gates = train ? (float *)(ws + lo.gates[l][d]) : nullptr;
@@ -488,7 +483,11 @@ TT_EXPORT int tt_encoder_forward_f32(const int64_t *ids, int B, int T, const flo
         }
         if (ndir == 1)
             gp.dir[1] = gp.dir[0];
-        if (H <= 256)
+        if (use16) {
+            rc = gru16_launch(gp, ndir, st);
+            if (rc != TT_OK)
+                return rc;
+        } else if (H <= 256)
             hipLaunchKernelGGL(gru_seq_kernel<8>, dim3((B + ENC_RB - 1) / ENC_RB, ndir), dim3(H / 32 * 64), lds, st, gp);
         else
             hipLaunchKernelGGL(gru_seq_kernel<16>, dim3((B + ENC_RB - 1) / ENC_RB, ndir), dim3(H / 32 * 64), lds, st, gp);
