@@ -128,7 +128,31 @@ struct GruParams {
     int slots; // workgroups resident at once (2 per CU): within one such round, long row groups pair with short ones
 };
 
+struct GruBwdDir {
+    const float *gates;   // [M][4][H]
+    const float *hseq;    // this layer's output sequence, packed [M+1][ld]
+    const float *d_seq;   // nullable: gradient w.r.t. that sequence, [M][ld]
+    const float *d_hfin;  // nullable: [B][H]
+    const float *wtp;     // packed W_hh for dh_prev = dGh W_hh (fp32 MFMA order, or fp16 hi/lo fragments)
+    const unsigned *wmax; // f16-split kernel: bit pattern of max|W_hh|
+    float *dgi;           // [M][3H]
+    float *dghn;          // [M][H]
+    int col0, reverse;
+};
+
+struct GruBwdParams {
+    GruBwdDir dir[2];
+    const int32_t *len, *tok_off, *perm;
+    int B, H, ld;
+    // inter-layer dropout on this layer's OUTPUT: d_seq is the gradient w.r.t. the dropped sequence
+    float drop_p;
+    uint64_t drop_seed;
+    int drop_layer, T;
+};
+
 // csrc/gru16.hip: the recurrence on the f16 matrix pipes (fp16 hi/lo split of both operands, fp32 accuracy)
 bool gru16_supported(int H);
 int gru16_pack(const float *W_hh, int H, unsigned *absmax, void *wp16, hipStream_t st);
 int gru16_launch(const GruParams &gp, int ndir, hipStream_t st);
+int gru16_pack_t(const float *W_hh, int H, unsigned *absmax, void *wtp16, hipStream_t st);
+int gru16_bwd_launch(const GruBwdParams &bp, int ndir, hipStream_t st);

@@ -13,6 +13,8 @@
 #include "encoder.h"
 #include "sgemm.h"
 
+#include <stdlib.h>
+
 int enc_check_shape(const char *who, int B, int T, int E, int H, int L, int64_t V);
 
 namespace {
@@ -107,26 +109,7 @@ __global__ __launch_bounds__(256) void pack_whh_t_kernel(const float *__restrict
     }
 }
 
-struct GruBwdDir {
-    const float *gates;  // [M][4][H]
-    const float *hseq;   // this layer's output sequence, packed [M+1][ld]
-    const float *d_seq;  // nullable: gradient w.r.t. that sequence, [M][ld]
-    const float *d_hfin; // nullable: [B][H]
-    const float *wtp;
-    float *dgi;          // [M][3H]
-    float *dghn;         // [M][H]
-    int col0, reverse;
-};
-
-struct GruBwdParams {
-    GruBwdDir dir[2];
-    const int32_t *len, *tok_off, *perm;
-    int B, H, ld;
-    // inter-layer dropout on this layer's OUTPUT: d_seq is the gradient w.r.t. the dropped sequence
-    float drop_p;
-    uint64_t drop_seed;
-    int drop_layer, T;
-};
+// (GruBwdDir / GruBwdParams: encoder.h)
 
 template <int MAXW>
 __global__ __launch_bounds__(MAXW * 64) void gru_bwd_seq_kernel(GruBwdParams p)
@@ -374,6 +357,8 @@ TT_EXPORT int tt_encoder_backward_f32(const int64_t *ids, int B, int T, const fl
     TT_LAUNCH_CHECK();
 
     const size_t lds = sizeof(float) * ENC_RB * (H3 + 4);
+    static const bool force_f32 = [] { const char *e = getenv("TT_GRU_F32"); return e && e[0] == '1'; }();
+    const bool use16 = gru16_supported(H) && !force_f32; // the reverse-time recurrence on the f16 pipes too (gru16.hip)
     for (int l = num_layers - 1; l >= 0; --l) {
         const int I = l == 0 ? E : ndir * H;
         const bool top = l == num_layers - 1;
@@ -392,7 +377,16 @@ TT_EXPORT int tt_encoder_backward_f32(const int64_t *ids, int B, int T, const fl
         bp.T = T;
         for (int d = 0; d < ndir; ++d) {
             const float *const *w = weights + ((size_t)l * ndir + d) * 4;
-            hipLaunchKernelGGL(pack_whh_t_kernel, dim3(96), dim3(256), 0, st, w[1], H, (float *)(ws + lo.wtp[d]));
+            unsigned *wmax = (unsigned *)(ws + lo.flag) + 32 + 2 * l + d; // the forward's status block: slots 32.. are free
+            if (use16) {
+                TT_HIP_CHECK(hipMemsetAsync(wmax, 0, sizeof(unsigned), st));
+                rc = gru16_pack_t(w[1], H, wmax, ws + lo.wtp[d], st);
+                if (rc != TT_OK)
+                    return rc;
+            } else {
+                hipLaunchKernelGGL(pack_whh_t_kernel, dim3(96), dim3(256), 0, st, w[1], H, (float *)(ws + lo.wtp[d]));
+            }
+            bp.dir[d].wmax = wmax;
             bp.dir[d].gates = (const float *)(ws + lo.gates[l][d]);
             bp.dir[d].hseq = hseq;
             bp.dir[d].d_seq = d_seq;
@@ -409,7 +403,11 @@ TT_EXPORT int tt_encoder_backward_f32(const int64_t *ids, int B, int T, const fl
             TT_HIP_CHECK(hipFuncSetAttribute((const void *)gru_bwd_seq_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             TT_HIP_CHECK(hipFuncSetAttribute((const void *)gru_bwd_seq_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         }
-        if (H <= 256)
+        if (use16) {
+            rc = gru16_bwd_launch(bp, ndir, st);
+            if (rc != TT_OK)
+                return rc;
+        } else if (H <= 256)
             hipLaunchKernelGGL(gru_bwd_seq_kernel<8>, dim3((B + ENC_RB - 1) / ENC_RB, ndir), dim3(H / 32 * 64), lds, st, bp);
         else
             hipLaunchKernelGGL(gru_bwd_seq_kernel<16>, dim3((B + ENC_RB - 1) / ENC_RB, ndir), dim3(H / 32 * 64), lds, st, bp);

@@ -72,20 +72,19 @@ struct Plan {
 
 // Spread the three kinds over the consumption order (largest-deficit-first), so that streamed fragments are
 // consumed at an even pace and the ring's NR loads in flight cover the L2 latency.
-template <int H>
+template <int NF, int R, int NL>
 constexpr Plan make_plan()
 {
-    using C = G16<H>;
     Plan p{};
-    const int total[3] = {C::R, C::NL, C::NS};
+    const int total[3] = {R, NL, NF - R - NL};
     int done[3] = {0, 0, 0};
-    for (int f = 0; f < C::NF; ++f) {
+    for (int f = 0; f < NF; ++f) {
         int best = -1;
         long best_def = -(1L << 60);
         for (int k = 2; k >= 0; --k) {
             if (done[k] >= total[k])
                 continue;
-            const long def = (long)total[k] * (f + 1) - (long)done[k] * C::NF; // scaled deficit
+            const long def = (long)total[k] * (f + 1) - (long)done[k] * NF; // scaled deficit
             if (def > best_def) {
                 best_def = def;
                 best = k;
@@ -100,9 +99,9 @@ constexpr Plan make_plan()
     return p;
 }
 
-template <int H>
+template <class C>
 struct PlanOf {
-    static constexpr Plan value = make_plan<H>();
+    static constexpr Plan value = make_plan<C::NF, C::R, C::NL>();
 };
 
 template <int I, int N, class F>
@@ -180,7 +179,7 @@ template <int H>
 __global__ __launch_bounds__(G16<H>::NW * 64) void gru_seq16_kernel(GruParams p)
 {
     using C = G16<H>;
-    using P = PlanOf<H>;
+    using P = PlanOf<C>;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const GruDir d = p.dir[blockIdx.y];
     const int lane = threadIdx.x & 63;
@@ -363,6 +362,285 @@ __global__ __launch_bounds__(G16<H>::NW * 64) void gru_seq16_kernel(GruParams p)
                 d.h_final[(size_t)rid_e[e] * H + unit[ct]] = hreg[ct][e];
 }
 
+// ------------------------------------------------------------------ reverse-time recurrence (training)
+// dh_{t-1} = dh_t z + dGh W_hh with dGh = [dr_pre, dz_pre, dn_pre r] (16 rows x 3H) on the same three-product
+// fp16 split.  W_hh is fixed, so its scale and its resident / LDS / streamed fragments work as in the forward
+// kernel (K = 3H: 24 k-steps, two column tiles per wave).  dGh are GRADIENTS: their magnitude is arbitrary and
+// changes from row to row and step to step, so every batch row is scaled by its own power of two, taken from the
+// row's largest |element| of THIS step (lane-local maxima -> 16-lane shuffle -> one LDS word per wave and row ->
+// barrier -> every lane reads the 8 words of its rows), which puts the row maximum in [2^13, 2^14): hi and lo are then
+// normal fp16 numbers for every element within 2^-27 of the row maximum, smaller ones err by <= 2^-25 in scaled units,
+// i.e. <= 2^-38 of the row maximum.  The scales are exact and are undone on the fp32 accumulator.
+template <int H>
+struct B16 {
+    static constexpr int NW = H / 32;
+    static constexpr int NK = 3 * H / 32;   // k-steps of 32 over the 3H gate columns
+    static constexpr int NF = 4 * NK;       // per k-step: {hi t0, hi t1, lo t0, lo t1}
+    static constexpr int LDG = 3 * H + 8;   // fp16 elements per row of the dGh images
+    static constexpr int IMG = 16 * LDG * 2;
+    static constexpr int A_BYTES = 2 * IMG; // hi, lo (single buffer: two barriers per step)
+    static constexpr int RM_BYTES = 2 * NW * 16 * 4; // per-wave row maxima, double-buffered
+    static constexpr int LDS_CAP = ((160 * 1024 - A_BYTES - RM_BYTES) / NW) / 1024;
+    static constexpr int R = H == 256 ? 17 : 16;
+    static constexpr int NL = NF - R < LDS_CAP ? NF - R : LDS_CAP;
+    static constexpr int NS = NF - R - NL;
+    static constexpr int NR = NS == 0 ? 1 : 6;
+    static constexpr int LDS_BYTES = A_BYTES + RM_BYTES + NW * NL * 1024;
+    static_assert(NS % NR == 0, "the ring must come round once per step");
+    static_assert(NF <= 96, "plan tables are sized for H <= 256");
+};
+
+// Packed order for dh = dGh W_hh: wave w, fragment f = (s, within): s = f / 4 the k-step over gate rows,
+// part = within >> 1, column tile t = within & 1.  Lane (n, kq) holds W_hh[32 s + 8 kq + i][32 w + 16 t + n], i < 8.
+__global__ __launch_bounds__(256) void pack_whh16_t_kernel(const float *__restrict__ W, int H, const unsigned *__restrict__ absmax,
+                                                           _Float16 *__restrict__ wtp16)
+{
+    const int NK = 3 * H / 32, NF = 4 * NK;
+    const float sc = ldexpf(1.0f, gru16_exponent(*absmax));
+    const int n = (H / 32) * NF * 64;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const int lane = i & 63;
+        const int f = (i >> 6) % NF, w = (i >> 6) / NF;
+        const int s = f / 4, within = f % 4, part = within >> 1, t = within & 1;
+        const float *src = W + (size_t)(32 * s + 8 * (lane >> 4)) * H + 32 * w + 16 * t + (lane & 15);
+        h8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float x = src[(size_t)e * H] * sc;
+            const _Float16 hi = (_Float16)x;
+            o[e] = part ? (_Float16)(x - (float)hi) : hi;
+        }
+        *(h8 *)(wtp16 + (size_t)i * 8) = o;
+    }
+}
+
+template <int H>
+__global__ __launch_bounds__(B16<H>::NW * 64) void gru_bwd16_kernel(GruBwdParams p)
+{
+    using C = B16<H>;
+    using P = PlanOf<C>;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const GruBwdDir d = p.dir[blockIdx.y];
+    constexpr int H3 = 3 * H;
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 15, kq = lane >> 4;
+    const int row0 = blockIdx.x * ENC_RB;
+
+    int len_e[4], off_e[4], rid_e[4], unit[2];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int br = row0 + kq * 4 + e;
+        rid_e[e] = br < p.B ? p.perm[br] : -1;
+        len_e[e] = rid_e[e] >= 0 ? p.len[rid_e[e]] : 0;
+        off_e[e] = rid_e[e] >= 0 ? p.tok_off[rid_e[e]] : 0;
+    }
+    int steps = max(max(len_e[0], len_e[1]), max(len_e[2], len_e[3]));
+    steps = max(steps, __shfl_xor(steps, 16));
+    steps = max(steps, __shfl_xor(steps, 32));
+    float dh[2][4];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+        unit[ct] = 32 * w + 16 * ct + j;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            dh[ct][e] = (d.d_hfin && rid_e[e] >= 0) ? d.d_hfin[(size_t)rid_e[e] * H + unit[ct]] : 0.0f;
+    }
+    const int exw = gru16_exponent(*d.wmax);
+
+    char *const img = lds;                                  // [hi, lo][16][LDG] fp16
+    float *const rmax = (float *)(lds + C::A_BYTES);        // [2][NW][16]
+    const __amdgpu_buffer_rsrc_t wsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)((const char *)d.wtp + (size_t)w * C::NF * 1024), 0, C::NF * 1024, 0x00020000);
+    const int loff = lane * 16;
+    char *wlds = lds + C::A_BYTES + C::RM_BYTES + w * C::NL * 1024 + lane * 16;
+    h8 wreg[C::R];
+    h8 ring[C::NR];
+    static_for<0, C::NF>([&](auto fc) {
+        constexpr int f = decltype(fc)::value;
+        constexpr int kind = P::value.kind[f], idx = P::value.idx[f];
+        if constexpr (kind == K_REG)
+            wreg[idx] = frag_load(wsrc, loff, f * 1024);
+        else if constexpr (kind == K_LDS)
+            *(h8 *)(wlds + idx * 1024) = frag_load(wsrc, loff, f * 1024);
+    });
+    if constexpr (C::NS > 0)
+        static_for<0, C::NR>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            constexpr int off = P::value.sfrag[i] * 1024;
+            ring[i] = frag_load(wsrc, loff, off);
+        });
+
+    // The stash of a step (gates r,z,n,ghn, h_{t-1}, upstream d_seq) is loaded one step AHEAD, so the global
+    // latency hides under the previous step's MFMA loop instead of sitting on the serial path of every step.
+    struct Stash {
+        float r[2][4], z[2][4], n[2][4], ghn[2][4], hp[2][4], dsv[2][4];
+    };
+    auto load_stash = [&](int s, Stash &st) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const bool a = s >= 0 && s < len_e[e];
+            const int t = d.reverse ? len_e[e] - 1 - s : s;
+            const size_t tok = (size_t)(off_e[e] + (a ? t : 0));
+            const size_t ptok = d.reverse ? tok + 1 : tok - 1;
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) {
+                const int u = unit[ct];
+                st.r[ct][e] = st.z[ct][e] = st.n[ct][e] = st.ghn[ct][e] = st.hp[ct][e] = st.dsv[ct][e] = 0.0f;
+                if (a) {
+                    const float *gs = d.gates + tok * 4 * H + u;
+                    st.r[ct][e] = gs[0];
+                    st.z[ct][e] = gs[H];
+                    st.n[ct][e] = gs[2 * H];
+                    st.ghn[ct][e] = gs[3 * H];
+                    if (s > 0)
+                        st.hp[ct][e] = d.hseq[ptok * p.ld + d.col0 + u];
+                    if (d.d_seq)
+                        st.dsv[ct][e] = d.d_seq[tok * p.ld + d.col0 + u];
+                }
+            }
+        }
+    };
+    Stash cur_st, next_st;
+    load_stash(steps - 1, cur_st);
+    int rb = 0;
+
+    for (int s = steps - 1; s >= 0; --s) {
+        float direct[2][4];
+        float gv[3][2][4]; // dr_pre, dz_pre, dn_pre r: this lane's elements of dGh
+        float mrow[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        bool act[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            act[e] = s < len_e[e];
+            const int t = d.reverse ? len_e[e] - 1 - s : s;
+            const size_t tok = (size_t)(off_e[e] + (act[e] ? t : 0));
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) {
+                const int u = unit[ct];
+                float dr_pre = 0.0f, dz_pre = 0.0f, dghn_v = 0.0f;
+                direct[ct][e] = 0.0f;
+                if (act[e]) {
+                    const float r = cur_st.r[ct][e], z = cur_st.z[ct][e], n = cur_st.n[ct][e], ghn = cur_st.ghn[ct][e];
+                    const float hp = cur_st.hp[ct][e];
+                    float dsv = cur_st.dsv[ct][e];
+                    if (d.d_seq && p.drop_p > 0.0f)
+                        dsv *= tt_dropout_scale(p.drop_seed, p.drop_layer,
+                                                ((uint64_t)rid_e[e] * p.T + t) * p.ld + d.col0 + u, p.drop_p);
+                    const float dhv = dh[ct][e] + dsv;
+                    const float dn_pre = dhv * (1.0f - z) * (1.0f - n * n);
+                    dz_pre = dhv * (hp - n) * z * (1.0f - z);
+                    dr_pre = dn_pre * ghn * r * (1.0f - r);
+                    dghn_v = dn_pre * r;
+                    direct[ct][e] = dhv * z;
+                    float *go = d.dgi + tok * H3 + u;
+                    go[0] = dr_pre;
+                    go[H] = dz_pre;
+                    go[2 * H] = dn_pre;
+                    d.dghn[tok * H + u] = dghn_v;
+                }
+                gv[0][ct][e] = dr_pre;
+                gv[1][ct][e] = dz_pre;
+                gv[2][ct][e] = dghn_v;
+                mrow[e] = fmaxf(mrow[e], fmaxf(fmaxf(fabsf(dr_pre), fabsf(dz_pre)), fabsf(dghn_v)));
+            }
+        }
+        // row maxima: the 16 lanes of a kq group hold the 32 units of this wave for rows 4 kq .. 4 kq + 3
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+#pragma unroll
+            for (int off = 1; off < 16; off <<= 1)
+                mrow[e] = fmaxf(mrow[e], __shfl_xor(mrow[e], off));
+            if (j == 0)
+                rmax[(rb * C::NW + w) * 16 + kq * 4 + e] = mrow[e];
+        }
+        load_stash(s - 1, next_st); // in flight during the MFMA loop below
+        __syncthreads();            // B1: row maxima visible; every wave is done reading the previous step's images
+        float down[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float m = 0.0f;
+#pragma unroll
+            for (int ww = 0; ww < C::NW; ++ww)
+                m = fmaxf(m, rmax[(rb * C::NW + ww) * 16 + kq * 4 + e]);
+            const int er = gru16_exponent(__float_as_uint(m));
+            const float upr = ldexpf(1.0f, er);
+            down[e] = ldexpf(1.0f, -(er + exw));
+            _Float16 *dst = (_Float16 *)img + (kq * 4 + e) * C::LDG;
+#pragma unroll
+            for (int g = 0; g < 3; ++g)
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) {
+                    const float x = gv[g][ct][e] * upr;
+                    const _Float16 hi = (_Float16)x;
+                    dst[g * H + unit[ct]] = hi;
+                    dst[C::IMG / 2 + g * H + unit[ct]] = (_Float16)(x - (float)hi);
+                }
+        }
+        rb ^= 1;
+        __syncthreads(); // B2: the dGh images are complete
+
+        f32x4v acc[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+        const char *arow = img + j * (C::LDG * 2) + kq * 16;
+        h8 a_hi[2], a_lo[2]; // by k-step parity
+        h8 lbuf[2][4];
+        a_hi[0] = *(const h8 *)(arow);
+        a_lo[0] = *(const h8 *)(arow + C::IMG);
+        static_for<0, 4>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            constexpr int kind = P::value.kind[i], idx = P::value.idx[i];
+            if constexpr (kind == K_LDS)
+                lbuf[0][i] = *(const h8 *)(wlds + idx * 1024);
+        });
+        static_for<0, C::NK>([&](auto qc) {
+            constexpr int q = decltype(qc)::value, f0 = 4 * q;
+            if constexpr (q + 1 < C::NK) {
+                static_for<0, 4>([&](auto ic) {
+                    constexpr int i = decltype(ic)::value, f = f0 + 4 + i;
+                    constexpr int kind = P::value.kind[f], idx = P::value.idx[f];
+                    if constexpr (kind == K_LDS)
+                        lbuf[(q + 1) & 1][i] = *(const h8 *)(wlds + idx * 1024);
+                });
+                a_hi[(q + 1) & 1] = *(const h8 *)(arow + (q + 1) * 64);
+                a_lo[(q + 1) & 1] = *(const h8 *)(arow + C::IMG + (q + 1) * 64);
+            }
+            h8 b[4];
+            static_for<0, 4>([&](auto ic) {
+                constexpr int i = decltype(ic)::value, f = f0 + i;
+                constexpr int kind = P::value.kind[f], idx = P::value.idx[f];
+                if constexpr (kind == K_REG)
+                    b[i] = wreg[idx];
+                else if constexpr (kind == K_LDS)
+                    b[i] = lbuf[q & 1][i];
+                else
+                    b[i] = ring[idx % C::NR];
+            });
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[q & 1], b[0], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[q & 1], b[1], acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo[q & 1], b[0], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo[q & 1], b[1], acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[q & 1], b[2], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[q & 1], b[3], acc[1], 0, 0, 0);
+            static_for<0, 4>([&](auto ic) {
+                constexpr int i = decltype(ic)::value, f = f0 + i;
+                constexpr int kind = P::value.kind[f], idx = P::value.idx[f];
+                if constexpr (kind == K_STR) {
+                    constexpr int off = P::value.sfrag[(idx + C::NR) % C::NS] * 1024;
+                    ring[idx % C::NR] = frag_load(wsrc, loff, off);
+                }
+            });
+            __builtin_amdgcn_sched_barrier(0);
+        });
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (act[e])
+                    dh[ct][e] = direct[ct][e] + acc[ct][e] * down[e];
+        cur_st = next_st;
+    }
+}
+
 template <int H>
 int launch16(const GruParams &gp, int ndir, hipStream_t st)
 {
@@ -393,4 +671,31 @@ int gru16_launch(const GruParams &gp, int ndir, hipStream_t st)
     if (gp.H == 128)
         return launch16<128>(gp, ndir, st);
     return tt_fail(TT_ERR_UNSUPPORTED, "gru16_launch: H=%d", gp.H);
+}
+
+int gru16_pack_t(const float *W_hh, int H, unsigned *absmax /*zeroed by the caller on the stream*/, void *wtp16, hipStream_t st)
+{
+    hipLaunchKernelGGL(whh_absmax_kernel, dim3(48), dim3(256), 0, st, W_hh, 3 * H * H, absmax);
+    hipLaunchKernelGGL(pack_whh16_t_kernel, dim3(96), dim3(256), 0, st, W_hh, H, (const unsigned *)absmax, (_Float16 *)wtp16);
+    TT_LAUNCH_CHECK();
+    return TT_OK;
+}
+
+template <int H>
+static int launch_bwd16(const GruBwdParams &bp, int ndir, hipStream_t st)
+{
+    using C = B16<H>;
+    TT_HIP_CHECK(hipFuncSetAttribute((const void *)gru_bwd16_kernel<H>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
+    hipLaunchKernelGGL(gru_bwd16_kernel<H>, dim3((bp.B + ENC_RB - 1) / ENC_RB, ndir), dim3(C::NW * 64), C::LDS_BYTES, st, bp);
+    TT_LAUNCH_CHECK();
+    return TT_OK;
+}
+
+int gru16_bwd_launch(const GruBwdParams &bp, int ndir, hipStream_t st)
+{
+    if (bp.H == 256)
+        return launch_bwd16<256>(bp, ndir, st);
+    if (bp.H == 128)
+        return launch_bwd16<128>(bp, ndir, st);
+    return tt_fail(TT_ERR_UNSUPPORTED, "gru16_bwd_launch: H=%d", bp.H);
 }
