@@ -20,10 +20,14 @@
 //    oracle/tt_oracle.c:o_score_topk (MFMA f32 = k-ordered fmaf chain; lane
 //    half h supplies feature 2s+h, so the chain order is 0,1,2,...,d-1).
 //  * selection: a score reaches the slow path only if it is >= its query's
-//    current k-th best; the slow path inserts into a sorted per-(wave,query)
-//    list in LDS, cooperatively (lane t owns slot t).  Ties: score desc,
-//    index asc.  Partial lists go to the workspace; topk_merge_kernel reduces
-//    them (also used for the cross-shard merge after the RCCL all-gather).
+//    current k-th best (a lane-local register); the slow path appends (score, doc)
+//    to the (wave, query) candidate buffer in the caller's workspace with a
+//    fire-and-forget 8-byte store; a nearly full buffer -- and every buffer once
+//    at the end -- is rank-compacted by the wave (each lane counts the entries
+//    ranking before its own, entries of rank < k are written back sorted, the
+//    k-th score becomes the new bound).  Ties: score desc, index asc.  Partial
+//    lists go to the workspace; topk_merge_kernel reduces them (also used for the
+//    sample-pass maxima and for the cross-shard merge after the RCCL all-gather).
 #include "tt_common.h"
 
 #include <limits.h>
@@ -793,41 +797,62 @@ __global__ __launch_bounds__(256) void kth_largest_kernel(const float *__restric
 
 // ---------------------------------------------------------------------------
 // Rank of a designated document (BatchEvaluator, evaluators.py:58-65).
-// One block per query; scores are the same ascending-index FMA chain.
+// One block per query; scores are the same ascending-index FMA chain, one lane per document (the chain is
+// sequential by definition).  A wave takes 64 documents at a time and stages them 32 features at a time through LDS:
+// the global reads are whole 128-byte row segments (8 lanes x 16 B per row), the chain reads its own row from a
+// 33-float-stride image (conflict-free).
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void score_rank_kernel(const float *__restrict__ Q,
                                                          const float *__restrict__ D, int N, int d,
                                                          const int64_t *__restrict__ target,
                                                          int64_t *rank)
 {
+    __shared__ float qs[512];
+    __shared__ float stage[4][64 * 33];
     __shared__ int cnt[4];
-    const int b = blockIdx.x;
-    const float *q = Q + (size_t)b * d;
+    const int b = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int tg = (int)target[b];
+    for (int x = threadIdx.x; x < d; x += 256)
+        qs[x] = Q[(size_t)b * d + x];
+    __syncthreads();
     float st = 0.0f;
     {
         const float *row = D + (size_t)tg * d;
         for (int x = 0; x < d; ++x)
-            st = fmaf(q[x], row[x], st);
+            st = fmaf(qs[x], row[x], st);
     }
+    float *img = stage[wv];
     int c = 0;
-    for (int n = threadIdx.x; n < N; n += blockDim.x) {
-        const float *row = D + (size_t)n * d;
+    for (int n0 = wv * 64; n0 < N; n0 += 256) { // wave-uniform trip count
         float acc = 0.0f;
-        for (int x = 0; x < d; x += 4) {
-            const f32x4 rv = *(const f32x4 *)(row + x);
-            acc = fmaf(q[x], rv.x, acc);
-            acc = fmaf(q[x + 1], rv.y, acc);
-            acc = fmaf(q[x + 2], rv.z, acc);
-            acc = fmaf(q[x + 3], rv.w, acc);
+        for (int x0 = 0; x0 < d; x0 += 32) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { // rows 8 i + lane / 8, 16-byte chunk lane % 8
+                const int r = 8 * i + (lane >> 3), n = min(n0 + r, N - 1);
+                f32x4 v = {0, 0, 0, 0};
+                if (x0 + 4 * (lane & 7) < d) // d is a multiple of 4, not necessarily of 32
+                    v = *(const f32x4 *)(D + (size_t)n * d + x0 + 4 * (lane & 7));
+                float *dst = img + r * 33 + 4 * (lane & 7);
+                dst[0] = v.x;
+                dst[1] = v.y;
+                dst[2] = v.z;
+                dst[3] = v.w;
+            }
+            __builtin_amdgcn_wave_barrier();
+            const float *mine = img + lane * 33;
+            const int xe = min(32, d - x0);
+            for (int x = 0; x < xe; ++x)
+                acc = fmaf(qs[x0 + x], mine[x], acc);
+            __builtin_amdgcn_wave_barrier();
         }
-        c += (n != tg) && (acc > st || (acc == st && n < tg));
+        const int n = n0 + lane;
+        c += (n < N) && (n != tg) && (acc > st || (acc == st && n < tg));
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1)
         c += __shfl_xor(c, off);
-    if ((threadIdx.x & 63) == 0)
-        cnt[threadIdx.x >> 6] = c;
+    if (lane == 0)
+        cnt[wv] = c;
     __syncthreads();
     if (threadIdx.x == 0)
         rank[b] = 1 + (int64_t)cnt[0] + cnt[1] + cnt[2] + cnt[3];
@@ -1039,7 +1064,9 @@ int score_partials(const float *Q, int B, int d, const float *D, int64_t N, int 
     char *ws = (char *)workspace;
     *plan_out = pl;
     const float *thr0 = nullptr;
-    if (pl.prepass) {
+    // (the predicated form -- the screened search's on-device fallback, a no-op unless a flag is raised -- skips
+    //  the sample pass: it only seeds thresholds, and two fewer empty launches sit behind every screened search)
+    if (pl.prepass && !run_if) {
         // sample pass over D[0:ns): per-(wave,query) maxima, then their k-th largest per query.
         // k distinct documents score at least that much, so it bounds the final k-th score from below.
         ScoreParams pp = pass_params(pl.pre, Q, B, D, k, 0, ws, pl);
@@ -1190,6 +1217,8 @@ TT_EXPORT int tt_score_rank_f32(const float *Q, int B, int d, const float *D, in
         return tt_fail(TT_ERR_BAD_SHAPE, "tt_score_rank_f32: B=%d N=%lld d=%d", B, (long long)N, d);
     if (N >= INT_MAX)
         return tt_fail(TT_ERR_UNSUPPORTED, "tt_score_rank_f32: N too large");
+    if (d > 512)
+        return tt_fail(TT_ERR_UNSUPPORTED, "tt_score_rank_f32: d=%d > 512", d);
     if (B == 0)
         return TT_OK;
     hipLaunchKernelGGL(score_rank_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, Q, D, (int)N, d, target, rank);
