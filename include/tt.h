@@ -167,7 +167,8 @@ int tt_score_rank_f32(const float *Q, int B, int d, const float *D, int64_t N, c
  * (sized with train = 1) must then be passed, untouched, to tt_encoder_backward_f32.
  * Supported: H multiple of 32 in [32,512], E multiple of 4, 1 <= num_layers <= 4.
  */
-size_t tt_encoder_workspace_bytes(int B, int T, int E, int H, int num_layers, int bidirectional, int train,
+size_t tt_encoder_workspace_bytes(int B, int T, int E, int H, int num_layers, int bidirectional,
+                                  int train /* 0 inference, 1 training, 2 training with a trainable table */,
                                   int dropout /* train && dropout_p > 0 && num_layers > 1 */);
 int tt_encoder_forward_f32(const int64_t *ids, int B, int T, const float *table, int64_t V, int E, int H,
                            int num_layers, int bidirectional, const float *const *weights /*host array*/,
@@ -180,14 +181,16 @@ int tt_encoder_forward_f32(const int64_t *ids, int B, int T, const float *table,
  * d_out [B,H] = gradient w.r.t. the forward's `out`.  `workspace` is the buffer a forward call with
  * train=1 and the SAME ids/weights filled.  grads: HOST array of DEVICE pointers laid out like
  * `weights`; every gradient buffer is OVERWRITTEN (the caller accumulates across calls, as autograd
- * does).  The embedding table is frozen (model.py:25-27) and gets no gradient.
+ * does).  With GloVe vectors the embedding table is frozen (model.py:25-27) and gets no gradient: g_table = NULL.
+ * Without them the reference trains it (nn.Embedding(V, E, padding_idx=0), model.py:23): pass g_table [V,E]
+ * (overwritten: dense gradient, row 0 = padding_idx stays zero) and size / run the forward with train = 2.
  */
 int tt_encoder_backward_f32(const int64_t *ids, int B, int T, const float *table, int64_t V, int E, int H,
                             int num_layers, int bidirectional, const float *const *weights /*host array*/,
                             const float *proj_w, const float *proj_b, int normalize, float dropout_p,
                             uint64_t dropout_seed, const float *d_out, float *const *grads /*host array*/,
-                            float *g_proj_w, float *g_proj_b, void *workspace, size_t workspace_bytes,
-                            tt_stream_t stream);
+                            float *g_proj_w, float *g_proj_b, float *g_table /*nullable*/, void *workspace,
+                            size_t workspace_bytes, tt_stream_t stream);
 
 /* ------------------------------------------------------------------ */
 /* Training step pieces                                                */

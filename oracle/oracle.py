@@ -98,8 +98,9 @@ def encoder_forward(ids, table, weights, hidden_dim, num_layers=1, bidirectional
 
 
 def encoder_backward(ids, table, weights, hidden_dim, d_out, num_layers=1, bidirectional=False,
-                     proj_w=None, proj_b=None, normalize=True, dropout_p=0.0, dropout_seed=0):
-    """Returns (grads, g_proj_w, g_proj_b); grads mirrors `weights`."""
+                     proj_w=None, proj_b=None, normalize=True, dropout_p=0.0, dropout_seed=0, table_grad=False):
+    """Returns (grads, g_proj_w, g_proj_b); grads mirrors `weights`.  table_grad=True (the reference's trainable
+    embedding table, model.py:23 without GloVe) appends the [V,E] table gradient as a fourth element."""
     ids = np.ascontiguousarray(ids, dtype=np.int64)
     table = _f32(table)
     B, T = ids.shape
@@ -116,11 +117,14 @@ def encoder_backward(ids, table, weights, hidden_dim, d_out, num_layers=1, bidir
     gpw = np.zeros_like(pw) if pw is not None else None
     gpb = np.zeros_like(pb) if pb is not None else None
     d_out = _f32(d_out)
+    gt = np.zeros_like(table) if table_grad else None
     rc = lib().o_encoder_backward(_p(ids), B, T, _p(table), C.c_int64(V), E, H, int(num_layers),
                                   int(bool(bidirectional)), wp, _p(pw), _p(pb),
                                   int(bool(normalize)), C.c_float(dropout_p), C.c_uint64(dropout_seed),
-                                  _p(d_out), gp, _p(gpw), _p(gpb))
+                                  _p(d_out), gp, _p(gpw), _p(gpb), _p(gt))
     _check(rc, "o_encoder_backward")
+    if table_grad:
+        return grads, gpw, gpb, gt
     return grads, gpw, gpb
 
 

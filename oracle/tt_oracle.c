@@ -567,16 +567,21 @@ static int o_gru_layer_bwd(const float *x, int B, int T, int I,
 /*
  * Gradient of the encoder output w.r.t. every trainable tensor, given
  * d_out [B,H] (gradient w.r.t. RNNEncoder.forward's return value).
- * The embedding table is frozen (model.py:25-27) so it gets no gradient.
- * g has the same layout as w (4 pointers per (layer,dir)); all gradient
- * buffers are OVERWRITTEN.  g_proj_w/g_proj_b only when bidir.
+ * With GloVe vectors the embedding table is frozen (model.py:25-27) and gets
+ * no gradient: pass g_table = NULL.  Without them the reference trains the
+ * table (model.py:23, nn.Embedding(..., padding_idx=0)): g_table [V,E] then
+ * receives the sum, over the valid positions holding each id, of the
+ * gradient w.r.t. that position's input vector; row 0 stays zero
+ * (padding_idx).  g has the same layout as w (4 pointers per (layer,dir));
+ * all gradient buffers are OVERWRITTEN.  g_proj_w/g_proj_b only when bidir.
  */
 int o_encoder_backward(const int64_t *ids, int B, int T, const float *table,
                        int64_t V, int E, int H, int num_layers, int bidir,
                        const float *const *w, const float *proj_w,
                        const float *proj_b, int normalize, float dropout_p,
                        uint64_t dropout_seed, const float *d_out,
-                       float *const *g, float *g_proj_w, float *g_proj_b)
+                       float *const *g, float *g_proj_w, float *g_proj_b,
+                       float *g_table)
 {
     int ndir = bidir ? 2 : 1;
     int rc = O_OK;
@@ -671,7 +676,7 @@ int o_encoder_backward(const int64_t *ids, int B, int T, const float *table,
     for (int l = num_layers - 1; l >= 0; --l) {
         int Il = l == 0 ? E : ndir * H;
         dseq_next = NULL;
-        if (l > 0) {
+        if (l > 0 || g_table) {
             dseq_next = (float *)calloc(BT * Il, sizeof(float));
             if (!dseq_next) { rc = O_ERR_NOMEM; goto done; }
         }
@@ -717,6 +722,19 @@ int o_encoder_backward(const int64_t *ids, int B, int T, const float *table,
         free(dseq);
         dseq = dseq_next;
         dseq_next = NULL;
+    }
+    if (g_table) { /* dseq = gradient w.r.t. the gathered vectors [B,T,E]; nn.Embedding backward, padding_idx 0 */
+        memset(g_table, 0, sizeof(float) * (size_t)V * E);
+        for (int b = 0; b < B; ++b)
+            for (int t = 0; t < len[b]; ++t) {
+                int64_t id = ids[(size_t)b * T + t];
+                if (id == 0)
+                    continue;
+                const float *dx = dseq + ((size_t)b * T + t) * E;
+                float *gr = g_table + (size_t)id * E;
+                for (int k = 0; k < E; ++k)
+                    gr[k] += dx[k];
+            }
     }
 done:
     free(len);

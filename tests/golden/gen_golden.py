@@ -19,6 +19,8 @@ Fixtures:
   g7_batch_eval.npz       BatchEvaluator metrics for fixed embeddings (evaluators.py:48-76)
   g8_tokenizer.json       PretrainedTokenizer.encode (tokenizer.py:41-43)
   g9_inferencer.npz       QueryInferencer.get_query_embedding (query_inferencer.py:59-75)
+  g12_table_grad.npz      RNNEncoder WITHOUT GloVe vectors: trainable nn.Embedding(padding_idx=0) (model.py:23-27),
+                          autograd gradient of the table and of the GRU weights, 1-layer uni and 2-layer bidirectional
   g11_hybrid.npz          SimpleHybridRetriever.fit/search blend alpha*dense + (1-alpha)*tfidf (simple_hybrid.py:28-67)
   g10_errors.json         error behaviour (all-zero row, empty row, interior zeros)
 """
@@ -303,6 +305,32 @@ def g9():
                         vocab_json=np.array(json.dumps(_vocab())))
 
 
+def g12():
+    """The reference trains the embedding table when no pretrained vectors are passed (model.py:23-27).  One encoder,
+    loss = sum(out * c) for a fixed random c; records d loss / d embedding.weight (row 0 = padding_idx gets none) and
+    the GRU weight gradients."""
+    out = {}
+    for tag, (layers, bi) in {"uni": (1, False), "bi": (2, True)}.items():
+        V, E, H, seed = 48, 12, 32, 1212 + (5 if bi else 0)
+        table = synth.make_table(seed, V, E)
+        sd = synth.make_encoder_state(seed + 1, E, H, layers, bi)
+        enc = refmodel.RNNEncoder(V, E, H, pretrained_embeddings=None, num_layers=layers, bidirectional=bi)
+        full = {"embedding.weight": torch.from_numpy(table)}
+        full.update({k: torch.from_numpy(v) for k, v in sd.items()})
+        enc.load_state_dict(full)
+        assert enc.embedding.weight.requires_grad
+        enc.train()
+        ids = synth.make_ids(seed + 2, B=7, T=9, V=V, zero_inside=0.15)
+        c = np.random.RandomState(seed + 3).standard_normal((7, H)).astype(np.float32)
+        y = enc(torch.from_numpy(ids))
+        (y * torch.from_numpy(c)).sum().backward()
+        out[f"{tag}_ids"], out[f"{tag}_c"], out[f"{tag}_out"] = ids, c, y.detach().numpy()
+        out[f"{tag}_dims"] = np.array([V, E, H, seed, layers, int(bi)])
+        for k, prm in enc.named_parameters():
+            out[f"{tag}_grad_{k}"] = prm.grad.numpy().copy()
+    np.savez_compressed(HERE / "g12_table_grad.npz", **out)
+
+
 def _hybrid_docs():
     """40 short passages over the synthetic vocabulary (none empty, none all-"the": both would raise or zero out)."""
     rs = np.random.RandomState(1109)
@@ -394,7 +422,7 @@ def g10():
 
 if __name__ == "__main__":
     only = set(sys.argv[1:])
-    for fn in (g1, g2, g3, g4, g5, g6, g7, g8, g9, g10, g11):
+    for fn in (g1, g2, g3, g4, g5, g6, g7, g8, g9, g10, g11, g12):
         if only and fn.__name__ not in only:
             continue
         fn()

@@ -211,3 +211,32 @@ def test_dropout_mask_statistics_and_eval_identity(oracle):
     y1 = oracle.encoder_forward(ids, table, quads, H, 2, True, sd["projection.weight"], sd["projection.bias"],
                                 dropout_p=0.2, dropout_seed=7)
     assert np.abs(y0 - y1).max() > 1e-3
+
+
+@pytest.mark.parametrize("tag", ["uni", "bi"])
+def test_g12_trainable_embedding_table_gradient(oracle, golden, tag):
+    """Without GloVe vectors the reference trains nn.Embedding(padding_idx=0) (model.py:23-27): the oracle's table
+    gradient (and, through the same call, every GRU weight gradient) against the reference's autograd."""
+    g = golden("g12_table_grad.npz")
+    V, E, H, seed, layers, bi = [int(x) for x in g[f"{tag}_dims"]]
+    table = synth.make_table(seed, V, E)
+    sd = synth.make_encoder_state(seed + 1, E, H, layers, bool(bi))
+    quads = synth.weight_quads(sd, layers, bool(bi))
+    pw, pb = sd.get("projection.weight"), sd.get("projection.bias")
+    ids = g[f"{tag}_ids"]
+    out = oracle.encoder_forward(ids, table, quads, H, layers, bool(bi), pw, pb, True)
+    np.testing.assert_allclose(out, g[f"{tag}_out"], atol=2e-6, rtol=0)
+    grads, gpw, gpb, gt = oracle.encoder_backward(ids, table, quads, H, g[f"{tag}_c"], layers, bool(bi), pw, pb, True,
+                                                  table_grad=True)
+    want = g[f"{tag}_grad_embedding.weight"]
+    assert not gt[0].any() and not want[0].any()            # padding_idx: row 0 gets no gradient
+    assert (ids == 0).any() and np.abs(want).max() > 0.1
+    np.testing.assert_allclose(gt, want, atol=2e-4 * np.abs(want).max(), rtol=0)
+    names = []
+    for layer in range(layers):
+        for d in range(2 if bi else 1):
+            sfx = f"_l{layer}" + ("_reverse" if d else "")
+            names += [f"rnn.{n}{sfx}" for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
+    for name, got in zip(names, [x for quad in grads for x in quad]):
+        w = g[f"{tag}_grad_{name}"]
+        np.testing.assert_allclose(got, w, atol=2e-4 * max(np.abs(w).max(), 1e-6), rtol=0, err_msg=name)

@@ -29,6 +29,7 @@ struct EncLayout {
     size_t dx[2];                                // ping-pong [MT][ndir*H]: gradient w.r.t. a layer's input
     size_t wtp[2];                               // W_hh packed for dh_prev = dGh * W_hh
     size_t slabs;                                // split-K partial products
+    size_t dx0;                                  // train == 2 (trainable table): gradient w.r.t. the gathered vectors [MT][E]
     size_t total;
 };
 
@@ -104,6 +105,8 @@ static inline EncLayout enc_layout(int B, int T, int E, int H, int L, int bidir,
         const size_t in_max = (size_t)(E > lo.ndir * H ? E : lo.ndir * H);
         lo.slabs = take(sizeof(float) * ENC_SPLITK * 3 * H * (in_max > (size_t)H ? in_max : (size_t)H));
     }
+    // last, so that the layouts of train == 1 and train == 2 agree on everything before it
+    lo.dx0 = train == 2 ? take(sizeof(float) * lo.MT * E) : 0;
     lo.total = off;
     return lo;
 }

@@ -386,7 +386,7 @@ TT_EXPORT size_t tt_encoder_workspace_bytes(int B, int T, int E, int H, int num_
 {
     if (B <= 0 || T <= 0 || num_layers < 1 || num_layers > ENC_MAX_LAYERS)
         return 0;
-    return enc_layout(B, T, E, H, num_layers, bidirectional, train, dropout).total;
+    return enc_layout(B, T, E, H, num_layers, bidirectional, train < 0 ? 0 : (train > 2 ? 2 : train), dropout).total;
 }
 
 TT_EXPORT int tt_encoder_forward_f32(const int64_t *ids, int B, int T, const float *table, int64_t V, int E, int H,
@@ -404,7 +404,7 @@ TT_EXPORT int tt_encoder_forward_f32(const int64_t *ids, int B, int T, const flo
     if (!(dropout_p >= 0.0f && dropout_p < 1.0f))
         return tt_fail(TT_ERR_BAD_SHAPE, "tt_encoder_forward_f32: dropout_p=%g", dropout_p);
     const bool drop = train && dropout_p > 0.0f && num_layers > 1;
-    const EncLayout lo = enc_layout(B, T, E, H, num_layers, bidirectional, train, drop);
+    const EncLayout lo = enc_layout(B, T, E, H, num_layers, bidirectional, train < 0 ? 0 : (train > 2 ? 2 : train), drop);
     if (!workspace || workspace_bytes < lo.total || ((uintptr_t)workspace & 255))
         return tt_fail(TT_ERR_WORKSPACE, "tt_encoder_forward_f32: workspace %zu < %zu bytes (or not 256-B aligned)",
                        workspace_bytes, lo.total);

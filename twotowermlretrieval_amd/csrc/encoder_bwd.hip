@@ -239,6 +239,22 @@ __global__ __launch_bounds__(MAXW * 64) void gru_bwd_seq_kernel(GruBwdParams p)
     }
 }
 
+// g_table[ids[m]][c] += dx[m][c] for the valid tokens m with ids[m] != 0 (float atomics at the memory side)
+__global__ __launch_bounds__(256) void table_scatter_kernel(const float *__restrict__ dx, const int32_t *__restrict__ ids,
+                                                            const int *__restrict__ m_dyn, int M, int E,
+                                                            float *__restrict__ g_table)
+{
+    const int Me = min(M, *m_dyn);
+    const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63, nw = gridDim.x * 4;
+    for (int m = wave; m < Me; m += nw) {
+        const int id = ids[m];
+        if (id == 0)
+            continue;
+        for (int c = lane; c < E; c += 64)
+            atomicAdd(g_table + (size_t)id * E + c, dx[(size_t)m * E + c]);
+    }
+}
+
 constexpr int COLSUM_SLICES = 256; // N <= 3H <= 1536 columns: 256 x N floats fit the split-K slab buffer
 
 int colsum(const float *X, int64_t ld, int N, int M, const int *m_dyn, float *slabs, float *out, hipStream_t st)
@@ -281,8 +297,8 @@ TT_EXPORT int tt_encoder_backward_f32(const int64_t *ids, int B, int T, const fl
                                       int num_layers, int bidirectional, const float *const *weights,
                                       const float *proj_w, const float *proj_b, int normalize, float dropout_p,
                                       uint64_t dropout_seed, const float *d_out, float *const *grads,
-                                      float *g_proj_w, float *g_proj_b, void *workspace, size_t workspace_bytes,
-                                      tt_stream_t stream)
+                                      float *g_proj_w, float *g_proj_b, float *g_table, void *workspace,
+                                      size_t workspace_bytes, tt_stream_t stream)
 {
     (void)ids;
     (void)proj_b;
@@ -293,10 +309,10 @@ TT_EXPORT int tt_encoder_backward_f32(const int64_t *ids, int B, int T, const fl
     if (!table || !weights || !d_out || !grads || (bidirectional && (!proj_w || !g_proj_w || !g_proj_b)))
         return tt_fail(TT_ERR_BAD_SHAPE, "tt_encoder_backward_f32: null pointer");
     const bool drop = dropout_p > 0.0f && num_layers > 1;
-    const EncLayout lo = enc_layout(B, T, E, H, num_layers, bidirectional, 1, drop);
+    const EncLayout lo = enc_layout(B, T, E, H, num_layers, bidirectional, g_table ? 2 : 1, drop);
     if (!workspace || workspace_bytes < lo.total || ((uintptr_t)workspace & 255))
         return tt_fail(TT_ERR_WORKSPACE, "tt_encoder_backward_f32: workspace %zu < %zu bytes: pass the buffer the "
-                                         "forward call (train=1) filled", workspace_bytes, lo.total);
+                                         "forward call (train=%d) filled", workspace_bytes, lo.total, g_table ? 2 : 1);
     char *ws = (char *)workspace;
     const int ndir = lo.ndir, H3 = 3 * H;
     const int32_t *len = (const int32_t *)(ws + lo.len), *tok_off = (const int32_t *)(ws + lo.tok_off);
@@ -442,12 +458,12 @@ TT_EXPORT int tt_encoder_backward_f32(const int64_t *ids, int B, int T, const fl
             rc = gemm_tn(dghn, H, H, hseq + (size_t)d * H, ndir * H, pm, H, MT, m_valid, slabs, g[1] + (size_t)2 * H * H, st);
             if (rc != TT_OK)
                 return rc;
-            // gradient w.r.t. this layer's input sequence (not needed below layer 0: frozen table)
-            if (l > 0) {
+            // gradient w.r.t. this layer's input sequence (below layer 0 only when the table is trained)
+            if (l > 0 || g_table) {
                 SgemmParams x;
                 x.A = dgi;
                 x.B = w[0];
-                x.C = (float *)(ws + lo.dx[l & 1]);
+                x.C = l > 0 ? (float *)(ws + lo.dx[l & 1]) : (float *)(ws + lo.dx0);
                 x.bias = nullptr;
                 x.a_map = x.b_map = nullptr;
                 x.m_dyn = m_valid;
@@ -465,6 +481,14 @@ TT_EXPORT int tt_encoder_backward_f32(const int64_t *ids, int B, int T, const fl
                     return rc;
             }
         }
+    }
+    if (g_table) {
+        // nn.Embedding backward (model.py:23-27 without GloVe vectors): row id accumulates the input gradients of the
+        // positions that hold it; padding_idx = 0 gets none.  Dense [V,E] gradient, as torch's.
+        TT_HIP_CHECK(hipMemsetAsync(g_table, 0, sizeof(float) * (size_t)V * E, st));
+        hipLaunchKernelGGL(table_scatter_kernel, dim3(2048), dim3(256), 0, st, (const float *)(ws + lo.dx0), idsp, m_valid, MT,
+                           E, g_table);
+        TT_LAUNCH_CHECK();
     }
     return TT_OK;
 }

@@ -10,7 +10,7 @@ Same constructor arguments, attribute names (`query_encoder.embedding.embedding_
 backend/main.py:104) and state_dict keys ({query,doc}_encoder.{embedding.weight,
 rnn.weight_ih_l0[_reverse], ..., projection.weight/bias}), so a model.pth written by either side
 loads in the other.  The nn.Module objects here only OWN the parameters; every forward/backward
-runs in hand-written HIP kernels (csrc/encoder*.hip, train.hip).  There is no PyTorch fallback:
+runs in hand-written HIP kernels (csrc/encoder*.hip, gru16.hip, train.hip).  There is no PyTorch fallback:
 CPU tensors and LSTM / vanilla-RNN towers raise.
 """
 from __future__ import annotations
@@ -189,7 +189,9 @@ class RNNEncoder(nn.Module):
         V, E = self.embedding.weight.shape
         H = self.hidden_dim
         drop = int(train and dropout_p > 0.0 and self.num_layers > 1)
-        need = L.tt_encoder_workspace_bytes(B, max(T, 1), E, H, self.num_layers, int(self.bidirectional), int(train), drop)
+        # train = 2: the workspace also holds the gradient w.r.t. the gathered vectors (trainable embedding table)
+        train_mode = (2 if self.embedding.weight.requires_grad else 1) if train else 0
+        need = L.tt_encoder_workspace_bytes(B, max(T, 1), E, H, self.num_layers, int(self.bidirectional), train_mode, drop)
         # One workspace per call, from torch's caching allocator (a cached block: microseconds).  In train mode the
         # autograd node owns it; in eval mode a per-call buffer keeps concurrent callers apart -- the reference serves
         # queries from a thread pool (frontend/main.py:103), and a buffer shared across threads or streams would be
@@ -206,7 +208,7 @@ class RNNEncoder(nn.Module):
             _lib.check(L.tt_encoder_forward_f32(
                 ids.data_ptr(), B, T, table.data_ptr(), V, E, H, self.num_layers, int(self.bidirectional), wptr,
                 pw.data_ptr() if pw is not None else None, pb.data_ptr() if pb is not None else None,
-                int(self.normalize_output), int(train), float(dropout_p), int(dropout_seed), out.data_ptr(),
+                int(self.normalize_output), train_mode, float(dropout_p), int(dropout_seed), out.data_ptr(),
                 ws.data_ptr(), ws.numel(), status.data_ptr(), _stream(ids.device)))
         if self.check_inputs:
             if self._deferred_status is not None:
@@ -223,6 +225,8 @@ class RNNEncoder(nn.Module):
         H = self.hidden_dim
         params = self._flat_params()
         grads = [torch.empty_like(p, memory_format=torch.contiguous_format) for p in params]
+        table = self.embedding.weight
+        g_table = torch.empty_like(table, memory_format=torch.contiguous_format) if table.requires_grad else None
         nq = 4 * self.num_layers * (2 if self.bidirectional else 1)
         quads = [p.detach().contiguous() for p in params[:nq]]
         wptr, gptr = _ptr_array(quads), _ptr_array(grads[:nq])
@@ -235,20 +239,21 @@ class RNNEncoder(nn.Module):
                 pb.data_ptr() if pb is not None else None, int(self.normalize_output), float(dropout_p),
                 int(dropout_seed), d_out.data_ptr(), gptr,
                 grads[nq].data_ptr() if pw is not None else None,
-                grads[nq + 1].data_ptr() if pb is not None else None, ws.data_ptr(), ws.numel(),
+                grads[nq + 1].data_ptr() if pb is not None else None,
+                g_table.data_ptr() if g_table is not None else None, ws.data_ptr(), ws.numel(),
                 _stream(ids.device)))
-        return grads
+        return grads + ([g_table] if g_table is not None else [])
 
     # ---- public -----------------------------------------------------------------
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         self._check_device(x)
         params = self._flat_params()
+        if self.embedding.weight.requires_grad:
+            # no GloVe vectors: the reference trains nn.Embedding(padding_idx=0) (model.py:23-27); the table is the
+            # last differentiable input of the autograd node (dense [V,E] gradient, row 0 stays zero)
+            params = params + [self.embedding.weight]
         needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
         if needs_grad:
-            if self.embedding.weight.requires_grad:
-                raise NotImplementedError("training the embedding table is not supported by the HIP path: the "
-                                          "reference freezes it whenever GloVe vectors are loaded (model.py:25-27); "
-                                          "pass pretrained_embeddings or set embedding.weight.requires_grad=False")
             return _EncoderFn.apply(self, x, *params)
         out, _, _ = self._run_forward(x, train=False)
         return out
