@@ -216,6 +216,7 @@ def test_g12_trainable_embedding_table_matches_reference_autograd(golden, tag):
     enc.load_state_dict(full)
     enc = enc.cuda().train()
     assert enc.embedding.weight.requires_grad
+    opt = FusedClipAdam(enc.parameters(), lr=1e-2, max_norm=1.0)   # (re-points .data / .grad at its flat buffers)
     ids = dev(g[f"{tag}_ids"])
     y = enc(ids)
     np.testing.assert_allclose(y.detach().cpu().numpy(), g[f"{tag}_out"], atol=1e-5, rtol=0)
@@ -228,12 +229,11 @@ def test_g12_trainable_embedding_table_matches_reference_autograd(golden, tag):
     gt = enc.embedding.weight.grad.cpu().numpy()
     assert not gt[0].any()                                   # padding_idx
     before = enc.embedding.weight.detach().clone()
-    opt = FusedClipAdam(enc.parameters(), lr=1e-2, max_norm=1.0)
     opt.step()
     torch.cuda.synchronize()
     moved = (enc.embedding.weight.detach() - before).abs().amax(dim=1).cpu().numpy() > 0
+    has_grad = np.abs(gt).max(axis=1) > 0
+    assert np.array_equal(moved, has_grad) and has_grad.sum() >= 10 and not moved[0]
     seen = np.zeros(V, dtype=bool)
     seen[np.unique(g[f"{tag}_ids"])] = True
-    seen[0] = False
-    assert moved[seen].all() or (np.abs(gt[seen]).max(axis=1) > 0).sum() == moved.sum()
-    assert not moved[~seen].any()
+    assert not has_grad[~seen].any()                         # ids that never occur get no gradient
