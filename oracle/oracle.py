@@ -78,9 +78,13 @@ def _weight_ptrs(weights):
     return arr, keep
 
 
+CELLS = {"GRU": 0, "LSTM": 1, "RNN": 2}
+
+
 def encoder_forward(ids, table, weights, hidden_dim, num_layers=1, bidirectional=False,
-                    proj_w=None, proj_b=None, normalize=True, dropout_p=0.0, dropout_seed=0) -> np.ndarray:
-    """RNNEncoder.forward (GRU).  weights: [(W_ih,W_hh,b_ih,b_hh)] per (layer,dir)."""
+                    proj_w=None, proj_b=None, normalize=True, dropout_p=0.0, dropout_seed=0,
+                    rnn_type="GRU") -> np.ndarray:
+    """RNNEncoder.forward.  weights: [(W_ih,W_hh,b_ih,b_hh)] per (layer,dir); rnn_type GRU / LSTM / RNN."""
     ids = np.ascontiguousarray(ids, dtype=np.int64)
     table = _f32(table)
     B, T = ids.shape
@@ -90,15 +94,16 @@ def encoder_forward(ids, table, weights, hidden_dim, num_layers=1, bidirectional
     pw = _f32(proj_w) if proj_w is not None else None
     pb = _f32(proj_b) if proj_b is not None else None
     out = np.zeros((B, H), dtype=np.float32)
-    rc = lib().o_encoder_forward(_p(ids), B, T, _p(table), C.c_int64(V), E, H, int(num_layers),
-                                 int(bool(bidirectional)), wp, _p(pw), _p(pb), int(bool(normalize)),
-                                 C.c_float(dropout_p), C.c_uint64(dropout_seed), _p(out))
+    rc = lib().o_encoder_forward_cell(CELLS[rnn_type.upper()], _p(ids), B, T, _p(table), C.c_int64(V), E, H,
+                                      int(num_layers), int(bool(bidirectional)), wp, _p(pw), _p(pb),
+                                      int(bool(normalize)), C.c_float(dropout_p), C.c_uint64(dropout_seed), _p(out))
     _check(rc, "o_encoder_forward")
     return out
 
 
 def encoder_backward(ids, table, weights, hidden_dim, d_out, num_layers=1, bidirectional=False,
-                     proj_w=None, proj_b=None, normalize=True, dropout_p=0.0, dropout_seed=0, table_grad=False):
+                     proj_w=None, proj_b=None, normalize=True, dropout_p=0.0, dropout_seed=0, table_grad=False,
+                     rnn_type="GRU"):
     """Returns (grads, g_proj_w, g_proj_b); grads mirrors `weights`.  table_grad=True (the reference's trainable
     embedding table, model.py:23 without GloVe) appends the [V,E] table gradient as a fourth element."""
     ids = np.ascontiguousarray(ids, dtype=np.int64)
@@ -118,10 +123,10 @@ def encoder_backward(ids, table, weights, hidden_dim, d_out, num_layers=1, bidir
     gpb = np.zeros_like(pb) if pb is not None else None
     d_out = _f32(d_out)
     gt = np.zeros_like(table) if table_grad else None
-    rc = lib().o_encoder_backward(_p(ids), B, T, _p(table), C.c_int64(V), E, H, int(num_layers),
-                                  int(bool(bidirectional)), wp, _p(pw), _p(pb),
-                                  int(bool(normalize)), C.c_float(dropout_p), C.c_uint64(dropout_seed),
-                                  _p(d_out), gp, _p(gpw), _p(gpb), _p(gt))
+    rc = lib().o_encoder_backward_cell(CELLS[rnn_type.upper()], _p(ids), B, T, _p(table), C.c_int64(V), E, H,
+                                       int(num_layers), int(bool(bidirectional)), wp, _p(pw), _p(pb),
+                                       int(bool(normalize)), C.c_float(dropout_p), C.c_uint64(dropout_seed),
+                                       _p(d_out), gp, _p(gpw), _p(gpb), _p(gt))
     _check(rc, "o_encoder_backward")
     if table_grad:
         return grads, gpw, gpb, gt

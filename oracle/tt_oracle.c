@@ -143,6 +143,127 @@ int o_gru_layer(const float *x, int B, int T, int I, const int32_t *len,
     return O_OK;
 }
 
+/*
+ * One LSTM direction (torch.nn.LSTM on a PackedSequence; the reference builds it with
+ * getattr(nn, rnn_type.upper()), backend/model.py:30-37, and keeps h_n: model.py:59-60).
+ * Gate order i,f,g,o over the rows of W_ih [4H,I] / W_hh [4H,H]:
+ *   i = s(.)  f = s(.)  g = tanh(.)  o = s(.)   of   W_i* x + b_i* + W_h* h + b_h*
+ *   c' = f c + i g ;  h' = o tanh(c')
+ * stash (nullable) [B,T,7,H]: i, f, g, o, c_prev, c', h_prev.
+ */
+int o_lstm_layer(const float *x, int B, int T, int I, const int32_t *len,
+                 const float *W_ih, const float *W_hh, const float *b_ih,
+                 const float *b_hh, int H, int reverse, float *out_seq,
+                 float *h_final, float *stash)
+{
+    float *gi = (float *)malloc(sizeof(float) * 4 * H);
+    float *gh = (float *)malloc(sizeof(float) * 4 * H);
+    float *h = (float *)malloc(sizeof(float) * H);
+    float *c = (float *)malloc(sizeof(float) * H);
+    if (!gi || !gh || !h || !c) {
+        free(gi); free(gh); free(h); free(c);
+        return O_ERR_NOMEM;
+    }
+    if (out_seq)
+        memset(out_seq, 0, sizeof(float) * (size_t)B * T * H);
+    for (int b = 0; b < B; ++b) {
+        memset(h, 0, sizeof(float) * H);
+        memset(c, 0, sizeof(float) * H);
+        int L = len[b];
+        for (int s = 0; s < L; ++s) {
+            int t = reverse ? (L - 1 - s) : s;
+            const float *xt = x + ((size_t)b * T + t) * I;
+            o_affine(xt, W_ih, b_ih, 4 * H, I, gi);
+            o_affine(h, W_hh, b_hh, 4 * H, H, gh);
+            float *st = stash ? stash + ((size_t)b * T + t) * 7 * H : NULL;
+            for (int u = 0; u < H; ++u) {
+                float ig = o_sigmoid(gi[u] + gh[u]);
+                float fg = o_sigmoid(gi[H + u] + gh[H + u]);
+                float gg = tanhf(gi[2 * H + u] + gh[2 * H + u]);
+                float og = o_sigmoid(gi[3 * H + u] + gh[3 * H + u]);
+                float cn = fg * c[u] + ig * gg;
+                if (st) {
+                    st[u] = ig;
+                    st[H + u] = fg;
+                    st[2 * H + u] = gg;
+                    st[3 * H + u] = og;
+                    st[4 * H + u] = c[u];
+                    st[5 * H + u] = cn;
+                    st[6 * H + u] = h[u];
+                }
+                c[u] = cn;
+                h[u] = og * tanhf(cn);
+            }
+            if (out_seq)
+                memcpy(out_seq + ((size_t)b * T + t) * H, h, sizeof(float) * H);
+        }
+        memcpy(h_final + (size_t)b * H, h, sizeof(float) * H);
+    }
+    free(gi); free(gh); free(h); free(c);
+    return O_OK;
+}
+
+/*
+ * One vanilla-RNN direction (torch.nn.RNN, default nonlinearity tanh; rnn_type "RNN",
+ * backend/model.py:30,61-62):  h' = tanh(W_ih x + b_ih + W_hh h + b_hh).
+ * stash (nullable) [B,T,2,H]: h', h_prev.
+ */
+int o_rnn_layer(const float *x, int B, int T, int I, const int32_t *len,
+                const float *W_ih, const float *W_hh, const float *b_ih,
+                const float *b_hh, int H, int reverse, float *out_seq,
+                float *h_final, float *stash)
+{
+    float *gi = (float *)malloc(sizeof(float) * H);
+    float *gh = (float *)malloc(sizeof(float) * H);
+    float *h = (float *)malloc(sizeof(float) * H);
+    if (!gi || !gh || !h) {
+        free(gi); free(gh); free(h);
+        return O_ERR_NOMEM;
+    }
+    if (out_seq)
+        memset(out_seq, 0, sizeof(float) * (size_t)B * T * H);
+    for (int b = 0; b < B; ++b) {
+        memset(h, 0, sizeof(float) * H);
+        int L = len[b];
+        for (int s = 0; s < L; ++s) {
+            int t = reverse ? (L - 1 - s) : s;
+            const float *xt = x + ((size_t)b * T + t) * I;
+            o_affine(xt, W_ih, b_ih, H, I, gi);
+            o_affine(h, W_hh, b_hh, H, H, gh);
+            float *st = stash ? stash + ((size_t)b * T + t) * 2 * H : NULL;
+            for (int u = 0; u < H; ++u) {
+                float hn = tanhf(gi[u] + gh[u]);
+                if (st) {
+                    st[u] = hn;
+                    st[H + u] = h[u];
+                }
+                h[u] = hn;
+            }
+            if (out_seq)
+                memcpy(out_seq + ((size_t)b * T + t) * H, h, sizeof(float) * H);
+        }
+        memcpy(h_final + (size_t)b * H, h, sizeof(float) * H);
+    }
+    free(gi); free(gh); free(h);
+    return O_OK;
+}
+
+/* cell: 0 GRU, 1 LSTM, 2 RNN(tanh) -- the reference's RNN_TYPE (config.json; model.py:30) */
+static int o_cell_gates(int cell) { return cell == 1 ? 4 : (cell == 2 ? 1 : 3); }
+static int o_cell_stash(int cell) { return cell == 1 ? 7 : (cell == 2 ? 2 : 5); }
+
+static int o_cell_layer(int cell, const float *x, int B, int T, int I, const int32_t *len,
+                        const float *W_ih, const float *W_hh, const float *b_ih,
+                        const float *b_hh, int H, int reverse, float *out_seq,
+                        float *h_final, float *stash)
+{
+    if (cell == 1)
+        return o_lstm_layer(x, B, T, I, len, W_ih, W_hh, b_ih, b_hh, H, reverse, out_seq, h_final, stash);
+    if (cell == 2)
+        return o_rnn_layer(x, B, T, I, len, W_ih, W_hh, b_ih, b_hh, H, reverse, out_seq, h_final, stash);
+    return o_gru_layer(x, B, T, I, len, W_ih, W_hh, b_ih, b_hh, H, reverse, out_seq, h_final, stash);
+}
+
 /* F.normalize(hidden, p=2, dim=1), eps 1e-12.  backend/model.py:73-74 */
 void o_l2_normalize(const float *x, int B, int H, float *y)
 {
@@ -193,13 +314,31 @@ void o_dropout_mask(uint64_t seed, int layer, int64_t n, float p, float *out)
  * -> Linear(2H,H) (model.py:65-69).  Inter-layer dropout is identity (eval
  * mode / DROPOUT 0): parity is defined per call in eval mode.
  */
+int o_encoder_forward_cell(int cell, const int64_t *ids, int B, int T, const float *table,
+                           int64_t V, int E, int H, int num_layers, int bidir,
+                           const float *const *w, const float *proj_w,
+                           const float *proj_b, int normalize, float dropout_p,
+                           uint64_t dropout_seed, float *out);
+
 int o_encoder_forward(const int64_t *ids, int B, int T, const float *table,
                       int64_t V, int E, int H, int num_layers, int bidir,
                       const float *const *w, const float *proj_w,
                       const float *proj_b, int normalize, float dropout_p,
                       uint64_t dropout_seed, float *out)
 {
-    if (B <= 0 || T <= 0 || num_layers < 1)
+    return o_encoder_forward_cell(0, ids, B, T, table, V, E, H, num_layers, bidir, w, proj_w, proj_b, normalize,
+                                  dropout_p, dropout_seed, out);
+}
+
+/* The same for any RNN_TYPE the reference accepts (cell: 0 GRU, 1 LSTM -- h_n is used, model.py:59-60 --, 2 RNN);
+ * W_ih / W_hh / biases then have 4H (LSTM) or H (RNN) rows. */
+int o_encoder_forward_cell(int cell, const int64_t *ids, int B, int T, const float *table,
+                           int64_t V, int E, int H, int num_layers, int bidir,
+                           const float *const *w, const float *proj_w,
+                           const float *proj_b, int normalize, float dropout_p,
+                           uint64_t dropout_seed, float *out)
+{
+    if (B <= 0 || T <= 0 || num_layers < 1 || cell < 0 || cell > 2)
         return O_ERR_BAD_SHAPE;
     int ndir = bidir ? 2 : 1;
     int32_t *len = (int32_t *)malloc(sizeof(int32_t) * B);
@@ -227,8 +366,8 @@ int o_encoder_forward(const int64_t *ids, int B, int T, const float *table,
     for (int l = 0; l < num_layers; ++l) {
         for (int d = 0; d < ndir; ++d) {
             const float *const *p = w + ((size_t)l * ndir + d) * 4;
-            rc = o_gru_layer(cur, B, T, I, len, p[0], p[1], p[2], p[3], H, d,
-                             seq, hfin + (size_t)d * B * H, NULL);
+            rc = o_cell_layer(cell, cur, B, T, I, len, p[0], p[1], p[2], p[3], H, d,
+                              seq, hfin + (size_t)d * B * H, NULL);
             if (rc != O_OK)
                 goto done;
             for (size_t i = 0; i < (size_t)B * T; ++i)
@@ -564,6 +703,148 @@ static int o_gru_layer_bwd(const float *x, int B, int T, int I,
     return O_OK;
 }
 
+/* Backward of one LSTM direction (stash of o_lstm_layer); same contract as o_gru_layer_bwd. */
+static int o_lstm_layer_bwd(const float *x, int B, int T, int I,
+                            const int32_t *len, const float *W_ih,
+                            const float *W_hh, int H, int reverse,
+                            const float *stash, const float *d_out_seq,
+                            const float *d_h_final, float *gW_ih, float *gW_hh,
+                            float *gb_ih, float *gb_hh, float *dx)
+{
+    float *dh = (float *)malloc(sizeof(float) * H);
+    float *dc = (float *)malloc(sizeof(float) * H);
+    float *dg = (float *)malloc(sizeof(float) * 4 * H);
+    float *dhp = (float *)malloc(sizeof(float) * H);
+    if (!dh || !dc || !dg || !dhp) {
+        free(dh); free(dc); free(dg); free(dhp);
+        return O_ERR_NOMEM;
+    }
+    for (int b = 0; b < B; ++b) {
+        int L = len[b];
+        memcpy(dh, d_h_final + (size_t)b * H, sizeof(float) * H);
+        memset(dc, 0, sizeof(float) * H);
+        for (int s = L - 1; s >= 0; --s) {
+            int t = reverse ? (L - 1 - s) : s;
+            const float *st = stash + ((size_t)b * T + t) * 7 * H;
+            const float *xt = x + ((size_t)b * T + t) * I;
+            if (d_out_seq)
+                for (int u = 0; u < H; ++u)
+                    dh[u] += d_out_seq[((size_t)b * T + t) * H + u];
+            for (int u = 0; u < H; ++u) {
+                float ig = st[u], fg = st[H + u], gg = st[2 * H + u], og = st[3 * H + u];
+                float cp = st[4 * H + u], cn = st[5 * H + u];
+                float tc = tanhf(cn);
+                float d_o = dh[u] * tc;
+                float dct = dc[u] + dh[u] * og * (1.0f - tc * tc);
+                dg[u] = dct * gg * ig * (1.0f - ig);
+                dg[H + u] = dct * cp * fg * (1.0f - fg);
+                dg[2 * H + u] = dct * ig * (1.0f - gg * gg);
+                dg[3 * H + u] = d_o * og * (1.0f - og);
+                dc[u] = dct * fg;
+                dhp[u] = 0.0f;
+            }
+            const float *hp = st + 6 * H;
+            for (int g = 0; g < 4 * H; ++g) {
+                float a = dg[g];
+                gb_ih[g] += a;
+                gb_hh[g] += a;
+                float *wi = gW_ih + (size_t)g * I;
+                float *wh = gW_hh + (size_t)g * H;
+                for (int k = 0; k < I; ++k)
+                    wi[k] += a * xt[k];
+                for (int k = 0; k < H; ++k)
+                    wh[k] += a * hp[k];
+                const float *whr = W_hh + (size_t)g * H;
+                for (int k = 0; k < H; ++k)
+                    dhp[k] += a * whr[k];
+                if (dx) {
+                    const float *wir = W_ih + (size_t)g * I;
+                    float *dxt = dx + ((size_t)b * T + t) * I;
+                    for (int k = 0; k < I; ++k)
+                        dxt[k] += a * wir[k];
+                }
+            }
+            memcpy(dh, dhp, sizeof(float) * H);
+        }
+    }
+    free(dh); free(dc); free(dg); free(dhp);
+    return O_OK;
+}
+
+/* Backward of one vanilla-RNN direction (stash of o_rnn_layer). */
+static int o_rnn_layer_bwd(const float *x, int B, int T, int I,
+                           const int32_t *len, const float *W_ih,
+                           const float *W_hh, int H, int reverse,
+                           const float *stash, const float *d_out_seq,
+                           const float *d_h_final, float *gW_ih, float *gW_hh,
+                           float *gb_ih, float *gb_hh, float *dx)
+{
+    float *dh = (float *)malloc(sizeof(float) * H);
+    float *dg = (float *)malloc(sizeof(float) * H);
+    float *dhp = (float *)malloc(sizeof(float) * H);
+    if (!dh || !dg || !dhp) {
+        free(dh); free(dg); free(dhp);
+        return O_ERR_NOMEM;
+    }
+    for (int b = 0; b < B; ++b) {
+        int L = len[b];
+        memcpy(dh, d_h_final + (size_t)b * H, sizeof(float) * H);
+        for (int s = L - 1; s >= 0; --s) {
+            int t = reverse ? (L - 1 - s) : s;
+            const float *st = stash + ((size_t)b * T + t) * 2 * H;
+            const float *xt = x + ((size_t)b * T + t) * I;
+            if (d_out_seq)
+                for (int u = 0; u < H; ++u)
+                    dh[u] += d_out_seq[((size_t)b * T + t) * H + u];
+            for (int u = 0; u < H; ++u) {
+                dg[u] = dh[u] * (1.0f - st[u] * st[u]);
+                dhp[u] = 0.0f;
+            }
+            const float *hp = st + H;
+            for (int g = 0; g < H; ++g) {
+                float a = dg[g];
+                gb_ih[g] += a;
+                gb_hh[g] += a;
+                float *wi = gW_ih + (size_t)g * I;
+                float *wh = gW_hh + (size_t)g * H;
+                for (int k = 0; k < I; ++k)
+                    wi[k] += a * xt[k];
+                for (int k = 0; k < H; ++k)
+                    wh[k] += a * hp[k];
+                const float *whr = W_hh + (size_t)g * H;
+                for (int k = 0; k < H; ++k)
+                    dhp[k] += a * whr[k];
+                if (dx) {
+                    const float *wir = W_ih + (size_t)g * I;
+                    float *dxt = dx + ((size_t)b * T + t) * I;
+                    for (int k = 0; k < I; ++k)
+                        dxt[k] += a * wir[k];
+                }
+            }
+            memcpy(dh, dhp, sizeof(float) * H);
+        }
+    }
+    free(dh); free(dg); free(dhp);
+    return O_OK;
+}
+
+static int o_cell_layer_bwd(int cell, const float *x, int B, int T, int I,
+                            const int32_t *len, const float *W_ih,
+                            const float *W_hh, int H, int reverse,
+                            const float *stash, const float *d_out_seq,
+                            const float *d_h_final, float *gW_ih, float *gW_hh,
+                            float *gb_ih, float *gb_hh, float *dx)
+{
+    if (cell == 1)
+        return o_lstm_layer_bwd(x, B, T, I, len, W_ih, W_hh, H, reverse, stash, d_out_seq, d_h_final, gW_ih, gW_hh,
+                                gb_ih, gb_hh, dx);
+    if (cell == 2)
+        return o_rnn_layer_bwd(x, B, T, I, len, W_ih, W_hh, H, reverse, stash, d_out_seq, d_h_final, gW_ih, gW_hh,
+                               gb_ih, gb_hh, dx);
+    return o_gru_layer_bwd(x, B, T, I, len, W_ih, W_hh, H, reverse, stash, d_out_seq, d_h_final, gW_ih, gW_hh,
+                           gb_ih, gb_hh, dx);
+}
+
 /*
  * Gradient of the encoder output w.r.t. every trainable tensor, given
  * d_out [B,H] (gradient w.r.t. RNNEncoder.forward's return value).
@@ -575,6 +856,14 @@ static int o_gru_layer_bwd(const float *x, int B, int T, int I,
  * (padding_idx).  g has the same layout as w (4 pointers per (layer,dir));
  * all gradient buffers are OVERWRITTEN.  g_proj_w/g_proj_b only when bidir.
  */
+int o_encoder_backward_cell(int cell, const int64_t *ids, int B, int T, const float *table,
+                            int64_t V, int E, int H, int num_layers, int bidir,
+                            const float *const *w, const float *proj_w,
+                            const float *proj_b, int normalize, float dropout_p,
+                            uint64_t dropout_seed, const float *d_out,
+                            float *const *g, float *g_proj_w, float *g_proj_b,
+                            float *g_table);
+
 int o_encoder_backward(const int64_t *ids, int B, int T, const float *table,
                        int64_t V, int E, int H, int num_layers, int bidir,
                        const float *const *w, const float *proj_w,
@@ -583,6 +872,22 @@ int o_encoder_backward(const int64_t *ids, int B, int T, const float *table,
                        float *const *g, float *g_proj_w, float *g_proj_b,
                        float *g_table)
 {
+    return o_encoder_backward_cell(0, ids, B, T, table, V, E, H, num_layers, bidir, w, proj_w, proj_b, normalize,
+                                   dropout_p, dropout_seed, d_out, g, g_proj_w, g_proj_b, g_table);
+}
+
+/* The same for any RNN_TYPE (cell: 0 GRU, 1 LSTM, 2 RNN); weight / gradient tensors have 4H or H rows. */
+int o_encoder_backward_cell(int cell, const int64_t *ids, int B, int T, const float *table,
+                            int64_t V, int E, int H, int num_layers, int bidir,
+                            const float *const *w, const float *proj_w,
+                            const float *proj_b, int normalize, float dropout_p,
+                            uint64_t dropout_seed, const float *d_out,
+                            float *const *g, float *g_proj_w, float *g_proj_b,
+                            float *g_table)
+{
+    if (cell < 0 || cell > 2)
+        return O_ERR_BAD_SHAPE;
+    const int NG = o_cell_gates(cell), SW = o_cell_stash(cell);
     int ndir = bidir ? 2 : 1;
     int rc = O_OK;
     int32_t *len = (int32_t *)malloc(sizeof(int32_t) * B);
@@ -618,11 +923,11 @@ int o_encoder_backward(const int64_t *ids, int B, int T, const float *table,
         if (!xin[l + 1]) { rc = O_ERR_NOMEM; goto done; }
         for (int d = 0; d < ndir; ++d) {
             const float *const *p = w + ((size_t)l * ndir + d) * 4;
-            stash[l * ndir + d] = (float *)malloc(sizeof(float) * BT * 5 * H);
+            stash[l * ndir + d] = (float *)malloc(sizeof(float) * BT * SW * H);
             if (!stash[l * ndir + d]) { rc = O_ERR_NOMEM; goto done; }
-            rc = o_gru_layer(xin[l], B, T, I, len, p[0], p[1], p[2], p[3], H,
-                             d, seq, hfin + (size_t)d * B * H,
-                             stash[l * ndir + d]);
+            rc = o_cell_layer(cell, xin[l], B, T, I, len, p[0], p[1], p[2], p[3], H,
+                              d, seq, hfin + (size_t)d * B * H,
+                              stash[l * ndir + d]);
             if (rc != O_OK)
                 goto done;
             for (size_t i = 0; i < BT; ++i)
@@ -683,10 +988,10 @@ int o_encoder_backward(const int64_t *ids, int B, int T, const float *table,
         for (int d = 0; d < ndir; ++d) {
             const float *const *p = w + ((size_t)l * ndir + d) * 4;
             float *const *gp = g + ((size_t)l * ndir + d) * 4;
-            memset(gp[0], 0, sizeof(float) * (size_t)3 * H * Il);
-            memset(gp[1], 0, sizeof(float) * (size_t)3 * H * H);
-            memset(gp[2], 0, sizeof(float) * 3 * H);
-            memset(gp[3], 0, sizeof(float) * 3 * H);
+            memset(gp[0], 0, sizeof(float) * (size_t)NG * H * Il);
+            memset(gp[1], 0, sizeof(float) * (size_t)NG * H * H);
+            memset(gp[2], 0, sizeof(float) * NG * H);
+            memset(gp[3], 0, sizeof(float) * NG * H);
             const float *dos = NULL;
             if (dseq) {
                 dtmp = (float *)malloc(sizeof(float) * BT * H);
@@ -710,9 +1015,9 @@ int o_encoder_backward(const int64_t *ids, int B, int T, const float *table,
                 if (!zero_hf) { rc = O_ERR_NOMEM; goto done; }
                 dhf = zero_hf;
             }
-            rc = o_gru_layer_bwd(xin[l], B, T, Il, len, p[0], p[1], H, d,
-                                 stash[l * ndir + d], dos, dhf, gp[0], gp[1],
-                                 gp[2], gp[3], dseq_next);
+            rc = o_cell_layer_bwd(cell, xin[l], B, T, Il, len, p[0], p[1], H, d,
+                                  stash[l * ndir + d], dos, dhf, gp[0], gp[1],
+                                  gp[2], gp[3], dseq_next);
             free(zero_hf);
             free(dtmp);
             dtmp = NULL;

@@ -21,6 +21,8 @@ Fixtures:
   g9_inferencer.npz       QueryInferencer.get_query_embedding (query_inferencer.py:59-75)
   g12_table_grad.npz      RNNEncoder WITHOUT GloVe vectors: trainable nn.Embedding(padding_idx=0) (model.py:23-27),
                           autograd gradient of the table and of the GRU weights, 1-layer uni and 2-layer bidirectional
+  g13_lstm_rnn.npz        RNN_TYPE = LSTM / RNN (model.py:30,59-62): forward outputs and autograd gradients of every tensor,
+                          1-layer unidirectional and 2-layer bidirectional
   g11_hybrid.npz          SimpleHybridRetriever.fit/search blend alpha*dense + (1-alpha)*tfidf (simple_hybrid.py:28-67)
   g10_errors.json         error behaviour (all-zero row, empty row, interior zeros)
 """
@@ -331,6 +333,34 @@ def g12():
     np.savez_compressed(HERE / "g12_table_grad.npz", **out)
 
 
+def g13():
+    """The reference builds getattr(nn, RNN_TYPE.upper()) (model.py:30): nn.LSTM (h_n is kept, :59-60) and nn.RNN
+    (tanh).  loss = sum(out * c) for a fixed random c; forward outputs and d loss / d every parameter."""
+    out = {}
+    for cell, gates in (("LSTM", 4), ("RNN", 1)):
+        for tag, (layers, bi) in {"uni": (1, False), "bi": (2, True)}.items():
+            V, E, H, seed = 40, 12, 32, 1313 + gates + (5 if bi else 0)
+            table = synth.make_table(seed, V, E)
+            sd = synth.make_encoder_state(seed + 1, E, H, layers, bi, gates=gates)
+            enc = refmodel.RNNEncoder(V, E, H, pretrained_embeddings=table, rnn_type=cell, num_layers=layers,
+                                      bidirectional=bi)
+            full = {"embedding.weight": torch.from_numpy(table)}
+            full.update({k: torch.from_numpy(v) for k, v in sd.items()})
+            enc.load_state_dict(full)
+            enc.train()
+            ids = synth.make_ids(seed + 2, B=6, T=10, V=V, zero_inside=0.1)
+            c = np.random.RandomState(seed + 3).standard_normal((6, H)).astype(np.float32)
+            y = enc(torch.from_numpy(ids))
+            (y * torch.from_numpy(c)).sum().backward()
+            key = f"{cell}_{tag}"
+            out[f"{key}_ids"], out[f"{key}_c"], out[f"{key}_out"] = ids, c, y.detach().numpy()
+            out[f"{key}_dims"] = np.array([V, E, H, seed, layers, int(bi), gates])
+            for k, prm in enc.named_parameters():
+                if prm.requires_grad:
+                    out[f"{key}_grad_{k}"] = prm.grad.numpy().copy()
+    np.savez_compressed(HERE / "g13_lstm_rnn.npz", **out)
+
+
 def _hybrid_docs():
     """40 short passages over the synthetic vocabulary (none empty, none all-"the": both would raise or zero out)."""
     rs = np.random.RandomState(1109)
@@ -422,7 +452,7 @@ def g10():
 
 if __name__ == "__main__":
     only = set(sys.argv[1:])
-    for fn in (g1, g2, g3, g4, g5, g6, g7, g8, g9, g10, g11, g12):
+    for fn in (g1, g2, g3, g4, g5, g6, g7, g8, g9, g10, g11, g12, g13):
         if only and fn.__name__ not in only:
             continue
         fn()

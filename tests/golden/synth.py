@@ -16,8 +16,9 @@ def make_table(seed: int, V: int, E: int) -> np.ndarray:
 
 
 def make_encoder_state(seed: int, E: int, H: int, num_layers: int = 1, bidirectional: bool = False,
-                       prefix: str = "") -> dict:
-    """state_dict-keyed numpy weights, nn.GRU default init U(-1/sqrt(H), 1/sqrt(H))."""
+                       prefix: str = "", gates: int = 3) -> dict:
+    """state_dict-keyed numpy weights, nn.GRU default init U(-1/sqrt(H), 1/sqrt(H)).
+    gates = rows / H of the recurrent tensors: 3 GRU, 4 LSTM, 1 vanilla RNN."""
     rs = np.random.RandomState(seed)
     k = 1.0 / np.sqrt(H)
     sd = {}
@@ -26,10 +27,10 @@ def make_encoder_state(seed: int, E: int, H: int, num_layers: int = 1, bidirecti
         I = E if layer == 0 else ndir * H
         for d in range(ndir):
             sfx = f"_l{layer}" + ("_reverse" if d == 1 else "")
-            sd[f"{prefix}rnn.weight_ih{sfx}"] = rs.uniform(-k, k, (3 * H, I)).astype(np.float32)
-            sd[f"{prefix}rnn.weight_hh{sfx}"] = rs.uniform(-k, k, (3 * H, H)).astype(np.float32)
-            sd[f"{prefix}rnn.bias_ih{sfx}"] = rs.uniform(-k, k, (3 * H,)).astype(np.float32)
-            sd[f"{prefix}rnn.bias_hh{sfx}"] = rs.uniform(-k, k, (3 * H,)).astype(np.float32)
+            sd[f"{prefix}rnn.weight_ih{sfx}"] = rs.uniform(-k, k, (gates * H, I)).astype(np.float32)
+            sd[f"{prefix}rnn.weight_hh{sfx}"] = rs.uniform(-k, k, (gates * H, H)).astype(np.float32)
+            sd[f"{prefix}rnn.bias_ih{sfx}"] = rs.uniform(-k, k, (gates * H,)).astype(np.float32)
+            sd[f"{prefix}rnn.bias_hh{sfx}"] = rs.uniform(-k, k, (gates * H,)).astype(np.float32)
     if bidirectional:
         kp = 1.0 / np.sqrt(2 * H)
         sd[f"{prefix}projection.weight"] = rs.uniform(-kp, kp, (H, 2 * H)).astype(np.float32)

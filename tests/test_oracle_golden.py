@@ -240,3 +240,35 @@ def test_g12_trainable_embedding_table_gradient(oracle, golden, tag):
     for name, got in zip(names, [x for quad in grads for x in quad]):
         w = g[f"{tag}_grad_{name}"]
         np.testing.assert_allclose(got, w, atol=2e-4 * max(np.abs(w).max(), 1e-6), rtol=0, err_msg=name)
+
+
+@pytest.mark.parametrize("cell", ["LSTM", "RNN"])
+@pytest.mark.parametrize("tag", ["uni", "bi"])
+def test_g13_lstm_and_vanilla_rnn_towers(oracle, golden, cell, tag):
+    """RNN_TYPE = LSTM / RNN (getattr(nn, rnn_type.upper()), model.py:30; LSTM keeps h_n, :59-60): the oracle's
+    forward and every parameter gradient against the reference's outputs and autograd."""
+    g = golden("g13_lstm_rnn.npz")
+    key = f"{cell}_{tag}"
+    V, E, H, seed, layers, bi, gates = [int(x) for x in g[f"{key}_dims"]]
+    table = synth.make_table(seed, V, E)
+    sd = synth.make_encoder_state(seed + 1, E, H, layers, bool(bi), gates=gates)
+    quads = synth.weight_quads(sd, layers, bool(bi))
+    pw, pb = sd.get("projection.weight"), sd.get("projection.bias")
+    ids = g[f"{key}_ids"]
+    out = oracle.encoder_forward(ids, table, quads, H, layers, bool(bi), pw, pb, True, rnn_type=cell)
+    np.testing.assert_allclose(out, g[f"{key}_out"], atol=2e-6, rtol=0)
+    grads, gpw, gpb = oracle.encoder_backward(ids, table, quads, H, g[f"{key}_c"], layers, bool(bi), pw, pb, True,
+                                              rnn_type=cell)
+    names = []
+    for layer in range(layers):
+        for d in range(2 if bi else 1):
+            sfx = f"_l{layer}" + ("_reverse" if d else "")
+            names += [f"rnn.{n}{sfx}" for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
+    flat = [x for quad in grads for x in quad]
+    if bi:
+        names += ["projection.weight", "projection.bias"]
+        flat += [gpw, gpb]
+    for name, got in zip(names, flat):
+        w = g[f"{key}_grad_{name}"]
+        assert got.shape == w.shape, name
+        np.testing.assert_allclose(got, w, atol=2e-4 * max(np.abs(w).max(), 1e-6), rtol=0, err_msg=name)
