@@ -142,16 +142,18 @@ int tt_score_rank_f32(const float *Q, int B, int d, const float *D, int64_t N, c
 /* ------------------------------------------------------------------ */
 
 /*
- * Replaces RNNEncoder.forward for rnn_type GRU            backend/model.py:48-75
+ * Replaces RNNEncoder.forward                              backend/model.py:48-75
  *   embedded = self.embedding(x)                           :49
  *   lengths = (x != 0).sum(dim=1)  (count of non-zero ids) :52
- *   pack_padded_sequence + nn.GRU (gate order r,z,n)       :55-62
+ *   pack_padded_sequence + getattr(nn, rnn_type.upper())   :30,55-62
+ *     rnn_type 0 = GRU (gate rows r,z,n), 1 = LSTM (i,f,g,o; h_n is kept, :59-60), 2 = RNN (tanh):
+ *     weight_ih / weight_hh / biases have G*H rows, G = 3 / 4 / 1
  *   h_n[-1], or cat(h_n[-2], h_n[-1]) -> Linear(2H,H)      :65-71
  *   F.normalize(p=2, dim=1, eps 1e-12)                     :73-74
  * ids [B,T] int64 right-padded with 0; table [V,E] f32 (row 0 is a real word vector and IS
  * used when id 0 occurs inside the first `length` positions); out [B,H] f32.
  * weights: HOST array of 4*num_layers*ndir DEVICE pointers, index (layer*ndir + dir)*4 +
- * {0: weight_ih [3H,I], 1: weight_hh [3H,H], 2: bias_ih [3H], 3: bias_hh [3H]} = the reference's
+ * {0: weight_ih [GH,I], 1: weight_hh [GH,H], 2: bias_ih [GH], 3: bias_hh [GH]} = the reference's
  * state_dict tensors rnn.{weight_ih,weight_hh,bias_ih,bias_hh}_l{layer}[_reverse]; I = E for
  * layer 0, ndir*H above.  proj_w [H,2H], proj_b [H] only when bidirectional.
  * Inter-layer dropout (nn.GRU(dropout=p), config.json DROPOUT) is applied when train != 0,
@@ -167,11 +169,11 @@ int tt_score_rank_f32(const float *Q, int B, int d, const float *D, int64_t N, c
  * (sized with train = 1) must then be passed, untouched, to tt_encoder_backward_f32.
  * Supported: H multiple of 32 in [32,512], E multiple of 4, 1 <= num_layers <= 4.
  */
-size_t tt_encoder_workspace_bytes(int B, int T, int E, int H, int num_layers, int bidirectional,
+size_t tt_encoder_workspace_bytes(int B, int T, int E, int H, int num_layers, int bidirectional, int rnn_type,
                                   int train /* 0 inference, 1 training, 2 training with a trainable table */,
                                   int dropout /* train && dropout_p > 0 && num_layers > 1 */);
 int tt_encoder_forward_f32(const int64_t *ids, int B, int T, const float *table, int64_t V, int E, int H,
-                           int num_layers, int bidirectional, const float *const *weights /*host array*/,
+                           int num_layers, int bidirectional, int rnn_type, const float *const *weights /*host array*/,
                            const float *proj_w, const float *proj_b, int normalize, int train, float dropout_p,
                            uint64_t dropout_seed, float *out, void *workspace, size_t workspace_bytes,
                            int32_t *status, tt_stream_t stream);
@@ -186,7 +188,7 @@ int tt_encoder_forward_f32(const int64_t *ids, int B, int T, const float *table,
  * (overwritten: dense gradient, row 0 = padding_idx stays zero) and size / run the forward with train = 2.
  */
 int tt_encoder_backward_f32(const int64_t *ids, int B, int T, const float *table, int64_t V, int E, int H,
-                            int num_layers, int bidirectional, const float *const *weights /*host array*/,
+                            int num_layers, int bidirectional, int rnn_type, const float *const *weights /*host array*/,
                             const float *proj_w, const float *proj_b, int normalize, float dropout_p,
                             uint64_t dropout_seed, const float *d_out, float *const *grads /*host array*/,
                             float *g_proj_w, float *g_proj_b, float *g_table /*nullable*/, void *workspace,

@@ -144,10 +144,71 @@ def test_error_behaviour_matches_reference():
     assert torch.isfinite(y).all()
 
 
-def test_unsupported_tower_types_fail_loudly():
+def test_unknown_tower_type_fails_like_the_reference():
+    """The reference does getattr(nn, rnn_type.upper()) (model.py:30): anything but GRU / LSTM / RNN is an AttributeError."""
     from twotowermlretrieval_amd.model import RNNEncoder
-    with pytest.raises(NotImplementedError):
-        RNNEncoder(10, 8, 32, rnn_type="LSTM")
+    with pytest.raises(AttributeError):
+        RNNEncoder(10, 8, 32, rnn_type="transformer")
+
+
+@pytest.mark.parametrize("cell", ["LSTM", "RNN"])
+@pytest.mark.parametrize("tag", ["uni", "bi"])
+def test_g13_lstm_and_vanilla_rnn_towers_forward_and_backward(golden, oracle, cell, tag):
+    """RNN_TYPE = LSTM / RNN through the HIP kernels: forward output and every parameter gradient against the reference's
+    own outputs and autograd (tests/golden/g13_lstm_rnn.npz), state_dict keys and shapes as nn.LSTM / nn.RNN."""
+    from twotowermlretrieval_amd.model import RNNEncoder
+    g = golden("g13_lstm_rnn.npz")
+    key = f"{cell}_{tag}"
+    V, E, H, seed, layers, bi, gates = [int(x) for x in g[f"{key}_dims"]]
+    table = synth.make_table(seed, V, E)
+    sd = synth.make_encoder_state(seed + 1, E, H, layers, bool(bi), gates=gates)
+    enc = RNNEncoder(V, E, H, pretrained_embeddings=table, rnn_type=cell.lower(), num_layers=layers, bidirectional=bool(bi))
+    full = {"embedding.weight": torch.from_numpy(table)}
+    full.update({k: torch.from_numpy(v) for k, v in sd.items()})
+    enc.load_state_dict(full)                                  # strict: exact nn.LSTM / nn.RNN key names and shapes
+    enc = enc.cuda().train()
+    ids = torch.from_numpy(g[f"{key}_ids"]).cuda()
+    y = enc(ids)
+    np.testing.assert_allclose(y.detach().cpu().numpy(), g[f"{key}_out"], atol=ATOL, rtol=0)
+    (y * torch.from_numpy(g[f"{key}_c"]).cuda()).sum().backward()
+    torch.cuda.synchronize()
+    for name, prm in enc.named_parameters():
+        if not prm.requires_grad:
+            continue
+        want = g[f"{key}_grad_{name}"]
+        np.testing.assert_allclose(prm.grad.cpu().numpy(), want, atol=5e-4 * max(np.abs(want).max(), 1e-6), rtol=0,
+                                   err_msg=name)
+    with torch.no_grad():                                      # eval path (no stash) gives the same output
+        np.testing.assert_allclose(enc.eval()(ids).cpu().numpy(), g[f"{key}_out"], atol=ATOL, rtol=0)
+
+
+@pytest.mark.parametrize("cell,B,T,E,H,layers,bi", [("LSTM", 37, 40, 300, 256, 1, False), ("RNN", 50, 33, 200, 128, 2, True),
+                                                    ("LSTM", 9, 17, 52, 96, 3, True), ("RNN", 20, 60, 300, 512, 1, False)])
+def test_lstm_rnn_towers_vs_oracle_on_larger_shapes(oracle, cell, B, T, E, H, layers, bi):
+    from twotowermlretrieval_amd.model import RNNEncoder
+    gates = 4 if cell == "LSTM" else 1
+    V = 300
+    table = synth.make_table(3, V, E)
+    sd = synth.make_encoder_state(4, E, H, layers, bi, gates=gates)
+    enc = RNNEncoder(V, E, H, pretrained_embeddings=table, rnn_type=cell, num_layers=layers, bidirectional=bi)
+    full = {"embedding.weight": torch.from_numpy(table)}
+    full.update({k: torch.from_numpy(v) for k, v in sd.items()})
+    enc.load_state_dict(full)
+    enc = enc.cuda().train()
+    ids = synth.make_ids(5, B, T, V, zero_inside=0.05)
+    quads = synth.weight_quads(sd, layers, bi)
+    pw, pb = sd.get("projection.weight"), sd.get("projection.bias")
+    y = enc(torch.from_numpy(ids).cuda())
+    want = oracle.encoder_forward(ids, table, quads, H, layers, bi, pw, pb, True, rnn_type=cell)
+    np.testing.assert_allclose(y.detach().cpu().numpy(), want, atol=ATOL, rtol=0)
+    d_out = np.random.RandomState(6).standard_normal((B, H)).astype(np.float32)
+    y.backward(torch.from_numpy(d_out).cuda())
+    og, gpw, gpb = oracle.encoder_backward(ids, table, quads, H, d_out, layers, bi, pw, pb, True, rnn_type=cell)
+    flat = [x for quad in og for x in quad] + ([gpw, gpb] if bi else [])
+    got = [p.grad.cpu().numpy() for n, p in enc.named_parameters() if p.requires_grad]
+    assert len(flat) == len(got)
+    for a, b in zip(got, flat):
+        np.testing.assert_allclose(a, b, atol=5e-4 * max(np.abs(b).max(), 1e-6), rtol=0)
 
 
 def test_encoder_forward_replays_from_a_hip_graph():

@@ -3,6 +3,11 @@
 #include "tt_common.h"
 
 constexpr int ENC_MAX_LAYERS = 4;
+
+// RNN_TYPE of the reference (getattr(nn, rnn_type.upper()), backend/model.py:30).  Gate rows of W_ih / W_hh: GRU r,z,n;
+// LSTM i,f,g,o (h_n is the output, model.py:59-60); RNN one (tanh).
+enum { CELL_GRU = 0, CELL_LSTM = 1, CELL_RNN = 2 };
+static inline int enc_gates(int cell) { return cell == CELL_LSTM ? 4 : (cell == CELL_RNN ? 1 : 3); }
 constexpr int ENC_RB = 16; // batch rows per recurrence block (one 16x16x4 MFMA M-tile)
 
 // All offsets are bytes from the start of the caller's workspace.  Token-indexed buffers use
@@ -14,10 +19,12 @@ struct EncLayout {
     size_t len, tok_off, perm, ids, flag;        // int32 metadata (tok_off has B+1 entries)
     size_t x[ENC_MAX_LAYERS + 1];                // x[l+1] = output sequence of layer l: [MT][ndir*H]
     size_t xd[ENC_MAX_LAYERS + 1];               // train + dropout: x[l+1] after the inter-layer dropout mask
-    size_t gates[ENC_MAX_LAYERS][2];             // train: [MT][4][H] = r, z, n, W_hn h + b_hn
+    size_t gates[ENC_MAX_LAYERS][2];             // train: [MT][4][H] = r, z, n, W_hn h + b_hn (GRU) / i, f, g, o (LSTM)
+    size_t cseq[ENC_MAX_LAYERS][2];              // train, LSTM: cell state after each token [MT+1][H] (row MT = zeros)
     size_t hfin;                                 // [ndir][B][H] final hidden of the LAST layer
     size_t hid;                                  // [B][H] head output before normalisation
-    size_t gi[2];                                // scratch: input projections [MT][3H] per direction
+    int ng;                                      // gate rows / H: 3 GRU, 4 LSTM, 1 RNN
+    size_t gi[2];                                // scratch: input projections [MT][ng H] per direction
     size_t wp[2];                                // scratch: W_hh packed for the MFMA B operand
     size_t fwd_end;
     // backward scratch (train only)
@@ -50,10 +57,13 @@ __host__ __device__ static inline float tt_dropout_scale(uint64_t seed, int laye
     return u >= thresh ? 1.0f / (1.0f - p) : 0.0f;
 }
 
-static inline EncLayout enc_layout(int B, int T, int E, int H, int L, int bidir, int train, int dropout = 0)
+static inline EncLayout enc_layout(int B, int T, int E, int H, int L, int bidir, int train, int dropout = 0,
+                                   int cell = CELL_GRU)
 {
     EncLayout lo;
     lo.B = B; lo.T = T; lo.E = E; lo.H = H; lo.L = L; lo.ndir = bidir ? 2 : 1; lo.train = train;
+    const int ng = enc_gates(cell);
+    lo.ng = ng;
     lo.MT = (int64_t)B * T;
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = tt_align_up(off + bytes, 256); return o; };
@@ -76,14 +86,16 @@ static inline EncLayout enc_layout(int B, int T, int E, int H, int L, int bidir,
             lo.x[l + 1] = l < 2 ? take(seq) : lo.x[l - 1]; // inference: two ping-pong buffers
         else
             lo.x[l + 1] = 0; // last layer's sequence is not needed for inference
-        for (int d = 0; d < 2; ++d)
-            lo.gates[l][d] = (train && d < lo.ndir) ? take(sizeof(float) * lo.MT * 4 * H) : 0;
+        for (int d = 0; d < 2; ++d) {
+            lo.gates[l][d] = (train && d < lo.ndir && cell != CELL_RNN) ? take(sizeof(float) * lo.MT * 4 * H) : 0;
+            lo.cseq[l][d] = (train && d < lo.ndir && cell == CELL_LSTM) ? take(sizeof(float) * (lo.MT + 1) * H) : 0;
+        }
     }
     lo.hfin = take(sizeof(float) * lo.ndir * B * H);
     lo.hid = take(sizeof(float) * B * H);
     for (int d = 0; d < 2; ++d) {
-        lo.gi[d] = d < lo.ndir ? take(sizeof(float) * lo.MT * 3 * H) : 0;
-        lo.wp[d] = d < lo.ndir ? take(sizeof(float) * 3 * H * H) : 0;
+        lo.gi[d] = d < lo.ndir ? take(sizeof(float) * lo.MT * ng * H) : 0;
+        lo.wp[d] = d < lo.ndir ? take(sizeof(float) * ng * H * H) : 0;
     }
     lo.fwd_end = off;
     lo.d_hfin = lo.d_hid = lo.slabs = 0;
@@ -95,15 +107,15 @@ static inline EncLayout enc_layout(int B, int T, int E, int H, int L, int bidir,
         for (int d = 0; d < lo.ndir; ++d)
             lo.prevmap[d] = take(sizeof(int32_t) * lo.MT);
         for (int d = 0; d < lo.ndir; ++d) {
-            lo.dgi[d] = take(sizeof(float) * lo.MT * 3 * H);
+            lo.dgi[d] = take(sizeof(float) * lo.MT * ng * H);
             lo.dghn[d] = take(sizeof(float) * lo.MT * H);
-            lo.wtp[d] = take(sizeof(float) * 3 * H * H);
+            lo.wtp[d] = take(sizeof(float) * ng * H * H);
         }
         if (L > 1)
             for (int i = 0; i < 2; ++i)
                 lo.dx[i] = take(seq);
         const size_t in_max = (size_t)(E > lo.ndir * H ? E : lo.ndir * H);
-        lo.slabs = take(sizeof(float) * ENC_SPLITK * 3 * H * (in_max > (size_t)H ? in_max : (size_t)H));
+        lo.slabs = take(sizeof(float) * ENC_SPLITK * (ng < 3 ? 3 : ng) * H * (in_max > (size_t)H ? in_max : (size_t)H));
     }
     // last, so that the layouts of train == 1 and train == 2 agree on everything before it
     lo.dx0 = train == 2 ? take(sizeof(float) * lo.MT * E) : 0;
@@ -119,6 +131,7 @@ struct GruDir {
     const float *b_hh;    // [3H]
     float *out_seq;       // nullable, [M][out_ld]
     float *gates;         // nullable, [M][4][H]
+    float *cseq;          // nullable (LSTM training): [M+1][H] cell state after each token
     float *h_final;       // [B][H]
     int out_col0;
     int reverse;
@@ -133,6 +146,7 @@ struct GruParams {
 
 struct GruBwdDir {
     const float *gates;   // [M][4][H]
+    const float *cseq;    // LSTM: cell state after each token [M+1][H] (row M = zeros: c before the first step)
     const float *hseq;    // this layer's output sequence, packed [M+1][ld]
     const float *d_seq;   // nullable: gradient w.r.t. that sequence, [M][ld]
     const float *d_hfin;  // nullable: [B][H]

@@ -153,10 +153,10 @@ __global__ __launch_bounds__(256) void prep_pack_ids_kernel(const int64_t *__res
 }
 
 // ------------------------------------------------------------------ W_hh -> MFMA B-operand order
-// wp[(((w*3 + g)*2 + ct)*(H/16) + c)*256 + lane*4 + e] = W_hh[g*H + 32w + 16ct + (lane&15)][16c + 4(lane>>4) + e]
-__global__ __launch_bounds__(256) void pack_whh_kernel(const float *__restrict__ W, int H, float *__restrict__ wp)
+// wp[(((w*ng + g)*2 + ct)*(H/16) + c)*256 + lane*4 + e] = W_hh[g*H + 32w + 16ct + (lane&15)][16c + 4(lane>>4) + e]
+__global__ __launch_bounds__(256) void pack_whh_kernel(const float *__restrict__ W, int H, int ng, float *__restrict__ wp)
 {
-    const int n = 3 * H * H / 4;
+    const int n = ng * H * H / 4;
     const int nc = H / 16;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
         const int lane = i & 63;
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256) void pack_whh_kernel(const float *__restrict__
         r /= nc;
         const int ct = r & 1;
         r >>= 1;
-        const int g = r % 3, w = r / 3;
+        const int g = r % ng, w = r / ng;
         const int row = g * H + 32 * w + 16 * ct + (lane & 15);
         const int col = 16 * c + 4 * (lane >> 4);
         *(f32x4 *)(wp + (size_t)i * 4) = *(const f32x4 *)(W + (size_t)row * H + col);
@@ -184,9 +184,11 @@ __device__ __forceinline__ float fast_tanh(float x)
 
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
-template <int MAXW>
+// CELL: CELL_GRU (gates r,z,n), CELL_LSTM (i,f,g,o; the cell state lives in registers next to h), CELL_RNN (tanh).
+template <int MAXW, int CELL>
 __global__ __launch_bounds__(MAXW * 64) void gru_seq_kernel(GruParams p)
 {
+    constexpr int NG = CELL == CELL_LSTM ? 4 : (CELL == CELL_RNN ? 1 : 3);
     extern __shared__ __attribute__((aligned(16))) float hbuf[]; // [2][16][H+4]
     const GruDir d = p.dir[blockIdx.y];
     const int H = p.H, LDH = H + 4, nc = H / 16;
@@ -217,40 +219,41 @@ __global__ __launch_bounds__(MAXW * 64) void gru_seq_kernel(GruParams p)
     steps = max(steps, __shfl_xor(steps, 16));
     steps = max(steps, __shfl_xor(steps, 32));
     int unit[2];
-    float bias[3][2];
+    float bias[NG][2];
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct) {
         unit[ct] = 32 * w + 16 * ct + j;
 #pragma unroll
-        for (int g = 0; g < 3; ++g)
+        for (int g = 0; g < NG; ++g)
             bias[g][ct] = d.b_hh[g * H + unit[ct]];
     }
     for (int i = threadIdx.x; i < 2 * ENC_RB * LDH; i += blockDim.x)
         hbuf[i] = 0.0f;
     float hreg[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+    float creg[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}}; // LSTM cell state
     __syncthreads();
 
-    const float *wbase = d.wp + (size_t)w * 6 * nc * 256 + lane * 4;
-    const int H3 = 3 * H;
+    const float *wbase = d.wp + (size_t)w * 2 * NG * nc * 256 + lane * 4;
+    const int HG = NG * H;
     int cur = 0;
     for (int s = 0; s < steps; ++s) {
         bool act[4];
         size_t tok[4];
-        float giv[3][2][4];
+        float giv[NG][2][4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             act[e] = s < len_e[e];
             const int t = d.reverse ? len_e[e] - 1 - s : s;
             tok[e] = (size_t)(off_e[e] + (act[e] ? t : 0));
 #pragma unroll
-            for (int g = 0; g < 3; ++g)
+            for (int g = 0; g < NG; ++g)
 #pragma unroll
                 for (int ct = 0; ct < 2; ++ct)
-                    giv[g][ct][e] = act[e] ? d.gi[tok[e] * H3 + g * H + unit[ct]] : 0.0f;
+                    giv[g][ct][e] = act[e] ? d.gi[tok[e] * HG + g * H + unit[ct]] : 0.0f;
         }
-        f32x4v acc[3][2];
+        f32x4v acc[NG][2];
 #pragma unroll
-        for (int g = 0; g < 3; ++g)
+        for (int g = 0; g < NG; ++g)
 #pragma unroll
             for (int ct = 0; ct < 2; ++ct)
                 acc[g][ct] = (f32x4v){bias[g][ct], bias[g][ct], bias[g][ct], bias[g][ct]};
@@ -258,16 +261,16 @@ __global__ __launch_bounds__(MAXW * 64) void gru_seq_kernel(GruParams p)
         const float *hA = hbuf + cur * ENC_RB * LDH + j * LDH + 4 * kq;
         for (int c = 0; c < nc; ++c) {
             const f32x4v a = *(const f32x4v *)(hA + 16 * c);
-            f32x4v b[3][2];
+            f32x4v b[NG][2];
 #pragma unroll
-            for (int g = 0; g < 3; ++g)
+            for (int g = 0; g < NG; ++g)
 #pragma unroll
                 for (int ct = 0; ct < 2; ++ct)
                     b[g][ct] = *(const f32x4v *)(wbase + ((size_t)(g * 2 + ct) * nc + c) * 256);
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
-                for (int g = 0; g < 3; ++g)
+                for (int g = 0; g < NG; ++g)
 #pragma unroll
                     for (int ct = 0; ct < 2; ++ct)
                         acc[g][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b[g][ct][e], acc[g][ct], 0, 0, 0);
@@ -278,22 +281,46 @@ __global__ __launch_bounds__(MAXW * 64) void gru_seq_kernel(GruParams p)
         for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float r = fast_sigmoid(giv[0][ct][e] + acc[0][ct][e]);
-                const float z = fast_sigmoid(giv[1][ct][e] + acc[1][ct][e]);
-                const float ghn = acc[2][ct][e];
-                const float n = fast_tanh(giv[2][ct][e] + r * ghn);
-                const float hn = (hreg[ct][e] - n) * z + n;
-                if (act[e]) {
-                    hreg[ct][e] = hn;
-                    if (d.out_seq)
-                        d.out_seq[tok[e] * p.out_ld + d.out_col0 + unit[ct]] = hn;
-                    if (d.gates) {
+                float hn;
+                if constexpr (CELL == CELL_GRU) {
+                    const float r = fast_sigmoid(giv[0][ct][e] + acc[0][ct][e]);
+                    const float z = fast_sigmoid(giv[1][ct][e] + acc[1][ct][e]);
+                    const float ghn = acc[2][ct][e];
+                    const float n = fast_tanh(giv[2][ct][e] + r * ghn);
+                    hn = (hreg[ct][e] - n) * z + n;
+                    if (act[e] && d.gates) {
                         float *gs = d.gates + tok[e] * 4 * H + unit[ct];
                         gs[0] = r;
                         gs[H] = z;
                         gs[2 * H] = n;
                         gs[3 * H] = ghn;
                     }
+                } else if constexpr (CELL == CELL_LSTM) {
+                    const float ig = fast_sigmoid(giv[0][ct][e] + acc[0][ct][e]);
+                    const float fg = fast_sigmoid(giv[1][ct][e] + acc[1][ct][e]);
+                    const float gg = fast_tanh(giv[2][ct][e] + acc[2][ct][e]);
+                    const float og = fast_sigmoid(giv[3][ct][e] + acc[3][ct][e]);
+                    const float cn = fg * creg[ct][e] + ig * gg;
+                    hn = og * fast_tanh(cn);
+                    if (act[e]) {
+                        creg[ct][e] = cn;
+                        if (d.gates) {
+                            float *gs = d.gates + tok[e] * 4 * H + unit[ct];
+                            gs[0] = ig;
+                            gs[H] = fg;
+                            gs[2 * H] = gg;
+                            gs[3 * H] = og;
+                        }
+                        if (d.cseq)
+                            d.cseq[tok[e] * H + unit[ct]] = cn;
+                    }
+                } else {
+                    hn = fast_tanh(giv[0][ct][e] + acc[0][ct][e]);
+                }
+                if (act[e]) {
+                    hreg[ct][e] = hn;
+                    if (d.out_seq)
+                        d.out_seq[tok[e] * p.out_ld + d.out_col0 + unit[ct]] = hn;
                 }
                 hN[(kq * 4 + e) * LDH + unit[ct]] = hreg[ct][e];
             }
@@ -306,6 +333,17 @@ __global__ __launch_bounds__(MAXW * 64) void gru_seq_kernel(GruParams p)
         for (int e = 0; e < 4; ++e)
             if (rid_e[e] >= 0)
                 d.h_final[(size_t)rid_e[e] * H + unit[ct]] = hreg[ct][e];
+}
+
+template <int CELL>
+int launch_seq(const GruParams &gp, int B, int H, int ndir, size_t lds, hipStream_t st)
+{
+    if (H <= 256)
+        hipLaunchKernelGGL((gru_seq_kernel<8, CELL>), dim3((B + ENC_RB - 1) / ENC_RB, ndir), dim3(H / 32 * 64), lds, st, gp);
+    else
+        hipLaunchKernelGGL((gru_seq_kernel<16, CELL>), dim3((B + ENC_RB - 1) / ENC_RB, ndir), dim3(H / 32 * 64), lds, st, gp);
+    TT_LAUNCH_CHECK();
+    return TT_OK;
 }
 
 // ------------------------------------------------------------------ inter-layer dropout (train mode)
@@ -381,16 +419,16 @@ int enc_check_shape(const char *who, int B, int T, int E, int H, int L, int64_t 
     return TT_OK;
 }
 
-TT_EXPORT size_t tt_encoder_workspace_bytes(int B, int T, int E, int H, int num_layers, int bidirectional, int train,
-                                            int dropout)
+TT_EXPORT size_t tt_encoder_workspace_bytes(int B, int T, int E, int H, int num_layers, int bidirectional, int rnn_type,
+                                            int train, int dropout)
 {
-    if (B <= 0 || T <= 0 || num_layers < 1 || num_layers > ENC_MAX_LAYERS)
+    if (B <= 0 || T <= 0 || num_layers < 1 || num_layers > ENC_MAX_LAYERS || rnn_type < 0 || rnn_type > 2)
         return 0;
-    return enc_layout(B, T, E, H, num_layers, bidirectional, train < 0 ? 0 : (train > 2 ? 2 : train), dropout).total;
+    return enc_layout(B, T, E, H, num_layers, bidirectional, train < 0 ? 0 : (train > 2 ? 2 : train), dropout, rnn_type).total;
 }
 
 TT_EXPORT int tt_encoder_forward_f32(const int64_t *ids, int B, int T, const float *table, int64_t V, int E, int H,
-                                     int num_layers, int bidirectional, const float *const *weights,
+                                     int num_layers, int bidirectional, int rnn_type, const float *const *weights,
                                      const float *proj_w, const float *proj_b, int normalize, int train,
                                      float dropout_p, uint64_t dropout_seed, float *out, void *workspace,
                                      size_t workspace_bytes, int32_t *status, tt_stream_t stream)
@@ -403,8 +441,12 @@ TT_EXPORT int tt_encoder_forward_f32(const int64_t *ids, int B, int T, const flo
         return tt_fail(TT_ERR_BAD_SHAPE, "tt_encoder_forward_f32: null pointer");
     if (!(dropout_p >= 0.0f && dropout_p < 1.0f))
         return tt_fail(TT_ERR_BAD_SHAPE, "tt_encoder_forward_f32: dropout_p=%g", dropout_p);
+    if (rnn_type < CELL_GRU || rnn_type > CELL_RNN)
+        return tt_fail(TT_ERR_UNSUPPORTED, "tt_encoder_forward_f32: rnn_type=%d (0 GRU, 1 LSTM, 2 RNN)", rnn_type);
+    const int NGH = enc_gates(rnn_type) * H;
     const bool drop = train && dropout_p > 0.0f && num_layers > 1;
-    const EncLayout lo = enc_layout(B, T, E, H, num_layers, bidirectional, train < 0 ? 0 : (train > 2 ? 2 : train), drop);
+    const EncLayout lo = enc_layout(B, T, E, H, num_layers, bidirectional, train < 0 ? 0 : (train > 2 ? 2 : train), drop,
+                                    rnn_type);
     if (!workspace || workspace_bytes < lo.total || ((uintptr_t)workspace & 255))
         return tt_fail(TT_ERR_WORKSPACE, "tt_encoder_forward_f32: workspace %zu < %zu bytes (or not 256-B aligned)",
                        workspace_bytes, lo.total);
@@ -425,7 +467,7 @@ TT_EXPORT int tt_encoder_forward_f32(const int64_t *ids, int B, int T, const flo
     // H = 128 / 256: the recurrence runs on the f16 matrix pipes with both operands split into fp16 hi + lo parts
     // (gru16.hip; fp32-grade accuracy at 3/16 of the fp32 MFMA time).  TT_GRU_F32=1 keeps the fp32-MFMA kernel.
     static const bool force_f32 = [] { const char *e = getenv("TT_GRU_F32"); return e && e[0] == '1'; }();
-    const bool use16 = gru16_supported(H) && !force_f32;
+    const bool use16 = rnn_type == CELL_GRU && gru16_supported(H) && !force_f32;
     for (int l = 0; l < num_layers; ++l) {
         const int I = l == 0 ? E : ndir * H;
         GruParams gp;
@@ -452,11 +494,11 @@ TT_EXPORT int tt_encoder_forward_f32(const int64_t *ids, int B, int T, const flo
             g.m_dyn = tok_off + B;
             g.k_dyn = nullptr;
             g.M = (int)lo.MT;
-            g.N = 3 * H;
+            g.N = NGH;
             g.K = I;
             g.lda = I;
             g.ldb = I;
-            g.ldc = 3 * H;
+            g.ldc = NGH;
             g.slab_stride = 0;
             g.accumulate = 0;
             rc = tt_sgemm(g, false, false, 1, st);
@@ -468,14 +510,20 @@ TT_EXPORT int tt_encoder_forward_f32(const int64_t *ids, int B, int T, const flo
                 if (rc != TT_OK)
                     return rc;
             } else {
-                hipLaunchKernelGGL(pack_whh_kernel, dim3(96), dim3(256), 0, st, w[1], H, (float *)(ws + lo.wp[d]));
+                hipLaunchKernelGGL(pack_whh_kernel, dim3(96), dim3(256), 0, st, w[1], H, enc_gates(rnn_type),
+                                   (float *)(ws + lo.wp[d]));
             }
             gp.dir[d].gi = (const float *)(ws + lo.gi[d]);
             gp.dir[d].wp = (const float *)(ws + lo.wp[d]);
             gp.dir[d].wmax = wmax;
             gp.dir[d].b_hh = w[3];
             gp.dir[d].out_seq = xout;
-            gp.dir[d].gates = train ? (float *)(ws + lo.gates[l][d]) : nullptr;
+            gp.dir[d].gates = (train && rnn_type != CELL_RNN) ? (float *)(ws + lo.gates[l][d]) : nullptr;
+            gp.dir[d].cseq = nullptr;
+            if (train && rnn_type == CELL_LSTM) { // c before the first step: the all-zero row at index MT
+                gp.dir[d].cseq = (float *)(ws + lo.cseq[l][d]);
+                TT_HIP_CHECK(hipMemsetAsync(gp.dir[d].cseq + (size_t)lo.MT * H, 0, sizeof(float) * H, st));
+            }
             // only the last layer's final hidden state is used (model.py:65-71)
             gp.dir[d].h_final = (float *)(ws + lo.hfin) + (size_t)d * B * H;
             gp.dir[d].out_col0 = d * H;
@@ -487,10 +535,13 @@ TT_EXPORT int tt_encoder_forward_f32(const int64_t *ids, int B, int T, const flo
             rc = gru16_launch(gp, ndir, st);
             if (rc != TT_OK)
                 return rc;
-        } else if (H <= 256)
-            hipLaunchKernelGGL(gru_seq_kernel<8>, dim3((B + ENC_RB - 1) / ENC_RB, ndir), dim3(H / 32 * 64), lds, st, gp);
-        else
-            hipLaunchKernelGGL(gru_seq_kernel<16>, dim3((B + ENC_RB - 1) / ENC_RB, ndir), dim3(H / 32 * 64), lds, st, gp);
+        } else {
+            rc = rnn_type == CELL_LSTM ? launch_seq<CELL_LSTM>(gp, B, H, ndir, lds, st)
+                                       : (rnn_type == CELL_RNN ? launch_seq<CELL_RNN>(gp, B, H, ndir, lds, st)
+                                                               : launch_seq<CELL_GRU>(gp, B, H, ndir, lds, st));
+            if (rc != TT_OK)
+                return rc;
+        }
         TT_LAUNCH_CHECK();
         if (drop && !last) { // nn.GRU's dropout sits on the outputs of every layer but the last
             hipLaunchKernelGGL(dropout_apply_kernel, dim3(B), dim3(256), 0, st, (const float *)xout,

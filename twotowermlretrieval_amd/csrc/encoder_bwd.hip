@@ -21,6 +21,11 @@ namespace {
 
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
+__device__ __forceinline__ float fast_tanh_b(float x) // the forward's tanh (v_exp / v_rcp), so tanh(c_t) is the value h_t used
+{
+    return 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.8853900817779268f * x)) - 1.0f;
+}
+
 // d_hid = backward of y = hid / max(|hid|, 1e-12) (or identity)
 __global__ __launch_bounds__(256) void head_bwd_kernel(const float *__restrict__ hid, const float *__restrict__ d_out,
                                                        int H, int normalize, float *__restrict__ d_hid)
@@ -88,11 +93,11 @@ __global__ __launch_bounds__(256) void prevmap_kernel(const int32_t *__restrict_
     }
 }
 
-// wtp[((w*2 + ct)*(3H/16) + c)*256 + lane*4 + e] = W_hh[16c + 4(lane>>4) + e][32w + 16ct + (lane&15)]
-__global__ __launch_bounds__(256) void pack_whh_t_kernel(const float *__restrict__ W, int H, float *__restrict__ wtp)
+// wtp[((w*2 + ct)*(GH/16) + c)*256 + lane*4 + e] = W_hh[16c + 4(lane>>4) + e][32w + 16ct + (lane&15)],  GH = ng*H rows
+__global__ __launch_bounds__(256) void pack_whh_t_kernel(const float *__restrict__ W, int H, int ng, float *__restrict__ wtp)
 {
-    const int n = 3 * H * H / 4;
-    const int nc = 3 * H / 16;
+    const int n = ng * H * H / 4;
+    const int nc = ng * H / 16;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
         const int lane = i & 63;
         int r = i >> 6;
@@ -111,12 +116,16 @@ __global__ __launch_bounds__(256) void pack_whh_t_kernel(const float *__restrict
 
 // (GruBwdDir / GruBwdParams: encoder.h)
 
-template <int MAXW>
+// CELL_GRU: dGh = [dr_pre, dz_pre, dn_pre r], dh_{t-1} = dh z + dGh W_hh.   CELL_LSTM: dG = [di_pre, df_pre, dg_pre,
+// do_pre] (the same for the input and the hidden side), dh_{t-1} = dG W_hh, dc carried in registers.   CELL_RNN:
+// dG = dh (1 - h'^2), dh_{t-1} = dG W_hh.
+template <int MAXW, int CELL>
 __global__ __launch_bounds__(MAXW * 64) void gru_bwd_seq_kernel(GruBwdParams p)
 {
-    extern __shared__ __attribute__((aligned(16))) float gt[]; // [16][3H+4]
+    constexpr int NG = CELL == CELL_LSTM ? 4 : (CELL == CELL_RNN ? 1 : 3);
+    extern __shared__ __attribute__((aligned(16))) float gt[]; // [16][NG*H+4]
     const GruBwdDir d = p.dir[blockIdx.y];
-    const int H = p.H, H3 = 3 * H, LDG = 3 * H + 4, nc = H3 / 16;
+    const int H = p.H, HG = NG * H, LDG = NG * H + 4, nc = HG / 16;
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 15, kq = lane >> 4;
@@ -134,6 +143,7 @@ __global__ __launch_bounds__(MAXW * 64) void gru_bwd_seq_kernel(GruBwdParams p)
     steps = max(steps, __shfl_xor(steps, 16));
     steps = max(steps, __shfl_xor(steps, 32));
     float dh[2][4];
+    float dc[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}}; // LSTM: gradient w.r.t. the cell state
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct) {
         unit[ct] = 32 * w + 16 * ct + j;
@@ -143,10 +153,11 @@ __global__ __launch_bounds__(MAXW * 64) void gru_bwd_seq_kernel(GruBwdParams p)
     }
     const float *wbase = d.wtp + (size_t)w * 2 * nc * 256 + lane * 4;
 
-    // The stash of a step (gates r,z,n,ghn, h_{t-1}, upstream d_seq) is loaded one step AHEAD, so the global
-    // latency hides under the previous step's MFMA loop instead of sitting on the serial path of every step.
+    // The stash of a step is loaded one step AHEAD, so the global latency hides under the previous step's MFMA loop
+    // instead of sitting on the serial path of every step.  GRU: r,z,n,ghn,h_{t-1}.  LSTM: i,f,g,o in r,z,n,ghn,
+    // c_{t-1} in hp, c_t in cn.  RNN: h_t in r.
     struct Stash {
-        float r[2][4], z[2][4], n[2][4], ghn[2][4], hp[2][4], dsv[2][4];
+        float r[2][4], z[2][4], n[2][4], ghn[2][4], hp[2][4], cn[2][4], dsv[2][4];
     };
     auto load_stash = [&](int s, Stash &st) {
 #pragma unroll
@@ -158,15 +169,26 @@ __global__ __launch_bounds__(MAXW * 64) void gru_bwd_seq_kernel(GruBwdParams p)
 #pragma unroll
             for (int ct = 0; ct < 2; ++ct) {
                 const int u = unit[ct];
-                st.r[ct][e] = st.z[ct][e] = st.n[ct][e] = st.ghn[ct][e] = st.hp[ct][e] = st.dsv[ct][e] = 0.0f;
+                st.r[ct][e] = st.z[ct][e] = st.n[ct][e] = st.ghn[ct][e] = st.hp[ct][e] = st.cn[ct][e] = st.dsv[ct][e] = 0.0f;
                 if (a) {
-                    const float *gs = d.gates + tok * 4 * H + u;
-                    st.r[ct][e] = gs[0];
-                    st.z[ct][e] = gs[H];
-                    st.n[ct][e] = gs[2 * H];
-                    st.ghn[ct][e] = gs[3 * H];
-                    if (s > 0)
-                        st.hp[ct][e] = d.hseq[ptok * p.ld + d.col0 + u];
+                    if constexpr (CELL != CELL_RNN) {
+                        const float *gs = d.gates + tok * 4 * H + u;
+                        st.r[ct][e] = gs[0];
+                        st.z[ct][e] = gs[H];
+                        st.n[ct][e] = gs[2 * H];
+                        st.ghn[ct][e] = gs[3 * H];
+                    } else {
+                        st.r[ct][e] = d.hseq[tok * p.ld + d.col0 + u];
+                    }
+                    if constexpr (CELL == CELL_GRU) {
+                        if (s > 0)
+                            st.hp[ct][e] = d.hseq[ptok * p.ld + d.col0 + u];
+                    }
+                    if constexpr (CELL == CELL_LSTM) {
+                        st.cn[ct][e] = d.cseq[tok * H + u];
+                        if (s > 0)
+                            st.hp[ct][e] = d.cseq[ptok * H + u];
+                    }
                     if (d.d_seq)
                         st.dsv[ct][e] = d.d_seq[tok * p.ld + d.col0 + u];
                 }
@@ -188,30 +210,54 @@ __global__ __launch_bounds__(MAXW * 64) void gru_bwd_seq_kernel(GruBwdParams p)
 #pragma unroll
             for (int ct = 0; ct < 2; ++ct) {
                 const int u = unit[ct];
-                float dr_pre = 0.0f, dz_pre = 0.0f, dghn_v = 0.0f;
+                float g0 = 0.0f, g1 = 0.0f, g2 = 0.0f, g3 = 0.0f; // this lane's elements of dGh
                 direct[ct][e] = 0.0f;
                 if (act[e]) {
-                    const float r = cur_st.r[ct][e], z = cur_st.z[ct][e], n = cur_st.n[ct][e], ghn = cur_st.ghn[ct][e];
-                    const float hp = cur_st.hp[ct][e];
                     float dsv = cur_st.dsv[ct][e];
                     if (d.d_seq && p.drop_p > 0.0f)
                         dsv *= tt_dropout_scale(p.drop_seed, p.drop_layer,
                                                 ((uint64_t)rid_e[e] * p.T + t) * p.ld + d.col0 + u, p.drop_p);
                     const float dhv = dh[ct][e] + dsv;
-                    const float dn_pre = dhv * (1.0f - z) * (1.0f - n * n);
-                    dz_pre = dhv * (hp - n) * z * (1.0f - z);
-                    dr_pre = dn_pre * ghn * r * (1.0f - r);
-                    dghn_v = dn_pre * r;
-                    direct[ct][e] = dhv * z;
-                    float *go = d.dgi + tok * H3 + u;
-                    go[0] = dr_pre;
-                    go[H] = dz_pre;
-                    go[2 * H] = dn_pre;
-                    d.dghn[tok * H + u] = dghn_v;
+                    float *go = d.dgi + tok * HG + u;
+                    if constexpr (CELL == CELL_GRU) {
+                        const float r = cur_st.r[ct][e], z = cur_st.z[ct][e], n = cur_st.n[ct][e], ghn = cur_st.ghn[ct][e];
+                        const float hp = cur_st.hp[ct][e];
+                        const float dn_pre = dhv * (1.0f - z) * (1.0f - n * n);
+                        g1 = dhv * (hp - n) * z * (1.0f - z);
+                        g0 = dn_pre * ghn * r * (1.0f - r);
+                        g2 = dn_pre * r;
+                        direct[ct][e] = dhv * z;
+                        go[0] = g0;
+                        go[H] = g1;
+                        go[2 * H] = dn_pre;
+                        d.dghn[tok * H + u] = g2;
+                    } else if constexpr (CELL == CELL_LSTM) {
+                        const float ig = cur_st.r[ct][e], fg = cur_st.z[ct][e], gg = cur_st.n[ct][e], og = cur_st.ghn[ct][e];
+                        const float cp = cur_st.hp[ct][e];
+                        const float tc = fast_tanh_b(cur_st.cn[ct][e]);
+                        const float dct = dc[ct][e] + dhv * og * (1.0f - tc * tc);
+                        g0 = dct * gg * ig * (1.0f - ig);
+                        g1 = dct * cp * fg * (1.0f - fg);
+                        g2 = dct * ig * (1.0f - gg * gg);
+                        g3 = dhv * tc * og * (1.0f - og);
+                        dc[ct][e] = dct * fg;
+                        go[0] = g0;
+                        go[H] = g1;
+                        go[2 * H] = g2;
+                        go[3 * H] = g3;
+                    } else {
+                        const float hn = cur_st.r[ct][e];
+                        g0 = dhv * (1.0f - hn * hn);
+                        go[0] = g0;
+                    }
                 }
-                grow[u] = dr_pre;
-                grow[H + u] = dz_pre;
-                grow[2 * H + u] = dghn_v;
+                grow[u] = g0;
+                if constexpr (NG > 1)
+                    grow[H + u] = g1;
+                if constexpr (NG > 2)
+                    grow[2 * H + u] = g2;
+                if constexpr (NG > 3)
+                    grow[3 * H + u] = g3;
             }
         }
         load_stash(s - 1, next_st); // in flight during the MFMA loop below
@@ -237,6 +283,21 @@ __global__ __launch_bounds__(MAXW * 64) void gru_bwd_seq_kernel(GruBwdParams p)
         cur_st = next_st;
         __syncthreads();
     }
+}
+
+template <int CELL>
+int launch_bwd_seq(const GruBwdParams &bp, int B, int H, int ndir, size_t lds, hipStream_t st)
+{
+    if (lds > 48 * 1024) {
+        TT_HIP_CHECK(hipFuncSetAttribute((const void *)gru_bwd_seq_kernel<8, CELL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        TT_HIP_CHECK(hipFuncSetAttribute((const void *)gru_bwd_seq_kernel<16, CELL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
+    if (H <= 256)
+        hipLaunchKernelGGL((gru_bwd_seq_kernel<8, CELL>), dim3((B + ENC_RB - 1) / ENC_RB, ndir), dim3(H / 32 * 64), lds, st, bp);
+    else
+        hipLaunchKernelGGL((gru_bwd_seq_kernel<16, CELL>), dim3((B + ENC_RB - 1) / ENC_RB, ndir), dim3(H / 32 * 64), lds, st, bp);
+    TT_LAUNCH_CHECK();
+    return TT_OK;
 }
 
 // g_table[ids[m]][c] += dx[m][c] for the valid tokens m with ids[m] != 0 (float atomics at the memory side)
@@ -294,7 +355,7 @@ int gemm_tn(const float *A, int64_t lda, int Mo, const float *Bsrc, int64_t ldb,
 } // namespace
 
 TT_EXPORT int tt_encoder_backward_f32(const int64_t *ids, int B, int T, const float *table, int64_t V, int E, int H,
-                                      int num_layers, int bidirectional, const float *const *weights,
+                                      int num_layers, int bidirectional, int rnn_type, const float *const *weights,
                                       const float *proj_w, const float *proj_b, int normalize, float dropout_p,
                                       uint64_t dropout_seed, const float *d_out, float *const *grads,
                                       float *g_proj_w, float *g_proj_b, float *g_table, void *workspace,
@@ -308,13 +369,15 @@ TT_EXPORT int tt_encoder_backward_f32(const int64_t *ids, int B, int T, const fl
         return rc;
     if (!table || !weights || !d_out || !grads || (bidirectional && (!proj_w || !g_proj_w || !g_proj_b)))
         return tt_fail(TT_ERR_BAD_SHAPE, "tt_encoder_backward_f32: null pointer");
+    if (rnn_type < CELL_GRU || rnn_type > CELL_RNN)
+        return tt_fail(TT_ERR_UNSUPPORTED, "tt_encoder_backward_f32: rnn_type=%d (0 GRU, 1 LSTM, 2 RNN)", rnn_type);
     const bool drop = dropout_p > 0.0f && num_layers > 1;
-    const EncLayout lo = enc_layout(B, T, E, H, num_layers, bidirectional, g_table ? 2 : 1, drop);
+    const EncLayout lo = enc_layout(B, T, E, H, num_layers, bidirectional, g_table ? 2 : 1, drop, rnn_type);
     if (!workspace || workspace_bytes < lo.total || ((uintptr_t)workspace & 255))
         return tt_fail(TT_ERR_WORKSPACE, "tt_encoder_backward_f32: workspace %zu < %zu bytes: pass the buffer the "
                                          "forward call (train=%d) filled", workspace_bytes, lo.total, g_table ? 2 : 1);
     char *ws = (char *)workspace;
-    const int ndir = lo.ndir, H3 = 3 * H;
+    const int ndir = lo.ndir, NG = lo.ng, H3 = NG * H; // H3: gate rows (3H for the GRU)
     const int32_t *len = (const int32_t *)(ws + lo.len), *tok_off = (const int32_t *)(ws + lo.tok_off);
     const int32_t *perm = (const int32_t *)(ws + lo.perm), *idsp = (const int32_t *)(ws + lo.ids);
     const int *m_valid = tok_off + B;
@@ -374,7 +437,7 @@ TT_EXPORT int tt_encoder_backward_f32(const int64_t *ids, int B, int T, const fl
 
     const size_t lds = sizeof(float) * ENC_RB * (H3 + 4);
     static const bool force_f32 = [] { const char *e = getenv("TT_GRU_F32"); return e && e[0] == '1'; }();
-    const bool use16 = gru16_supported(H) && !force_f32; // the reverse-time recurrence on the f16 pipes too (gru16.hip)
+    const bool use16 = rnn_type == CELL_GRU && gru16_supported(H) && !force_f32; // (gru16.hip)
     for (int l = num_layers - 1; l >= 0; --l) {
         const int I = l == 0 ? E : ndir * H;
         const bool top = l == num_layers - 1;
@@ -400,10 +463,11 @@ TT_EXPORT int tt_encoder_backward_f32(const int64_t *ids, int B, int T, const fl
                 if (rc != TT_OK)
                     return rc;
             } else {
-                hipLaunchKernelGGL(pack_whh_t_kernel, dim3(96), dim3(256), 0, st, w[1], H, (float *)(ws + lo.wtp[d]));
+                hipLaunchKernelGGL(pack_whh_t_kernel, dim3(96), dim3(256), 0, st, w[1], H, NG, (float *)(ws + lo.wtp[d]));
             }
             bp.dir[d].wmax = wmax;
             bp.dir[d].gates = (const float *)(ws + lo.gates[l][d]);
+            bp.dir[d].cseq = rnn_type == CELL_LSTM ? (const float *)(ws + lo.cseq[l][d]) : nullptr;
             bp.dir[d].hseq = hseq;
             bp.dir[d].d_seq = d_seq;
             bp.dir[d].d_hfin = top ? d_hfin + (size_t)d * B * H : nullptr;
@@ -415,33 +479,34 @@ TT_EXPORT int tt_encoder_backward_f32(const int64_t *ids, int B, int T, const fl
         }
         if (ndir == 1)
             bp.dir[1] = bp.dir[0];
-        if (lds > 48 * 1024) {
-            TT_HIP_CHECK(hipFuncSetAttribute((const void *)gru_bwd_seq_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            TT_HIP_CHECK(hipFuncSetAttribute((const void *)gru_bwd_seq_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        }
         if (use16) {
             rc = gru16_bwd_launch(bp, ndir, st);
-            if (rc != TT_OK)
-                return rc;
-        } else if (H <= 256)
-            hipLaunchKernelGGL(gru_bwd_seq_kernel<8>, dim3((B + ENC_RB - 1) / ENC_RB, ndir), dim3(H / 32 * 64), lds, st, bp);
-        else
-            hipLaunchKernelGGL(gru_bwd_seq_kernel<16>, dim3((B + ENC_RB - 1) / ENC_RB, ndir), dim3(H / 32 * 64), lds, st, bp);
-        TT_LAUNCH_CHECK();
+        } else {
+            rc = rnn_type == CELL_LSTM ? launch_bwd_seq<CELL_LSTM>(bp, B, H, ndir, lds, st)
+                                       : (rnn_type == CELL_RNN ? launch_bwd_seq<CELL_RNN>(bp, B, H, ndir, lds, st)
+                                                               : launch_bwd_seq<CELL_GRU>(bp, B, H, ndir, lds, st));
+        }
+        if (rc != TT_OK)
+            return rc;
 
         for (int d = 0; d < ndir; ++d) {
             const float *const *w = weights + ((size_t)l * ndir + d) * 4;
             float *const *g = grads + ((size_t)l * ndir + d) * 4;
             const float *dgi = (const float *)(ws + lo.dgi[d]);
             const float *dghn = (const float *)(ws + lo.dghn[d]);
-            // biases: b_ih <- colsum(dGi); b_hh <- [colsum(dGi)[0:2H], colsum(dghn)]
+            // biases: b_ih <- colsum(dGi); b_hh <- [colsum(dGi)[0:2H], colsum(dghn)] (GRU: the n gate's hidden-side
+            // pre-activation is scaled by r) or the same sums (LSTM / RNN: one pre-activation per gate)
             rc = colsum(dgi, H3, H3, MT, m_valid, slabs, g[2], st);
             if (rc != TT_OK)
                 return rc;
-            TT_HIP_CHECK(hipMemcpyAsync(g[3], g[2], sizeof(float) * 2 * H, hipMemcpyDeviceToDevice, st));
-            rc = colsum(dghn, H, H, MT, m_valid, slabs, g[3] + 2 * H, st);
-            if (rc != TT_OK)
-                return rc;
+            if (rnn_type == CELL_GRU) {
+                TT_HIP_CHECK(hipMemcpyAsync(g[3], g[2], sizeof(float) * 2 * H, hipMemcpyDeviceToDevice, st));
+                rc = colsum(dghn, H, H, MT, m_valid, slabs, g[3] + 2 * H, st);
+                if (rc != TT_OK)
+                    return rc;
+            } else {
+                TT_HIP_CHECK(hipMemcpyAsync(g[3], g[2], sizeof(float) * H3, hipMemcpyDeviceToDevice, st));
+            }
             // W_ih <- dGi^T X   (X = gathered table rows for layer 0, the layer below's output above)
             if (l == 0)
                 rc = gemm_tn(dgi, H3, H3, table, E, idsp, E, MT, m_valid, slabs, g[0], st);
@@ -452,10 +517,14 @@ TT_EXPORT int tt_encoder_backward_f32(const int64_t *ids, int B, int T, const fl
                 return rc;
             // W_hh <- dGh^T H_prev, H_prev rows through the previous-token map into this layer's own output
             const int32_t *pm = (const int32_t *)(ws + lo.prevmap[d]);
-            rc = gemm_tn(dgi, H3, 2 * H, hseq + (size_t)d * H, ndir * H, pm, H, MT, m_valid, slabs, g[1], st);
-            if (rc != TT_OK)
-                return rc;
-            rc = gemm_tn(dghn, H, H, hseq + (size_t)d * H, ndir * H, pm, H, MT, m_valid, slabs, g[1] + (size_t)2 * H * H, st);
+            if (rnn_type == CELL_GRU) {
+                rc = gemm_tn(dgi, H3, 2 * H, hseq + (size_t)d * H, ndir * H, pm, H, MT, m_valid, slabs, g[1], st);
+                if (rc != TT_OK)
+                    return rc;
+                rc = gemm_tn(dghn, H, H, hseq + (size_t)d * H, ndir * H, pm, H, MT, m_valid, slabs, g[1] + (size_t)2 * H * H, st);
+            } else {
+                rc = gemm_tn(dgi, H3, H3, hseq + (size_t)d * H, ndir * H, pm, H, MT, m_valid, slabs, g[1], st);
+            }
             if (rc != TT_OK)
                 return rc;
             // gradient w.r.t. this layer's input sequence (below layer 0 only when the table is trained)

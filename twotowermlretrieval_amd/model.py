@@ -11,7 +11,7 @@ backend/main.py:104) and state_dict keys ({query,doc}_encoder.{embedding.weight,
 rnn.weight_ih_l0[_reverse], ..., projection.weight/bias}), so a model.pth written by either side
 loads in the other.  The nn.Module objects here only OWN the parameters; every forward/backward
 runs in hand-written HIP kernels (csrc/encoder*.hip, gru16.hip, train.hip).  There is no PyTorch fallback:
-CPU tensors and LSTM / vanilla-RNN towers raise.
+CPU tensors raise.  RNN_TYPE GRU, LSTM and RNN (tanh) are the three the reference's getattr(nn, ...) accepts.
 """
 from __future__ import annotations
 
@@ -32,10 +32,14 @@ def _stream(dev) -> int:
     return torch.cuda.current_stream(dev).cuda_stream
 
 
-class _GRUParams(nn.Module):
-    """Parameter container with torch.nn.GRU's names, shapes and default init (U(-1/sqrt(H), 1/sqrt(H)))."""
+_CELLS = {"GRU": (0, 3), "LSTM": (1, 4), "RNN": (2, 1)}  # RNN_TYPE -> (C-ABI rnn_type, gate rows / H)
 
-    def __init__(self, input_size: int, hidden_size: int, num_layers: int, bidirectional: bool):
+
+class _GRUParams(nn.Module):
+    """Parameter container with torch.nn.GRU's / nn.LSTM's / nn.RNN's names, shapes (gates * H rows) and default init
+    (U(-1/sqrt(H), 1/sqrt(H)))."""
+
+    def __init__(self, input_size: int, hidden_size: int, num_layers: int, bidirectional: bool, gates: int = 3):
         super().__init__()
         self.input_size, self.hidden_size = input_size, hidden_size
         self.num_layers, self.bidirectional = num_layers, bidirectional
@@ -45,8 +49,8 @@ class _GRUParams(nn.Module):
             I = input_size if layer == 0 else ndir * hidden_size
             for d in range(ndir):
                 sfx = f"_l{layer}" + ("_reverse" if d else "")
-                for name, shape in (("weight_ih", (3 * hidden_size, I)), ("weight_hh", (3 * hidden_size, hidden_size)),
-                                    ("bias_ih", (3 * hidden_size,)), ("bias_hh", (3 * hidden_size,))):
+                for name, shape in (("weight_ih", (gates * hidden_size, I)), ("weight_hh", (gates * hidden_size, hidden_size)),
+                                    ("bias_ih", (gates * hidden_size,)), ("bias_hh", (gates * hidden_size,))):
                     self.register_parameter(name + sfx, nn.Parameter(torch.empty(shape).uniform_(-k, k)))
 
     def quads(self):
@@ -136,7 +140,7 @@ class _EncoderFn(torch.autograd.Function):
 
 
 class RNNEncoder(nn.Module):
-    """GRU text encoder: embedding gather -> (stacked / bidirectional) GRU -> final hidden -> L2-normalise."""
+    """Text encoder: embedding gather -> (stacked / bidirectional) GRU | LSTM | RNN -> final hidden -> L2-normalise."""
 
     def __init__(self, vocab_size: int, embed_dim: int, hidden_dim: int,
                  pretrained_embeddings: Optional[np.ndarray] = None, rnn_type: str = "GRU", num_layers: int = 1,
@@ -148,14 +152,15 @@ class RNNEncoder(nn.Module):
             self.embedding.weight.data.copy_(torch.from_numpy(np.asarray(pretrained_embeddings)))
             self.embedding.weight.requires_grad = False
         self.rnn_type = rnn_type.upper()
-        if self.rnn_type != "GRU":
-            raise NotImplementedError(f"RNN_TYPE={rnn_type!r}: only the GRU tower has HIP kernels; there is no "
-                                      "PyTorch fallback in this package")
+        if self.rnn_type not in _CELLS:  # the reference's getattr(nn, rnn_type.upper()) accepts exactly these three
+            raise AttributeError(f"module 'torch.nn' has no attribute {self.rnn_type!r} usable as RNN_TYPE "
+                                 "(supported: GRU, LSTM, RNN)")
+        self._cell, gates = _CELLS[self.rnn_type]
         self.bidirectional = bidirectional
         self.num_layers = num_layers
         self.hidden_dim = hidden_dim
         self.dropout = float(dropout) if num_layers > 1 else 0.0
-        self.rnn = _GRUParams(embed_dim, hidden_dim, num_layers, bidirectional)
+        self.rnn = _GRUParams(embed_dim, hidden_dim, num_layers, bidirectional, gates)
         self.normalize_output = normalize_output
         self.projection = _LinearParams(hidden_dim * 2, hidden_dim) if bidirectional else None
         self.check_inputs = True  # read the device status word after each call (one 4-byte D2H sync)
@@ -191,7 +196,8 @@ class RNNEncoder(nn.Module):
         drop = int(train and dropout_p > 0.0 and self.num_layers > 1)
         # train = 2: the workspace also holds the gradient w.r.t. the gathered vectors (trainable embedding table)
         train_mode = (2 if self.embedding.weight.requires_grad else 1) if train else 0
-        need = L.tt_encoder_workspace_bytes(B, max(T, 1), E, H, self.num_layers, int(self.bidirectional), train_mode, drop)
+        need = L.tt_encoder_workspace_bytes(B, max(T, 1), E, H, self.num_layers, int(self.bidirectional), self._cell,
+                                            train_mode, drop)
         # One workspace per call, from torch's caching allocator (a cached block: microseconds).  In train mode the
         # autograd node owns it; in eval mode a per-call buffer keeps concurrent callers apart -- the reference serves
         # queries from a thread pool (frontend/main.py:103), and a buffer shared across threads or streams would be
@@ -206,8 +212,8 @@ class RNNEncoder(nn.Module):
         table = self.embedding.weight.detach()
         with torch.cuda.device(ids.device):
             _lib.check(L.tt_encoder_forward_f32(
-                ids.data_ptr(), B, T, table.data_ptr(), V, E, H, self.num_layers, int(self.bidirectional), wptr,
-                pw.data_ptr() if pw is not None else None, pb.data_ptr() if pb is not None else None,
+                ids.data_ptr(), B, T, table.data_ptr(), V, E, H, self.num_layers, int(self.bidirectional), self._cell,
+                wptr, pw.data_ptr() if pw is not None else None, pb.data_ptr() if pb is not None else None,
                 int(self.normalize_output), train_mode, float(dropout_p), int(dropout_seed), out.data_ptr(),
                 ws.data_ptr(), ws.numel(), status.data_ptr(), _stream(ids.device)))
         if self.check_inputs:
@@ -235,7 +241,7 @@ class RNNEncoder(nn.Module):
         with torch.cuda.device(ids.device):
             _lib.check(L.tt_encoder_backward_f32(
                 ids.contiguous().data_ptr(), B, T, self.embedding.weight.detach().data_ptr(), V, E, H,
-                self.num_layers, int(self.bidirectional), wptr, pw.data_ptr() if pw is not None else None,
+                self.num_layers, int(self.bidirectional), self._cell, wptr, pw.data_ptr() if pw is not None else None,
                 pb.data_ptr() if pb is not None else None, int(self.normalize_output), float(dropout_p),
                 int(dropout_seed), d_out.data_ptr(), gptr,
                 grads[nq].data_ptr() if pw is not None else None,
