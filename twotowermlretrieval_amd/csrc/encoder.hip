@@ -455,7 +455,7 @@ TT_EXPORT int tt_encoder_forward_f32(const int64_t *ids, int B, int T, const flo
     int32_t *perm = (int32_t *)(ws + lo.perm), *idsp = (int32_t *)(ws + lo.ids), *flag = (int32_t *)(ws + lo.flag);
     const int ndir = lo.ndir;
 
-    TT_HIP_CHECK(hipMemsetAsync(flag, 0, 256, st));
+    TT_RC_CHECK(tt_zero_async(flag, 256, st));
     hipLaunchKernelGGL(prep_len_kernel, dim3((B + 3) / 4), dim3(256), 0, st, ids, B, T, V, len, flag);
     hipLaunchKernelGGL(prep_scan_sort_kernel, dim3(1), dim3(1024), 0, st, len, B, T, tok_off, perm);
     hipLaunchKernelGGL(prep_pack_ids_kernel, dim3(B), dim3(256), 0, st, ids, B, T, len, tok_off, V, idsp);
@@ -481,7 +481,7 @@ TT_EXPORT int tt_encoder_forward_f32(const int64_t *ids, int B, int T, const flo
         const bool last = l == num_layers - 1;
         float *xout = (last && !train) ? nullptr : (float *)(ws + lo.x[l + 1]);
         if (train) // the all-zero row that stands for "h before the first step" in the backward GEMMs
-            TT_HIP_CHECK(hipMemsetAsync(xout + (size_t)lo.MT * ndir * H, 0, sizeof(float) * ndir * H, st));
+            TT_RC_CHECK(tt_zero_async(xout + (size_t)lo.MT * ndir * H, sizeof(float) * ndir * H, st));
         for (int d = 0; d < ndir; ++d) {
             const float *const *w = weights + ((size_t)l * ndir + d) * 4;
             SgemmParams g;
@@ -501,7 +501,22 @@ TT_EXPORT int tt_encoder_forward_f32(const int64_t *ids, int B, int T, const flo
             g.ldc = NGH;
             g.slab_stride = 0;
             g.accumulate = 0;
-            rc = tt_sgemm(g, false, false, 1, st);
+            if (!force_f32) {
+                // K1 on the f16 pipes (fp16 hi/lo split, fp32-grade; sgemm.h): W_ih is scaled by the power of two
+                // that puts its largest element in [2^13, 2^14); layer 0's A rows are embedding vectors, taken as they
+                // are (|x| < 65504), deeper layers' are hidden states in (-1, 1) (times 1/(1-p) under dropout): 2^6
+                unsigned *wih_max = (unsigned *)flag + 40 + 2 * l + d; // in the status block cleared above
+                rc = tt_absmax(w[0], (int64_t)NGH * I, wih_max, st);
+                if (rc != TT_OK)
+                    return rc;
+                g.a_absmax = nullptr;
+                g.a_exp = l == 0 ? 0 : 6;
+                g.b_absmax = wih_max;
+                g.b_exp = 0;
+                rc = tt_sgemm16_nn(g, st);
+            } else {
+                rc = tt_sgemm(g, false, false, 1, st);
+            }
             if (rc != TT_OK)
                 return rc;
             unsigned *wmax = (unsigned *)flag + 16 + 2 * l + d; // in the status block cleared above
@@ -522,7 +537,7 @@ TT_EXPORT int tt_encoder_forward_f32(const int64_t *ids, int B, int T, const flo
             gp.dir[d].cseq = nullptr;
             if (train && rnn_type == CELL_LSTM) { // c before the first step: the all-zero row at index MT
                 gp.dir[d].cseq = (float *)(ws + lo.cseq[l][d]);
-                TT_HIP_CHECK(hipMemsetAsync(gp.dir[d].cseq + (size_t)lo.MT * H, 0, sizeof(float) * H, st));
+                TT_RC_CHECK(tt_zero_async(gp.dir[d].cseq + (size_t)lo.MT * H, sizeof(float) * H, st));
             }
             // only the last layer's final hidden state is used (model.py:65-71)
             gp.dir[d].h_final = (float *)(ws + lo.hfin) + (size_t)d * B * H;
@@ -546,8 +561,7 @@ TT_EXPORT int tt_encoder_forward_f32(const int64_t *ids, int B, int T, const flo
         if (drop && !last) { // nn.GRU's dropout sits on the outputs of every layer but the last
             hipLaunchKernelGGL(dropout_apply_kernel, dim3(B), dim3(256), 0, st, (const float *)xout,
                                (float *)(ws + lo.xd[l + 1]), len, tok_off, T, ndir * H, l, dropout_p, dropout_seed);
-            TT_HIP_CHECK(hipMemsetAsync((float *)(ws + lo.xd[l + 1]) + (size_t)lo.MT * ndir * H, 0,
-                                        sizeof(float) * ndir * H, st));
+            TT_RC_CHECK(tt_zero_async((float *)(ws + lo.xd[l + 1]) + (size_t)lo.MT * ndir * H, sizeof(float) * ndir * H, st));
             TT_LAUNCH_CHECK();
         }
     }

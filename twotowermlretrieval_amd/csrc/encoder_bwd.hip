@@ -458,7 +458,7 @@ TT_EXPORT int tt_encoder_backward_f32(const int64_t *ids, int B, int T, const fl
             const float *const *w = weights + ((size_t)l * ndir + d) * 4;
             unsigned *wmax = (unsigned *)(ws + lo.flag) + 32 + 2 * l + d; // the forward's status block: slots 32.. are free
             if (use16) {
-                TT_HIP_CHECK(hipMemsetAsync(wmax, 0, sizeof(unsigned), st));
+                TT_RC_CHECK(tt_zero_async(wmax, sizeof(unsigned), st));
                 rc = gru16_pack_t(w[1], H, wmax, ws + lo.wtp[d], st);
                 if (rc != TT_OK)
                     return rc;
@@ -554,7 +554,7 @@ TT_EXPORT int tt_encoder_backward_f32(const int64_t *ids, int B, int T, const fl
     if (g_table) {
         // nn.Embedding backward (model.py:23-27 without GloVe vectors): row id accumulates the input gradients of the
         // positions that hold it; padding_idx = 0 gets none.  Dense [V,E] gradient, as torch's.
-        TT_HIP_CHECK(hipMemsetAsync(g_table, 0, sizeof(float) * (size_t)V * E, st));
+        TT_RC_CHECK(tt_zero_async(g_table, sizeof(float) * (size_t)V * E, st));
         hipLaunchKernelGGL(table_scatter_kernel, dim3(2048), dim3(256), 0, st, (const float *)(ws + lo.dx0), idsp, m_valid, MT,
                            E, g_table);
         TT_LAUNCH_CHECK();

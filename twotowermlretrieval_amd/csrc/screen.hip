@@ -1162,7 +1162,7 @@ TT_EXPORT int tt_index_build_f16(const float *D, int64_t N, int d, void *D16, fl
     if (!stats || (N > 0 && (!D || !D16)))
         return tt_fail(TT_ERR_BAD_SHAPE, "tt_index_build_f16: null pointer");
     hipStream_t st = (hipStream_t)stream;
-    TT_HIP_CHECK(hipMemsetAsync(stats, 0, 2 * sizeof(float), st));
+    TT_RC_CHECK(tt_zero_async(stats, 2 * sizeof(float), st));
     if (N == 0)
         return TT_OK;
     const int64_t want_blocks = (N + 3) / 4;
@@ -1181,7 +1181,7 @@ TT_EXPORT int tt_index_build_from_bf16(const void *D_bf16, int64_t N, int d, flo
         return tt_fail(TT_ERR_BAD_SHAPE, "tt_index_build_from_bf16: null pointer");
     hipStream_t st = (hipStream_t)stream;
     if (stats && reset_stats)
-        TT_HIP_CHECK(hipMemsetAsync(stats, 0, 2 * sizeof(float), st));
+        TT_RC_CHECK(tt_zero_async(stats, 2 * sizeof(float), st));
     if (N == 0)
         return TT_OK;
     const int64_t want_blocks = (N + 3) / 4;

@@ -24,10 +24,35 @@ struct SgemmParams {
     int64_t lda, ldb, ldc;
     int64_t slab_stride; // split-K: slice z writes C + z*slab_stride (0 when gridDim.z == 1)
     int accumulate;      // C += result (gridDim.z must be 1)
+    // tt_sgemm16 only: power-of-two operand scales applied before the fp16 hi/lo split (exact; undone on the fp32
+    // accumulator).  exponent = *_absmax ? tt_pow2_exponent(*_absmax) (largest element -> [2^13, 2^14)) : *_exp
+    const unsigned *a_absmax, *b_absmax; // device: bit pattern of max |element| (nullable)
+    int a_exp, b_exp;
 };
+
+// exponent e with max|x| 2^e in [2^13, 2^14) (0 for an all-zero or non-finite tensor)
+__host__ __device__ static inline int tt_pow2_exponent(unsigned absmax_bits)
+{
+    const int ex = (int)((absmax_bits >> 23) & 0xff);
+    if (ex == 0 || ex == 255)
+        return 0;
+    int e = 13 - (ex - 127);
+    e = e > 100 ? 100 : e;
+    e = e < -100 ? -100 : e;
+    return e;
+}
 
 // Launch: grid (ceil(N/128), ceil(M/128), splits), block 256.
 int tt_sgemm(const SgemmParams &p, bool a_t, bool b_t, int splits, hipStream_t st);
+
+// The same product (A_T = B_T = false only: C = A * B^T, A rows optionally gathered through a_map) on the f16 matrix
+// pipes: both operands are split into fp16 hi + lo parts while they are staged into LDS and the product is taken as
+// hi*hi + lo*hi + hi*lo on v_mfma_f32_32x32x16_f16 with fp32 accumulation -- every product good to ~3 * 2^-24
+// relative, i.e. one fp32 rounding, at 3/16 of the fp32-MFMA time (csrc/gru16.hip has the error argument).
+int tt_sgemm16_nn(const SgemmParams &p, hipStream_t st);
+
+// bit pattern of max |x| over n floats -> *out (atomicMax; the caller zeroes *out on the stream first)
+int tt_absmax(const float *x, int64_t n, unsigned *out, hipStream_t st);
 
 // out[i] (+)= sum_z slabs[z][i], fixed order (deterministic split-K reduction)
 int tt_slab_reduce(const float *slabs, int nslab, int64_t n, float *out, int accumulate, hipStream_t st);

@@ -150,6 +150,159 @@ __global__ __launch_bounds__(256) void sgemm_kernel(SgemmParams p)
         }
 }
 
+// ------------------------------------------------------------------ C = A * B^T on the f16 pipes, fp32-grade
+// 128 x 128 x 32 tiles, 4 waves, 2 x 2 accumulators of 32 x 32 per wave (v_mfma_f32_32x32x16_f16).  The fp32 operands
+// are fetched as in sgemm_kernel (16 consecutive k per thread, next tile in flight under the MFMAs), scaled by their
+// power of two, split into fp16 hi / lo and committed to FOUR LDS images (row stride 40 halves = 80 B: the 16-byte
+// fragment reads of 16 different rows fall into 16 different bank groups).
+typedef _Float16 h8v __attribute__((ext_vector_type(8)));
+constexpr int BK16 = 32, LDT16 = 40;
+
+__device__ __forceinline__ void fetch16(f32x4 (&v)[4], const float *__restrict__ src, int64_t ld,
+                                        const int32_t *__restrict__ map, int row0, int rows_eff, int k0, int k_end, int tid)
+{
+    const int r = tid >> 1, kc = (tid & 1) * 16;
+    const int row = row0 + r;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        v[q] = (f32x4){0, 0, 0, 0};
+    if (row < rows_eff) {
+        const int64_t srow = map ? (int64_t)map[row] : (int64_t)row;
+        const float *p = src + srow * ld + k0 + kc;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (k0 + kc + 4 * q < k_end)
+                v[q] = *(const f32x4 *)(p + 4 * q);
+    }
+}
+
+__device__ __forceinline__ void commit16(_Float16 *__restrict__ hi_img, _Float16 *__restrict__ lo_img, const f32x4 (&v)[4],
+                                         float scale, int tid)
+{
+    const int r = tid >> 1, kc = (tid & 1) * 16;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        h8v hi, lo;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float x = v[2 * half + (e >> 2)][e & 3] * scale;
+            const _Float16 hv = (_Float16)x;
+            hi[e] = hv;
+            lo[e] = (_Float16)(x - (float)hv);
+        }
+        *(h8v *)(hi_img + r * LDT16 + kc + 8 * half) = hi;
+        *(h8v *)(lo_img + r * LDT16 + kc + 8 * half) = lo;
+    }
+}
+
+__global__ __launch_bounds__(256) void sgemm16_nn_kernel(SgemmParams p)
+{
+    __shared__ __attribute__((aligned(16))) _Float16 img[4][BM * LDT16]; // A hi, A lo, B hi, B lo
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int M = p.m_dyn ? min(p.M, *p.m_dyn) : p.M;
+    const int K = p.k_dyn ? min(p.K, *p.k_dyn) : p.K;
+    int bx = blockIdx.x, by = blockIdx.y; // the n-blocks of an m-block on one XCD (see sgemm_kernel)
+    {
+        const int nbx = gridDim.x, nby = gridDim.y;
+        const int L = by * nbx + bx, xcd = L & 7, slot = L >> 3;
+        const int mb = (slot / nbx) * 8 + xcd, nb = slot % nbx;
+        const int full = (nby / 8) * 8;
+        if (by < full && mb < full) {
+            by = mb;
+            bx = nb;
+        }
+    }
+    const int m0 = by * BM, n0 = bx * BN;
+    if (m0 >= M)
+        return;
+    const int ea = p.a_absmax ? tt_pow2_exponent(*p.a_absmax) : p.a_exp;
+    const int eb = p.b_absmax ? tt_pow2_exponent(*p.b_absmax) : p.b_exp;
+    const float sa = ldexpf(1.0f, ea), sb = ldexpf(1.0f, eb), down = ldexpf(1.0f, -(ea + eb));
+
+    const int wr = wave >> 1, wc = wave & 1, i = lane & 31, h = lane >> 5;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                acc[a][b][r] = 0.0f;
+
+    f32x4 ra[4], rb[4];
+    fetch16(ra, p.A, p.lda, p.a_map, m0, M, 0, K, tid);
+    fetch16(rb, p.B, p.ldb, p.b_map, n0, p.N, 0, K, tid);
+    for (int k0 = 0; k0 < K; k0 += BK16) {
+        commit16(img[0], img[1], ra, sa, tid);
+        commit16(img[2], img[3], rb, sb, tid);
+        __syncthreads();
+        if (k0 + BK16 < K) { // next tile's global loads fly under this tile's MFMAs
+            fetch16(ra, p.A, p.lda, p.a_map, m0, M, k0 + BK16, K, tid);
+            fetch16(rb, p.B, p.ldb, p.b_map, n0, p.N, k0 + BK16, K, tid);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            h8v ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int ao = (64 * wr + 32 * t + i) * LDT16 + 16 * ks + 8 * h;
+                const int bo = (64 * wc + 32 * t + i) * LDT16 + 16 * ks + 8 * h;
+                ah[t] = *(const h8v *)(img[0] + ao);
+                al[t] = *(const h8v *)(img[1] + ao);
+                bh[t] = *(const h8v *)(img[2] + bo);
+                bl[t] = *(const h8v *)(img[3] + bo);
+            }
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bl[nt], acc[mt][nt], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const int col = n0 + 64 * wc + 32 * nt + i;
+            if (col >= p.N)
+                continue;
+            const float bv = p.bias ? p.bias[col] : 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + 64 * wr + 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (row < M) {
+                    float *dst = p.C + (size_t)row * p.ldc + col;
+                    const float v = acc[mt][nt][r] * down + bv;
+                    *dst = p.accumulate ? *dst + v : v;
+                }
+            }
+        }
+}
+
+__global__ __launch_bounds__(256) void absmax_kernel(const float *__restrict__ x, int64_t n, unsigned *__restrict__ out)
+{
+    float m = 0.0f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        m = fmaxf(m, fabsf(x[i]));
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1)
+        m = fmaxf(m, __shfl_xor(m, off));
+    if ((threadIdx.x & 63) == 0)
+        atomicMax(out, __float_as_uint(m)); // non-negative floats order like their bit patterns
+}
+
 __global__ void slab_reduce_kernel(const float *__restrict__ slabs, int nslab, int64_t n, float *out, int accumulate)
 {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -182,6 +335,28 @@ int tt_sgemm(const SgemmParams &p, bool a_t, bool b_t, int splits, hipStream_t s
         hipLaunchKernelGGL((sgemm_kernel<true, false>), grid, dim3(256), 0, st, p);
     else
         hipLaunchKernelGGL((sgemm_kernel<true, true>), grid, dim3(256), 0, st, p);
+    TT_LAUNCH_CHECK();
+    return TT_OK;
+}
+
+int tt_sgemm16_nn(const SgemmParams &p, hipStream_t st)
+{
+    if (p.M <= 0 || p.N <= 0 || p.K <= 0)
+        return TT_OK;
+    if ((p.K & 3) || (p.lda & 3) || (p.ldb & 3))
+        return tt_fail(TT_ERR_UNSUPPORTED, "tt_sgemm16_nn: K and the leading dimensions must be multiples of 4 (K=%d)", p.K);
+    dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM, 1);
+    hipLaunchKernelGGL(sgemm16_nn_kernel, grid, dim3(256), 0, st, p);
+    TT_LAUNCH_CHECK();
+    return TT_OK;
+}
+
+int tt_absmax(const float *x, int64_t n, unsigned *out, hipStream_t st)
+{
+    if (n <= 0)
+        return TT_OK;
+    const int64_t want = (n + 255) / 256;
+    hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)(want > 256 ? 256 : want)), dim3(256), 0, st, x, n, out);
     TT_LAUNCH_CHECK();
     return TT_OK;
 }

@@ -21,9 +21,23 @@ int tt_fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3))
 
 #define TT_LAUNCH_CHECK() TT_HIP_CHECK(hipGetLastError())
 
+#define TT_RC_CHECK(expr)       \
+    do {                        \
+        const int rc_ = (expr); \
+        if (rc_ != TT_OK)       \
+            return rc_;         \
+    } while (0)
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 static inline size_t tt_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// Zero `bytes` bytes (multiple of 4, 4-byte aligned) at p with a KERNEL.  Never hipMemsetAsync on a path a caller may
+// capture into a HIP graph: on ROCm 7.2 a captured memset node of a larger graph fills with garbage from the second
+// replay on (a repeating 16-byte pattern that looks like two kernel-argument pointers: the node's pattern staging is
+// recycled) -- observed in torch.cuda.graph captures of the encoder forward and of a screened search
+// (tools/experiments/encoder_graph_flags.py; small stand-alone graphs do not show it: memset_graph.hip).
+int tt_zero_async(void *p, size_t bytes, hipStream_t st);
 
 #define TT_WAVE 64

@@ -34,3 +34,34 @@ TT_EXPORT int tt_event_elapsed_ms(void *start, void *stop, float *ms) /* blocks 
     TT_HIP_CHECK(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
     return TT_OK;
 }
+
+namespace {
+__global__ __launch_bounds__(256) void zero_kernel(unsigned *__restrict__ p, size_t n_words)
+{
+    const size_t stride = (size_t)gridDim.x * 256;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if ((((uintptr_t)p) & 15) == 0) { // 16-byte stores over the aligned body
+        uint4 *q = (uint4 *)p;
+        const size_t n4 = n_words / 4;
+        for (size_t k = i; k < n4; k += stride)
+            q[k] = make_uint4(0u, 0u, 0u, 0u);
+        for (size_t k = n4 * 4 + i; k < n_words; k += stride)
+            p[k] = 0u;
+    } else {
+        for (; i < n_words; i += stride)
+            p[i] = 0u;
+    }
+}
+} // namespace
+
+int tt_zero_async(void *p, size_t bytes, hipStream_t st)
+{
+    if (bytes == 0)
+        return TT_OK;
+    if (!p || (bytes & 3) || ((uintptr_t)p & 3))
+        return tt_fail(TT_ERR_BAD_SHAPE, "tt_zero_async: %zu bytes at %p (need 4-byte alignment)", bytes, p);
+    const size_t words = bytes / 4, want = (words / 4 + 255) / 256 + 1;
+    hipLaunchKernelGGL(zero_kernel, dim3((unsigned)(want > 4096 ? 4096 : want)), dim3(256), 0, st, (unsigned *)p, words);
+    TT_LAUNCH_CHECK();
+    return TT_OK;
+}
