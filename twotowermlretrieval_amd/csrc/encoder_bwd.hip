@@ -65,20 +65,43 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float *__restrict__
     }
 }
 
-// column sums of X[m][n], m < *m_dyn, split over gridDim.y row slices -> slabs[y][n]
+// column sums of X[m][n], m < *m_dyn, split over gridDim.y row slices -> slabs[y][n]; optionally the bit pattern of
+// max |X| over the same elements -> *absmax (atomicMax; zeroed by the caller): the scale of the f16-split GEMMs
+// that consume X next, for the price of this pass
 __global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ X, int64_t ld, int N, int M,
-                                                     const int *__restrict__ m_dyn, float *__restrict__ slabs)
+                                                     const int *__restrict__ m_dyn, float *__restrict__ slabs,
+                                                     unsigned *__restrict__ absmax)
 {
     const int Me = m_dyn ? min(M, *m_dyn) : M;
     const int n = blockIdx.x * 256 + threadIdx.x;
     const int per = (Me + gridDim.y - 1) / gridDim.y;
     const int m0 = blockIdx.y * per, m1 = min(m0 + per, Me);
-    if (n >= N)
-        return;
-    float s = 0.0f;
-    for (int m = m0; m < m1; ++m)
-        s += X[(size_t)m * ld + n];
-    slabs[(size_t)blockIdx.y * N + n] = s;
+    float s = 0.0f, mx = 0.0f;
+    if (n < N) {
+        int m = m0;
+        for (; m + 4 <= m1; m += 4) { // four loads in flight; the sum keeps its row order
+            const float a = X[(size_t)m * ld + n], b = X[(size_t)(m + 1) * ld + n];
+            const float c = X[(size_t)(m + 2) * ld + n], d = X[(size_t)(m + 3) * ld + n];
+            s += a;
+            s += b;
+            s += c;
+            s += d;
+            mx = fmaxf(fmaxf(mx, fmaxf(fabsf(a), fabsf(b))), fmaxf(fabsf(c), fabsf(d)));
+        }
+        for (; m < m1; ++m) {
+            const float a = X[(size_t)m * ld + n];
+            s += a;
+            mx = fmaxf(mx, fabsf(a));
+        }
+        slabs[(size_t)blockIdx.y * N + n] = s;
+    }
+    if (absmax) {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1)
+            mx = fmaxf(mx, __shfl_xor(mx, off));
+        if ((threadIdx.x & 63) == 0 && mx > 0.0f)
+            atomicMax(absmax, __float_as_uint(mx));
+    }
 }
 
 __global__ __launch_bounds__(256) void prevmap_kernel(const int32_t *__restrict__ len, const int32_t *__restrict__ tok_off,
@@ -318,16 +341,21 @@ __global__ __launch_bounds__(256) void table_scatter_kernel(const float *__restr
 
 constexpr int COLSUM_SLICES = 256; // N <= 3H <= 1536 columns: 256 x N floats fit the split-K slab buffer
 
-int colsum(const float *X, int64_t ld, int N, int M, const int *m_dyn, float *slabs, float *out, hipStream_t st)
+int colsum(const float *X, int64_t ld, int N, int M, const int *m_dyn, float *slabs, float *out, hipStream_t st,
+           unsigned *absmax = nullptr)
 {
-    hipLaunchKernelGGL(colsum_kernel, dim3((N + 255) / 256, COLSUM_SLICES), dim3(256), 0, st, X, ld, N, M, m_dyn, slabs);
+    hipLaunchKernelGGL(colsum_kernel, dim3((N + 255) / 256, COLSUM_SLICES), dim3(256), 0, st, X, ld, N, M, m_dyn, slabs,
+                       absmax);
     TT_LAUNCH_CHECK();
     return tt_slab_reduce(slabs, COLSUM_SLICES, N, out, 0, st);
 }
 
-// C[Mo][No] = A[:, a0:a0+Mo]^T * Bsrc (both summed over tokens), split-K + deterministic reduce
+// C[Mo][No] = A[:, a0:a0+Mo]^T * Bsrc (both summed over tokens), split-K + deterministic reduce.
+// a_absmax != nullptr: on the f16 pipes (fp16 hi/lo split of both operands, sgemm.h): A = gradients, scaled by the
+// power of two that *a_absmax (max |A|, from the colsum pass over the same matrix) implies; B scaled by 2^b_exp.
 int gemm_tn(const float *A, int64_t lda, int Mo, const float *Bsrc, int64_t ldb, const int32_t *b_map, int No,
-            int Ktok, const int *k_dyn, float *slabs, float *out, hipStream_t st)
+            int Ktok, const int *k_dyn, float *slabs, float *out, hipStream_t st, const unsigned *a_absmax = nullptr,
+            int b_exp = 0)
 {
     SgemmParams g;
     g.A = A;
@@ -346,7 +374,11 @@ int gemm_tn(const float *A, int64_t lda, int Mo, const float *Bsrc, int64_t ldb,
     g.ldc = No;
     g.slab_stride = (int64_t)Mo * No;
     g.accumulate = 0;
-    int rc = tt_sgemm(g, true, true, ENC_SPLITK, st);
+    g.a_absmax = a_absmax;
+    g.b_absmax = nullptr;
+    g.a_exp = 0;
+    g.b_exp = b_exp;
+    int rc = a_absmax ? tt_sgemm16(g, true, true, ENC_SPLITK, st) : tt_sgemm(g, true, true, ENC_SPLITK, st);
     if (rc != TT_OK)
         return rc;
     return tt_slab_reduce(slabs, ENC_SPLITK, (int64_t)Mo * No, out, 0, st);
@@ -385,6 +417,10 @@ TT_EXPORT int tt_encoder_backward_f32(const int64_t *ids, int B, int T, const fl
     float *d_hfin = (float *)(ws + lo.d_hfin), *d_hid = (float *)(ws + lo.d_hid);
     const float *hfin = (const float *)(ws + lo.hfin);
     const int MT = (int)lo.MT;
+
+    // scale words of the f16-split weight-gradient products (max |dGi|, max |dGh_n| per layer and direction), written
+    // by the colsum passes: words 48..63 of the forward's status block
+    TT_RC_CHECK(tt_zero_async((unsigned *)(ws + lo.flag) + 48, 16 * sizeof(unsigned), st));
 
     // ---- head ------------------------------------------------------------------
     hipLaunchKernelGGL(head_bwd_kernel, dim3(B), dim3(256), 0, st, (const float *)(ws + lo.hid), d_out, H, normalize,
@@ -496,34 +532,38 @@ TT_EXPORT int tt_encoder_backward_f32(const int64_t *ids, int B, int T, const fl
             const float *dghn = (const float *)(ws + lo.dghn[d]);
             // biases: b_ih <- colsum(dGi); b_hh <- [colsum(dGi)[0:2H], colsum(dghn)] (GRU: the n gate's hidden-side
             // pre-activation is scaled by r) or the same sums (LSTM / RNN: one pre-activation per gate)
-            rc = colsum(dgi, H3, H3, MT, m_valid, slabs, g[2], st);
+            unsigned *mx_dgi = force_f32 ? nullptr : (unsigned *)(ws + lo.flag) + 48 + 2 * (2 * l + d);
+            unsigned *mx_dghn = force_f32 ? nullptr : mx_dgi + 1;
+            rc = colsum(dgi, H3, H3, MT, m_valid, slabs, g[2], st, mx_dgi);
             if (rc != TT_OK)
                 return rc;
             if (rnn_type == CELL_GRU) {
                 TT_HIP_CHECK(hipMemcpyAsync(g[3], g[2], sizeof(float) * 2 * H, hipMemcpyDeviceToDevice, st));
-                rc = colsum(dghn, H, H, MT, m_valid, slabs, g[3] + 2 * H, st);
+                rc = colsum(dghn, H, H, MT, m_valid, slabs, g[3] + 2 * H, st, mx_dghn);
                 if (rc != TT_OK)
                     return rc;
             } else {
                 TT_HIP_CHECK(hipMemcpyAsync(g[3], g[2], sizeof(float) * H3, hipMemcpyDeviceToDevice, st));
             }
             // W_ih <- dGi^T X   (X = gathered table rows for layer 0, the layer below's output above)
+            // (f16-split products: embedding rows as they are, hidden states (|h| < 1, times 1/(1-p) when dropped) 2^6)
             if (l == 0)
-                rc = gemm_tn(dgi, H3, H3, table, E, idsp, E, MT, m_valid, slabs, g[0], st);
+                rc = gemm_tn(dgi, H3, H3, table, E, idsp, E, MT, m_valid, slabs, g[0], st, mx_dgi, 0);
             else
                 rc = gemm_tn(dgi, H3, H3, (const float *)(ws + (drop ? lo.xd[l] : lo.x[l])), I, nullptr, I, MT, m_valid,
-                             slabs, g[0], st);
+                             slabs, g[0], st, mx_dgi, 6);
             if (rc != TT_OK)
                 return rc;
             // W_hh <- dGh^T H_prev, H_prev rows through the previous-token map into this layer's own output
             const int32_t *pm = (const int32_t *)(ws + lo.prevmap[d]);
             if (rnn_type == CELL_GRU) {
-                rc = gemm_tn(dgi, H3, 2 * H, hseq + (size_t)d * H, ndir * H, pm, H, MT, m_valid, slabs, g[1], st);
+                rc = gemm_tn(dgi, H3, 2 * H, hseq + (size_t)d * H, ndir * H, pm, H, MT, m_valid, slabs, g[1], st, mx_dgi, 10);
                 if (rc != TT_OK)
                     return rc;
-                rc = gemm_tn(dghn, H, H, hseq + (size_t)d * H, ndir * H, pm, H, MT, m_valid, slabs, g[1] + (size_t)2 * H * H, st);
+                rc = gemm_tn(dghn, H, H, hseq + (size_t)d * H, ndir * H, pm, H, MT, m_valid, slabs, g[1] + (size_t)2 * H * H, st,
+                             mx_dghn, 10);
             } else {
-                rc = gemm_tn(dgi, H3, H3, hseq + (size_t)d * H, ndir * H, pm, H, MT, m_valid, slabs, g[1], st);
+                rc = gemm_tn(dgi, H3, H3, hseq + (size_t)d * H, ndir * H, pm, H, MT, m_valid, slabs, g[1], st, mx_dgi, 10);
             }
             if (rc != TT_OK)
                 return rc;

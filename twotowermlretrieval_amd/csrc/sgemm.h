@@ -50,6 +50,9 @@ int tt_sgemm(const SgemmParams &p, bool a_t, bool b_t, int splits, hipStream_t s
 // hi*hi + lo*hi + hi*lo on v_mfma_f32_32x32x16_f16 with fp32 accumulation -- every product good to ~3 * 2^-24
 // relative, i.e. one fp32 rounding, at 3/16 of the fp32-MFMA time (csrc/gru16.hip has the error argument).
 int tt_sgemm16_nn(const SgemmParams &p, hipStream_t st);
+// ... and with both operands stored [K][rows] (C = A^T * B summed over their rows: the weight-gradient products over
+// all tokens), split-K like tt_sgemm.  Same four [row][k] LDS images; only the staging differs.
+int tt_sgemm16(const SgemmParams &p, bool a_t, bool b_t, int splits, hipStream_t st);
 
 // bit pattern of max |x| over n floats -> *out (atomicMax; the caller zeroes *out on the stream first)
 int tt_absmax(const float *x, int64_t n, unsigned *out, hipStream_t st);

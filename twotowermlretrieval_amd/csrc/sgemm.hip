@@ -158,44 +158,88 @@ __global__ __launch_bounds__(256) void sgemm_kernel(SgemmParams p)
 typedef _Float16 h8v __attribute__((ext_vector_type(8)));
 constexpr int BK16 = 32, LDT16 = 40;
 
+//  TR == false: source [rows][K]: thread -> (row t>>1, 16 consecutive k)
+//  TR == true : source [K][rows] (weight-gradient products: K = tokens): thread -> (token pair p = t & 15, row quads
+//               4c .. 4c+3 and 64 + 4c .. 64 + 4c + 3, c = t >> 4): a wave's four c values read 64 contiguous bytes of
+//               each token row; commit packs the two tokens of a row into one dword per image (2-way LDS conflicts,
+//               which ds_write_b32 absorbs) -- the [row][k] images are the same as for TR == false.
+template <bool TR>
 __device__ __forceinline__ void fetch16(f32x4 (&v)[4], const float *__restrict__ src, int64_t ld,
                                         const int32_t *__restrict__ map, int row0, int rows_eff, int k0, int k_end, int tid)
 {
-    const int r = tid >> 1, kc = (tid & 1) * 16;
-    const int row = row0 + r;
 #pragma unroll
     for (int q = 0; q < 4; ++q)
         v[q] = (f32x4){0, 0, 0, 0};
-    if (row < rows_eff) {
-        const int64_t srow = map ? (int64_t)map[row] : (int64_t)row;
-        const float *p = src + srow * ld + k0 + kc;
+    if (!TR) {
+        const int r = tid >> 1, kc = (tid & 1) * 16;
+        const int row = row0 + r;
+        if (row < rows_eff) {
+            const int64_t srow = map ? (int64_t)map[row] : (int64_t)row;
+            const float *p = src + srow * ld + k0 + kc;
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-            if (k0 + kc + 4 * q < k_end)
-                v[q] = *(const f32x4 *)(p + 4 * q);
+            for (int q = 0; q < 4; ++q)
+                if (k0 + kc + 4 * q < k_end)
+                    v[q] = *(const f32x4 *)(p + 4 * q);
+        }
+    } else {
+        const int pp = tid & 15, c = tid >> 4;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int k = k0 + 2 * pp + t;
+            if (k < k_end) {
+                const int64_t srow = map ? (int64_t)map[k] : (int64_t)k;
+#pragma unroll
+                for (int g = 0; g < 2; ++g) // v[2 g + t]: rows 64 g + 4 c .. + 3 of token k
+                    if (row0 + 64 * g + 4 * c < rows_eff)
+                        v[2 * g + t] = *(const f32x4 *)(src + srow * ld + row0 + 64 * g + 4 * c);
+            }
+        }
     }
 }
 
+template <bool TR>
 __device__ __forceinline__ void commit16(_Float16 *__restrict__ hi_img, _Float16 *__restrict__ lo_img, const f32x4 (&v)[4],
                                          float scale, int tid)
 {
-    const int r = tid >> 1, kc = (tid & 1) * 16;
+    if (!TR) {
+        const int r = tid >> 1, kc = (tid & 1) * 16;
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
-        h8v hi, lo;
+        for (int half = 0; half < 2; ++half) {
+            h8v hi, lo;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float x = v[2 * half + (e >> 2)][e & 3] * scale;
-            const _Float16 hv = (_Float16)x;
-            hi[e] = hv;
-            lo[e] = (_Float16)(x - (float)hv);
+            for (int e = 0; e < 8; ++e) {
+                const float x = v[2 * half + (e >> 2)][e & 3] * scale;
+                const _Float16 hv = (_Float16)x;
+                hi[e] = hv;
+                lo[e] = (_Float16)(x - (float)hv);
+            }
+            *(h8v *)(hi_img + r * LDT16 + kc + 8 * half) = hi;
+            *(h8v *)(lo_img + r * LDT16 + kc + 8 * half) = lo;
         }
-        *(h8v *)(hi_img + r * LDT16 + kc + 8 * half) = hi;
-        *(h8v *)(lo_img + r * LDT16 + kc + 8 * half) = lo;
+    } else {
+        typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+        const int pp = tid & 15, c = tid >> 4;
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                h2v hi, lo;
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const float x = v[2 * g + t][e] * scale;
+                    const _Float16 hv = (_Float16)x;
+                    hi[t] = hv;
+                    lo[t] = (_Float16)(x - (float)hv);
+                }
+                const int o = (64 * g + 4 * c + e) * LDT16 + 2 * pp;
+                *(h2v *)(hi_img + o) = hi;
+                *(h2v *)(lo_img + o) = lo;
+            }
     }
 }
 
-__global__ __launch_bounds__(256) void sgemm16_nn_kernel(SgemmParams p)
+template <bool A_T, bool B_T>
+__global__ __launch_bounds__(256) void sgemm16_kernel(SgemmParams p)
 {
     __shared__ __attribute__((aligned(16))) _Float16 img[4][BM * LDT16]; // A hi, A lo, B hi, B lo
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -215,6 +259,12 @@ __global__ __launch_bounds__(256) void sgemm16_nn_kernel(SgemmParams p)
     const int m0 = by * BM, n0 = bx * BN;
     if (m0 >= M)
         return;
+    // split-K range (multiples of BK16)
+    const int splits = gridDim.z;
+    int kchunk = (K + splits - 1) / splits;
+    kchunk = (kchunk + BK16 - 1) / BK16 * BK16;
+    const int kb = blockIdx.z * kchunk, ke = min(kb + kchunk, K);
+    float *C = p.C + (size_t)blockIdx.z * p.slab_stride;
     const int ea = p.a_absmax ? tt_pow2_exponent(*p.a_absmax) : p.a_exp;
     const int eb = p.b_absmax ? tt_pow2_exponent(*p.b_absmax) : p.b_exp;
     const float sa = ldexpf(1.0f, ea), sb = ldexpf(1.0f, eb), down = ldexpf(1.0f, -(ea + eb));
@@ -230,15 +280,15 @@ __global__ __launch_bounds__(256) void sgemm16_nn_kernel(SgemmParams p)
                 acc[a][b][r] = 0.0f;
 
     f32x4 ra[4], rb[4];
-    fetch16(ra, p.A, p.lda, p.a_map, m0, M, 0, K, tid);
-    fetch16(rb, p.B, p.ldb, p.b_map, n0, p.N, 0, K, tid);
-    for (int k0 = 0; k0 < K; k0 += BK16) {
-        commit16(img[0], img[1], ra, sa, tid);
-        commit16(img[2], img[3], rb, sb, tid);
+    fetch16<A_T>(ra, p.A, p.lda, p.a_map, m0, M, kb, ke, tid);
+    fetch16<B_T>(rb, p.B, p.ldb, p.b_map, n0, p.N, kb, ke, tid);
+    for (int k0 = kb; k0 < ke; k0 += BK16) {
+        commit16<A_T>(img[0], img[1], ra, sa, tid);
+        commit16<B_T>(img[2], img[3], rb, sb, tid);
         __syncthreads();
-        if (k0 + BK16 < K) { // next tile's global loads fly under this tile's MFMAs
-            fetch16(ra, p.A, p.lda, p.a_map, m0, M, k0 + BK16, K, tid);
-            fetch16(rb, p.B, p.ldb, p.b_map, n0, p.N, k0 + BK16, K, tid);
+        if (k0 + BK16 < ke) { // next tile's global loads fly under this tile's MFMAs
+            fetch16<A_T>(ra, p.A, p.lda, p.a_map, m0, M, k0 + BK16, ke, tid);
+            fetch16<B_T>(rb, p.B, p.ldb, p.b_map, n0, p.N, k0 + BK16, ke, tid);
         }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -278,12 +328,12 @@ __global__ __launch_bounds__(256) void sgemm16_nn_kernel(SgemmParams p)
             const int col = n0 + 64 * wc + 32 * nt + i;
             if (col >= p.N)
                 continue;
-            const float bv = p.bias ? p.bias[col] : 0.0f;
+            const float bv = (p.bias && blockIdx.z == 0) ? p.bias[col] : 0.0f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + 64 * wr + 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * h;
                 if (row < M) {
-                    float *dst = p.C + (size_t)row * p.ldc + col;
+                    float *dst = C + (size_t)row * p.ldc + col;
                     const float v = acc[mt][nt][r] * down + bv;
                     *dst = p.accumulate ? *dst + v : v;
                 }
@@ -339,17 +389,28 @@ int tt_sgemm(const SgemmParams &p, bool a_t, bool b_t, int splits, hipStream_t s
     return TT_OK;
 }
 
-int tt_sgemm16_nn(const SgemmParams &p, hipStream_t st)
+int tt_sgemm16(const SgemmParams &p, bool a_t, bool b_t, int splits, hipStream_t st)
 {
     if (p.M <= 0 || p.N <= 0 || p.K <= 0)
         return TT_OK;
-    if ((p.K & 3) || (p.lda & 3) || (p.ldb & 3))
-        return tt_fail(TT_ERR_UNSUPPORTED, "tt_sgemm16_nn: K and the leading dimensions must be multiples of 4 (K=%d)", p.K);
-    dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM, 1);
-    hipLaunchKernelGGL(sgemm16_nn_kernel, grid, dim3(256), 0, st, p);
+    if (a_t != b_t)
+        return tt_fail(TT_ERR_UNSUPPORTED, "tt_sgemm16: only A*B^T (both row operands) and A^T*B (both [K][rows]) are built");
+    if ((!a_t && (p.K & 3)) || (a_t && ((p.M & 3) || (p.N & 3))) || (p.lda & 3) || (p.ldb & 3))
+        return tt_fail(TT_ERR_UNSUPPORTED, "tt_sgemm16: dims must be multiples of 4 (M=%d N=%d K=%d)", p.M, p.N, p.K);
+    if (splits < 1)
+        splits = 1;
+    if (splits > 1 && p.accumulate)
+        return tt_fail(TT_ERR_BAD_SHAPE, "tt_sgemm16: accumulate with split-K");
+    dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM, splits);
+    if (!a_t)
+        hipLaunchKernelGGL((sgemm16_kernel<false, false>), grid, dim3(256), 0, st, p);
+    else
+        hipLaunchKernelGGL((sgemm16_kernel<true, true>), grid, dim3(256), 0, st, p);
     TT_LAUNCH_CHECK();
     return TT_OK;
 }
+
+int tt_sgemm16_nn(const SgemmParams &p, hipStream_t st) { return tt_sgemm16(p, false, false, 1, st); }
 
 int tt_absmax(const float *x, int64_t n, unsigned *out, hipStream_t st)
 {
