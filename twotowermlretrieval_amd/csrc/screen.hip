@@ -51,6 +51,9 @@ typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void gbl_void;
 
+#ifndef TT_SCREEN_STAGGER
+#define TT_SCREEN_STAGGER 1
+#endif
 constexpr int SW = 8;                 // waves per workgroup
 constexpr int STILE_BYTES = 32 * 512; // 32 docs x 256 f16
 constexpr int SRING = 8;              // ring depth in tiles
@@ -342,6 +345,106 @@ __global__ __launch_bounds__(SW * 64, 2) void screen_kernel(ScreenParams p)
             dma_issue(t0 + gi, gi);
         int stage = 0;
         const int rd_base = n * 512; // A row (document) n of sub-tile 0; sub-tile 1 is 16 rows = 8 KiB further
+        // acc[u][c][r] = s16(doc tile*32 + 16u + 4g + r, query qbase + 16c + n) (main pass: minus the query's threshold)
+        f32x4 acc[2][NSET];
+        // Stagger: all eight waves run the same program between the same barriers, so left alone the two waves of a SIMD
+        // reach their MFMA block, their LDS reads and their selection epilogue together.  Waves 4-7 (the second wave of
+        // each SIMD) therefore DEFER a tile's selection until after the next tile iteration has started -- their
+        // accumulators stay in registers across the barrier -- so that one half selects (VALU, stores) while the other
+        // multiplies (MI355X_MICROARCH.md, "Two waves per SIMD", item 9).  Same work, same results, shifted by one phase.
+        const bool late = TT_SCREEN_STAGGER && w >= 4;
+        bool pending = false;
+        int ptile = 0;
+        auto epilogue = [&](int tile) {
+                const int tile_base = tile * 32;
+            const bool partial = tile_base + 32 > p.N;
+            if (!MAXONLY) {
+                if (partial) { // rows past the corpus never pass: -inf has its sign bit set
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (tile_base + 16 * u + 4 * g + r >= p.N) {
+#pragma unroll
+                                for (int c = 0; c < NSET; ++c)
+                                    acc[u][c][r] = -INFINITY;
+                            }
+                }
+                // any score at or above its threshold <=> some accumulator has a clear sign bit
+                // <=> the signed-integer maximum of the raw registers is >= 0
+                int mall = INT_MIN;
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int c = 0; c < NSET; ++c)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            mall = max(mall, __float_as_int(acc[u][c][r]));
+                if (__ballot(mall >= 0) != 0ull) {
+#pragma unroll
+                    for (int c = 0; c < NSET; ++c) {
+                        int mu[2];
+#pragma unroll
+                        for (int u = 0; u < 2; ++u)
+                            mu[u] = max(max(__float_as_int(acc[u][c][0]), __float_as_int(acc[u][c][1])),
+                                        max(__float_as_int(acc[u][c][2]), __float_as_int(acc[u][c][3])));
+                        if (__ballot(max(mu[0], mu[1]) >= 0) == 0ull)
+                            continue;
+                        // append pass: every lane appends to its own quarter of the query's buffer with its
+                        // own counter (no ballots), through inline-asm stores (a compiler-visible VMEM op here
+                        // would put s_waitcnt vmcnt(0) on the hot path and drain the DMA ring)
+                        const unsigned mine = (unsigned)(((16 * c + n) * SCAP + SQUART * g) * sizeof(SCand));
+                        const float thr_c = -negthr[c][0];
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            if (__ballot(mu[u] >= 0) == 0ull)
+                                continue;
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                if (__float_as_int(acc[u][c][r]) >= 0) {
+                                    scand_store_async(cwave, mine + (unsigned)cnt[c] * (unsigned)sizeof(SCand),
+                                                      acc[u][c][r] + thr_c, tile_base + 16 * u + 4 * g + r);
+                                    ++cnt[c];
+                                }
+                            }
+                        }
+                        unsigned long long full = __ballot(cnt[c] > SQ_TRIGGER);
+                        full = (full | (full >> 32));
+                        full = (full | (full >> 16)) & 0xffffull;
+                        if (full)
+                            compact_where(c, (unsigned)full);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < NSET; ++c) { // one maximum per (tile, query): the k-th largest of them seeds the thresholds
+                    float m = -INFINITY;
+                    if (!partial) {
+                        // signed-integer max of the raw bits = the float max when any value is >= 0, else the
+                        // smallest one: still the score of a real document of this tile, which is all the
+                        // threshold argument needs (v_max3_i32: no NaN canonicalisation, 4 instructions)
+                        int mi = INT_MIN;
+#pragma unroll
+                        for (int u = 0; u < 2; ++u)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                                mi = max(mi, __float_as_int(acc[u][c][r]));
+                        m = __int_as_float(mi);
+                    } else {
+#pragma unroll
+                        for (int u = 0; u < 2; ++u)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                                m = fmaxf(m, tile_base + 16 * u + 4 * g + r < p.N ? acc[u][c][r] : -INFINITY);
+                    }
+                    m = fmaxf(m, __shfl_xor(m, 16));
+                    m = fmaxf(m, __shfl_xor(m, 32));
+                    const int qrow = qbase + 16 * c + n;
+                    if (g == 0 && qrow < p.B)
+                        f32_store_async(p.max_val + (size_t)qrow * p.n_tiles + tile, m);
+                }
+            }
+                };
         for (int tile = t0; tile < t1; ++tile) {
             if ((tile - t0) % STPB == 0) {
                 // own DMAs of this interval's tiles have landed; the barrier extends that to every wave's
@@ -359,9 +462,10 @@ __global__ __launch_bounds__(SW * 64, 2) void screen_kernel(ScreenParams p)
                 dma_piece(1, fill_stage);
             }
             if (wave_live) {
+                if (late && pending)
+                    epilogue(ptile);
                 // acc[u][c][r] = s16(doc tile*32 + 16u + 4g + r, query qbase + 16c + n)
                 // (main pass: minus the query's threshold, see negthr)
-                f32x4 acc[2][NSET];
                 const char *buf = ring + stage * STILE_BYTES + rd_base;
                 // A fragments run two k-steps ahead of the MFMAs that consume them (three register sets);
                 // the scheduling fences keep hipcc from sinking the reads back next to their use
@@ -391,97 +495,17 @@ __global__ __launch_bounds__(SW * 64, 2) void screen_kernel(ScreenParams p)
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                const int tile_base = tile * 32;
-                const bool partial = tile_base + 32 > p.N;
-                if (!MAXONLY) {
-                    if (partial) { // rows past the corpus never pass: -inf has its sign bit set
-#pragma unroll
-                        for (int u = 0; u < 2; ++u)
-#pragma unroll
-                            for (int r = 0; r < 4; ++r)
-                                if (tile_base + 16 * u + 4 * g + r >= p.N) {
-#pragma unroll
-                                    for (int c = 0; c < NSET; ++c)
-                                        acc[u][c][r] = -INFINITY;
-                                }
-                    }
-                    // any score at or above its threshold <=> some accumulator has a clear sign bit
-                    // <=> the signed-integer maximum of the raw registers is >= 0
-                    int mall = INT_MIN;
-#pragma unroll
-                    for (int u = 0; u < 2; ++u)
-#pragma unroll
-                        for (int c = 0; c < NSET; ++c)
-#pragma unroll
-                            for (int r = 0; r < 4; ++r)
-                                mall = max(mall, __float_as_int(acc[u][c][r]));
-                    if (__ballot(mall >= 0) != 0ull) {
-#pragma unroll
-                        for (int c = 0; c < NSET; ++c) {
-                            int mu[2];
-#pragma unroll
-                            for (int u = 0; u < 2; ++u)
-                                mu[u] = max(max(__float_as_int(acc[u][c][0]), __float_as_int(acc[u][c][1])),
-                                            max(__float_as_int(acc[u][c][2]), __float_as_int(acc[u][c][3])));
-                            if (__ballot(max(mu[0], mu[1]) >= 0) == 0ull)
-                                continue;
-                            // append pass: every lane appends to its own quarter of the query's buffer with its
-                            // own counter (no ballots), through inline-asm stores (a compiler-visible VMEM op here
-                            // would put s_waitcnt vmcnt(0) on the hot path and drain the DMA ring)
-                            const unsigned mine = (unsigned)(((16 * c + n) * SCAP + SQUART * g) * sizeof(SCand));
-                            const float thr_c = -negthr[c][0];
-#pragma unroll
-                            for (int u = 0; u < 2; ++u) {
-                                if (__ballot(mu[u] >= 0) == 0ull)
-                                    continue;
-#pragma unroll
-                                for (int r = 0; r < 4; ++r) {
-                                    if (__float_as_int(acc[u][c][r]) >= 0) {
-                                        scand_store_async(cwave, mine + (unsigned)cnt[c] * (unsigned)sizeof(SCand),
-                                                          acc[u][c][r] + thr_c, tile_base + 16 * u + 4 * g + r);
-                                        ++cnt[c];
-                                    }
-                                }
-                            }
-                            unsigned long long full = __ballot(cnt[c] > SQ_TRIGGER);
-                            full = (full | (full >> 32));
-                            full = (full | (full >> 16)) & 0xffffull;
-                            if (full)
-                                compact_where(c, (unsigned)full);
-                        }
-                    }
+                if (late) { // this tile's selection runs after the next barrier, beside the other half's MFMAs
+                    pending = true;
+                    ptile = tile;
                 } else {
-#pragma unroll
-                    for (int c = 0; c < NSET; ++c) { // one maximum per (tile, query): the k-th largest of them seeds the thresholds
-                        float m = -INFINITY;
-                        if (!partial) {
-                            // signed-integer max of the raw bits = the float max when any value is >= 0, else the
-                            // smallest one: still the score of a real document of this tile, which is all the
-                            // threshold argument needs (v_max3_i32: no NaN canonicalisation, 4 instructions)
-                            int mi = INT_MIN;
-#pragma unroll
-                            for (int u = 0; u < 2; ++u)
-#pragma unroll
-                                for (int r = 0; r < 4; ++r)
-                                    mi = max(mi, __float_as_int(acc[u][c][r]));
-                            m = __int_as_float(mi);
-                        } else {
-#pragma unroll
-                            for (int u = 0; u < 2; ++u)
-#pragma unroll
-                                for (int r = 0; r < 4; ++r)
-                                    m = fmaxf(m, tile_base + 16 * u + 4 * g + r < p.N ? acc[u][c][r] : -INFINITY);
-                        }
-                        m = fmaxf(m, __shfl_xor(m, 16));
-                        m = fmaxf(m, __shfl_xor(m, 32));
-                        const int qrow = qbase + 16 * c + n;
-                        if (g == 0 && qrow < p.B)
-                            f32_store_async(p.max_val + (size_t)qrow * p.n_tiles + tile, m);
-                    }
+                    epilogue(tile);
                 }
             }
             stage = (stage + 1) % SRING;
         }
+        if (wave_live && late && pending)
+            epilogue(ptile);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier(); // no wave may leave while a sibling's LDS-DMA could still be consumed
