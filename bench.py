@@ -250,8 +250,12 @@ def encoder_legs(dev):
     def leg(tokens, t, extra):
         tf = tokens * FLOP_PER_TOKEN_FWD / t / 1e12
         return {"tokens_per_s": round(tokens / t), "ms": round(t * 1e3, 3), "tokens": tokens,
-                "TFLOPs": round(tf, 2), "frac_f32_mfma": round(tf / MFMA_F32_PEAK_TFLOPS, 4), **extra}
+                "TFLOPs": round(tf, 2), "frac_f32_mfma": round(tf / MFMA_F32_PEAK_TFLOPS, 4),
+                "frac_f16_mfma_3x": round(3.0 * tf / MFMA_F16_PEAK_TFLOPS, 4), **extra}
     enc = {"model": f"1-layer GRU, V={ENC_V}, E={ENC_E}, H={ENC_H}, fp32 (model.py:48-75)",
+           "arith": "fp32-grade: every product is three f16 MFMAs on fp16 hi/lo splits of the fp32 operands (DESIGN 4); "
+                    "TFLOPs counts each fp32 multiply-add once, so frac_f32_mfma may exceed 1; frac_f16_mfma_3x = 3 x "
+                    "TFLOPs / f16 peak is the share of the matrix pipes actually used",
            "doc_tower_b512": leg(pt, t_doc, {"batch": B, "T": int(p.shape[1])}),
            "query_tower_b512": leg(qt, t_q, {"batch": B, "T": int(q.shape[1]), "queries_per_s": round(B / t_q)}),
            "index_build_b8192": leg(bt, t_big, {"batch": 8192, "T": int(big.shape[1]), "docs_per_s": round(8192 / t_big)})}
@@ -263,7 +267,8 @@ def encoder_legs(dev):
     train = {"triplets_per_s": round(B / t_tr), "ms_per_step": round(t_tr * 1e3, 3), "triplets": B, "tokens": tok,
              "step": "3 tower forwards + triplet loss + backward + clip_grad_norm_(1.0) + Adam (main.py:244-259), default "
                      "input checking",
-             "TFLOPs": round(tf, 2), "frac_f32_mfma": round(tf / MFMA_F32_PEAK_TFLOPS, 4)}
+             "TFLOPs": round(tf, 2), "frac_f32_mfma": round(tf / MFMA_F32_PEAK_TFLOPS, 4),
+             "frac_f16_mfma_3x": round(3.0 * tf / MFMA_F16_PEAK_TFLOPS, 4)}
     del m, opt
     torch.cuda.empty_cache()
     return enc, train, (table, q, p, n)

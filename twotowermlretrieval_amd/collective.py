@@ -90,7 +90,7 @@ class Collective:
             self.via = f"torch.distributed ({dist.get_backend(group)})"
             if device is not None and device.type == "cuda":
                 ptr = rccl_comm_of_group(group, device)
-                if ptr is not None and self._usable(ptr):
+                if ptr is not None and self._usable(ptr) and self._self_test(ptr, device):
                     self.comm_ptr, self.via = ptr, "rccl-c-abi (torch.distributed's communicator)"
         else:
             self.world, self.rank = 1, 0
@@ -103,6 +103,27 @@ class Collective:
         except Exception:  # noqa: BLE001
             return False
         return w.value == self.world and r.value == self.rank
+
+    def _self_test(self, ptr: int, device: torch.device) -> bool:
+        """One 16-byte all-gather through the C ABI, checked on the host (every rank takes part: a collective).  All
+        ranks agree on the outcome -- a second gather, by torch.distributed, of each rank's verdict -- so either every
+        rank uses the C-ABI transport or none does."""
+        import torch.distributed as dist
+        ok = True
+        try:
+            send = torch.full((2,), self.rank, dtype=torch.int64, device=device)
+            recv = torch.full((2 * self.world,), -1, dtype=torch.int64, device=device)
+            with torch.cuda.device(device):
+                _lib.check(_lib.lib().tt_allgather_topk(C.c_void_p(ptr), send.data_ptr(), recv.data_ptr(), 16,
+                                                        torch.cuda.current_stream(device).cuda_stream))
+            torch.cuda.synchronize(device)
+            want = torch.arange(self.world, dtype=torch.int64).repeat_interleave(2)
+            ok = bool(torch.equal(recv.cpu(), want))
+        except Exception:  # noqa: BLE001
+            ok = False
+        verdict = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device)
+        dist.all_reduce(verdict, op=dist.ReduceOp.MIN, group=self.group)
+        return bool(verdict.item() == 1)
 
     def all_gather_blocks(self, send: torch.Tensor, recv: torch.Tensor) -> None:
         """recv (world * send.numel() bytes) <- every rank's `send` block, rank order."""
