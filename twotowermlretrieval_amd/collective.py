@@ -88,9 +88,9 @@ class Collective:
         if dist.is_available() and dist.is_initialized():
             self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
             self.via = f"torch.distributed ({dist.get_backend(group)})"
-            if device is not None and device.type == "cuda":
+            if device is not None and device.type == "cuda" and dist.get_backend(group) == "nccl":
                 ptr = rccl_comm_of_group(group, device)
-                if ptr is not None and self._usable(ptr) and self._self_test(ptr, device):
+                if self._self_test(ptr, device):  # collective: every rank of an nccl group gets here
                     self.comm_ptr, self.via = ptr, "rccl-c-abi (torch.distributed's communicator)"
         else:
             self.world, self.rank = 1, 0
@@ -104,11 +104,15 @@ class Collective:
             return False
         return w.value == self.world and r.value == self.rank
 
-    def _self_test(self, ptr: int, device: torch.device) -> bool:
+    def _self_test(self, ptr: Optional[int], device: torch.device) -> bool:
         """One 16-byte all-gather through the C ABI, checked on the host (every rank takes part: a collective).  All
         ranks agree on the outcome -- a second gather, by torch.distributed, of each rank's verdict -- so either every
         rank uses the C-ABI transport or none does."""
         import torch.distributed as dist
+        usable = torch.tensor([1 if (ptr is not None and self._usable(ptr)) else 0], dtype=torch.int32, device=device)
+        dist.all_reduce(usable, op=dist.ReduceOp.MIN, group=self.group)
+        if usable.item() != 1:  # some rank has no handle: nobody takes the C-ABI transport
+            return False
         ok = True
         try:
             send = torch.full((2,), self.rank, dtype=torch.int64, device=device)
