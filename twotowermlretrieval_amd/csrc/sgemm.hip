@@ -363,6 +363,31 @@ __global__ void slab_reduce_kernel(const float *__restrict__ slabs, int nslab, i
     }
 }
 
+// The same sum for SHORT vectors and many slabs (bias gradients: n = G*H columns, 256 row slices): one thread per
+// element would walk 256 dependent loads in a handful of workgroups (60-100 us for 768 elements).  Here a workgroup
+// takes 32 elements x 8 slab groups; every group sums its slabs in order, the 8 partial sums are combined in a fixed
+// order through LDS: still deterministic, ~30 loads deep.
+__global__ __launch_bounds__(256) void slab_reduce_wide_kernel(const float *__restrict__ slabs, int nslab, int n,
+                                                               float *out, int accumulate)
+{
+    __shared__ float part[8][32];
+    const int col = blockIdx.x * 32 + (threadIdx.x & 31), zg = threadIdx.x >> 5;
+    const int per = (nslab + 7) / 8;
+    float s = 0.0f;
+    if (col < n)
+        for (int z = zg * per; z < min(zg * per + per, nslab); ++z)
+            s += slabs[(size_t)z * n + col];
+    part[zg][threadIdx.x & 31] = s;
+    __syncthreads();
+    if (zg == 0 && col < n) {
+        float t = part[0][threadIdx.x];
+#pragma unroll
+        for (int g = 1; g < 8; ++g)
+            t += part[g][threadIdx.x];
+        out[col] = accumulate ? out[col] + t : t;
+    }
+}
+
 } // namespace
 
 int tt_sgemm(const SgemmParams &p, bool a_t, bool b_t, int splits, hipStream_t st)
@@ -426,6 +451,12 @@ int tt_slab_reduce(const float *slabs, int nslab, int64_t n, float *out, int acc
 {
     if (n <= 0)
         return TT_OK;
+    if (n <= 8192 && nslab >= 64) {
+        hipLaunchKernelGGL(slab_reduce_wide_kernel, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, st, slabs, nslab, (int)n,
+                           out, accumulate);
+        TT_LAUNCH_CHECK();
+        return TT_OK;
+    }
     int blocks = (int)((n + 255) / 256);
     if (blocks > 2048)
         blocks = 2048;
