@@ -30,12 +30,20 @@ def sources():
     return sorted(CSRC.glob("*.hip"))
 
 
+def _headers():
+    return list(CSRC.glob("*.h")) + list((PKG.parent / "include").glob("*.h"))  # every source may include any of them
+
+
+def _stale(obj: Path, src: Path) -> bool:
+    return (not obj.exists()) or any(p.stat().st_mtime > obj.stat().st_mtime for p in [src, *_headers()])
+
+
 def needs_build() -> bool:
     if not LIB.exists():
         return True
-    t = LIB.stat().st_mtime
-    deps = list(CSRC.glob("*")) + [PKG.parent / "include" / "tt.h"]
-    return any(p.stat().st_mtime > t for p in deps)
+    objdir = PKG / "build"
+    objs = [objdir / (src.stem + ".o") for src in sources()]
+    return any(_stale(o, s) for o, s in zip(objs, sources())) or any(o.stat().st_mtime > LIB.stat().st_mtime for o in objs)
 
 
 def build(force: bool = False, verbose: bool = False) -> Path:
@@ -51,8 +59,7 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     for src in sources():
         obj = objdir / (src.stem + ".o")
         objs.append(obj)
-        dep_newer = (not obj.exists()) or force or any(
-            p.stat().st_mtime > obj.stat().st_mtime for p in (src, CSRC / "tt_common.h", PKG.parent / "include" / "tt.h"))
+        dep_newer = force or _stale(obj, src)
         if dep_newer:
             cmd = [hipcc, *flags, "-c", str(src), "-o", str(obj)]
             if verbose:

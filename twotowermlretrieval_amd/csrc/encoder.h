@@ -32,7 +32,7 @@ struct EncLayout {
     size_t d_hid;                                // [B][H] gradient w.r.t. the head output before normalisation
     size_t prevmap[2];                           // [MT] int32: packed index of the token one step earlier (MT = none)
     size_t dgi[2];                               // [MT][3H] per direction
-    size_t dghn[2];                              // [MT][H]: the n-gate column of dGh (= dn_pre * r)
+    size_t dghn[2];                              // GRU: dGh = [dr_pre, dz_pre, dn_pre * r], [MT][3H] (the hidden-side pre-activation gradients)
     size_t dx[2];                                // ping-pong [MT][ndir*H]: gradient w.r.t. a layer's input
     size_t wtp[2];                               // W_hh packed for dh_prev = dGh * W_hh
     size_t slabs;                                // split-K partial products
@@ -108,7 +108,7 @@ static inline EncLayout enc_layout(int B, int T, int E, int H, int L, int bidir,
             lo.prevmap[d] = take(sizeof(int32_t) * lo.MT);
         for (int d = 0; d < lo.ndir; ++d) {
             lo.dgi[d] = take(sizeof(float) * lo.MT * ng * H);
-            lo.dghn[d] = take(sizeof(float) * lo.MT * H);
+            lo.dghn[d] = take(sizeof(float) * lo.MT * 3 * H);
             lo.wtp[d] = take(sizeof(float) * ng * H * H);
         }
         if (L > 1)
@@ -153,7 +153,7 @@ struct GruBwdDir {
     const float *wtp;     // packed W_hh for dh_prev = dGh W_hh (fp32 MFMA order, or fp16 hi/lo fragments)
     const unsigned *wmax; // f16-split kernel: bit pattern of max|W_hh|
     float *dgi;           // [M][3H]
-    float *dghn;          // [M][H]
+    float *dghn;          // GRU: dGh [M][3H] = [dr_pre, dz_pre, dn_pre * r]
     int col0, reverse;
 };
 

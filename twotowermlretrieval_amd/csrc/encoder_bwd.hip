@@ -253,7 +253,10 @@ __global__ __launch_bounds__(MAXW * 64) void gru_bwd_seq_kernel(GruBwdParams p)
                         go[0] = g0;
                         go[H] = g1;
                         go[2 * H] = dn_pre;
-                        d.dghn[tok * H + u] = g2;
+                        float *gh = d.dghn + tok * HG + u; // dGh differs from dGi in the n column only; kept whole so
+                        gh[0] = g0;                        // that dW_hh and db_hh are ONE product / column sum each
+                        gh[H] = g1;
+                        gh[2 * H] = g2;
                     } else if constexpr (CELL == CELL_LSTM) {
                         const float ig = cur_st.r[ct][e], fg = cur_st.z[ct][e], gg = cur_st.n[ct][e], og = cur_st.ghn[ct][e];
                         const float cp = cur_st.hp[ct][e];
@@ -530,16 +533,15 @@ TT_EXPORT int tt_encoder_backward_f32(const int64_t *ids, int B, int T, const fl
             float *const *g = grads + ((size_t)l * ndir + d) * 4;
             const float *dgi = (const float *)(ws + lo.dgi[d]);
             const float *dghn = (const float *)(ws + lo.dghn[d]);
-            // biases: b_ih <- colsum(dGi); b_hh <- [colsum(dGi)[0:2H], colsum(dghn)] (GRU: the n gate's hidden-side
-            // pre-activation is scaled by r) or the same sums (LSTM / RNN: one pre-activation per gate)
+            // biases: b_ih <- colsum(dGi); b_hh <- colsum(dGh) (GRU: the n gate's hidden-side pre-activation is scaled by r)
+            // or the same sums (LSTM / RNN: one pre-activation per gate)
             unsigned *mx_dgi = force_f32 ? nullptr : (unsigned *)(ws + lo.flag) + 48 + 2 * (2 * l + d);
             unsigned *mx_dghn = force_f32 ? nullptr : mx_dgi + 1;
             rc = colsum(dgi, H3, H3, MT, m_valid, slabs, g[2], st, mx_dgi);
             if (rc != TT_OK)
                 return rc;
             if (rnn_type == CELL_GRU) {
-                TT_HIP_CHECK(hipMemcpyAsync(g[3], g[2], sizeof(float) * 2 * H, hipMemcpyDeviceToDevice, st));
-                rc = colsum(dghn, H, H, MT, m_valid, slabs, g[3] + 2 * H, st, mx_dghn);
+                rc = colsum(dghn, H3, H3, MT, m_valid, slabs, g[3], st, mx_dghn);
                 if (rc != TT_OK)
                     return rc;
             } else {
@@ -556,15 +558,9 @@ TT_EXPORT int tt_encoder_backward_f32(const int64_t *ids, int B, int T, const fl
                 return rc;
             // W_hh <- dGh^T H_prev, H_prev rows through the previous-token map into this layer's own output
             const int32_t *pm = (const int32_t *)(ws + lo.prevmap[d]);
-            if (rnn_type == CELL_GRU) {
-                rc = gemm_tn(dgi, H3, 2 * H, hseq + (size_t)d * H, ndir * H, pm, H, MT, m_valid, slabs, g[1], st, mx_dgi, 10);
-                if (rc != TT_OK)
-                    return rc;
-                rc = gemm_tn(dghn, H, H, hseq + (size_t)d * H, ndir * H, pm, H, MT, m_valid, slabs, g[1] + (size_t)2 * H * H, st,
-                             mx_dghn, 10);
-            } else {
-                rc = gemm_tn(dgi, H3, H3, hseq + (size_t)d * H, ndir * H, pm, H, MT, m_valid, slabs, g[1], st, mx_dgi, 10);
-            }
+            // (GRU: the hidden-side gradients dGh = [dr_pre, dz_pre, dn_pre r]; LSTM / RNN: the same matrix as dGi)
+            rc = gemm_tn(rnn_type == CELL_GRU ? dghn : dgi, H3, H3, hseq + (size_t)d * H, ndir * H, pm, H, MT, m_valid, slabs, g[1],
+                         st, rnn_type == CELL_GRU ? mx_dghn : mx_dgi, 10);
             if (rc != TT_OK)
                 return rc;
             // gradient w.r.t. this layer's input sequence (below layer 0 only when the table is trained)

@@ -537,7 +537,10 @@ __global__ __launch_bounds__(B16<H>::NW * 64) void gru_bwd16_kernel(GruBwdParams
                     go[0] = dr_pre;
                     go[H] = dz_pre;
                     go[2 * H] = dn_pre;
-                    d.dghn[tok * H + u] = dghn_v;
+                    float *gh = d.dghn + tok * H3 + u; // dGh whole (differs from dGi in the n column only)
+                    gh[0] = dr_pre;
+                    gh[H] = dz_pre;
+                    gh[2 * H] = dghn_v;
                 }
                 gv[0][ct][e] = dr_pre;
                 gv[1][ct][e] = dz_pre;
