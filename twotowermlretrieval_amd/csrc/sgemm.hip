@@ -153,10 +153,14 @@ __global__ __launch_bounds__(256) void sgemm_kernel(SgemmParams p)
 // ------------------------------------------------------------------ C = A * B^T on the f16 pipes, fp32-grade
 // 128 x 128 x 32 tiles, 4 waves, 2 x 2 accumulators of 32 x 32 per wave (v_mfma_f32_32x32x16_f16).  The fp32 operands
 // are fetched as in sgemm_kernel (16 consecutive k per thread, next tile in flight under the MFMAs), scaled by their
-// power of two, split into fp16 hi / lo and committed to FOUR LDS images (row stride 40 halves = 80 B: the 16-byte
-// fragment reads of 16 different rows fall into 16 different bank groups).
+// power of two, split into fp16 hi / lo and committed to FOUR LDS images of 64-byte rows (32 KB in all: five workgroups per
+// CU -- the kernel hides its gather latency with occupancy).  The four 16-byte chunks of a row are XOR-swizzled with
+// f(row) = ((row >> 2) + (row >> 1)) & 3: the ds_read_b128 fragment reads of a 16-lane group fall into 16 different
+// bank groups, the ds_write_b128 of rows r and r + 2 (same bank base) into different chunks, and the transposed
+// staging's packed dword writes stay 2-way (free for ds_write_b32).
 typedef _Float16 h8v __attribute__((ext_vector_type(8)));
-constexpr int BK16 = 32, LDT16 = 40;
+constexpr int BK16 = 32, LDT16 = 32;
+__device__ __forceinline__ int swz16(int row) { return ((row >> 2) + (row >> 1)) & 3; }
 
 //  TR == false: source [rows][K]: thread -> (row t>>1, 16 consecutive k)
 //  TR == true : source [K][rows] (weight-gradient products: K = tokens): thread -> (token pair p = t & 15, row quads
@@ -213,8 +217,9 @@ __device__ __forceinline__ void commit16(_Float16 *__restrict__ hi_img, _Float16
                 hi[e] = hv;
                 lo[e] = (_Float16)(x - (float)hv);
             }
-            *(h8v *)(hi_img + r * LDT16 + kc + 8 * half) = hi;
-            *(h8v *)(lo_img + r * LDT16 + kc + 8 * half) = lo;
+            const int o = r * LDT16 + ((((tid & 1) * 2 + half) ^ swz16(r)) << 3);
+            *(h8v *)(hi_img + o) = hi;
+            *(h8v *)(lo_img + o) = lo;
         }
     } else {
         typedef _Float16 h2v __attribute__((ext_vector_type(2)));
@@ -231,7 +236,8 @@ __device__ __forceinline__ void commit16(_Float16 *__restrict__ hi_img, _Float16
                     hi[t] = hv;
                     lo[t] = (_Float16)(x - (float)hv);
                 }
-                const int o = (64 * g + 4 * c + e) * LDT16 + 2 * pp;
+                const int row = 64 * g + 4 * c + e;
+                const int o = row * LDT16 + ((((pp >> 2) ^ swz16(row)) << 3) | ((2 * pp) & 7));
                 *(h2v *)(hi_img + o) = hi;
                 *(h2v *)(lo_img + o) = lo;
             }
@@ -295,8 +301,9 @@ __global__ __launch_bounds__(256) void sgemm16_kernel(SgemmParams p)
             h8v ah[2], al[2], bh[2], bl[2];
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
-                const int ao = (64 * wr + 32 * t + i) * LDT16 + 16 * ks + 8 * h;
-                const int bo = (64 * wc + 32 * t + i) * LDT16 + 16 * ks + 8 * h;
+                const int ar = 64 * wr + 32 * t + i, br = 64 * wc + 32 * t + i;
+                const int ao = ar * LDT16 + (((2 * ks + h) ^ swz16(ar)) << 3);
+                const int bo = br * LDT16 + (((2 * ks + h) ^ swz16(br)) << 3);
                 ah[t] = *(const h8v *)(img[0] + ao);
                 al[t] = *(const h8v *)(img[1] + ao);
                 bh[t] = *(const h8v *)(img[2] + bo);
