@@ -241,3 +241,71 @@ def test_encoder_forward_replays_from_a_hip_graph():
                 g.replay()
                 torch.cuda.synchronize()
                 assert torch.equal(out, w), rep
+
+
+@pytest.mark.parametrize("w_scale,x_scale", [(1.0e-3, 1.0), (4.0, 1.0), (1.0, 1.0e-3), (1.0, 20.0), (5.0e-5, 2.0e3)])
+def test_f16_split_scaling_holds_for_extreme_weights_and_embeddings(oracle, w_scale, x_scale):
+    """The f16-pipe kernels (K1, K2, K7) scale their operands by powers of two before the fp16 hi/lo split: W_ih / W_hh from
+    their largest element, dGh per row and step, dGi from its largest element.  Weights three orders of magnitude smaller or
+    larger than the default init, tiny and large embedding vectors: outputs and gradients must still match the fp32
+    oracle at the usual tolerances (H = 256: the f16 recurrence; E = 300).  (Weights 30x the default init make the
+    recurrence chaotic -- saturated gates flip on last-bit differences of ANY summation order -- and are not a test of
+    anything; tiny weights are: the output normalisation divides by a ~1e-2 norm, which is what exposed the absolute
+    error of the exp-based tanh and led to its small-argument polynomial.)"""
+    from twotowermlretrieval_amd.model import RNNEncoder
+    V, E, H, B, T = 200, 300, 256, 21, 37
+    table = (synth.make_table(31, V, E) * np.float32(x_scale)).astype(np.float32)
+    sd = {k: (v * np.float32(w_scale)).astype(np.float32) for k, v in synth.make_encoder_state(32, E, H).items()}
+    enc = RNNEncoder(V, E, H, pretrained_embeddings=table)
+    full = {"embedding.weight": torch.from_numpy(table)}
+    full.update({k: torch.from_numpy(v) for k, v in sd.items()})
+    enc.load_state_dict(full)
+    enc = enc.cuda().train()
+    ids = synth.make_ids(33, B, T, V, zero_inside=0.05)
+    quads = synth.weight_quads(sd)
+    y = enc(torch.from_numpy(ids).cuda())
+    want = oracle.encoder_forward(ids, table, quads, H)
+    np.testing.assert_allclose(y.detach().cpu().numpy(), want, atol=ATOL, rtol=0)
+    d_out = np.random.RandomState(34).standard_normal((B, H)).astype(np.float32)
+    y.backward(torch.from_numpy(d_out).cuda())
+    og, _, _ = oracle.encoder_backward(ids, table, quads, H, d_out)
+    got = [p.grad.cpu().numpy() for n, p in enc.named_parameters() if p.requires_grad]
+    for a, b in zip(got, og[0]):
+        assert np.isfinite(a).all()
+        np.testing.assert_allclose(a, b, atol=5e-4 * max(np.abs(b).max(), 1e-30), rtol=0)
+
+
+@pytest.mark.parametrize("cell", ["LSTM", "RNN"])
+def test_lstm_rnn_inter_layer_dropout_and_trainable_table_vs_oracle(oracle, cell):
+    """Train-mode inter-layer dropout (the package's counter-based mask) and the trainable embedding table through the
+    LSTM / RNN kernels: forward and every gradient, the table's included, against the oracle with the same mask."""
+    from twotowermlretrieval_amd.model import RNNEncoder, _EncoderFn
+    gates = 4 if cell == "LSTM" else 1
+    V, E, H, B, T, layers, bi, p = 90, 24, 64, 11, 14, 2, True, 0.3
+    table = synth.make_table(41, V, E)
+    sd = synth.make_encoder_state(42, E, H, layers, bi, gates=gates)
+    enc = RNNEncoder(V, E, H, pretrained_embeddings=None, rnn_type=cell, num_layers=layers, dropout=p, bidirectional=bi)
+    full = {"embedding.weight": torch.from_numpy(table)}
+    full.update({k: torch.from_numpy(v) for k, v in sd.items()})
+    enc.load_state_dict(full)
+    enc = enc.cuda().train()
+    ids = synth.make_ids(43, B, T, V, zero_inside=0.1)
+    torch.manual_seed(1234)
+    seed = int(torch.randint(0, 2 ** 62, (1,)).item())      # what _EncoderFn.forward will draw
+    torch.manual_seed(1234)
+    y = enc(torch.from_numpy(ids).cuda())
+    quads = synth.weight_quads(sd, layers, bi)
+    pw, pb = sd["projection.weight"], sd["projection.bias"]
+    want = oracle.encoder_forward(ids, table, quads, H, layers, bi, pw, pb, True, p, seed, rnn_type=cell)
+    np.testing.assert_allclose(y.detach().cpu().numpy(), want, atol=ATOL, rtol=0)
+    d_out = np.random.RandomState(44).standard_normal((B, H)).astype(np.float32)
+    y.backward(torch.from_numpy(d_out).cuda())
+    og, gpw, gpb, gt = oracle.encoder_backward(ids, table, quads, H, d_out, layers, bi, pw, pb, True, p, seed,
+                                               table_grad=True, rnn_type=cell)
+    named = dict(enc.named_parameters())
+    np.testing.assert_allclose(named["embedding.weight"].grad.cpu().numpy(), gt, atol=5e-4 * np.abs(gt).max(), rtol=0)
+    flat = [x for quad in og for x in quad] + [gpw, gpb]
+    got = [prm.grad.cpu().numpy() for n, prm in named.items() if n != "embedding.weight"]
+    assert len(flat) == len(got)
+    for a, b in zip(got, flat):
+        np.testing.assert_allclose(a, b, atol=5e-4 * max(np.abs(b).max(), 1e-30), rtol=0)

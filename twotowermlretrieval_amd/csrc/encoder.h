@@ -123,6 +123,25 @@ static inline EncLayout enc_layout(int B, int T, int E, int H, int L, int bidir,
     return lo;
 }
 
+// ------------------------------------------------------------------ gate nonlinearities (forward and backward kernels)
+// v_exp_f32 / v_rcp_f32 based.  sigmoid has no cancellation (values near 1/2 for small x).  tanh as 2/(1+e^-2x) - 1 has
+// an ABSOLUTE error of ~1e-7 (one rounding at magnitude 1), i.e. a relative error of 1e-7/|x| for small pre-activations --
+// a model whose hidden state is tiny everywhere would see it amplified by F.normalize -- so |x| < 1/8 takes the odd
+// polynomial x (1 - x^2/3 + 2x^4/15 - 17x^6/315), truncation error < 0.022 x^8 relative (1.3e-9 at the switch point).
+#ifdef __HIPCC__
+__device__ __forceinline__ float tt_fast_sigmoid(float x)
+{
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
+__device__ __forceinline__ float tt_fast_tanh(float x)
+{
+    const float big = 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.8853900817779268f * x)) - 1.0f;
+    const float t = x * x;
+    const float small = x * fmaf(t, fmaf(t, fmaf(t, -17.0f / 315.0f, 2.0f / 15.0f), -1.0f / 3.0f), 1.0f);
+    return fabsf(x) < 0.125f ? small : big;
+}
+#endif
+
 // ------------------------------------------------------------------ K2 recurrence: shared launch parameters
 struct GruDir {
     const float *gi;      // [M][3H] packed tokens

@@ -173,14 +173,8 @@ __global__ __launch_bounds__(256) void pack_whh_kernel(const float *__restrict__
 }
 
 // ------------------------------------------------------------------ K2 recurrence (GruDir / GruParams: encoder.h)
-__device__ __forceinline__ float fast_sigmoid(float x)
-{
-    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
-}
-__device__ __forceinline__ float fast_tanh(float x)
-{
-    return 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.8853900817779268f * x)) - 1.0f;
-}
+__device__ __forceinline__ float fast_sigmoid(float x) { return tt_fast_sigmoid(x); }
+__device__ __forceinline__ float fast_tanh(float x) { return tt_fast_tanh(x); }
 
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 

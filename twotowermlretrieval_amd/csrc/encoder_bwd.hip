@@ -21,10 +21,7 @@ namespace {
 
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ float fast_tanh_b(float x) // the forward's tanh (v_exp / v_rcp), so tanh(c_t) is the value h_t used
-{
-    return 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.8853900817779268f * x)) - 1.0f;
-}
+__device__ __forceinline__ float fast_tanh_b(float x) { return tt_fast_tanh(x); } // the forward's tanh: tanh(c_t) is the value h_t used
 
 // d_hid = backward of y = hid / max(|hid|, 1e-12) (or identity)
 __global__ __launch_bounds__(256) void head_bwd_kernel(const float *__restrict__ hid, const float *__restrict__ d_out,

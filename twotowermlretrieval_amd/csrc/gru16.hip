@@ -166,14 +166,8 @@ __global__ __launch_bounds__(256) void pack_whh16_kernel(const float *__restrict
     }
 }
 
-__device__ __forceinline__ float fast_sigmoid16(float x)
-{
-    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
-}
-__device__ __forceinline__ float fast_tanh16(float x)
-{
-    return 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.8853900817779268f * x)) - 1.0f;
-}
+__device__ __forceinline__ float fast_sigmoid16(float x) { return tt_fast_sigmoid(x); }
+__device__ __forceinline__ float fast_tanh16(float x) { return tt_fast_tanh(x); }
 
 template <int H>
 __global__ __launch_bounds__(G16<H>::NW * 64) void gru_seq16_kernel(GruParams p)
