@@ -22,6 +22,7 @@
 // in LDS as two fp16 images (hi, lo), double-buffered: one barrier per step.  Gate math, length mask, training stash
 // and outputs are those of gru_seq_kernel.
 #include "encoder.h"
+#include "sgemm.h"
 
 #include <type_traits>
 
@@ -113,30 +114,6 @@ __device__ __forceinline__ void static_for(F &&f)
     }
 }
 
-// exponent e with max|W| 2^e in [2^13, 2^14) (0 for an all-zero or non-finite matrix)
-__host__ __device__ inline int gru16_exponent(unsigned absmax_bits)
-{
-    const int ex = (int)((absmax_bits >> 23) & 0xff);
-    if (ex == 0 || ex == 255)
-        return 0;
-    int e = 13 - (ex - 127);
-    e = e > 100 ? 100 : e;
-    e = e < -100 ? -100 : e;
-    return e;
-}
-
-__global__ __launch_bounds__(256) void whh_absmax_kernel(const float *__restrict__ W, int n, unsigned *__restrict__ out)
-{
-    float m = 0.0f;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256)
-        m = fmaxf(m, fabsf(W[i]));
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1)
-        m = fmaxf(m, __shfl_xor(m, off));
-    if ((threadIdx.x & 63) == 0)
-        atomicMax(out, __float_as_uint(m)); // non-negative floats order like their bit patterns
-}
-
 // Packed order: wave w, fragment f = (s, pair, within): s = f / 12 the k-step, pair = (f % 12) / 4 the pair of column
 // tiles {2 pair, 2 pair + 1}, within = f % 4 -> part = within >> 1 (0 hi, 1 lo), tile t = 2 pair + (within & 1),
 // gate g = t >> 1, ct = t & 1.  Lane (n = lane & 15, kq = lane >> 4) holds the 8 fp16 of
@@ -146,7 +123,7 @@ __global__ __launch_bounds__(256) void pack_whh16_kernel(const float *__restrict
                                                          _Float16 *__restrict__ wp16)
 {
     const int NK = H / 32, NF = 12 * NK;
-    const float sc = ldexpf(1.0f, gru16_exponent(*absmax));
+    const float sc = ldexpf(1.0f, tt_pow2_exponent(*absmax));
     const int n = (H / 32) * NF * 64; // (wave, fragment, lane) triples
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
         const int lane = i & 63;
@@ -193,7 +170,7 @@ __global__ __launch_bounds__(G16<H>::NW * 64) void gru_seq16_kernel(GruParams p)
     steps = max(steps, __shfl_xor(steps, 16));
     steps = max(steps, __shfl_xor(steps, 32));
 
-    const int ex = gru16_exponent(*d.wmax);
+    const int ex = tt_pow2_exponent(*d.wmax);
     const float up = ldexpf(1.0f, H_SHIFT + ex), down = ldexpf(1.0f, -(H_SHIFT + ex));
     int unit[2];
     float bias[3][2]; // b_hh scaled like the products: the accumulators start there
@@ -390,7 +367,7 @@ __global__ __launch_bounds__(256) void pack_whh16_t_kernel(const float *__restri
                                                            _Float16 *__restrict__ wtp16)
 {
     const int NK = 3 * H / 32, NF = 4 * NK;
-    const float sc = ldexpf(1.0f, gru16_exponent(*absmax));
+    const float sc = ldexpf(1.0f, tt_pow2_exponent(*absmax));
     const int n = (H / 32) * NF * 64;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
         const int lane = i & 63;
@@ -440,7 +417,7 @@ __global__ __launch_bounds__(B16<H>::NW * 64) void gru_bwd16_kernel(GruBwdParams
         for (int e = 0; e < 4; ++e)
             dh[ct][e] = (d.d_hfin && rid_e[e] >= 0) ? d.d_hfin[(size_t)rid_e[e] * H + unit[ct]] : 0.0f;
     }
-    const int exw = gru16_exponent(*d.wmax);
+    const int exw = tt_pow2_exponent(*d.wmax);
 
     char *const img = lds;                                  // [hi, lo][16][LDG] fp16
     float *const rmax = (float *)(lds + C::A_BYTES);        // [2][NW][16]
@@ -560,7 +537,7 @@ __global__ __launch_bounds__(B16<H>::NW * 64) void gru_bwd16_kernel(GruBwdParams
 #pragma unroll
             for (int ww = 0; ww < C::NW; ++ww)
                 m = fmaxf(m, rmax[(rb * C::NW + ww) * 16 + kq * 4 + e]);
-            const int er = gru16_exponent(__float_as_uint(m));
+            const int er = tt_pow2_exponent(__float_as_uint(m));
             const float upr = ldexpf(1.0f, er);
             down[e] = ldexpf(1.0f, -(er + exw));
             _Float16 *dst = (_Float16 *)img + (kq * 4 + e) * C::LDG;
@@ -655,7 +632,7 @@ bool gru16_supported(int H) { return H == 256 || H == 128; }
 // W_hh [3H][H] fp32 -> absmax word + packed fp16 hi/lo fragments (3H*H*4 bytes: the size of the fp32 matrix)
 int gru16_pack(const float *W_hh, int H, unsigned *absmax /*zeroed by the caller on the stream*/, void *wp16, hipStream_t st)
 {
-    hipLaunchKernelGGL(whh_absmax_kernel, dim3(48), dim3(256), 0, st, W_hh, 3 * H * H, absmax);
+    TT_RC_CHECK(tt_absmax(W_hh, (int64_t)3 * H * H, absmax, st));
     hipLaunchKernelGGL(pack_whh16_kernel, dim3(96), dim3(256), 0, st, W_hh, H, (const unsigned *)absmax, (_Float16 *)wp16);
     TT_LAUNCH_CHECK();
     return TT_OK;
@@ -672,7 +649,7 @@ int gru16_launch(const GruParams &gp, int ndir, hipStream_t st)
 
 int gru16_pack_t(const float *W_hh, int H, unsigned *absmax /*zeroed by the caller on the stream*/, void *wtp16, hipStream_t st)
 {
-    hipLaunchKernelGGL(whh_absmax_kernel, dim3(48), dim3(256), 0, st, W_hh, 3 * H * H, absmax);
+    TT_RC_CHECK(tt_absmax(W_hh, (int64_t)3 * H * H, absmax, st));
     hipLaunchKernelGGL(pack_whh16_t_kernel, dim3(96), dim3(256), 0, st, W_hh, H, (const unsigned *)absmax, (_Float16 *)wtp16);
     TT_LAUNCH_CHECK();
     return TT_OK;
