@@ -137,6 +137,15 @@ int tt_topk_merge_shards(const void *gathered, int world, size_t rank_stride, si
 int tt_score_rank_f32(const float *Q, int B, int d, const float *D, int64_t N, const int64_t *target,
                       int64_t *rank, tt_stream_t stream);
 
+/*
+ * Every score of every query, for callers that blend the dense score of ALL documents with another signal:
+ *   dense_scores = cosine_similarity([query_emb], self.doc_embeddings)[0]     backend/simple_hybrid.py:53-54
+ * Q [B,d], D [N,d] -> S [B,N] f32, S[b][n] = the same ascending-index fp32 FMA chain tt_score_topk_f32 selects from
+ * (for unit-norm rows that is the cosine).  Materialises B*N floats: meant for the small corpora that idiom is
+ * used on; the top-k entry points above never form this matrix.  d multiple of 4, <= 512.
+ */
+int tt_score_all_f32(const float *Q, int B, int d, const float *D, int64_t N, float *S, tt_stream_t stream);
+
 /* ------------------------------------------------------------------ */
 /* Encoder tower (GloVe gather -> GRU -> L2-normalise)                 */
 /* ------------------------------------------------------------------ */

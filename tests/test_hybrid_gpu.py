@@ -44,3 +44,30 @@ def test_hybrid_blend_matches_reference_simple_hybrid(tmp_path, golden):
             tenth = min(r["score"] for r in res)
             outside = np.delete(want, [r["index"] for r in res])
             assert outside.max() <= tenth + 2e-5
+
+
+def test_simple_hybrid_retriever_drop_in_matches_reference(tmp_path, golden):
+    """hybrid.SimpleHybridRetriever mirrors backend/simple_hybrid.py:13-67 (same constructor, fit, search): for every alpha
+    and query of G11 the (document, score) pairs it returns carry the reference's scores, in the reference's order."""
+    from twotowermlretrieval_amd.hybrid import SimpleHybridRetriever
+    from twotowermlretrieval_amd import score_all
+    g = golden("g11_hybrid.npz")
+    docs = [str(d) for d in g["docs"]]
+    art = str(_artifacts(tmp_path, g))
+    for ai, alpha in enumerate(g["alphas"]):
+        r = SimpleHybridRetriever(art, alpha=float(alpha))
+        r.fit(docs)
+        np.testing.assert_allclose(r.doc_embeddings.cpu().numpy(), g["doc_emb"], atol=1e-5, rtol=0)
+        for qi, q in enumerate(g["queries"]):
+            want = g["combined"][ai, qi]
+            res = r.search(str(q), top_k=10)
+            assert len(res) == 10 and all(isinstance(d, str) for d, _ in res)
+            ref_sorted = np.sort(want)[::-1]
+            for pos, (doc, score) in enumerate(res):
+                assert abs(score - ref_sorted[pos]) < 1e-5, (alpha, q, pos)        # the reference's pos-th best score
+                assert abs(score - want[docs.index(doc)]) < 1e-5                    # ... and it belongs to this document
+    # the all-scores entry point itself: the same fp32 chain the top-k kernels select from
+    emb = r.doc_embeddings
+    S = score_all(emb[:5], emb)
+    v, i = __import__("twotowermlretrieval_amd").score_topk(emb[:5], emb, 10)
+    assert torch.equal(torch.gather(S, 1, i), v)

@@ -8,15 +8,8 @@ import numpy as np
 import torch
 import twotowermlretrieval_amd as tt
 
-def make_ids(rs, B, mean, lo, hi, V):
-    L = np.clip(rs.poisson(mean, B), lo, hi)
-    T = int(L.max())
-    ids = np.zeros((B, T), dtype=np.int64)
-    for b in range(B):
-        z = rs.zipf(1.07, L[b]) % V          # Zipf over [0,V): id 0 ("the") shows up inside sentences
-        z[0] = max(z[0], 1)
-        ids[b, :L[b]] = z
-    return torch.from_numpy(ids), int((ids != 0).sum())
+from bench import make_ids  # the synthetic MS-MARCO-shaped token batches of SURVEY 8d
+
 
 def timeit(fn, iters=10, warm=3):
     for _ in range(warm): fn()

@@ -2,14 +2,14 @@
 jpe17/TwoTowerMLRetrieval: fused brute-force scoring + top-k, GRU encoder towers,
 triplet-loss training.  Python host over a C-ABI HIP library (libtt.so, include/tt.h)."""
 from . import collective, evaluators, hybrid, model, query_inferencer, tokenizer, trainer
-from .index import (BruteForceIndex, GraphedSearch, PendingSearch, ShardedIndex, StreamedIndex, score_rank, score_topk, shard_bounds,
+from .index import (BruteForceIndex, GraphedSearch, PendingSearch, ShardedIndex, StreamedIndex, score_all, score_rank, score_topk, shard_bounds,
                     topk_merge)
 from .model import RNNEncoder, TwoTowerModel, triplet_loss_cosine
 from .query_inferencer import QueryInferencer
 from .tokenizer import PretrainedTokenizer
 from .trainer import DataParallelTrainer, FusedClipAdam, train_step
 
-__all__ = ["BruteForceIndex", "GraphedSearch", "ShardedIndex", "PendingSearch", "StreamedIndex", "score_topk", "topk_merge", "score_rank", "shard_bounds",
+__all__ = ["BruteForceIndex", "GraphedSearch", "ShardedIndex", "PendingSearch", "StreamedIndex", "score_topk", "topk_merge", "score_rank", "score_all", "shard_bounds",
            "RNNEncoder", "TwoTowerModel", "triplet_loss_cosine", "QueryInferencer", "PretrainedTokenizer",
            "FusedClipAdam", "DataParallelTrainer", "train_step", "model", "trainer", "tokenizer", "query_inferencer",
            "evaluators", "hybrid", "collective"]

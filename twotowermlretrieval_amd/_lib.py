@@ -36,6 +36,7 @@ SIGNATURES = {
     "tt_topk_merge": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "tt_topk_merge_shards": (_i, [_vp, _i, _sz, _sz, _i, _i, _i, _vp, _vp, _vp]),
     "tt_score_rank_f32": (_i, [_vp, _i, _i, _vp, _i64, _vp, _vp, _vp]),
+    "tt_score_all_f32": (_i, [_vp, _i, _i, _vp, _i64, _vp, _vp]),
     "tt_tok_create": (_i, [_vp, _vp, _vp, _i64, _i64, _vp]),
     "tt_tok_destroy": (None, [_vp]),
     "tt_tok_encode": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _i]),

@@ -858,6 +858,47 @@ __global__ __launch_bounds__(256) void score_rank_kernel(const float *__restrict
         rank[b] = 1 + (int64_t)cnt[0] + cnt[1] + cnt[2] + cnt[3];
 }
 
+// All scores of a query: S[b][n] = the ascending-index FMA chain of <Q[b], D[n]> (the scores score_topk selects from),
+// for the callers that blend the dense score of EVERY document with another signal (backend/simple_hybrid.py:53-56).
+// grid (ceil(N / 256), B); a wave takes 64 documents, staged 32 features at a time through LDS like score_rank_kernel.
+__global__ __launch_bounds__(256) void score_all_kernel(const float *__restrict__ Q, const float *__restrict__ D, int N,
+                                                        int d, float *__restrict__ S)
+{
+    __shared__ float qs[512];
+    __shared__ float stage[4][64 * 33];
+    const int b = blockIdx.y, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int x = threadIdx.x; x < d; x += 256)
+        qs[x] = Q[(size_t)b * d + x];
+    __syncthreads();
+    float *img = stage[wv];
+    const int n0 = blockIdx.x * 256 + wv * 64;
+    if (n0 >= N)
+        return; // wave-uniform; no block barrier below
+    float acc = 0.0f;
+    for (int x0 = 0; x0 < d; x0 += 32) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int r = 8 * i + (lane >> 3), n = min(n0 + r, N - 1);
+            f32x4 v = {0, 0, 0, 0};
+            if (x0 + 4 * (lane & 7) < d)
+                v = *(const f32x4 *)(D + (size_t)n * d + x0 + 4 * (lane & 7));
+            float *dst = img + r * 33 + 4 * (lane & 7);
+            dst[0] = v.x;
+            dst[1] = v.y;
+            dst[2] = v.z;
+            dst[3] = v.w;
+        }
+        __builtin_amdgcn_wave_barrier();
+        const float *mine = img + lane * 33;
+        const int xe = min(32, d - x0);
+        for (int x = 0; x < xe; ++x)
+            acc = fmaf(qs[x0 + x], mine[x], acc);
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (n0 + lane < N)
+        S[(size_t)b * N + n0 + lane] = acc;
+}
+
 // One launch of score_topk_kernel over docs [0,N): how the work is cut and where its
 // partial lists live inside the workspace.
 struct Pass {
@@ -1206,6 +1247,21 @@ TT_EXPORT int tt_topk_merge_shards(const void *gathered, int world, size_t rank_
     hipLaunchKernelGGL(topk_merge_kernel, dim3(B), dim3(MERGE_THREADS), 0, (hipStream_t)stream, (const float *)gathered,
                        (const int64_t *)((const char *)gathered + idx_byte_offset), world * kp, k, out_val, out_idx,
                        (const int *)nullptr, kp, rank_stride);
+    TT_LAUNCH_CHECK();
+    return TT_OK;
+}
+
+TT_EXPORT int tt_score_all_f32(const float *Q, int B, int d, const float *D, int64_t N, float *S, tt_stream_t stream)
+{
+    if (B < 0 || N <= 0 || d <= 0 || (d & 3))
+        return tt_fail(TT_ERR_BAD_SHAPE, "tt_score_all_f32: B=%d N=%lld d=%d", B, (long long)N, d);
+    if (N >= INT_MAX || d > 512 || B > 65535)
+        return tt_fail(TT_ERR_UNSUPPORTED, "tt_score_all_f32: N, d (<= 512) or B (<= 65535) too large");
+    if (B == 0)
+        return TT_OK;
+    if (!Q || !D || !S)
+        return tt_fail(TT_ERR_BAD_SHAPE, "tt_score_all_f32: null pointer");
+    hipLaunchKernelGGL(score_all_kernel, dim3((unsigned)((N + 255) / 256), B), dim3(256), 0, (hipStream_t)stream, Q, D, (int)N, d, S);
     TT_LAUNCH_CHECK();
     return TT_OK;
 }

@@ -21,7 +21,7 @@ from typing import Dict, List, Sequence
 import numpy as np
 import torch
 
-from .index import BruteForceIndex
+from .index import BruteForceIndex, score_all
 
 
 class HybridSearcher:
@@ -63,3 +63,35 @@ class HybridSearcher:
         order = np.argsort(-final, kind="stable")[:n_results]
         return [{"doc": self.documents[cand[i]], "index": cand[i], "score": float(final[i]),
                  "dense_score": float(dense[i]), "tfidf_score": float(tf[i])} for i in order]
+
+
+class SimpleHybridRetriever:
+    """Drop-in for backend/simple_hybrid.py:13-67 (same constructor, `fit`, `search` and return types): TF-IDF + dense
+    scores of EVERY document, combined = alpha * dense + (1 - alpha) * tfidf, descending argsort, top_k (doc, score)
+    pairs.  As in the reference the corpus is embedded with the SAME (query) encoder (:37-41) and the vectorizer is
+    TfidfVectorizer(stop_words='english', max_features=10000) (:24).  The dense scores come from the HIP path
+    (query tower + tt_score_all_f32); the TF-IDF half is sklearn on the CPU, as in the reference."""
+
+    def __init__(self, artifacts_path: str, alpha: float = 0.5, device=None):
+        from sklearn.feature_extraction.text import TfidfVectorizer
+        from .query_inferencer import QueryInferencer
+        self.dense_retriever = QueryInferencer(artifacts_path, device=device)
+        self.alpha = alpha
+        self.tfidf = TfidfVectorizer(stop_words="english", max_features=10000)
+        self.documents: List[str] = []
+        self.doc_embeddings = None
+
+    def fit(self, documents: Sequence[str]) -> None:
+        self.documents = list(documents)
+        self.tfidf_matrix = self.tfidf.fit_transform(self.documents)
+        # one batched call of the query tower instead of the reference's per-document loop: same rows
+        self.doc_embeddings = self.dense_retriever.get_query_embeddings(self.documents)
+
+    def search(self, query: str, top_k: int = 10):
+        from sklearn.metrics.pairwise import cosine_similarity
+        tfidf_scores = cosine_similarity(self.tfidf.transform([query]), self.tfidf_matrix)[0]
+        q = torch.from_numpy(self.dense_retriever.get_query_embedding(query)).to(self.doc_embeddings.device)
+        dense_scores = score_all(q, self.doc_embeddings).cpu().numpy().astype(np.float64)
+        combined = self.alpha * dense_scores + (1 - self.alpha) * tfidf_scores
+        top = np.argsort(combined)[::-1][:top_k]
+        return [(self.documents[i], combined[i]) for i in top]

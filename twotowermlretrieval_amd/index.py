@@ -20,7 +20,7 @@ import torch
 
 from . import _lib
 
-__all__ = ["GraphedSearch", "score_topk", "topk_merge", "score_rank", "BruteForceIndex", "ShardedIndex", "PendingSearch", "StreamedIndex",
+__all__ = ["GraphedSearch", "score_topk", "topk_merge", "score_rank", "score_all", "BruteForceIndex", "ShardedIndex", "PendingSearch", "StreamedIndex",
            "shard_bounds"]
 
 
@@ -94,6 +94,23 @@ def score_rank(q: torch.Tensor, docs: torch.Tensor, target: torch.Tensor) -> tor
         _lib.check(_lib.lib().tt_score_rank_f32(q.data_ptr(), B, d, docs.data_ptr(), docs.shape[0], target.data_ptr(),
                                                 rank.data_ptr(), _stream(q)))
     return rank
+
+
+def score_all(q: torch.Tensor, docs: torch.Tensor) -> torch.Tensor:
+    """q @ docs.T as a [B,N] matrix (same fp32 FMA chain as score_topk's scores): for callers that blend the dense score
+    of EVERY document with another signal (backend/simple_hybrid.py:53-56).  Small corpora only: it materialises B*N."""
+    squeeze = q.dim() == 1
+    if squeeze:
+        q = q.unsqueeze(0)
+    _need_cuda(q, docs)
+    q, docs = _f32c(q), _f32c(docs)
+    if docs.dim() != 2 or docs.shape[1] != q.shape[1]:
+        raise ValueError(f"shape mismatch: q {tuple(q.shape)} vs docs {tuple(docs.shape)}")
+    out = torch.empty((q.shape[0], docs.shape[0]), dtype=torch.float32, device=q.device)
+    with torch.cuda.device(q.device):
+        _lib.check(_lib.lib().tt_score_all_f32(q.data_ptr(), q.shape[0], q.shape[1], docs.data_ptr(), docs.shape[0],
+                                               out.data_ptr(), _stream(q)))
+    return out[0] if squeeze else out
 
 
 SCREEN_MIN_BATCH = 1     # the screened path wins at every batch size once the corpus is large enough to sample:
