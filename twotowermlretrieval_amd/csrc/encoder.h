@@ -26,6 +26,7 @@ struct EncLayout {
     int ng;                                      // gate rows / H: 3 GRU, 4 LSTM, 1 RNN
     size_t gi[2];                                // scratch: input projections [MT][ng H] per direction
     size_t wp[2];                                // scratch: W_hh packed for the MFMA B operand
+    size_t wih16[2];                             // scratch: W_ih split into fp16 hi | lo images [ng H][Kp] each
     size_t fwd_end;
     // backward scratch (train only)
     size_t d_hfin;                               // [ndir][B][H]
@@ -96,6 +97,10 @@ static inline EncLayout enc_layout(int B, int T, int E, int H, int L, int bidir,
     for (int d = 0; d < 2; ++d) {
         lo.gi[d] = d < lo.ndir ? take(sizeof(float) * lo.MT * ng * H) : 0;
         lo.wp[d] = d < lo.ndir ? take(sizeof(float) * ng * H * H) : 0;
+        {
+            const int in_w = E > lo.ndir * H ? E : lo.ndir * H;
+            lo.wih16[d] = d < lo.ndir ? take((size_t)2 * sizeof(uint16_t) * ng * H * ((in_w + 31) / 32 * 32)) : 0;
+        }
     }
     lo.fwd_end = off;
     lo.d_hfin = lo.d_hid = lo.slabs = 0;

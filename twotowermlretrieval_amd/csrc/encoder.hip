@@ -503,11 +503,21 @@ TT_EXPORT int tt_encoder_forward_f32(const int64_t *ids, int B, int T, const flo
                 rc = tt_absmax(w[0], (int64_t)NGH * I, wih_max, st);
                 if (rc != TT_OK)
                     return rc;
+                // W_ih is split into fp16 hi / lo images ONCE here (every 128-token workgroup would otherwise convert the
+                // tiles of it it touches: the conversion VALU work, not the MFMAs, bound the launch)
+                const int Kp = (I + 31) / 32 * 32;
+                char *w16 = ws + lo.wih16[d];
+                rc = tt_pack_rows16(w[0], NGH, I, wih_max, w16, w16 + (size_t)NGH * Kp * sizeof(uint16_t), st);
+                if (rc != TT_OK)
+                    return rc;
                 g.a_absmax = nullptr;
                 g.a_exp = l == 0 ? 0 : 6;
                 g.b_absmax = wih_max;
                 g.b_exp = 0;
-                rc = tt_sgemm16_nn(g, st);
+                g.b_hi16 = w16;
+                g.b_lo16 = w16 + (size_t)NGH * Kp * sizeof(uint16_t);
+                g.ldb16 = Kp;
+                rc = tt_sgemm16(g, false, false, 1, st);
             } else {
                 rc = tt_sgemm(g, false, false, 1, st);
             }

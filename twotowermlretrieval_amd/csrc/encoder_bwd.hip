@@ -378,6 +378,8 @@ int gemm_tn(const float *A, int64_t lda, int Mo, const float *Bsrc, int64_t ldb,
     g.b_absmax = nullptr;
     g.a_exp = 0;
     g.b_exp = b_exp;
+    g.b_hi16 = g.b_lo16 = nullptr;
+    g.ldb16 = 0;
     int rc = a_absmax ? tt_sgemm16(g, true, true, ENC_SPLITK, st) : tt_sgemm(g, true, true, ENC_SPLITK, st);
     if (rc != TT_OK)
         return rc;

@@ -28,6 +28,11 @@ struct SgemmParams {
     // accumulator).  exponent = *_absmax ? tt_pow2_exponent(*_absmax) (largest element -> [2^13, 2^14)) : *_exp
     const unsigned *a_absmax, *b_absmax; // device: bit pattern of max |element| (nullable)
     int a_exp, b_exp;
+    // tt_sgemm16 with B_T == false only: B given ALREADY split (tt_pack_rows16: [N][ldb16] fp16 hi and lo images, k padded
+    // with zeros to a multiple of 32, scaled by *b_absmax's power of two).  A weight matrix is then converted once per
+    // call instead of once per workgroup that touches a tile of it.  Null: B is split on the fly like A.
+    const void *b_hi16, *b_lo16;
+    int64_t ldb16;
 };
 
 // exponent e with max|x| 2^e in [2^13, 2^14) (0 for an all-zero or non-finite tensor)
@@ -53,6 +58,10 @@ int tt_sgemm16_nn(const SgemmParams &p, hipStream_t st);
 // ... and with both operands stored [K][rows] (C = A^T * B summed over their rows: the weight-gradient products over
 // all tokens), split-K like tt_sgemm.  Same four [row][k] LDS images; only the staging differs.
 int tt_sgemm16(const SgemmParams &p, bool a_t, bool b_t, int splits, hipStream_t st);
+
+// W [N][K] fp32 -> hi / lo fp16 images [N][Kp] (Kp = K rounded up to 32, zero padded), W scaled by the power of two
+// that *absmax implies (tt_pow2_exponent)
+int tt_pack_rows16(const float *W, int N, int K, const unsigned *absmax, void *hi16, void *lo16, hipStream_t st);
 
 // bit pattern of max |x| over n floats -> *out (atomicMax; the caller zeroes *out on the stream first)
 int tt_absmax(const float *x, int64_t n, unsigned *out, hipStream_t st);

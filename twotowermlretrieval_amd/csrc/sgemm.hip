@@ -244,7 +244,36 @@ __device__ __forceinline__ void commit16(_Float16 *__restrict__ hi_img, _Float16
     }
 }
 
-template <bool A_T, bool B_T>
+// B operand already split (tt_pack_rows16): 16 halves of hi and of lo per thread, straight into the images
+__device__ __forceinline__ void fetch16_pre(h8v (&v)[4], const _Float16 *__restrict__ hi, const _Float16 *__restrict__ lo,
+                                            int64_t ld, int row0, int rows_eff, int k0, int tid)
+{
+    const int r = tid >> 1, kc = (tid & 1) * 16;
+    const int row = row0 + r;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        v[q] = (h8v){0, 0, 0, 0, 0, 0, 0, 0};
+    if (row < rows_eff) {
+        const _Float16 *ph = hi + (int64_t)row * ld + k0 + kc, *pl = lo + (int64_t)row * ld + k0 + kc;
+        v[0] = *(const h8v *)ph;
+        v[1] = *(const h8v *)(ph + 8);
+        v[2] = *(const h8v *)pl;
+        v[3] = *(const h8v *)(pl + 8);
+    }
+}
+__device__ __forceinline__ void commit16_pre(_Float16 *__restrict__ hi_img, _Float16 *__restrict__ lo_img, const h8v (&v)[4],
+                                             int tid)
+{
+    const int r = tid >> 1;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const int o = r * LDT16 + ((((tid & 1) * 2 + half) ^ swz16(r)) << 3);
+        *(h8v *)(hi_img + o) = v[half];
+        *(h8v *)(lo_img + o) = v[2 + half];
+    }
+}
+
+template <bool A_T, bool B_T, bool B_PRE = false>
 __global__ __launch_bounds__(256) void sgemm16_kernel(SgemmParams p)
 {
     __shared__ __attribute__((aligned(16))) _Float16 img[4][BM * LDT16]; // A hi, A lo, B hi, B lo
@@ -286,15 +315,26 @@ __global__ __launch_bounds__(256) void sgemm16_kernel(SgemmParams p)
                 acc[a][b][r] = 0.0f;
 
     f32x4 ra[4], rb[4];
+    h8v rbp[4];
+    const _Float16 *bhi = (const _Float16 *)p.b_hi16, *blo = (const _Float16 *)p.b_lo16;
     fetch16<A_T>(ra, p.A, p.lda, p.a_map, m0, M, kb, ke, tid);
-    fetch16<B_T>(rb, p.B, p.ldb, p.b_map, n0, p.N, kb, ke, tid);
+    if constexpr (B_PRE)
+        fetch16_pre(rbp, bhi, blo, p.ldb16, n0, p.N, kb, tid);
+    else
+        fetch16<B_T>(rb, p.B, p.ldb, p.b_map, n0, p.N, kb, ke, tid);
     for (int k0 = kb; k0 < ke; k0 += BK16) {
         commit16<A_T>(img[0], img[1], ra, sa, tid);
-        commit16<B_T>(img[2], img[3], rb, sb, tid);
+        if constexpr (B_PRE)
+            commit16_pre(img[2], img[3], rbp, tid);
+        else
+            commit16<B_T>(img[2], img[3], rb, sb, tid);
         __syncthreads();
         if (k0 + BK16 < ke) { // next tile's global loads fly under this tile's MFMAs
             fetch16<A_T>(ra, p.A, p.lda, p.a_map, m0, M, k0 + BK16, ke, tid);
-            fetch16<B_T>(rb, p.B, p.ldb, p.b_map, n0, p.N, k0 + BK16, ke, tid);
+            if constexpr (B_PRE)
+                fetch16_pre(rbp, bhi, blo, p.ldb16, n0, p.N, k0 + BK16, tid);
+            else
+                fetch16<B_T>(rb, p.B, p.ldb, p.b_map, n0, p.N, k0 + BK16, ke, tid);
         }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -309,43 +349,78 @@ __global__ __launch_bounds__(256) void sgemm16_kernel(SgemmParams p)
                 bh[t] = *(const h8v *)(img[2] + bo);
                 bl[t] = *(const h8v *)(img[3] + bo);
             }
+            // The B-image fragment is the MFMA's A operand and vice versa: the accumulator tile is C^T (rows = output
+            // columns, columns = output rows), so a lane holds FOUR CONSECUTIVE output columns of one output row in
+            // registers 4g .. 4g+3 and the epilogue stores 16 bytes at a time (with the natural orientation it issued 64
+            // dword stores per lane -- 1.8 GB of input projections went out 256 bytes per instruction).
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[nt], ah[mt], acc[mt][nt], 0, 0, 0);
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[nt], al[mt], acc[mt][nt], 0, 0, 0);
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bl[nt], acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[nt], ah[mt], acc[mt][nt], 0, 0, 0);
         }
         __syncthreads();
     }
 
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < 2; ++mt) {
+        const int row = m0 + 64 * wr + 32 * mt + i; // lane i <-> output row; registers 4g .. 4g+3 <-> 4 consecutive columns
+        if (row >= M)
+            continue;
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-            const int col = n0 + 64 * wc + 32 * nt + i;
-            if (col >= p.N)
-                continue;
-            const float bv = (p.bias && blockIdx.z == 0) ? p.bias[col] : 0.0f;
+        for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + 64 * wr + 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (row < M) {
-                    float *dst = C + (size_t)row * p.ldc + col;
-                    const float v = acc[mt][nt][r] * down + bv;
-                    *dst = p.accumulate ? *dst + v : v;
-                }
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int col = n0 + 64 * wc + 32 * nt + 8 * g4 + 4 * h;
+                if (col >= p.N) // N is a multiple of 4
+                    continue;
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    v[e] = acc[mt][nt][4 * g4 + e] * down;
+                if (p.bias && blockIdx.z == 0)
+                    v += *(const f32x4 *)(p.bias + col);
+                f32x4 *dst = (f32x4 *)(C + (size_t)row * p.ldc + col);
+                if (p.accumulate)
+                    *dst = *dst + v;
+                else // write-once output (1.8 GB of input projections per index-build call): keep it from evicting the
+                    __builtin_nontemporal_store(v, dst); // gathered A rows the other n-blocks of this m-block re-read from L2
+
             }
+    }
+}
+
+// W [N][K] fp32 -> hi / lo [N][Kp] fp16 (zero padded), one thread per 8 consecutive k
+__global__ __launch_bounds__(256) void pack_rows16_kernel(const float *__restrict__ W, int N, int K, int Kp,
+                                                          const unsigned *__restrict__ absmax, _Float16 *__restrict__ hi,
+                                                          _Float16 *__restrict__ lo)
+{
+    const float sc = ldexpf(1.0f, tt_pow2_exponent(*absmax));
+    const int per_row = Kp / 8;
+    const int64_t total = (int64_t)N * per_row;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int row = (int)(i / per_row), k0 = (int)(i % per_row) * 8;
+        h8v vh, vl;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float x = (k0 + e < K) ? W[(size_t)row * K + k0 + e] * sc : 0.0f;
+            const _Float16 hv = (_Float16)x;
+            vh[e] = hv;
+            vl[e] = (_Float16)(x - (float)hv);
         }
+        *(h8v *)(hi + (size_t)row * Kp + k0) = vh;
+        *(h8v *)(lo + (size_t)row * Kp + k0) = vl;
+    }
 }
 
 __global__ __launch_bounds__(256) void absmax_kernel(const float *__restrict__ x, int64_t n, unsigned *__restrict__ out)
@@ -427,14 +502,20 @@ int tt_sgemm16(const SgemmParams &p, bool a_t, bool b_t, int splits, hipStream_t
         return TT_OK;
     if (a_t != b_t)
         return tt_fail(TT_ERR_UNSUPPORTED, "tt_sgemm16: only A*B^T (both row operands) and A^T*B (both [K][rows]) are built");
-    if ((!a_t && (p.K & 3)) || (a_t && ((p.M & 3) || (p.N & 3))) || (p.lda & 3) || (p.ldb & 3))
-        return tt_fail(TT_ERR_UNSUPPORTED, "tt_sgemm16: dims must be multiples of 4 (M=%d N=%d K=%d)", p.M, p.N, p.K);
+    if ((!a_t && (p.K & 3)) || (a_t && (p.M & 3)) || (p.N & 3) || (p.lda & 3) || (p.ldb & 3) || (p.ldc & 3) ||
+        ((uintptr_t)p.C & 15) || (p.bias && ((uintptr_t)p.bias & 15)))
+        return tt_fail(TT_ERR_UNSUPPORTED, "tt_sgemm16: dims / leading dimensions must be multiples of 4 and C, bias 16-byte "
+                                           "aligned (M=%d N=%d K=%d)", p.M, p.N, p.K);
     if (splits < 1)
         splits = 1;
     if (splits > 1 && p.accumulate)
         return tt_fail(TT_ERR_BAD_SHAPE, "tt_sgemm16: accumulate with split-K");
     dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM, splits);
-    if (!a_t)
+    if (!a_t && p.b_hi16 && p.b_lo16) {
+        if (!p.b_absmax || (p.ldb16 & 31) || p.ldb16 < p.K)
+            return tt_fail(TT_ERR_BAD_SHAPE, "tt_sgemm16: pre-split B needs b_absmax and ldb16 >= K, a multiple of 32");
+        hipLaunchKernelGGL((sgemm16_kernel<false, false, true>), grid, dim3(256), 0, st, p);
+    } else if (!a_t)
         hipLaunchKernelGGL((sgemm16_kernel<false, false>), grid, dim3(256), 0, st, p);
     else
         hipLaunchKernelGGL((sgemm16_kernel<true, true>), grid, dim3(256), 0, st, p);
@@ -443,6 +524,18 @@ int tt_sgemm16(const SgemmParams &p, bool a_t, bool b_t, int splits, hipStream_t
 }
 
 int tt_sgemm16_nn(const SgemmParams &p, hipStream_t st) { return tt_sgemm16(p, false, false, 1, st); }
+
+int tt_pack_rows16(const float *W, int N, int K, const unsigned *absmax, void *hi16, void *lo16, hipStream_t st)
+{
+    if (N <= 0 || K <= 0)
+        return TT_OK;
+    const int Kp = (K + 31) / 32 * 32;
+    const int64_t want = ((int64_t)N * (Kp / 8) + 255) / 256;
+    hipLaunchKernelGGL(pack_rows16_kernel, dim3((unsigned)(want > 1024 ? 1024 : want)), dim3(256), 0, st, W, N, K, Kp, absmax,
+                       (_Float16 *)hi16, (_Float16 *)lo16);
+    TT_LAUNCH_CHECK();
+    return TT_OK;
+}
 
 int tt_absmax(const float *x, int64_t n, unsigned *out, hipStream_t st)
 {
