@@ -507,17 +507,29 @@ TT_EXPORT int tt_encoder_forward_f32(const int64_t *ids, int B, int T, const flo
                 // tiles of it it touches: the conversion VALU work, not the MFMAs, bound the launch)
                 const int Kp = (I + 31) / 32 * 32;
                 char *w16 = ws + lo.wih16[d];
-                rc = tt_pack_rows16(w[0], NGH, I, wih_max, w16, w16 + (size_t)NGH * Kp * sizeof(uint16_t), st);
-                if (rc != TT_OK)
-                    return rc;
                 g.a_absmax = nullptr;
                 g.a_exp = l == 0 ? 0 : 6;
                 g.b_absmax = wih_max;
                 g.b_exp = 0;
-                g.b_hi16 = w16;
-                g.b_lo16 = w16 + (size_t)NGH * Kp * sizeof(uint16_t);
-                g.ldb16 = Kp;
-                rc = tt_sgemm16(g, false, false, 1, st);
+                static const bool tiled_k1 = getenv("TT_K1_TILED") && atoi(getenv("TT_K1_TILED")) != 0; // A/B switch
+                if (!tiled_k1 && tt_gemm_rows16_supported(NGH, I, g.lda, g.ldc)) {
+                    // token-stationary form (gemm_rows16.hip): W_ih as a fragment stream, the token block split once
+                    rc = tt_pack_frag16(w[0], NGH, I, wih_max, w16, st);
+                    if (rc != TT_OK)
+                        return rc;
+                    g.b_hi16 = w16;
+                    g.b_lo16 = nullptr;
+                    g.ldb16 = 0;
+                    rc = tt_gemm_rows16(g, st);
+                } else {
+                    rc = tt_pack_rows16(w[0], NGH, I, wih_max, w16, w16 + (size_t)NGH * Kp * sizeof(uint16_t), st);
+                    if (rc != TT_OK)
+                        return rc;
+                    g.b_hi16 = w16;
+                    g.b_lo16 = w16 + (size_t)NGH * Kp * sizeof(uint16_t);
+                    g.ldb16 = Kp;
+                    rc = tt_sgemm16(g, false, false, 1, st);
+                }
             } else {
                 rc = tt_sgemm(g, false, false, 1, st);
             }

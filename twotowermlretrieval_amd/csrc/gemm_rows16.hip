@@ -1,0 +1,290 @@
+// K1r: the input projections Gi = X W_ih^T + b_ih of a whole packed batch (model.py:59-62: nn.GRU's first half; X rows
+// are GloVe table rows gathered by token id) as a TOKEN-STATIONARY GEMM on the f16 matrix pipes.
+//
+// Same arithmetic as tt_sgemm16 (sgemm.hip): both operands split into fp16 hi + lo parts after an exact power-of-two
+// scaling, product = hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16 with fp32 accumulation.  What changes is who
+// stays put.  The tiled kernel (128 x 128 output tile, both operands through LDS, two barriers per 32-wide k-tile)
+// re-converts every token tile once per 128-column block (6x at N = 768) and hides one tile's worth of load latency
+// behind 24 MFMAs; measured 1.45 ms for 573 k tokens x 768 x 300 where the MFMAs need 0.34 ms.  Here
+//   * a workgroup owns 64 tokens and ALL N output columns: the 64 x K token block is gathered, scaled, split ONCE into
+//     two fp16 LDS images (64 x 312 halves each: 78 KiB per workgroup, two workgroups per CU) and never moves again;
+//   * W_ih arrives pre-split in MFMA-fragment order (tt_pack_frag16: 1 KiB per fragment, lane-linear), streamed from
+//     L2 straight into registers by buffer loads through a 4-deep register ring -- no LDS, no barrier in the main loop;
+//   * each of the 4 waves walks its own N/4 columns in passes of 64 (2 x 2 accumulator tiles of 32 x 32 against the
+//     64 tokens), re-reading the token fragments from LDS (42 B/clk per CU) and storing C^T-oriented accumulators as
+//     16-byte non-temporal stores at the end of each pass.
+// One barrier per workgroup (after the fill); the second resident workgroup's fill overlaps the first one's MFMAs.
+// Bounds per 573 k-token launch: MFMA 0.34 ms, L2 -> CU fragment stream 8.4 GB (0.4 ms at the ~87 GB/s per CU measured
+// for gru16), output 1.76 GB (0.3 ms of HBM writes), all overlapped.
+#include "sgemm.h"
+
+#include <type_traits>
+
+namespace {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+typedef float f32x16v __attribute__((ext_vector_type(16)));
+
+#define RS_MFMA(wf, tf, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(tf, wf, c, 0, 0, 0)
+constexpr int RS_ROWS = 64;                     // tokens per workgroup
+constexpr int RS_LDH = 312;                     // halves per image row: 624 B = 156 dwords = 28 mod 32 banks
+constexpr int RS_IMG = RS_ROWS * RS_LDH * 2;    // bytes per image (hi | lo)
+constexpr int RS_LDS = 2 * RS_IMG;              // 79 872 B: two workgroups per 160 KiB CU
+#ifndef TT_ROWS_NR
+#define TT_ROWS_NR 4
+#endif
+constexpr int RS_NR = TT_ROWS_NR;                        // ring depth in k-steps (4 fragments = 16 VGPRs each)
+
+__device__ __forceinline__ h8 frag_load(__amdgpu_buffer_rsrc_t rsrc, int lane_off, int byte_off)
+{
+    return __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane_off, byte_off, 0));
+}
+
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F &&f)
+{
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+// NKS = ceil(K / 16) k-steps, NP = N / 256 passes per wave
+template <int NKS, int NP>
+__global__ __launch_bounds__(256, 2) void gemm_rows16_kernel(SgemmParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6); // wave-uniform: the buffer resource below must live in SGPRs
+    const int M = p.m_dyn ? min(p.M, *p.m_dyn) : p.M;
+    const int row0 = blockIdx.x * RS_ROWS;
+    if (row0 >= M)
+        return;
+    const int ea = p.a_absmax ? tt_pow2_exponent(*p.a_absmax) : p.a_exp;
+    const int eb = p.b_absmax ? tt_pow2_exponent(*p.b_absmax) : p.b_exp;
+    const float sa = ldexpf(1.0f, ea), down = ldexpf(1.0f, -(ea + eb)), up = ldexpf(1.0f, ea + eb);
+    const int i = lane & 31, h = lane >> 5;
+    // The bias is the accumulators' starting value (times the operand scales), fetched one pass ahead: a load issued in
+    // the epilogue would have to be waited for with vmcnt(0), draining the fragment ring 16 times per pass.
+    float bnext[2]; // [ct]: column (pass 4 + w) 64 + 32 ct + i
+    auto load_bias = [&](int pass) {
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+            bnext[ct] = p.bias ? p.bias[(pass * 4 + w) * 64 + 32 * ct + i] : 0.0f;
+    };
+    load_bias(0);
+
+    // ---- this wave's fragment stream: the ring's first RS_NR k-steps fly under the fill ----
+    constexpr int TOTAL = NP * NKS;
+    const __amdgpu_buffer_rsrc_t wsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)((const char *)p.b_hi16 + (size_t)w * TOTAL * 4096), 0, TOTAL * 4096, 0x00020000);
+    const int loff = lane * 16;
+    h8 ring[RS_NR][4];
+    static_for<0, RS_NR>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        if constexpr (i < TOTAL)
+            static_for<0, 4>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                ring[i][j] = frag_load(wsrc, loff, (i * 4 + j) * 1024);
+            });
+    });
+
+    // ---- fill: thread -> (token tid >> 2, 16-byte pieces 4 q + 16 j of its row) ----
+    {
+        const int r = tid >> 2, q = tid & 3, row = row0 + r;
+        const float *src = nullptr;
+        if (row < M)
+            src = p.A + (size_t)(p.a_map ? (int64_t)p.a_map[row] : (int64_t)row) * p.lda;
+        f32x4v v[NKS];
+#pragma unroll
+        for (int j = 0; j < NKS; ++j) {
+            v[j] = (f32x4v){0, 0, 0, 0};
+            if (src && 16 * j + 4 * q < p.K)
+                v[j] = *(const f32x4v *)(src + 16 * j + 4 * q);
+        }
+        char *dst = lds + r * (RS_LDH * 2) + q * 8;
+#pragma unroll
+        for (int j = 0; j < NKS; ++j) {
+            h4 hi, lo;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float x = v[j][e] * sa;
+                const _Float16 hv = (_Float16)x;
+                hi[e] = hv;
+                lo[e] = (_Float16)(x - (float)hv);
+            }
+            *(h4 *)(dst + j * 32) = hi;
+            *(h4 *)(dst + RS_IMG + j * 32) = lo;
+        }
+    }
+    __syncthreads();
+
+    // ---- main loop: flat over (pass, k-step); token fragments one k-step ahead, W fragments RS_NR ahead ----
+    const char *abase = lds + i * (RS_LDH * 2) + h * 16;
+    f32x16v acc[2][2]; // [ct][rt]
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                acc[a][b][e] = bnext[a] * up;
+    h8 ahi[2][2], alo[2][2]; // [parity][rt]
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+        ahi[0][rt] = *(const h8 *)(abase + rt * 32 * (RS_LDH * 2));
+        alo[0][rt] = *(const h8 *)(abase + RS_IMG + rt * 32 * (RS_LDH * 2));
+    }
+    // lane <-> column, registers <-> tokens: a store instruction writes two whole 128-byte lines.  (The C^T orientation's
+    // 16-byte stores put 32 bytes into each of 32 lines per instruction: the launch ran at the 1.9 TB/s those writes
+    // reached, 0.9 ms of its 1.5; whole lines: 0.35 ms.  Plain stores: non-temporal ones are no faster for whole lines
+    // even at 1.8 GB, and an output that fits the MALL is read back from it by the recurrence.)
+    f32x16v stage[2][2];
+    float *const cbase = p.C + (size_t)(row0 + 4 * h) * p.ldc + w * 64 + i;
+    const int mrem = M - row0 - 4 * h; // token offset t of this lane's base row is stored iff t < mrem
+    auto store_one = [&](auto nc, int pass, const f32x16v(&st)[2][2]) {
+        constexpr int n = decltype(nc)::value, rt = n >> 5, ct = (n >> 4) & 1, r = n & 15;
+        constexpr int t = rt * 32 + 8 * (r >> 2) + (r & 3);
+        if (t < mrem) {
+            cbase[(size_t)t * p.ldc + pass * 256 + 32 * ct] = st[ct][rt][r];
+        }
+    };
+    static_for<0, TOTAL>([&](auto qc) {
+        constexpr int q = decltype(qc)::value;
+        constexpr int s = q % NKS, pass = q / NKS, par = q & 1;
+        if constexpr (q + 1 < TOTAL) {
+            constexpr int s1 = (q + 1) % NKS;
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+                ahi[par ^ 1][rt] = *(const h8 *)(abase + rt * 32 * (RS_LDH * 2) + s1 * 32);
+                alo[par ^ 1][rt] = *(const h8 *)(abase + RS_IMG + rt * 32 * (RS_LDH * 2) + s1 * 32);
+            }
+        }
+        // ring slot: [0] hi of column tile 0, [1] lo of it, [2] hi of column tile 1, [3] lo of it.  The W fragment is the
+        // MFMA's A operand: the accumulator tile is C^T, a lane holds 4 consecutive output columns of one token.
+        h8(&b)[4] = ring[q % RS_NR];
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+                acc[ct][rt] = RS_MFMA(b[2 * ct], ahi[par][rt], acc[ct][rt]);
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+                acc[ct][rt] = RS_MFMA(b[2 * ct], alo[par][rt], acc[ct][rt]);
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+                acc[ct][rt] = RS_MFMA(b[2 * ct + 1], ahi[par][rt], acc[ct][rt]);
+        if constexpr (q + RS_NR < TOTAL)
+            static_for<0, 4>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                ring[q % RS_NR][j] = frag_load(wsrc, loff, ((q + RS_NR) * 4 + j) * 1024);
+            });
+        if constexpr (s == 0 && pass + 1 < NP)
+            load_bias(pass + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (s == NKS - 1) { // end of a pass: 64 tokens x 64 columns out
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        stage[ct][rt][r] = acc[ct][rt][r] * down;
+                        acc[ct][rt][r] = bnext[ct] * up; // (the next pass's, if there is one)
+                    }
+            static_for<0, 64>([&](auto nc) { store_one(nc, pass, stage); });
+        }
+    });
+}
+
+// W [N][K] fp32 -> the fragment stream gemm_rows16_kernel reads: 1-KiB blocks ordered (wave, pass, k-step, column tile,
+// hi | lo), lane l of a block = 8 halves of column (pass 4 + wave) 64 + 32 ct + (l & 31) at k = 16 s + 8 (l >> 5) ..
+__global__ __launch_bounds__(256) void pack_frag16_kernel(const float *__restrict__ W, int N, int K, int nks,
+                                                          const unsigned *__restrict__ absmax, _Float16 *__restrict__ out)
+{
+    const float sc = ldexpf(1.0f, tt_pow2_exponent(*absmax));
+    const int np = N / 256;
+    const int total = 4 * np * nks * 2 * 64; // (w, pass, s, ct, lane)
+    for (int t = blockIdx.x * 256 + threadIdx.x; t < total; t += gridDim.x * 256) {
+        const int l = t & 63, ct = (t >> 6) & 1;
+        int rest = t >> 7;
+        const int s = rest % nks;
+        rest /= nks;
+        const int pass = rest % np, w = rest / np;
+        const int col = (pass * 4 + w) * 64 + 32 * ct + (l & 31), k0 = 16 * s + 8 * (l >> 5);
+        h8 vh, vl;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float x = (k0 + e < K) ? W[(size_t)col * K + k0 + e] * sc : 0.0f;
+            const _Float16 hv = (_Float16)x;
+            vh[e] = hv;
+            vl[e] = (_Float16)(x - (float)hv);
+        }
+        _Float16 *blk = out + ((size_t)(((w * np + pass) * nks + s) * 2 + ct) * 2) * 512 + l * 8;
+        *(h8 *)blk = vh;
+        *(h8 *)(blk + 512) = vl;
+    }
+}
+
+template <int NKS, int NP>
+int launch_rows16(const SgemmParams &p, hipStream_t st)
+{
+    static bool attr_done = false; // (idempotent: a race sets the same value twice)
+    if (!attr_done) {
+        TT_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_rows16_kernel<NKS, NP>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         RS_LDS));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((gemm_rows16_kernel<NKS, NP>), dim3((unsigned)((p.M + RS_ROWS - 1) / RS_ROWS)), dim3(256), RS_LDS, st, p);
+    TT_LAUNCH_CHECK();
+    return TT_OK;
+}
+
+} // namespace
+
+bool tt_gemm_rows16_supported(int N, int K, int64_t lda, int64_t ldc)
+{
+    const int nks = (K + 15) / 16, np = N / 256;
+    return N % 256 == 0 && K % 4 == 0 && lda % 4 == 0 && ldc % 4 == 0 && (nks == 19 || nks == 16) && (np == 3 || np == 4 || np == 1);
+}
+
+size_t tt_pack_frag16_bytes(int N, int K)
+{
+    return (size_t)N * ((K + 15) / 16 * 16) * 2 * sizeof(uint16_t);
+}
+
+int tt_pack_frag16(const float *W, int N, int K, const unsigned *absmax, void *out, hipStream_t st)
+{
+    const int nks = (K + 15) / 16;
+    const int total = N / 32 * nks * 2 * 32;
+    hipLaunchKernelGGL(pack_frag16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, W, N, K, nks, absmax,
+                       (_Float16 *)out);
+    TT_LAUNCH_CHECK();
+    return TT_OK;
+}
+
+int tt_gemm_rows16(const SgemmParams &p, hipStream_t st)
+{
+    if (p.M <= 0)
+        return TT_OK;
+    if (!tt_gemm_rows16_supported(p.N, p.K, p.lda, p.ldc) || !p.b_hi16 || p.accumulate || p.k_dyn || p.b_map)
+        return TT_ERR_UNSUPPORTED;
+    const int nks = (p.K + 15) / 16, np = p.N / 256;
+#define TT_ROWS16_CASE(a, b)                                                                                                    \
+    if (nks == a && np == b)                                                                                                    \
+    return launch_rows16<a, b>(p, st)
+    TT_ROWS16_CASE(19, 3);
+    TT_ROWS16_CASE(16, 3);
+    TT_ROWS16_CASE(19, 4);
+    TT_ROWS16_CASE(16, 4);
+    TT_ROWS16_CASE(19, 1);
+    TT_ROWS16_CASE(16, 1);
+#undef TT_ROWS16_CASE
+    return TT_ERR_UNSUPPORTED;
+}

@@ -63,6 +63,14 @@ int tt_sgemm16(const SgemmParams &p, bool a_t, bool b_t, int splits, hipStream_t
 // that *absmax implies (tt_pow2_exponent)
 int tt_pack_rows16(const float *W, int N, int K, const unsigned *absmax, void *hi16, void *lo16, hipStream_t st);
 
+// Token-stationary form of the same product for the input projections (csrc/gemm_rows16.hip): C = A * B^T with A's rows
+// gathered through a_map, K <= 304, N a multiple of 256.  p.b_hi16 = tt_pack_frag16's fragment stream (p.b_lo16 / ldb16
+// unused); a_exp / a_absmax, b_absmax, bias, m_dyn as for tt_sgemm16.
+bool tt_gemm_rows16_supported(int N, int K, int64_t lda, int64_t ldc);
+size_t tt_pack_frag16_bytes(int N, int K);
+int tt_pack_frag16(const float *W, int N, int K, const unsigned *absmax, void *out, hipStream_t st);
+int tt_gemm_rows16(const SgemmParams &p, hipStream_t st);
+
 // bit pattern of max |x| over n floats -> *out (atomicMax; the caller zeroes *out on the stream first)
 int tt_absmax(const float *x, int64_t n, unsigned *out, hipStream_t st);
 
