@@ -51,8 +51,11 @@ __device__ __forceinline__ void static_for(F &&f)
     }
 }
 
-// NKS = ceil(K / 16) k-steps, NP = N / 256 passes per wave
-template <int NKS, int NP>
+// NKS = ceil(K / 16) k-steps (compile time: the k loop is fully unrolled and software-pipelined).  The N / 64 column
+// chunks go round the four waves: wave w takes chunks w, w + 4, ..., one per PASS (runtime loop).
+__host__ __device__ static inline int rs_chunks_of(int nchunks, int w) { return (nchunks - w + 3) / 4; }
+
+template <int NKS>
 __global__ __launch_bounds__(256, 2) void gemm_rows16_kernel(SgemmParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -66,29 +69,34 @@ __global__ __launch_bounds__(256, 2) void gemm_rows16_kernel(SgemmParams p)
     const int eb = p.b_absmax ? tt_pow2_exponent(*p.b_absmax) : p.b_exp;
     const float sa = ldexpf(1.0f, ea), down = ldexpf(1.0f, -(ea + eb)), up = ldexpf(1.0f, ea + eb);
     const int i = lane & 31, h = lane >> 5;
+    const int nchunks = p.N >> 6, npass = rs_chunks_of(nchunks, w);
+    int first = 0; // this wave's first pass in the (wave-major) fragment stream
+    for (int j = 0; j < w; ++j)
+        first += rs_chunks_of(nchunks, j);
     // The bias is the accumulators' starting value (times the operand scales), fetched one pass ahead: a load issued in
-    // the epilogue would have to be waited for with vmcnt(0), draining the fragment ring 16 times per pass.
-    float bnext[2]; // [ct]: column (pass 4 + w) 64 + 32 ct + i
+    // the epilogue would have to be waited for with vmcnt(0), draining the fragment ring at every pass boundary.
+    float bnext[2]; // [ct]: column (4 pass + w) 64 + 32 ct + i
     auto load_bias = [&](int pass) {
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct)
-            bnext[ct] = p.bias ? p.bias[(pass * 4 + w) * 64 + 32 * ct + i] : 0.0f;
+            bnext[ct] = (p.bias && pass < npass) ? p.bias[(pass * 4 + w) * 64 + 32 * ct + i] : 0.0f;
     };
     load_bias(0);
 
-    // ---- this wave's fragment stream: the ring's first RS_NR k-steps fly under the fill ----
-    constexpr int TOTAL = NP * NKS;
+    // ---- this wave's fragment stream (4 KiB per k-step: hi/lo of two column tiles): ring slot of k-step s of any pass is
+    // s % RS_NR, so a pass is PER = NKS rounded up to a multiple of RS_NR ring turns, the last PER - NKS of them refill-only.
+    // Loads past the end of the stream (the prefetch for a pass that does not exist) return zeros: buffer bounds. ----
+    constexpr int PER = (NKS + RS_NR - 1) / RS_NR * RS_NR;
     const __amdgpu_buffer_rsrc_t wsrc = __builtin_amdgcn_make_buffer_rsrc(
-        (void *)((const char *)p.b_hi16 + (size_t)w * TOTAL * 4096), 0, TOTAL * 4096, 0x00020000);
+        (void *)((const char *)p.b_hi16 + (size_t)first * NKS * 4096), 0, npass * NKS * 4096, 0x00020000);
     const int loff = lane * 16;
     h8 ring[RS_NR][4];
     static_for<0, RS_NR>([&](auto ic) {
-        constexpr int i = decltype(ic)::value;
-        if constexpr (i < TOTAL)
-            static_for<0, 4>([&](auto jc) {
-                constexpr int j = decltype(jc)::value;
-                ring[i][j] = frag_load(wsrc, loff, (i * 4 + j) * 1024);
-            });
+        constexpr int k = decltype(ic)::value;
+        static_for<0, 4>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            ring[k][j] = frag_load(wsrc, loff, (k * 4 + j) * 1024);
+        });
     });
 
     // ---- fill: thread -> (token tid >> 2, 16-byte pieces 4 q + 16 j of its row) ----
@@ -121,7 +129,7 @@ __global__ __launch_bounds__(256, 2) void gemm_rows16_kernel(SgemmParams p)
     }
     __syncthreads();
 
-    // ---- main loop: flat over (pass, k-step); token fragments one k-step ahead, W fragments RS_NR ahead ----
+    // ---- main loop: token fragments one k-step ahead (LDS), W fragments RS_NR k-steps ahead (L2 -> registers) ----
     const char *abase = lds + i * (RS_LDH * 2) + h * 16;
     f32x16v acc[2][2]; // [ct][rt]
 #pragma unroll
@@ -131,7 +139,7 @@ __global__ __launch_bounds__(256, 2) void gemm_rows16_kernel(SgemmParams p)
 #pragma unroll
             for (int e = 0; e < 16; ++e)
                 acc[a][b][e] = bnext[a] * up;
-    h8 ahi[2][2], alo[2][2]; // [parity][rt]
+    h8 ahi[2][2], alo[2][2]; // [parity of the k-step][rt]
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt) {
         ahi[0][rt] = *(const h8 *)(abase + rt * 32 * (RS_LDH * 2));
@@ -141,83 +149,104 @@ __global__ __launch_bounds__(256, 2) void gemm_rows16_kernel(SgemmParams p)
     // 16-byte stores put 32 bytes into each of 32 lines per instruction: the launch ran at the 1.9 TB/s those writes
     // reached, 0.9 ms of its 1.5; whole lines: 0.35 ms.  Plain stores: non-temporal ones are no faster for whole lines
     // even at 1.8 GB, and an output that fits the MALL is read back from it by the recurrence.)
-    f32x16v stage[2][2];
     float *const cbase = p.C + (size_t)(row0 + 4 * h) * p.ldc + w * 64 + i;
     const int mrem = M - row0 - 4 * h; // token offset t of this lane's base row is stored iff t < mrem
-    auto store_one = [&](auto nc, int pass, const f32x16v(&st)[2][2]) {
-        constexpr int n = decltype(nc)::value, rt = n >> 5, ct = (n >> 4) & 1, r = n & 15;
-        constexpr int t = rt * 32 + 8 * (r >> 2) + (r & 3);
-        if (t < mrem) {
-            cbase[(size_t)t * p.ldc + pass * 256 + 32 * ct] = st[ct][rt][r];
-        }
-    };
-    static_for<0, TOTAL>([&](auto qc) {
-        constexpr int q = decltype(qc)::value;
-        constexpr int s = q % NKS, pass = q / NKS, par = q & 1;
-        if constexpr (q + 1 < TOTAL) {
-            constexpr int s1 = (q + 1) % NKS;
+    for (int pass = 0; pass < npass; ++pass) {
+        const int sbase = pass * NKS * 4096; // byte offset of this pass in the wave's stream
+        static_for<0, PER>([&](auto sc) {
+            constexpr int s = decltype(sc)::value;
+            // A double buffer: k-step s of a pass reads buffer s & 1 and fetches k-step s + 1 into the other one.  The
+            // fragments of the next pass's k-step 0 go into buffer 0: from the last k-step when NKS is even (it reads
+            // buffer 1), from the first refill-only turn when NKS is odd (the last k-step is still reading buffer 0).
+            constexpr int par = s & 1;
+            if constexpr (s == NKS && (NKS & 1)) {
 #pragma unroll
-            for (int rt = 0; rt < 2; ++rt) {
-                ahi[par ^ 1][rt] = *(const h8 *)(abase + rt * 32 * (RS_LDH * 2) + s1 * 32);
-                alo[par ^ 1][rt] = *(const h8 *)(abase + RS_IMG + rt * 32 * (RS_LDH * 2) + s1 * 32);
+                for (int rt = 0; rt < 2; ++rt) {
+                    ahi[0][rt] = *(const h8 *)(abase + rt * 32 * (RS_LDH * 2));
+                    alo[0][rt] = *(const h8 *)(abase + RS_IMG + rt * 32 * (RS_LDH * 2));
+                }
             }
-        }
-        // ring slot: [0] hi of column tile 0, [1] lo of it, [2] hi of column tile 1, [3] lo of it.  The W fragment is the
-        // MFMA's A operand: the accumulator tile is C^T, a lane holds 4 consecutive output columns of one token.
-        h8(&b)[4] = ring[q % RS_NR];
+            if constexpr (s < NKS) {
+                if constexpr (s + 1 < NKS || !(NKS & 1)) {
+                    constexpr int s1 = (s + 1) % NKS;
 #pragma unroll
-        for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-            for (int rt = 0; rt < 2; ++rt)
-                acc[ct][rt] = RS_MFMA(b[2 * ct], ahi[par][rt], acc[ct][rt]);
-#pragma unroll
-        for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-            for (int rt = 0; rt < 2; ++rt)
-                acc[ct][rt] = RS_MFMA(b[2 * ct], alo[par][rt], acc[ct][rt]);
-#pragma unroll
-        for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-            for (int rt = 0; rt < 2; ++rt)
-                acc[ct][rt] = RS_MFMA(b[2 * ct + 1], ahi[par][rt], acc[ct][rt]);
-        if constexpr (q + RS_NR < TOTAL)
-            static_for<0, 4>([&](auto jc) {
-                constexpr int j = decltype(jc)::value;
-                ring[q % RS_NR][j] = frag_load(wsrc, loff, ((q + RS_NR) * 4 + j) * 1024);
-            });
-        if constexpr (s == 0 && pass + 1 < NP)
-            load_bias(pass + 1);
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (s == NKS - 1) { // end of a pass: 64 tokens x 64 columns out
-#pragma unroll
-            for (int rt = 0; rt < 2; ++rt)
+                    for (int rt = 0; rt < 2; ++rt) {
+                        ahi[par ^ 1][rt] = *(const h8 *)(abase + rt * 32 * (RS_LDH * 2) + s1 * 32);
+                        alo[par ^ 1][rt] = *(const h8 *)(abase + RS_IMG + rt * 32 * (RS_LDH * 2) + s1 * 32);
+                    }
+                }
+                // ring slot: [0] hi of column tile 0, [1] lo of it, [2] hi of column tile 1, [3] lo of it
+                h8(&b)[4] = ring[s % RS_NR];
 #pragma unroll
                 for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        stage[ct][rt][r] = acc[ct][rt][r] * down;
-                        acc[ct][rt][r] = bnext[ct] * up; // (the next pass's, if there is one)
-                    }
-            static_for<0, 64>([&](auto nc) { store_one(nc, pass, stage); });
-        }
-    });
+                    for (int rt = 0; rt < 2; ++rt)
+                        acc[ct][rt] = RS_MFMA(b[2 * ct], ahi[par][rt], acc[ct][rt]);
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                    for (int rt = 0; rt < 2; ++rt)
+                        acc[ct][rt] = RS_MFMA(b[2 * ct], alo[par][rt], acc[ct][rt]);
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                    for (int rt = 0; rt < 2; ++rt)
+                        acc[ct][rt] = RS_MFMA(b[2 * ct + 1], ahi[par][rt], acc[ct][rt]);
+            }
+            // refill the slot just consumed (or, on a refill-only turn, the slot of this turn) with the k-step RS_NR
+            // turns on: k-step s + RS_NR of this pass, or k-step s + RS_NR - PER of the next one
+            {
+                constexpr int tgt = s + RS_NR;
+                if constexpr (tgt < NKS) {
+                    static_for<0, 4>([&](auto jc) {
+                        constexpr int j = decltype(jc)::value;
+                        ring[s % RS_NR][j] = frag_load(wsrc, loff + sbase, (tgt * 4 + j) * 1024);
+                    });
+                } else if constexpr (tgt >= PER) {
+                    static_for<0, 4>([&](auto jc) {
+                        constexpr int j = decltype(jc)::value;
+                        ring[s % RS_NR][j] = frag_load(wsrc, loff + sbase, ((NKS + tgt - PER) * 4 + j) * 1024);
+                    });
+                }
+            }
+            if constexpr (s == 0)
+                load_bias(pass + 1);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        // end of a pass: 64 tokens x 64 columns out
+        float *cp = cbase + pass * 256;
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int t = rt * 32 + 8 * (r >> 2) + (r & 3);
+                    const float v = acc[ct][rt][r] * down;
+                    acc[ct][rt][r] = bnext[ct] * up; // (the next pass's, if there is one)
+                    if (t < mrem)
+                        cp[(size_t)t * p.ldc + 32 * ct] = v;
+                }
+    }
 }
 
 // W [N][K] fp32 -> the fragment stream gemm_rows16_kernel reads: 1-KiB blocks ordered (wave, pass, k-step, column tile,
-// hi | lo), lane l of a block = 8 halves of column (pass 4 + wave) 64 + 32 ct + (l & 31) at k = 16 s + 8 (l >> 5) ..
+// hi | lo), lane l of a block = 8 halves of column (4 pass + wave) 64 + 32 ct + (l & 31) at k = 16 s + 8 (l >> 5) ..
 __global__ __launch_bounds__(256) void pack_frag16_kernel(const float *__restrict__ W, int N, int K, int nks,
                                                           const unsigned *__restrict__ absmax, _Float16 *__restrict__ out)
 {
     const float sc = ldexpf(1.0f, tt_pow2_exponent(*absmax));
-    const int np = N / 256;
-    const int total = 4 * np * nks * 2 * 64; // (w, pass, s, ct, lane)
+    const int nchunks = N / 64;
+    const int total = nchunks * nks * 2 * 64; // (chunk, s, ct, lane)
     for (int t = blockIdx.x * 256 + threadIdx.x; t < total; t += gridDim.x * 256) {
         const int l = t & 63, ct = (t >> 6) & 1;
         int rest = t >> 7;
-        const int s = rest % nks;
-        rest /= nks;
-        const int pass = rest % np, w = rest / np;
-        const int col = (pass * 4 + w) * 64 + 32 * ct + (l & 31), k0 = 16 * s + 8 * (l >> 5);
+        const int s = rest % nks, chunk = rest / nks;
+        const int w = chunk & 3, pass = chunk >> 2;
+        int first = 0;
+        for (int j = 0; j < w; ++j)
+            first += rs_chunks_of(nchunks, j);
+        const int col = chunk * 64 + 32 * ct + (l & 31), k0 = 16 * s + 8 * (l >> 5);
         h8 vh, vl;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -226,22 +255,22 @@ __global__ __launch_bounds__(256) void pack_frag16_kernel(const float *__restric
             vh[e] = hv;
             vl[e] = (_Float16)(x - (float)hv);
         }
-        _Float16 *blk = out + ((size_t)(((w * np + pass) * nks + s) * 2 + ct) * 2) * 512 + l * 8;
+        _Float16 *blk = out + ((size_t)(((first + pass) * nks + s) * 2 + ct) * 2) * 512 + l * 8;
         *(h8 *)blk = vh;
         *(h8 *)(blk + 512) = vl;
     }
 }
 
-template <int NKS, int NP>
+template <int NKS>
 int launch_rows16(const SgemmParams &p, hipStream_t st)
 {
     static bool attr_done = false; // (idempotent: a race sets the same value twice)
     if (!attr_done) {
-        TT_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_rows16_kernel<NKS, NP>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        TT_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_rows16_kernel<NKS>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                          RS_LDS));
         attr_done = true;
     }
-    hipLaunchKernelGGL((gemm_rows16_kernel<NKS, NP>), dim3((unsigned)((p.M + RS_ROWS - 1) / RS_ROWS)), dim3(256), RS_LDS, st, p);
+    hipLaunchKernelGGL((gemm_rows16_kernel<NKS>), dim3((unsigned)((p.M + RS_ROWS - 1) / RS_ROWS)), dim3(256), RS_LDS, st, p);
     TT_LAUNCH_CHECK();
     return TT_OK;
 }
@@ -250,8 +279,8 @@ int launch_rows16(const SgemmParams &p, hipStream_t st)
 
 bool tt_gemm_rows16_supported(int N, int K, int64_t lda, int64_t ldc)
 {
-    const int nks = (K + 15) / 16, np = N / 256;
-    return N % 256 == 0 && K % 4 == 0 && lda % 4 == 0 && ldc % 4 == 0 && (nks == 19 || nks == 16) && (np == 3 || np == 4 || np == 1);
+    const int nks = (K + 15) / 16;
+    return N % 64 == 0 && N >= 256 && K % 4 == 0 && lda % 4 == 0 && ldc % 4 == 0 && (nks == 19 || nks == 16 || nks == 13);
 }
 
 size_t tt_pack_frag16_bytes(int N, int K)
@@ -262,7 +291,7 @@ size_t tt_pack_frag16_bytes(int N, int K)
 int tt_pack_frag16(const float *W, int N, int K, const unsigned *absmax, void *out, hipStream_t st)
 {
     const int nks = (K + 15) / 16;
-    const int total = N / 32 * nks * 2 * 32;
+    const int total = N / 64 * nks * 2 * 64;
     hipLaunchKernelGGL(pack_frag16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, W, N, K, nks, absmax,
                        (_Float16 *)out);
     TT_LAUNCH_CHECK();
@@ -275,16 +304,10 @@ int tt_gemm_rows16(const SgemmParams &p, hipStream_t st)
         return TT_OK;
     if (!tt_gemm_rows16_supported(p.N, p.K, p.lda, p.ldc) || !p.b_hi16 || p.accumulate || p.k_dyn || p.b_map)
         return TT_ERR_UNSUPPORTED;
-    const int nks = (p.K + 15) / 16, np = p.N / 256;
-#define TT_ROWS16_CASE(a, b)                                                                                                    \
-    if (nks == a && np == b)                                                                                                    \
-    return launch_rows16<a, b>(p, st)
-    TT_ROWS16_CASE(19, 3);
-    TT_ROWS16_CASE(16, 3);
-    TT_ROWS16_CASE(19, 4);
-    TT_ROWS16_CASE(16, 4);
-    TT_ROWS16_CASE(19, 1);
-    TT_ROWS16_CASE(16, 1);
-#undef TT_ROWS16_CASE
+    switch ((p.K + 15) / 16) {
+    case 19: return launch_rows16<19>(p, st); // E = 300 (GloVe 6B.300d: the north-star tower)
+    case 16: return launch_rows16<16>(p, st); // 256: a stacked layer's input
+    case 13: return launch_rows16<13>(p, st); // E = 200 (config.json's embedding width)
+    }
     return TT_ERR_UNSUPPORTED;
 }
