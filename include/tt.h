@@ -188,6 +188,25 @@ int tt_encoder_forward_f32(const int64_t *ids, int B, int T, const float *table,
                            int32_t *status, tt_stream_t stream);
 
 /*
+ * Inference with the weights converted ONCE.  tt_encoder_forward_f32 re-derives, on every call, what its kernels read
+ * instead of the nn.GRU tensors (W_ih as an fp16 hi/lo MFMA-fragment stream, W_hh in packed fragment order, one
+ * power-of-two scale word each): six small launches, ~40 us -- a quarter of a query-tower call.  A serving host
+ * (backend/query_inferencer.py:51-75, frontend/main.py:150-156: weights loaded once, never changed) prepares them once:
+ *   tt_encoder_prepared_bytes(...)  size of the caller-owned device buffer `prepared` (256-B aligned)
+ *   tt_encoder_prepare_f32(...)     fills it from `weights` on `stream`; call again after the weights change
+ *   tt_encoder_forward_prepared_f32 = tt_encoder_forward_f32 with train = 0 reading `prepared` (same results, bit for bit)
+ */
+size_t tt_encoder_prepared_bytes(int E, int H, int num_layers, int bidirectional, int rnn_type);
+int tt_encoder_prepare_f32(int E, int H, int num_layers, int bidirectional, int rnn_type,
+                           const float *const *weights /*host array*/, void *prepared, size_t prepared_bytes,
+                           tt_stream_t stream);
+int tt_encoder_forward_prepared_f32(const int64_t *ids, int B, int T, const float *table, int64_t V, int E, int H,
+                                    int num_layers, int bidirectional, int rnn_type,
+                                    const float *const *weights /*host array*/, const void *prepared,
+                                    const float *proj_w, const float *proj_b, int normalize, float *out, void *workspace,
+                                    size_t workspace_bytes, int32_t *status, tt_stream_t stream);
+
+/*
  * Replaces loss.backward() through RNNEncoder.forward     backend/main.py:254 over model.py:48-75
  * d_out [B,H] = gradient w.r.t. the forward's `out`.  `workspace` is the buffer a forward call with
  * train=1 and the SAME ids/weights filled.  grads: HOST array of DEVICE pointers laid out like

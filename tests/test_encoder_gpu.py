@@ -312,3 +312,70 @@ def test_lstm_rnn_inter_layer_dropout_and_trainable_table_vs_oracle(oracle, cell
     assert len(flat) == len(got)
     for a, b in zip(got, flat):
         np.testing.assert_allclose(a, b, atol=5e-4 * max(np.abs(b).max(), 1e-30), rtol=0)
+
+
+def test_prepared_weights_are_bit_identical_and_follow_weight_changes(oracle):
+    """Inference keeps the weights in kernel form (tt_encoder_prepare_f32 / tt_encoder_forward_prepared_f32): same bits as the
+    per-call derivation, and every way the weights can change is noticed (in-place op, load_state_dict, optimizer step)."""
+    import twotowermlretrieval_amd as tt
+    for layers, bi, E, H in ((1, False, 300, 256), (2, True, 52, 64)):
+        V, seed, B, T = 400, 77, 23, 19
+        enc, table, sd = make_encoder(V, E, H, seed, layers, bi)
+        ids = torch.from_numpy(synth.make_ids(seed + 1, B, T, V, zero_inside=0.05)).cuda()
+        with torch.no_grad():
+            enc.cache_prepared = False
+            plain = enc(ids).clone()
+            enc.cache_prepared = True
+            first = enc(ids).clone()          # prepares
+            blob = enc._prep[ids.device][1]
+            again = enc(ids).clone()          # reuses
+            assert enc._prep[ids.device][1] is blob
+        assert torch.equal(plain, first) and torch.equal(plain, again)
+        # 1. in-place change of one weight
+        with torch.no_grad():
+            enc.rnn.weight_hh_l0.mul_(0.5)
+            changed = enc(ids).clone()
+            enc.cache_prepared = False
+            want = enc(ids).clone()
+            enc.cache_prepared = True
+        assert enc._prep[ids.device][1] is not blob
+        assert torch.equal(changed, want) and not torch.equal(changed, plain)
+        # 2. an optimizer step writes the parameters through raw pointers
+        enc.train()
+        opt = tt.FusedClipAdam(enc.parameters(), lr=1e-2, max_norm=1.0)
+        enc(ids).square().sum().backward()
+        opt.step()
+        enc.eval()
+        with torch.no_grad():
+            after = enc(ids).clone()
+            enc.cache_prepared = False
+            want2 = enc(ids).clone()
+            enc.cache_prepared = True
+        assert torch.equal(after, want2) and not torch.equal(after, changed)
+        # 3. against the oracle with the final weights
+        sd2 = {k: v.detach().cpu().numpy() for k, v in enc.state_dict().items() if k != "embedding.weight"}
+        o = oracle.encoder_forward(ids.cpu().numpy(), table, synth.weight_quads(sd2, layers, bi), H, layers, bi,
+                                   sd2.get("projection.weight"), sd2.get("projection.bias"), True)
+        np.testing.assert_allclose(after.cpu().numpy(), o, atol=ATOL, rtol=0)
+
+
+def test_prepared_weights_inside_a_hip_graph_and_deepcopy():
+    import copy
+    V, E, H = 300, 300, 256
+    enc, _, _ = make_encoder(V, E, H, 5)
+    ids = torch.from_numpy(synth.make_ids(6, 8, 12, V)).cuda()
+    with torch.no_grad():
+        want = enc(ids).clone()               # cache filled outside the capture
+        enc.check_inputs = False
+        s = torch.cuda.Stream()
+        with torch.cuda.stream(s):
+            enc(ids)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            out = enc(ids)
+        g.replay(); g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, want)
+        twin = copy.deepcopy(enc)             # the cache (and the module-level lock) must not break copying
+        assert torch.equal(twin(ids), want)

@@ -128,6 +128,32 @@ static inline EncLayout enc_layout(int B, int T, int E, int H, int L, int bidir,
     return lo;
 }
 
+// Weights in the forms the forward kernels read (tt_encoder_prepare_f32): a 256-byte header of scale words
+// (word 2 (2 l + d): bit pattern of max |W_ih|, word 2 (2 l + d) + 1: of max |W_hh|) and, per layer and direction, the
+// W_ih images (fragment stream or [rows][Kp] hi | lo) and the packed W_hh
+struct EncPrepared {
+    size_t wih[ENC_MAX_LAYERS][2], wp[ENC_MAX_LAYERS][2];
+    size_t total;
+};
+static inline EncPrepared enc_prepared_layout(int E, int H, int L, int bidir, int cell)
+{
+    EncPrepared pl;
+    const int ng = enc_gates(cell), ndir = bidir ? 2 : 1;
+    size_t off = 256;
+    auto take = [&](size_t bytes) { size_t o = off; off = tt_align_up(off + bytes, 256); return o; };
+    for (int l = 0; l < ENC_MAX_LAYERS; ++l)
+        for (int d = 0; d < 2; ++d) {
+            pl.wih[l][d] = pl.wp[l][d] = 0;
+            if (l < L && d < ndir) {
+                const int in_w = l == 0 ? E : ndir * H;
+                pl.wih[l][d] = take((size_t)2 * sizeof(uint16_t) * ng * H * ((in_w + 31) / 32 * 32));
+                pl.wp[l][d] = take(sizeof(float) * ng * H * H);
+            }
+        }
+    pl.total = off;
+    return pl;
+}
+
 // ------------------------------------------------------------------ gate nonlinearities (forward and backward kernels)
 // v_exp_f32 / v_rcp_f32 based.  sigmoid has no cancellation (values near 1/2 for small x).  tanh as 2/(1+e^-2x) - 1 has
 // an ABSOLUTE error of ~1e-7 (one rounding at magnitude 1), i.e. a relative error of 1e-7/|x| for small pre-activations --

@@ -421,29 +421,100 @@ TT_EXPORT size_t tt_encoder_workspace_bytes(int B, int T, int E, int H, int num_
     return enc_layout(B, T, E, H, num_layers, bidirectional, train < 0 ? 0 : (train > 2 ? 2 : train), dropout, rnn_type).total;
 }
 
-TT_EXPORT int tt_encoder_forward_f32(const int64_t *ids, int B, int T, const float *table, int64_t V, int E, int H,
-                                     int num_layers, int bidirectional, int rnn_type, const float *const *weights,
-                                     const float *proj_w, const float *proj_b, int normalize, int train,
-                                     float dropout_p, uint64_t dropout_seed, float *out, void *workspace,
-                                     size_t workspace_bytes, int32_t *status, tt_stream_t stream)
+// H = 128 / 256: the recurrence runs on the f16 matrix pipes with both operands split into fp16 hi + lo parts
+// (gru16.hip; fp32-grade accuracy at 3/16 of the fp32 MFMA time).  TT_GRU_F32=1 keeps the fp32-MFMA kernels.
+static bool enc_force_f32()
+{
+    static const bool v = [] { const char *e = getenv("TT_GRU_F32"); return e && e[0] == '1'; }();
+    return v;
+}
+static bool enc_tiled_k1() // A/B switch: the tiled f16 GEMM instead of the token-stationary one
+{
+    static const bool v = [] { const char *e = getenv("TT_K1_TILED"); return e && atoi(e) != 0; }();
+    return v;
+}
+static bool enc_rows16(int NGH, int I) { return !enc_tiled_k1() && tt_gemm_rows16_supported(NGH, I, I, NGH); }
+
+// One layer and direction's weights into the forms the forward kernels read.  wih_max / wmax: zeroed words that receive
+// the bit patterns of max |W_ih| / max |W_hh|; w16: W_ih split into fp16 hi/lo parts (scaled by the power of two its
+// maximum implies) as gemm_rows16's fragment stream or the tiled GEMM's [rows][Kp] images; wp: W_hh in packed order.
+static int enc_pack_weights(int I, int H, int rnn_type, const float *const *w, unsigned *wih_max, unsigned *wmax, char *w16,
+                            char *wp, hipStream_t st)
+{
+    const int NGH = enc_gates(rnn_type) * H;
+    if (!enc_force_f32()) {
+        TT_RC_CHECK(tt_absmax(w[0], (int64_t)NGH * I, wih_max, st));
+        if (enc_rows16(NGH, I)) {
+            TT_RC_CHECK(tt_pack_frag16(w[0], NGH, I, wih_max, w16, st));
+        } else {
+            // (every 128-token workgroup would otherwise convert the tiles of W_ih it touches)
+            const int Kp = (I + 31) / 32 * 32;
+            TT_RC_CHECK(tt_pack_rows16(w[0], NGH, I, wih_max, w16, w16 + (size_t)NGH * Kp * sizeof(uint16_t), st));
+        }
+    }
+    if (rnn_type == CELL_GRU && gru16_supported(H) && !enc_force_f32()) {
+        TT_RC_CHECK(gru16_pack(w[1], H, wmax, wp, st));
+    } else {
+        hipLaunchKernelGGL(pack_whh_kernel, dim3(96), dim3(256), 0, st, w[1], H, enc_gates(rnn_type), (float *)wp);
+        TT_LAUNCH_CHECK();
+    }
+    return TT_OK;
+}
+
+TT_EXPORT size_t tt_encoder_prepared_bytes(int E, int H, int num_layers, int bidirectional, int rnn_type)
+{
+    if (num_layers < 1 || num_layers > ENC_MAX_LAYERS || rnn_type < 0 || rnn_type > 2 || E <= 0 || H <= 0)
+        return 0;
+    return enc_prepared_layout(E, H, num_layers, bidirectional, rnn_type).total;
+}
+
+TT_EXPORT int tt_encoder_prepare_f32(int E, int H, int num_layers, int bidirectional, int rnn_type,
+                                     const float *const *weights, void *prepared, size_t prepared_bytes, tt_stream_t stream)
 {
     hipStream_t st = (hipStream_t)stream;
-    int rc = enc_check_shape("tt_encoder_forward_f32", B, T, E, H, num_layers, V);
+    int rc = enc_check_shape("tt_encoder_prepare_f32", 1, 1, E, H, num_layers, 1);
+    if (rc != TT_OK)
+        return rc;
+    if (rnn_type < CELL_GRU || rnn_type > CELL_RNN)
+        return tt_fail(TT_ERR_UNSUPPORTED, "tt_encoder_prepare_f32: rnn_type=%d (0 GRU, 1 LSTM, 2 RNN)", rnn_type);
+    const EncPrepared pl = enc_prepared_layout(E, H, num_layers, bidirectional, rnn_type);
+    if (!weights || !prepared || prepared_bytes < pl.total || ((uintptr_t)prepared & 255))
+        return tt_fail(TT_ERR_WORKSPACE, "tt_encoder_prepare_f32: buffer %zu < %zu bytes (or null / not 256-B aligned)",
+                       prepared_bytes, pl.total);
+    char *pb = (char *)prepared;
+    const int ndir = bidirectional ? 2 : 1;
+    TT_RC_CHECK(tt_zero_async(pb, 256, st));
+    for (int l = 0; l < num_layers; ++l)
+        for (int d = 0; d < ndir; ++d) {
+            unsigned *words = (unsigned *)pb + 2 * (2 * l + d);
+            TT_RC_CHECK(enc_pack_weights(l == 0 ? E : ndir * H, H, rnn_type, weights + ((size_t)l * ndir + d) * 4, words,
+                                         words + 1, pb + pl.wih[l][d], pb + pl.wp[l][d], st));
+        }
+    return TT_OK;
+}
+
+static int encoder_forward(const char *who, const int64_t *ids, int B, int T, const float *table, int64_t V, int E, int H,
+                           int num_layers, int bidirectional, int rnn_type, const float *const *weights,
+                           const void *prepared, const float *proj_w, const float *proj_b, int normalize, int train,
+                           float dropout_p, uint64_t dropout_seed, float *out, void *workspace, size_t workspace_bytes,
+                           int32_t *status, hipStream_t st)
+{
+    int rc = enc_check_shape(who, B, T, E, H, num_layers, V);
     if (rc != TT_OK)
         return rc;
     if (!ids || !table || !weights || !out || (bidirectional && (!proj_w || !proj_b)))
-        return tt_fail(TT_ERR_BAD_SHAPE, "tt_encoder_forward_f32: null pointer");
+        return tt_fail(TT_ERR_BAD_SHAPE, "%s: null pointer", who);
     if (!(dropout_p >= 0.0f && dropout_p < 1.0f))
-        return tt_fail(TT_ERR_BAD_SHAPE, "tt_encoder_forward_f32: dropout_p=%g", dropout_p);
+        return tt_fail(TT_ERR_BAD_SHAPE, "%s: dropout_p=%g", who, dropout_p);
     if (rnn_type < CELL_GRU || rnn_type > CELL_RNN)
-        return tt_fail(TT_ERR_UNSUPPORTED, "tt_encoder_forward_f32: rnn_type=%d (0 GRU, 1 LSTM, 2 RNN)", rnn_type);
+        return tt_fail(TT_ERR_UNSUPPORTED, "%s: rnn_type=%d (0 GRU, 1 LSTM, 2 RNN)", who, rnn_type);
     const int NGH = enc_gates(rnn_type) * H;
     const bool drop = train && dropout_p > 0.0f && num_layers > 1;
     const EncLayout lo = enc_layout(B, T, E, H, num_layers, bidirectional, train < 0 ? 0 : (train > 2 ? 2 : train), drop,
                                     rnn_type);
     if (!workspace || workspace_bytes < lo.total || ((uintptr_t)workspace & 255))
-        return tt_fail(TT_ERR_WORKSPACE, "tt_encoder_forward_f32: workspace %zu < %zu bytes (or not 256-B aligned)",
-                       workspace_bytes, lo.total);
+        return tt_fail(TT_ERR_WORKSPACE, "%s: workspace %zu < %zu bytes (or not 256-B aligned)", who, workspace_bytes,
+                       lo.total);
     char *ws = (char *)workspace;
     int32_t *len = (int32_t *)(ws + lo.len), *tok_off = (int32_t *)(ws + lo.tok_off);
     int32_t *perm = (int32_t *)(ws + lo.perm), *idsp = (int32_t *)(ws + lo.ids), *flag = (int32_t *)(ws + lo.flag);
@@ -458,10 +529,10 @@ TT_EXPORT int tt_encoder_forward_f32(const int64_t *ids, int B, int T, const flo
         TT_HIP_CHECK(hipMemcpyAsync(status, flag, sizeof(int32_t), hipMemcpyDeviceToDevice, st));
 
     const size_t lds = sizeof(float) * 2 * ENC_RB * (H + 4);
-    // H = 128 / 256: the recurrence runs on the f16 matrix pipes with both operands split into fp16 hi + lo parts
-    // (gru16.hip; fp32-grade accuracy at 3/16 of the fp32 MFMA time).  TT_GRU_F32=1 keeps the fp32-MFMA kernel.
-    static const bool force_f32 = [] { const char *e = getenv("TT_GRU_F32"); return e && e[0] == '1'; }();
+    const bool force_f32 = enc_force_f32();
     const bool use16 = rnn_type == CELL_GRU && gru16_supported(H) && !force_f32;
+    const EncPrepared pl = enc_prepared_layout(E, H, num_layers, bidirectional, rnn_type);
+    const char *pb = (const char *)prepared;
     for (int l = 0; l < num_layers; ++l) {
         const int I = l == 0 ? E : ndir * H;
         GruParams gp;
@@ -495,37 +566,38 @@ TT_EXPORT int tt_encoder_forward_f32(const int64_t *ids, int B, int T, const flo
             g.ldc = NGH;
             g.slab_stride = 0;
             g.accumulate = 0;
+            // the weights in kernel form: from the caller's prepared buffer, or derived here into the workspace
+            unsigned *wih_max, *wmax;
+            char *w16, *wp;
+            if (pb) {
+                wih_max = (unsigned *)pb + 2 * (2 * l + d);
+                wmax = wih_max + 1;
+                w16 = (char *)pb + pl.wih[l][d];
+                wp = (char *)pb + pl.wp[l][d];
+            } else {
+                wih_max = (unsigned *)flag + 40 + 2 * l + d; // in the status block cleared above
+                wmax = (unsigned *)flag + 16 + 2 * l + d;
+                w16 = ws + lo.wih16[d];
+                wp = ws + lo.wp[d];
+                rc = enc_pack_weights(I, H, rnn_type, w, wih_max, wmax, w16, wp, st);
+                if (rc != TT_OK)
+                    return rc;
+            }
             if (!force_f32) {
                 // K1 on the f16 pipes (fp16 hi/lo split, fp32-grade; sgemm.h): W_ih is scaled by the power of two
                 // that puts its largest element in [2^13, 2^14); layer 0's A rows are embedding vectors, taken as they
                 // are (|x| < 65504), deeper layers' are hidden states in (-1, 1) (times 1/(1-p) under dropout): 2^6
-                unsigned *wih_max = (unsigned *)flag + 40 + 2 * l + d; // in the status block cleared above
-                rc = tt_absmax(w[0], (int64_t)NGH * I, wih_max, st);
-                if (rc != TT_OK)
-                    return rc;
-                // W_ih is split into fp16 hi / lo images ONCE here (every 128-token workgroup would otherwise convert the
-                // tiles of it it touches: the conversion VALU work, not the MFMAs, bound the launch)
-                const int Kp = (I + 31) / 32 * 32;
-                char *w16 = ws + lo.wih16[d];
                 g.a_absmax = nullptr;
                 g.a_exp = l == 0 ? 0 : 6;
                 g.b_absmax = wih_max;
                 g.b_exp = 0;
-                static const bool tiled_k1 = getenv("TT_K1_TILED") && atoi(getenv("TT_K1_TILED")) != 0; // A/B switch
-                if (!tiled_k1 && tt_gemm_rows16_supported(NGH, I, g.lda, g.ldc)) {
-                    // token-stationary form (gemm_rows16.hip): W_ih as a fragment stream, the token block split once
-                    rc = tt_pack_frag16(w[0], NGH, I, wih_max, w16, st);
-                    if (rc != TT_OK)
-                        return rc;
-                    g.b_hi16 = w16;
+                g.b_hi16 = w16;
+                if (enc_rows16(NGH, I)) { // token-stationary form (gemm_rows16.hip): W_ih as a fragment stream
                     g.b_lo16 = nullptr;
                     g.ldb16 = 0;
                     rc = tt_gemm_rows16(g, st);
                 } else {
-                    rc = tt_pack_rows16(w[0], NGH, I, wih_max, w16, w16 + (size_t)NGH * Kp * sizeof(uint16_t), st);
-                    if (rc != TT_OK)
-                        return rc;
-                    g.b_hi16 = w16;
+                    const int Kp = (I + 31) / 32 * 32;
                     g.b_lo16 = w16 + (size_t)NGH * Kp * sizeof(uint16_t);
                     g.ldb16 = Kp;
                     rc = tt_sgemm16(g, false, false, 1, st);
@@ -535,17 +607,8 @@ TT_EXPORT int tt_encoder_forward_f32(const int64_t *ids, int B, int T, const flo
             }
             if (rc != TT_OK)
                 return rc;
-            unsigned *wmax = (unsigned *)flag + 16 + 2 * l + d; // in the status block cleared above
-            if (use16) {
-                rc = gru16_pack(w[1], H, wmax, ws + lo.wp[d], st);
-                if (rc != TT_OK)
-                    return rc;
-            } else {
-                hipLaunchKernelGGL(pack_whh_kernel, dim3(96), dim3(256), 0, st, w[1], H, enc_gates(rnn_type),
-                                   (float *)(ws + lo.wp[d]));
-            }
             gp.dir[d].gi = (const float *)(ws + lo.gi[d]);
-            gp.dir[d].wp = (const float *)(ws + lo.wp[d]);
+            gp.dir[d].wp = (const float *)wp;
             gp.dir[d].wmax = wmax;
             gp.dir[d].b_hh = w[3];
             gp.dir[d].out_seq = xout;
@@ -585,4 +648,28 @@ TT_EXPORT int tt_encoder_forward_f32(const int64_t *ids, int B, int T, const flo
                        proj_b, normalize, train ? (float *)(ws + lo.hid) : (float *)nullptr, out);
     TT_LAUNCH_CHECK();
     return TT_OK;
+}
+
+TT_EXPORT int tt_encoder_forward_f32(const int64_t *ids, int B, int T, const float *table, int64_t V, int E, int H,
+                                     int num_layers, int bidirectional, int rnn_type, const float *const *weights,
+                                     const float *proj_w, const float *proj_b, int normalize, int train,
+                                     float dropout_p, uint64_t dropout_seed, float *out, void *workspace,
+                                     size_t workspace_bytes, int32_t *status, tt_stream_t stream)
+{
+    return encoder_forward("tt_encoder_forward_f32", ids, B, T, table, V, E, H, num_layers, bidirectional, rnn_type, weights,
+                           nullptr, proj_w, proj_b, normalize, train, dropout_p, dropout_seed, out, workspace,
+                           workspace_bytes, status, (hipStream_t)stream);
+}
+
+TT_EXPORT int tt_encoder_forward_prepared_f32(const int64_t *ids, int B, int T, const float *table, int64_t V, int E, int H,
+                                              int num_layers, int bidirectional, int rnn_type,
+                                              const float *const *weights, const void *prepared, const float *proj_w,
+                                              const float *proj_b, int normalize, float *out, void *workspace,
+                                              size_t workspace_bytes, int32_t *status, tt_stream_t stream)
+{
+    if (!prepared || ((uintptr_t)prepared & 255))
+        return tt_fail(TT_ERR_WORKSPACE, "tt_encoder_forward_prepared_f32: prepared buffer null or not 256-B aligned");
+    return encoder_forward("tt_encoder_forward_prepared_f32", ids, B, T, table, V, E, H, num_layers, bidirectional, rnn_type,
+                           weights, prepared, proj_w, proj_b, normalize, 0, 0.0f, 0, out, workspace, workspace_bytes, status,
+                           (hipStream_t)stream);
 }

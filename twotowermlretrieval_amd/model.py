@@ -17,6 +17,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import threading
 from typing import Dict, Optional, Tuple
 
 import numpy as np
@@ -31,6 +32,8 @@ __all__ = ["RNNEncoder", "TwoTowerModel", "triplet_loss_cosine"]
 def _stream(dev) -> int:
     return torch.cuda.current_stream(dev).cuda_stream
 
+
+_PREP_LOCK = threading.Lock()  # module level: nn.Module instances must stay deep-copyable / picklable
 
 _CELLS = {"GRU": (0, 3), "LSTM": (1, 4), "RNN": (2, 1)}  # RNN_TYPE -> (C-ABI rnn_type, gate rows / H)
 
@@ -164,6 +167,9 @@ class RNNEncoder(nn.Module):
         self.normalize_output = normalize_output
         self.projection = _LinearParams(hidden_dim * 2, hidden_dim) if bidirectional else None
         self.check_inputs = True  # read the device status word after each call (one 4-byte D2H sync)
+        # inference keeps the weights in kernel form (tt_encoder_prepare_f32) until they change: see _prepared_weights
+        self.cache_prepared = True
+        self._prep: dict = {}
         self._deferred_status = None  # a list while a caller (trainer.train_step) batches the status reads
 
     # ---- plumbing ---------------------------------------------------------------
@@ -182,6 +188,37 @@ class RNNEncoder(nn.Module):
                 raise RuntimeError(f"parameter on {p.device} but ids on {x.device}: call model.to(device) first")
             if p.dtype != torch.float32:
                 raise TypeError("parameters must be float32")
+
+    def invalidate_prepared(self) -> None:
+        """Drop the cached kernel-form weights.  Needed only after writing the weights through raw pointers: in-place torch
+        ops, load_state_dict, .to() and FusedClipAdam are noticed by themselves (tensor version counters / addresses)."""
+        self._prep = {}
+
+    def _prepared_weights(self, device: torch.device, quads, wptr) -> Optional[torch.Tensor]:
+        """The weights converted once into what the forward kernels read (W_ih fp16 hi/lo fragment stream, packed W_hh,
+        scale words): a serving process (query_inferencer.py:51-75) loads its weights once, and re-deriving them is six
+        small launches, a quarter of a query-tower call.  Keyed on every weight's (address, version counter)."""
+        key = tuple((w.data_ptr(), w._version) for w in quads)
+        ent = self._prep.get(device)
+        if ent is not None and ent[0] == key:
+            return ent[1]
+        if torch.cuda.is_current_stream_capturing():
+            return None  # (no synchronisation inside a capture: this call derives them in its workspace)
+        with _PREP_LOCK:
+            ent = self._prep.get(device)
+            if ent is not None and ent[0] == key:
+                return ent[1]
+            L = _lib.lib()
+            E, H = self.embedding.weight.shape[1], self.hidden_dim
+            need = L.tt_encoder_prepared_bytes(E, H, self.num_layers, int(self.bidirectional), self._cell)
+            blob = torch.empty(max(need, 256), dtype=torch.uint8, device=device)
+            with torch.cuda.device(device):
+                _lib.check(L.tt_encoder_prepare_f32(E, H, self.num_layers, int(self.bidirectional), self._cell, wptr,
+                                                    blob.data_ptr(), blob.numel(), _stream(device)))
+                torch.cuda.current_stream(device).synchronize()  # once per weight version: any stream may read it now
+            # the buffer it replaces stays referenced until the next replacement: calls queued on other streams may still read it
+            self._prep[device] = (key, blob, ent[1] if ent is not None else None)
+        return blob
 
     def _run_forward(self, x: torch.Tensor, train: bool, dropout_p: float = 0.0, dropout_seed: int = 0):
         L = _lib.lib()
@@ -210,12 +247,21 @@ class RNNEncoder(nn.Module):
         pw = self.projection.weight.detach().contiguous() if self.projection is not None else None
         pb = self.projection.bias.detach().contiguous() if self.projection is not None else None
         table = self.embedding.weight.detach()
+        prepared = self._prepared_weights(ids.device, quads, wptr) if (train_mode == 0 and self.cache_prepared) else None
         with torch.cuda.device(ids.device):
-            _lib.check(L.tt_encoder_forward_f32(
-                ids.data_ptr(), B, T, table.data_ptr(), V, E, H, self.num_layers, int(self.bidirectional), self._cell,
-                wptr, pw.data_ptr() if pw is not None else None, pb.data_ptr() if pb is not None else None,
-                int(self.normalize_output), train_mode, float(dropout_p), int(dropout_seed), out.data_ptr(),
-                ws.data_ptr(), ws.numel(), status.data_ptr(), _stream(ids.device)))
+            if prepared is not None:
+                _lib.check(L.tt_encoder_forward_prepared_f32(
+                    ids.data_ptr(), B, T, table.data_ptr(), V, E, H, self.num_layers, int(self.bidirectional),
+                    self._cell, wptr, prepared.data_ptr(), pw.data_ptr() if pw is not None else None,
+                    pb.data_ptr() if pb is not None else None, int(self.normalize_output), out.data_ptr(),
+                    ws.data_ptr(), ws.numel(), status.data_ptr(), _stream(ids.device)))
+            else:
+                _lib.check(L.tt_encoder_forward_f32(
+                    ids.data_ptr(), B, T, table.data_ptr(), V, E, H, self.num_layers, int(self.bidirectional),
+                    self._cell, wptr, pw.data_ptr() if pw is not None else None,
+                    pb.data_ptr() if pb is not None else None, int(self.normalize_output), train_mode, float(dropout_p),
+                    int(dropout_seed), out.data_ptr(), ws.data_ptr(), ws.numel(), status.data_ptr(),
+                    _stream(ids.device)))
         if self.check_inputs:
             if self._deferred_status is not None:
                 self._deferred_status.append(status)  # the caller reads them once, after enqueuing its other calls

@@ -93,6 +93,9 @@ class _FlatClipAdam:
         self.step_count += 1
         self._step_fn(self.flat_params, self.flat_grads, self.exp_avg, self.exp_avg_sq, self.step_count, self.lr,
                       self.betas, self.eps, self.max_norm, 1.0 / self.world, self.total_norm, self._scratch)
+        # the kernel wrote the parameters through raw pointers: tell torch (and RNNEncoder's cache of kernel-form
+        # weights, keyed on these counters) that they changed
+        torch.autograd.graph.increment_version(self.params)
         return self.total_norm
 
 
