@@ -23,5 +23,25 @@ for n in sizes:
         e1.record()
         torch.cuda.synchronize()
         print(json.dumps(dict(docs=n, k=k, ms=round(e0.elapsed_time(e1) / 10, 4))), flush=True)
+    # the sharded step as the product runs it (ShardedIndex.submit, world 1: per-shard top-50 -> exchange -> merge to
+    # top-10, the tail launches and the exchange on the second stream)
+    sx = tt.ShardedIndex(docs, 0, shard_k=50, screen=True)
+    pend = []
+    def step():
+        pend.append(sx.submit(q, 10))
+        return pend.pop(0).result() if len(pend) > 1 else None
+    for _ in range(4):
+        step()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        step()
+    while pend:
+        pend.pop(0).result()
+    e1.record()
+    torch.cuda.synchronize()
+    print(json.dumps(dict(docs=n, k="50->10 pipelined submit", ms=round(e0.elapsed_time(e1) / 20, 4))), flush=True)
+    del sx
     del ix, docs
     torch.cuda.empty_cache()
