@@ -119,7 +119,7 @@ def kernel_only_ms(q, docs, k, iters=5, warm=2):
     return main / iters, e0.elapsed_time(e1) / iters
 
 
-def screen_kernel_ms(index, q, k, iters=5, warm=2):
+def screen_kernel_ms(index, q, k, iters=20, warm=5):
     """Average duration of screen_kernel<false> alone: HIP events recorded on the launch stream right
     before and after that launch inside tt_score_topk_screened_f32 (prof_events)."""
     from twotowermlretrieval_amd import _lib

@@ -87,6 +87,11 @@ struct ScreenParams {
     const _Float16 *D16;
     int B, N, k;
     int n_chunks, tiles_per_chunk, n_tiles;
+    // Shared-tile main pass: tiles [0, static_tiles) are split evenly over the chunks; tiles [static_tiles, n_tiles) are a
+    // POOL of tail_blocks blocks of tail_g tiles per query group that the workgroups draw from (tail_ctr[qgroup],
+    // atomicAdd) once their own range is done.  static_tiles == n_tiles, tail_blocks == 0: everything static.
+    int static_tiles, tail_g, tail_blocks;
+    int *tail_ctr; // [n_qgroups], zeroed by q_image_kernel
     float dmax;
     SCand *cand;   // [n_blocks][512][SCAP]
     int *pcnt;     // [rows_pad][n_chunks]
@@ -196,9 +201,13 @@ __device__ __forceinline__ void screen_compact(SCand *base, const int (&n)[4], i
 // their norms, and the initial fallback flags (2 = fp16 cannot hold a query of this 32-query tile, else 0).
 // One workgroup of two waves per 32-query tile, one wave per 16-query set; rows >= B read as zeros.
 __global__ __launch_bounds__(128) void q_image_kernel(const float *__restrict__ Q, int B, h8 *__restrict__ img,
-                                                      float *__restrict__ qnorm, int *__restrict__ flag, int n_flags)
+                                                      float *__restrict__ qnorm, int *__restrict__ flag, int n_flags,
+                                                      int *__restrict__ tail_ctr, int n_ctr)
 {
     __shared__ int any_bad[2];
+    if (blockIdx.x == 0)
+        for (int i = threadIdx.x; i < n_ctr; i += 128)
+            tail_ctr[i] = 0;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int S = blockIdx.x * 2 + wv;
     const int g = lane >> 4, n = lane & 15;
@@ -244,8 +253,9 @@ __global__ __launch_bounds__(SW * 64, 2) void screen_kernel(ScreenParams p)
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int chunk = blockIdx.x % p.n_chunks;
     const int qgroup = blockIdx.x / p.n_chunks;
-    const int t0 = chunk * p.tiles_per_chunk;
-    const int t1 = min(t0 + p.tiles_per_chunk, p.n_tiles);
+    int t0 = chunk * p.tiles_per_chunk;                   // this workgroup's own range first, then blocks of the pool
+    int t1 = min(t0 + p.tiles_per_chunk, p.static_tiles);
+    __shared__ int next_block;
     const int k = p.k;
     const int g = lane >> 4, n = lane & 15;
     constexpr int QW = 16 * NSET, QB = SW * QW; // queries per wave / per workgroup
@@ -338,6 +348,7 @@ __global__ __launch_bounds__(SW * 64, 2) void screen_kernel(ScreenParams p)
         __builtin_amdgcn_global_load_lds((gbl_void *)rowp[i], (lds_void *)dst, 16, 0, 0);
     };
 
+    for (;;) { // segments: the own range, then pool blocks
     if (t0 < t1) {
         // DMA runs SRING - STPB tiles ahead; one barrier per STPB tiles.
 #pragma unroll
@@ -506,6 +517,23 @@ __global__ __launch_bounds__(SW * 64, 2) void screen_kernel(ScreenParams p)
         }
         if (wave_live && late && pending)
             epilogue(ptile);
+    }
+    if (MAXONLY || p.tail_blocks == 0)
+        break;
+    // The chip's eight XCDs do not run this loop at one speed (per-workgroup clocks: 3.61 .. 3.97 ms for identical
+    // 10M-document shares, the medians of the XCDs 3.62 .. 3.96): with equal static shares the launch ends with its
+    // slowest workgroup while the fastest idle for 9 % of it.  The last part of the corpus is therefore handed out in
+    // blocks: whoever is done draws the next one (a fresh pipeline per block: ring primed again, ~3 us per ~30-50 us).
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the clamped over-prefetch of the segment's end
+    __builtin_amdgcn_s_barrier();                    // ... has landed for every wave; nobody reads the ring any more
+    if (threadIdx.x == 0)
+        next_block = atomicAdd(p.tail_ctr + qgroup, 1);
+    __syncthreads();
+    const int blk = next_block;
+    if (blk >= p.tail_blocks)
+        break;
+    t0 = p.static_tiles + blk * p.tail_g;
+    t1 = min(t0 + p.tail_g, p.n_tiles);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier(); // no wave may leave while a sibling's LDS-DMA could still be consumed
@@ -1087,6 +1115,8 @@ struct SPlan {
     int n_qgroups;    // query groups of q_per_block rows (workgroup rows of 128 nset queries, or 32-query tiles when streaming)
     int q_per_block;
     int n_tiles, n_chunks, tiles_per_chunk, n_blocks;
+    int static_tiles, tail_g, tail_blocks; // shared-tile main pass: see ScreenParams
+    size_t tailctr_off;
     // sample pass
     bool sample;
     int s_tiles, s_chunks, s_tiles_per_chunk, s_blocks;
@@ -1137,6 +1167,24 @@ SPlan make_splan(int B, int64_t N, int k)
     want = want < 1 ? 1 : want;
     pl.tiles_per_chunk = (pl.n_tiles + want - 1) / want;
     pl.n_chunks = (pl.n_tiles + pl.tiles_per_chunk - 1) / pl.tiles_per_chunk;
+    pl.static_tiles = pl.n_tiles;
+    pl.tail_g = 1;
+    pl.tail_blocks = 0;
+    {
+        // pool = the last 1/TT_SCREEN_TAIL_DIV of every chunk's share (0: everything static), in blocks of a quarter of
+        // that share, 8..32 tiles; only worth it when a share is long enough for several blocks
+        static const int tail_div = [] { const char *e = getenv("TT_SCREEN_TAIL_DIV"); return e ? atoi(e) : 8; }();
+        const int share = tail_div > 0 ? pl.tiles_per_chunk / tail_div : 0;
+        if (!pl.stream && share >= 16) {
+            const int own = pl.tiles_per_chunk - share;
+            int g = share / 4;
+            g = g < 8 ? 8 : (g > 32 ? 32 : g);
+            pl.tiles_per_chunk = own;
+            pl.static_tiles = own * pl.n_chunks < pl.n_tiles ? own * pl.n_chunks : pl.n_tiles;
+            pl.tail_g = g;
+            pl.tail_blocks = (pl.n_tiles - pl.static_tiles + g - 1) / g;
+        }
+    }
     const int n_tasks = pl.n_qgroups * pl.n_chunks;
     pl.n_blocks = pl.stream ? (n_tasks + TW - 1) / TW : n_tasks;
     const size_t rows = (size_t)pl.n_qgroups * pl.q_per_block;
@@ -1172,6 +1220,8 @@ SPlan make_splan(int B, int64_t N, int k)
     off = tt_align_up(off + rows * 256 * sizeof(_Float16), 256);
     pl.qnorm_off = off;
     off = tt_align_up(off + rows * sizeof(float), 256);
+    pl.tailctr_off = off;
+    off = tt_align_up(off + (size_t)pl.n_qgroups * sizeof(int), 256);
     pl.ws_bytes = off;
     pl.lds = pl.stream ? (size_t)TW * TSTAGE * TSLAB_BYTES : (size_t)SRING * STILE_BYTES;
     return pl;
@@ -1258,6 +1308,10 @@ TT_EXPORT int tt_score_topk_screened_f32(const float *Q, int B, int d, const flo
     sp.n_chunks = pl.n_chunks;
     sp.tiles_per_chunk = pl.tiles_per_chunk;
     sp.n_tiles = pl.n_tiles;
+    sp.static_tiles = pl.static_tiles;
+    sp.tail_g = pl.tail_g;
+    sp.tail_blocks = pl.tail_blocks;
+    sp.tail_ctr = (int *)(ws + pl.tailctr_off);
     sp.dmax = dmax_norm;
     sp.cand = (SCand *)(ws + pl.cand_off);
     sp.pcnt = (int *)(ws + pl.pcnt_off);
@@ -1269,7 +1323,8 @@ TT_EXPORT int tt_score_topk_screened_f32(const float *Q, int B, int d, const flo
     sp.qnorm = (const float *)(ws + pl.qnorm_off);
     sp.dbg_thr = nullptr;
     hipLaunchKernelGGL(q_image_kernel, dim3(pl.rows_pad / 32), dim3(128), 0, st, Q, B, (h8 *)(ws + pl.qimg_off),
-                       (float *)(ws + pl.qnorm_off), fallback_flag, (B + 31) / 32);
+                       (float *)(ws + pl.qnorm_off), fallback_flag, (B + 31) / 32, (int *)(ws + pl.tailctr_off),
+                       pl.n_qgroups);
     TT_LAUNCH_CHECK();
     auto launch = [&](const ScreenParams &a, int blocks, bool maxonly) -> int {
         if (pl.stream) {
@@ -1313,6 +1368,8 @@ TT_EXPORT int tt_score_topk_screened_f32(const float *Q, int B, int d, const flo
         ss.n_tiles = pl.s_tiles;
         ss.n_chunks = pl.s_chunks;
         ss.tiles_per_chunk = pl.s_tiles_per_chunk;
+        ss.static_tiles = pl.s_tiles;
+        ss.tail_blocks = 0;
         ss.max_val = (float *)(ws + pl.smax_val_off);
         int rc = launch(ss, pl.s_blocks, true);
         if (rc != TT_OK)
@@ -1423,6 +1480,10 @@ TT_EXPORT int tt_debug_screen_s16(const float *Q, int B, const void *D16, int64_
     sp.n_chunks = pl.n_chunks;
     sp.tiles_per_chunk = pl.tiles_per_chunk;
     sp.n_tiles = pl.n_tiles;
+    sp.static_tiles = pl.n_tiles;
+    sp.tail_g = 1;
+    sp.tail_blocks = 0;
+    sp.tail_ctr = nullptr;
     sp.dmax = dmax_norm;
     sp.cand = nullptr;
     sp.pcnt = nullptr;
@@ -1434,7 +1495,7 @@ TT_EXPORT int tt_debug_screen_s16(const float *Q, int B, const void *D16, int64_
     sp.qnorm = (const float *)(ws + pl.qnorm_off);
     sp.dbg_thr = thr;
     hipLaunchKernelGGL(q_image_kernel, dim3(pl.rows_pad / 32), dim3(128), 0, st, Q, B, (h8 *)(ws + pl.qimg_off),
-                       (float *)(ws + pl.qnorm_off), sp.flag, pl.rows_pad / 32);
+                       (float *)(ws + pl.qnorm_off), sp.flag, pl.rows_pad / 32, (int *)nullptr, 0);
     TT_LAUNCH_CHECK();
     if (form == 0) {
         const size_t lds = (size_t)TW * TSTAGE * TSLAB_BYTES;
