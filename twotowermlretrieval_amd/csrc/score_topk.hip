@@ -56,6 +56,12 @@ struct ScoreParams {
     int tiles_per_chunk;
     int n_tiles;
     int n_tasks;
+    // tiles [0, static_tiles) are split evenly over the chunks (tiles_per_chunk each); tiles [static_tiles, n_tiles) are a
+    // pool of tail_blocks blocks of tail_g tiles per query tile that the waves draw from (tail_ctr[qtile], atomicAdd) once
+    // their own range is done: the chip's XCDs do not stream / multiply at one speed (wave end times spread over 10-13 %
+    // of the launch with equal shares).  tail_ctr == nullptr: everything static.
+    int static_tiles, tail_g, tail_blocks;
+    int *tail_ctr;
     float *pval;   // [n_qtiles*32][n_chunks][k]
     int64_t *pidx; // same shape, global indices (idx_offset applied), -1 = empty
     int64_t idx_offset;
@@ -169,8 +175,8 @@ __global__ __launch_bounds__(WPB * 64, 2) void score_topk_kernel(ScoreParams p)
     if (p.run_if && p.run_if[qtile] == 0)
         return;
     const int chunk = task / p.n_qtiles;
-    const int t0 = chunk * p.tiles_per_chunk;
-    const int t1 = min(t0 + p.tiles_per_chunk, p.n_tiles);
+    int t0 = chunk * p.tiles_per_chunk; // the wave's own range first, then blocks of the pool
+    int t1 = min(t0 + p.tiles_per_chunk, p.static_tiles);
     const int k = p.k;
     const int h = lane >> 5;
     const int j = lane & 31;
@@ -263,6 +269,7 @@ __global__ __launch_bounds__(WPB * 64, 2) void score_topk_kernel(ScoreParams p)
         }
     };
 
+    for (;;) { // segments: the own range, then pool blocks
     if (t0 < t1) {
         set_rows(t0);
 #pragma unroll
@@ -339,6 +346,20 @@ __global__ __launch_bounds__(WPB * 64, 2) void score_topk_kernel(ScoreParams p)
             }
         }
     }
+    if (MAXONLY || !p.tail_ctr)
+        break;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the over-prefetch of the segment's end has landed: the ring is free
+    int blk = 0;
+    if (lane == 0)
+        blk = atomicAdd(p.tail_ctr + qtile, 1);
+    blk = __builtin_amdgcn_readfirstlane(blk);
+    if (blk >= p.tail_blocks)
+        break;
+    t0 = p.static_tiles + blk * p.tail_g;
+    t1 = min(t0 + p.tail_g, p.n_tiles);
+    dma_tile = t0;
+    dma_s = 0;
+    }
     // LDS-DMA still in flight would land after the wave has ended: drain it (and the stores).
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
@@ -401,8 +422,8 @@ __global__ __launch_bounds__(WPB * 64, 2) void score_topk16_kernel(ScoreParams p
     if (p.run_if && p.run_if[qtile >> 1] == 0)
         return;
     const int chunk = task / p.n_qtiles;
-    const int t0 = chunk * p.tiles_per_chunk;
-    const int t1 = min(t0 + p.tiles_per_chunk, p.n_tiles);
+    int t0 = chunk * p.tiles_per_chunk; // the wave's own range first, then blocks of the pool
+    int t1 = min(t0 + p.tiles_per_chunk, p.static_tiles);
     const int k = p.k;
     const int n = lane & 15, kq = lane >> 4;
 
@@ -466,6 +487,7 @@ __global__ __launch_bounds__(WPB * 64, 2) void score_topk16_kernel(ScoreParams p
         }
     };
 
+    for (;;) { // segments: the own range, then pool blocks
     if (t0 < t1) {
         set_rows(t0);
 #pragma unroll
@@ -538,6 +560,20 @@ __global__ __launch_bounds__(WPB * 64, 2) void score_topk16_kernel(ScoreParams p
                     compact_where((unsigned)full);
             }
         }
+    }
+    if (MAXONLY || !p.tail_ctr)
+        break;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the over-prefetch of the segment's end has landed: the ring is free
+    int blk = 0;
+    if (lane == 0)
+        blk = atomicAdd(p.tail_ctr + qtile, 1);
+    blk = __builtin_amdgcn_readfirstlane(blk);
+    if (blk >= p.tail_blocks)
+        break;
+    t0 = p.static_tiles + blk * p.tail_g;
+    t1 = min(t0 + p.tail_g, p.n_tiles);
+    dma_tile = t0;
+    dma_s = 0;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
@@ -903,6 +939,7 @@ __global__ __launch_bounds__(256) void score_all_kernel(const float *__restrict_
 // partial lists live inside the workspace.
 struct Pass {
     int n_qtiles, n_tiles, n_chunks, tiles_per_chunk, n_tasks;
+    int tail_own, static_tiles, tail_g, tail_blocks; // with the pool on: tail_own tiles per chunk are static (see ScoreParams)
     int64_t N;
 };
 
@@ -912,7 +949,7 @@ struct Plan {
     Pass main, pre;
     bool prepass;  // sample pass first: its k-th scores seed the main pass's thresholds
     // workspace layout (byte offsets)
-    size_t cand_off, pval_off, pidx_off, pre_val_off, pre_idx_off, ws_bytes;
+    size_t cand_off, pval_off, pidx_off, pre_val_off, pre_idx_off, tailctr_off, ws_bytes;
 };
 
 int device_cus()
@@ -926,7 +963,7 @@ int device_cus()
     return cus;
 }
 
-Pass make_pass(int B, int64_t N, int slots, int qt)
+Pass make_pass(int B, int64_t N, int slots, int qt, bool tail = false)
 {
     Pass ps;
     ps.N = N;
@@ -939,6 +976,25 @@ Pass make_pass(int B, int64_t N, int slots, int qt)
     ps.tiles_per_chunk = ps.n_tiles > 0 ? (ps.n_tiles + want - 1) / want : 1;
     ps.n_chunks = ps.n_tiles > 0 ? (ps.n_tiles + ps.tiles_per_chunk - 1) / ps.tiles_per_chunk : 1;
     ps.n_tasks = ps.n_qtiles * ps.n_chunks;
+    ps.tail_own = ps.tiles_per_chunk;
+    ps.static_tiles = ps.n_tiles;
+    ps.tail_g = 1;
+    ps.tail_blocks = 0;
+    if (tail) {
+        // pool = the last 1/TT_SCORE_TAIL_DIV of every chunk's share (0: everything static) in blocks of a quarter of it,
+        // 4..64 tiles (a block costs one refill of the wave's ring, ~2 us)
+        static const int tail_div = [] { const char *e = getenv("TT_SCORE_TAIL_DIV"); return e ? atoi(e) : 8; }();
+        const int share = tail_div > 0 ? ps.tiles_per_chunk / tail_div : 0;
+        if (share >= 8) {
+            const int own = ps.tiles_per_chunk - share;
+            int g = share / 4;
+            g = g < 4 ? 4 : (g > 64 ? 64 : g);
+            ps.tail_own = own;
+            ps.static_tiles = (int64_t)own * ps.n_chunks < ps.n_tiles ? own * ps.n_chunks : ps.n_tiles;
+            ps.tail_g = g;
+            ps.tail_blocks = (ps.n_tiles - ps.static_tiles + g - 1) / g;
+        }
+    }
     return ps;
 }
 
@@ -958,7 +1014,7 @@ Plan make_plan(int B, int64_t N, int k, int d)
     pl.cap = k <= 16 ? 64 : 128;
     pl.smem = (size_t)WPB * NSTAGE * SLAB_BYTES;
     const int slots = device_cus() * 8;
-    pl.main = make_pass(B, N, slots, qt);
+    pl.main = make_pass(B, N, slots, qt, true);
     pl.prepass = N >= PREPASS_MIN_N && (int64_t)pl.main.tiles_per_chunk * TILE_DOCS < PREPASS_MAX_CHUNK_DOCS;
     int max_tasks = pl.main.n_tasks;
     if (pl.prepass) {
@@ -985,6 +1041,8 @@ Plan make_plan(int B, int64_t N, int k, int d)
     off = tt_align_up(off + rows * k * sizeof(float), 256);
     pl.pre_idx_off = off;
     off = tt_align_up(off + rows * k * sizeof(int64_t), 256);
+    pl.tailctr_off = off;
+    off = tt_align_up(off + (size_t)pl.main.n_qtiles * sizeof(int), 256);
     pl.ws_bytes = off;
     return pl;
 }
@@ -1072,6 +1130,10 @@ ScoreParams pass_params(const Pass &ps, const float *Q, int B, const float *D, i
     sp.tiles_per_chunk = ps.tiles_per_chunk;
     sp.n_tiles = ps.n_tiles;
     sp.n_tasks = ps.n_tasks;
+    sp.static_tiles = ps.n_tiles; // (the caller turns the pool on for the main pass)
+    sp.tail_g = 1;
+    sp.tail_blocks = 0;
+    sp.tail_ctr = nullptr;
     sp.pval = (float *)(ws + pl.pval_off);
     sp.pidx = (int64_t *)(ws + pl.pidx_off);
     sp.idx_offset = idx_offset;
@@ -1125,6 +1187,16 @@ int score_partials(const float *Q, int B, int d, const float *D, int64_t N, int 
     sp.thr0_stride = 1;
     sp.thr0_off = 0;
     sp.run_if = run_if;
+    if (pl.main.tail_blocks > 0 && !run_if) {
+        // (the predicated form keeps the static split: its launches sit behind every screened search as no-ops, and a
+        //  counter reset would be one more)
+        sp.tiles_per_chunk = pl.main.tail_own;
+        sp.static_tiles = pl.main.static_tiles;
+        sp.tail_g = pl.main.tail_g;
+        sp.tail_blocks = pl.main.tail_blocks;
+        sp.tail_ctr = (int *)(ws + pl.tailctr_off);
+        TT_RC_CHECK(tt_zero_async(sp.tail_ctr, sizeof(int) * pl.main.n_qtiles, st));
+    }
     if (prof_events)
         TT_HIP_CHECK(hipEventRecord((hipEvent_t)prof_events[0], st));
     const int rc = launch_score(d, sp, pl, st, false);
