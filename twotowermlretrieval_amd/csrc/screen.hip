@@ -1198,7 +1198,9 @@ SPlan make_splan(int B, int64_t N, int k)
     // Sample size: 1/64 of the corpus, or enough documents that the k-th sample maximum lets through about
     // one candidate per 32x32 score tile or fewer (k / s_docs per score): matters for small shards, large k.
     int64_t s_docs = N / 64;
-    constexpr int per_k = 2048; // measured optimum is broad (1024..4096) for k = 10..50 on 1.25M..10M documents
+    // measured on a 1.25M-document shard (B = 1024, A/B on one box): k = 10: 2048 -> 0.697, 4096 -> 0.664, 8192 -> 0.677 ms;
+    // k = 50: 2048 -> 0.735, 4096 -> 0.767, 8192 -> 0.827 ms (the sample pass itself grows with k * per_k)
+    const int per_k = k <= 16 ? 4096 : 2048;
     const int64_t s_min = (int64_t)k * per_k < N / 4 ? (int64_t)k * per_k : N / 4;
     s_docs = s_docs < s_min ? s_min : s_docs;
     s_docs = s_docs < 32 ? 32 : s_docs;
