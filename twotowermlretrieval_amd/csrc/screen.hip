@@ -249,6 +249,10 @@ template <bool MAXONLY, int NSET>
 __global__ __launch_bounds__(SW * 64, 2) void screen_kernel(ScreenParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char ring[]; // [SRING][STILE_BYTES]
+    // NSET < 4 (B <= 256): one query group, so every tile is read once by one workgroup: nt policy like the streaming
+    // form (TSTREAM_AUX; here -2.5 % at B = 33 .. 128, -1.5 % at 256, A/B on one box); NSET == 4 may have two groups per
+    // chunk that share the tile through L2: default policy
+    constexpr int DMA_AUX = NSET < 4 ? 2 : 0;
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int chunk = blockIdx.x % p.n_chunks;
@@ -339,13 +343,13 @@ __global__ __launch_bounds__(SW * 64, 2) void screen_kernel(ScreenParams p)
     auto dma_issue = [&](int tile, int stage) {
         set_rows(min(tile, t1 - 1));
         char *dst = ring + stage * STILE_BYTES + (2 * w) * 1024;
-        __builtin_amdgcn_global_load_lds((gbl_void *)rowp[0], (lds_void *)dst, 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((gbl_void *)rowp[1], (lds_void *)(dst + 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_void *)rowp[0], (lds_void *)dst, 16, 0, DMA_AUX);
+        __builtin_amdgcn_global_load_lds((gbl_void *)rowp[1], (lds_void *)(dst + 1024), 16, 0, DMA_AUX);
     };
     // one of a tile's two pieces (the addresses were prepared by set_rows)
     auto dma_piece = [&](int i, int stage) {
         char *dst = ring + stage * STILE_BYTES + (2 * w + i) * 1024;
-        __builtin_amdgcn_global_load_lds((gbl_void *)rowp[i], (lds_void *)dst, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_void *)rowp[i], (lds_void *)dst, 16, 0, DMA_AUX);
     };
 
     for (;;) { // segments: the own range, then pool blocks
@@ -568,6 +572,11 @@ constexpr int TW = 4;                    // waves per workgroup (2 workgroups pe
 constexpr int TSLAB_BYTES = 32 * 128;    // 32 docs x 64 f16
 constexpr int TSTAGE = 4;                // ring depth in slabs
 constexpr int TDMA = 4;                  // DMA instructions per slab
+// Cache policy of the document stream: nt (aux = 2).  Every byte is read once by one wave; with the default policy the
+// same kernel reached 6.1-6.2 TB/s, with nt 6.8-6.9 (0.910 -> 0.816-0.824 ms per B = 32 search over 10M documents, A/B on
+// one box; MI355X_MICROARCH.md 'nt-weights').  NOT for the exact kernel at large batches, whose 32 query tiles re-read a
+// chunk from L2 (44.2 -> 52.9 ms at B = 1024 with nt), nor for the shared-tile screen (two workgroups per chunk).
+constexpr int TSTREAM_AUX = 2;
 
 template <bool MAXONLY>
 __global__ __launch_bounds__(TW * 64, 2) void screen_stream_kernel(ScreenParams p)
@@ -653,7 +662,7 @@ __global__ __launch_bounds__(TW * 64, 2) void screen_stream_kernel(ScreenParams 
         char *dst = ring + stage * TSLAB_BYTES;
 #pragma unroll
         for (int jj = 0; jj < TDMA; ++jj)
-            __builtin_amdgcn_global_load_lds((gbl_void *)(rowp[jj] + dma_kq * 128), (lds_void *)(dst + jj * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_void *)(rowp[jj] + dma_kq * 128), (lds_void *)(dst + jj * 1024), 16, 0, TSTREAM_AUX);
         if (++dma_kq == 4) {
             dma_kq = 0;
             dma_tile = min(dma_tile + 1, t1 - 1); // past the end: harmless re-read
