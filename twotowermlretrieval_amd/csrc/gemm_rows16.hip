@@ -283,11 +283,6 @@ bool tt_gemm_rows16_supported(int N, int K, int64_t lda, int64_t ldc)
     return N % 64 == 0 && N >= 256 && K % 4 == 0 && lda % 4 == 0 && ldc % 4 == 0 && (nks == 19 || nks == 16 || nks == 13);
 }
 
-size_t tt_pack_frag16_bytes(int N, int K)
-{
-    return (size_t)N * ((K + 15) / 16 * 16) * 2 * sizeof(uint16_t);
-}
-
 int tt_pack_frag16(const float *W, int N, int K, const unsigned *absmax, void *out, hipStream_t st)
 {
     const int nks = (K + 15) / 16;

@@ -50,11 +50,10 @@ __host__ __device__ static inline int tt_pow2_exponent(unsigned absmax_bits)
 // Launch: grid (ceil(N/128), ceil(M/128), splits), block 256.
 int tt_sgemm(const SgemmParams &p, bool a_t, bool b_t, int splits, hipStream_t st);
 
-// The same product (A_T = B_T = false only: C = A * B^T, A rows optionally gathered through a_map) on the f16 matrix
-// pipes: both operands are split into fp16 hi + lo parts while they are staged into LDS and the product is taken as
-// hi*hi + lo*hi + hi*lo on v_mfma_f32_32x32x16_f16 with fp32 accumulation -- every product good to ~3 * 2^-24
-// relative, i.e. one fp32 rounding, at 3/16 of the fp32-MFMA time (csrc/gru16.hip has the error argument).
-int tt_sgemm16_nn(const SgemmParams &p, hipStream_t st);
+// The same products on the f16 matrix pipes: both operands are split into fp16 hi + lo parts while they are staged into LDS
+// and the product is taken as hi*hi + lo*hi + hi*lo on v_mfma_f32_32x32x16_f16 with fp32 accumulation -- every product good to
+// ~3 * 2^-24 relative, i.e. one fp32 rounding, at 3/16 of the fp32-MFMA time (csrc/gru16.hip has the error argument).
+// A_T = B_T = false: C = A * B^T, A rows optionally gathered through a_map;
 // ... and with both operands stored [K][rows] (C = A^T * B summed over their rows: the weight-gradient products over
 // all tokens), split-K like tt_sgemm.  Same four [row][k] LDS images; only the staging differs.
 int tt_sgemm16(const SgemmParams &p, bool a_t, bool b_t, int splits, hipStream_t st);
@@ -67,7 +66,6 @@ int tt_pack_rows16(const float *W, int N, int K, const unsigned *absmax, void *h
 // gathered through a_map, K <= 304, N a multiple of 256.  p.b_hi16 = tt_pack_frag16's fragment stream (p.b_lo16 / ldb16
 // unused); a_exp / a_absmax, b_absmax, bias, m_dyn as for tt_sgemm16.
 bool tt_gemm_rows16_supported(int N, int K, int64_t lda, int64_t ldc);
-size_t tt_pack_frag16_bytes(int N, int K);
 int tt_pack_frag16(const float *W, int N, int K, const unsigned *absmax, void *out, hipStream_t st);
 int tt_gemm_rows16(const SgemmParams &p, hipStream_t st);
 

@@ -206,7 +206,7 @@ __device__ __forceinline__ void commit16(_Float16 *__restrict__ hi_img, _Float16
                                          float scale, int tid)
 {
     if (!TR) {
-        const int r = tid >> 1, kc = (tid & 1) * 16;
+        const int r = tid >> 1;
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             h8v hi, lo;
@@ -523,7 +523,6 @@ int tt_sgemm16(const SgemmParams &p, bool a_t, bool b_t, int splits, hipStream_t
     return TT_OK;
 }
 
-int tt_sgemm16_nn(const SgemmParams &p, hipStream_t st) { return tt_sgemm16(p, false, false, 1, st); }
 
 int tt_pack_rows16(const float *W, int N, int K, const unsigned *absmax, void *hi16, void *lo16, hipStream_t st)
 {
