@@ -29,9 +29,22 @@ typedef float f32x16v __attribute__((ext_vector_type(16)));
 
 #define RS_MFMA(wf, tf, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(tf, wf, c, 0, 0, 0)
 constexpr int RS_ROWS = 64;                     // tokens per workgroup
-constexpr int RS_LDH = 312;                     // halves per image row: 624 B = 156 dwords = 28 mod 32 banks
-constexpr int RS_IMG = RS_ROWS * RS_LDH * 2;    // bytes per image (hi | lo)
-constexpr int RS_LDS = 2 * RS_IMG;              // 79 872 B: two workgroups per 160 KiB CU
+// Two forms.  NARROW (K <= 304: the embedding layer, a stacked unidirectional layer): 4 waves, 2 column tiles (64 columns) per
+// pass, 78 KiB of token images -> two workgroups per CU.  WIDE (K = 512: the input of a stacked BIDIRECTIONAL layer,
+// config.json's default shape): the images are 130 KiB, so ONE workgroup of 8 waves per CU, one 32-column tile per wave and
+// pass (24 chunks of N = 768 over 8 waves: 3 passes each; 64-column chunks would leave half the waves a pass short).
+template <int NKS, bool WIDE>
+struct RSCfg {
+    static constexpr int WAVES = WIDE ? 8 : 4;
+    static constexpr int CT = WIDE ? 1 : 2;              // 32-column tiles per pass
+    static constexpr int CHUNK = 32 * CT;                // columns per (wave, pass)
+    static constexpr int FRAGS = 2 * CT;                 // 1-KiB fragments per k-step: hi, lo of each tile
+    static constexpr int LDH = WIDE ? NKS * 16 + 8 : 312; // halves per image row: 156 / 260 dwords = 28 / 4 mod 32 banks
+    static constexpr int IMG = RS_ROWS * LDH * 2;        // bytes per image (hi | lo)
+    static constexpr int LDS = 2 * IMG;                  // 79 872 B (two per CU) / 133 120 B (one per CU)
+    static constexpr int TPR = WAVES * 64 / RS_ROWS;     // threads per token row in the fill
+    static constexpr int NJ = (NKS * 4 + TPR - 1) / TPR; // 16-byte pieces per thread
+};
 #ifndef TT_ROWS_NR
 #define TT_ROWS_NR 4
 #endif
@@ -51,13 +64,14 @@ __device__ __forceinline__ void static_for(F &&f)
     }
 }
 
-// NKS = ceil(K / 16) k-steps (compile time: the k loop is fully unrolled and software-pipelined).  The N / 64 column
-// chunks go round the four waves: wave w takes chunks w, w + 4, ..., one per PASS (runtime loop).
-__host__ __device__ static inline int rs_chunks_of(int nchunks, int w) { return (nchunks - w + 3) / 4; }
+// NKS = ceil(K / 16) k-steps (compile time: the k loop is fully unrolled and software-pipelined).  The column chunks go
+// round the waves: wave w takes chunks w, w + W, ..., one per PASS (runtime loop).
+__host__ __device__ static inline int rs_chunks_of(int nchunks, int w, int W) { return (nchunks - w + W - 1) / W; }
 
-template <int NKS>
-__global__ __launch_bounds__(256, 2) void gemm_rows16_kernel(SgemmParams p)
+template <int NKS, bool WIDE>
+__global__ __launch_bounds__(WIDE ? 512 : 256, WIDE ? 1 : 2) void gemm_rows16_kernel(SgemmParams p)
 {
+    using C = RSCfg<NKS, WIDE>;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6); // wave-uniform: the buffer resource below must live in SGPRs
@@ -69,52 +83,54 @@ __global__ __launch_bounds__(256, 2) void gemm_rows16_kernel(SgemmParams p)
     const int eb = p.b_absmax ? tt_pow2_exponent(*p.b_absmax) : p.b_exp;
     const float sa = ldexpf(1.0f, ea), down = ldexpf(1.0f, -(ea + eb)), up = ldexpf(1.0f, ea + eb);
     const int i = lane & 31, h = lane >> 5;
-    const int nchunks = p.N >> 6, npass = rs_chunks_of(nchunks, w);
+    const int nchunks = p.N / C::CHUNK, npass = rs_chunks_of(nchunks, w, C::WAVES);
     int first = 0; // this wave's first pass in the (wave-major) fragment stream
     for (int j = 0; j < w; ++j)
-        first += rs_chunks_of(nchunks, j);
+        first += rs_chunks_of(nchunks, j, C::WAVES);
     // The bias is the accumulators' starting value (times the operand scales), fetched one pass ahead: a load issued in
     // the epilogue would have to be waited for with vmcnt(0), draining the fragment ring at every pass boundary.
-    float bnext[2]; // [ct]: column (4 pass + w) 64 + 32 ct + i
+    float bnext[C::CT]; // [ct]: column (W pass + w) CHUNK + 32 ct + i
     auto load_bias = [&](int pass) {
 #pragma unroll
-        for (int ct = 0; ct < 2; ++ct)
-            bnext[ct] = (p.bias && pass < npass) ? p.bias[(pass * 4 + w) * 64 + 32 * ct + i] : 0.0f;
+        for (int ct = 0; ct < C::CT; ++ct)
+            bnext[ct] = (p.bias && pass < npass) ? p.bias[(pass * C::WAVES + w) * C::CHUNK + 32 * ct + i] : 0.0f;
     };
     load_bias(0);
 
-    // ---- this wave's fragment stream (4 KiB per k-step: hi/lo of two column tiles): ring slot of k-step s of any pass is
+    // ---- this wave's fragment stream (FRAGS KiB per k-step: hi/lo of each column tile): ring slot of k-step s of any pass is
     // s % RS_NR, so a pass is PER = NKS rounded up to a multiple of RS_NR ring turns, the last PER - NKS of them refill-only.
     // Loads past the end of the stream (the prefetch for a pass that does not exist) return zeros: buffer bounds. ----
     constexpr int PER = (NKS + RS_NR - 1) / RS_NR * RS_NR;
     const __amdgpu_buffer_rsrc_t wsrc = __builtin_amdgcn_make_buffer_rsrc(
-        (void *)((const char *)p.b_hi16 + (size_t)first * NKS * 4096), 0, npass * NKS * 4096, 0x00020000);
+        (void *)((const char *)p.b_hi16 + (size_t)first * NKS * C::FRAGS * 1024), 0, npass * NKS * C::FRAGS * 1024, 0x00020000);
     const int loff = lane * 16;
-    h8 ring[RS_NR][4];
+    h8 ring[RS_NR][C::FRAGS];
     static_for<0, RS_NR>([&](auto ic) {
         constexpr int k = decltype(ic)::value;
-        static_for<0, 4>([&](auto jc) {
+        static_for<0, C::FRAGS>([&](auto jc) {
             constexpr int j = decltype(jc)::value;
-            ring[k][j] = frag_load(wsrc, loff, (k * 4 + j) * 1024);
+            ring[k][j] = frag_load(wsrc, loff, (k * C::FRAGS + j) * 1024);
         });
     });
 
-    // ---- fill: thread -> (token tid >> 2, 16-byte pieces 4 q + 16 j of its row) ----
+    // ---- fill: thread -> (token tid / TPR, 16-byte pieces q + TPR j of its row: TPR lanes read 16 TPR contiguous bytes) ----
     {
-        const int r = tid >> 2, q = tid & 3, row = row0 + r;
+        const int r = tid / C::TPR, q = tid % C::TPR, row = row0 + r;
         const float *src = nullptr;
         if (row < M)
             src = p.A + (size_t)(p.a_map ? (int64_t)p.a_map[row] : (int64_t)row) * p.lda;
-        f32x4v v[NKS];
+        f32x4v v[C::NJ];
 #pragma unroll
-        for (int j = 0; j < NKS; ++j) {
+        for (int j = 0; j < C::NJ; ++j) {
             v[j] = (f32x4v){0, 0, 0, 0};
-            if (src && 16 * j + 4 * q < p.K)
-                v[j] = *(const f32x4v *)(src + 16 * j + 4 * q);
+            if (src && 4 * (q + C::TPR * j) < p.K)
+                v[j] = *(const f32x4v *)(src + 4 * (q + C::TPR * j));
         }
-        char *dst = lds + r * (RS_LDH * 2) + q * 8;
+        char *dst = lds + r * (C::LDH * 2) + q * 8;
 #pragma unroll
-        for (int j = 0; j < NKS; ++j) {
+        for (int j = 0; j < C::NJ; ++j) {
+            if (4 * (q + C::TPR * j) >= NKS * 16) // (only when NKS * 4 is not a multiple of TPR)
+                continue;
             h4 hi, lo;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -123,17 +139,17 @@ __global__ __launch_bounds__(256, 2) void gemm_rows16_kernel(SgemmParams p)
                 hi[e] = hv;
                 lo[e] = (_Float16)(x - (float)hv);
             }
-            *(h4 *)(dst + j * 32) = hi;
-            *(h4 *)(dst + RS_IMG + j * 32) = lo;
+            *(h4 *)(dst + j * (8 * C::TPR)) = hi;
+            *(h4 *)(dst + C::IMG + j * (8 * C::TPR)) = lo;
         }
     }
     __syncthreads();
 
     // ---- main loop: token fragments one k-step ahead (LDS), W fragments RS_NR k-steps ahead (L2 -> registers) ----
-    const char *abase = lds + i * (RS_LDH * 2) + h * 16;
-    f32x16v acc[2][2]; // [ct][rt]
+    const char *abase = lds + i * (C::LDH * 2) + h * 16;
+    f32x16v acc[C::CT][2]; // [ct][rt]
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < C::CT; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
@@ -142,17 +158,17 @@ __global__ __launch_bounds__(256, 2) void gemm_rows16_kernel(SgemmParams p)
     h8 ahi[2][2], alo[2][2]; // [parity of the k-step][rt]
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt) {
-        ahi[0][rt] = *(const h8 *)(abase + rt * 32 * (RS_LDH * 2));
-        alo[0][rt] = *(const h8 *)(abase + RS_IMG + rt * 32 * (RS_LDH * 2));
+        ahi[0][rt] = *(const h8 *)(abase + rt * 32 * (C::LDH * 2));
+        alo[0][rt] = *(const h8 *)(abase + C::IMG + rt * 32 * (C::LDH * 2));
     }
     // lane <-> column, registers <-> tokens: a store instruction writes two whole 128-byte lines.  (The C^T orientation's
     // 16-byte stores put 32 bytes into each of 32 lines per instruction: the launch ran at the 1.9 TB/s those writes
     // reached, 0.9 ms of its 1.5; whole lines: 0.35 ms.  Plain stores: non-temporal ones are no faster for whole lines
     // even at 1.8 GB, and an output that fits the MALL is read back from it by the recurrence.)
-    float *const cbase = p.C + (size_t)(row0 + 4 * h) * p.ldc + w * 64 + i;
+    float *const cbase = p.C + (size_t)(row0 + 4 * h) * p.ldc + w * C::CHUNK + i;
     const int mrem = M - row0 - 4 * h; // token offset t of this lane's base row is stored iff t < mrem
     for (int pass = 0; pass < npass; ++pass) {
-        const int sbase = pass * NKS * 4096; // byte offset of this pass in the wave's stream
+        const int sbase = pass * NKS * C::FRAGS * 1024; // byte offset of this pass in the wave's stream
         static_for<0, PER>([&](auto sc) {
             constexpr int s = decltype(sc)::value;
             // A double buffer: k-step s of a pass reads buffer s & 1 and fetches k-step s + 1 into the other one.  The
@@ -162,8 +178,8 @@ __global__ __launch_bounds__(256, 2) void gemm_rows16_kernel(SgemmParams p)
             if constexpr (s == NKS && (NKS & 1)) {
 #pragma unroll
                 for (int rt = 0; rt < 2; ++rt) {
-                    ahi[0][rt] = *(const h8 *)(abase + rt * 32 * (RS_LDH * 2));
-                    alo[0][rt] = *(const h8 *)(abase + RS_IMG + rt * 32 * (RS_LDH * 2));
+                    ahi[0][rt] = *(const h8 *)(abase + rt * 32 * (C::LDH * 2));
+                    alo[0][rt] = *(const h8 *)(abase + C::IMG + rt * 32 * (C::LDH * 2));
                 }
             }
             if constexpr (s < NKS) {
@@ -171,24 +187,24 @@ __global__ __launch_bounds__(256, 2) void gemm_rows16_kernel(SgemmParams p)
                     constexpr int s1 = (s + 1) % NKS;
 #pragma unroll
                     for (int rt = 0; rt < 2; ++rt) {
-                        ahi[par ^ 1][rt] = *(const h8 *)(abase + rt * 32 * (RS_LDH * 2) + s1 * 32);
-                        alo[par ^ 1][rt] = *(const h8 *)(abase + RS_IMG + rt * 32 * (RS_LDH * 2) + s1 * 32);
+                        ahi[par ^ 1][rt] = *(const h8 *)(abase + rt * 32 * (C::LDH * 2) + s1 * 32);
+                        alo[par ^ 1][rt] = *(const h8 *)(abase + C::IMG + rt * 32 * (C::LDH * 2) + s1 * 32);
                     }
                 }
-                // ring slot: [0] hi of column tile 0, [1] lo of it, [2] hi of column tile 1, [3] lo of it
-                h8(&b)[4] = ring[s % RS_NR];
+                // ring slot: [2 ct] hi of column tile ct, [2 ct + 1] lo of it
+                h8(&b)[C::FRAGS] = ring[s % RS_NR];
 #pragma unroll
-                for (int ct = 0; ct < 2; ++ct)
+                for (int ct = 0; ct < C::CT; ++ct)
 #pragma unroll
                     for (int rt = 0; rt < 2; ++rt)
                         acc[ct][rt] = RS_MFMA(b[2 * ct], ahi[par][rt], acc[ct][rt]);
 #pragma unroll
-                for (int ct = 0; ct < 2; ++ct)
+                for (int ct = 0; ct < C::CT; ++ct)
 #pragma unroll
                     for (int rt = 0; rt < 2; ++rt)
                         acc[ct][rt] = RS_MFMA(b[2 * ct], alo[par][rt], acc[ct][rt]);
 #pragma unroll
-                for (int ct = 0; ct < 2; ++ct)
+                for (int ct = 0; ct < C::CT; ++ct)
 #pragma unroll
                     for (int rt = 0; rt < 2; ++rt)
                         acc[ct][rt] = RS_MFMA(b[2 * ct + 1], ahi[par][rt], acc[ct][rt]);
@@ -198,14 +214,14 @@ __global__ __launch_bounds__(256, 2) void gemm_rows16_kernel(SgemmParams p)
             {
                 constexpr int tgt = s + RS_NR;
                 if constexpr (tgt < NKS) {
-                    static_for<0, 4>([&](auto jc) {
+                    static_for<0, C::FRAGS>([&](auto jc) {
                         constexpr int j = decltype(jc)::value;
-                        ring[s % RS_NR][j] = frag_load(wsrc, loff + sbase, (tgt * 4 + j) * 1024);
+                        ring[s % RS_NR][j] = frag_load(wsrc, loff + sbase, (tgt * C::FRAGS + j) * 1024);
                     });
                 } else if constexpr (tgt >= PER) {
-                    static_for<0, 4>([&](auto jc) {
+                    static_for<0, C::FRAGS>([&](auto jc) {
                         constexpr int j = decltype(jc)::value;
-                        ring[s % RS_NR][j] = frag_load(wsrc, loff + sbase, ((NKS + tgt - PER) * 4 + j) * 1024);
+                        ring[s % RS_NR][j] = frag_load(wsrc, loff + sbase, ((NKS + tgt - PER) * C::FRAGS + j) * 1024);
                     });
                 }
             }
@@ -213,12 +229,12 @@ __global__ __launch_bounds__(256, 2) void gemm_rows16_kernel(SgemmParams p)
                 load_bias(pass + 1);
             __builtin_amdgcn_sched_barrier(0);
         });
-        // end of a pass: 64 tokens x 64 columns out
-        float *cp = cbase + pass * 256;
+        // end of a pass: 64 tokens x CHUNK columns out
+        float *cp = cbase + pass * (C::WAVES * C::CHUNK);
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-            for (int ct = 0; ct < 2; ++ct)
+            for (int ct = 0; ct < C::CT; ++ct)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int t = rt * 32 + 8 * (r >> 2) + (r & 3);
@@ -231,22 +247,24 @@ __global__ __launch_bounds__(256, 2) void gemm_rows16_kernel(SgemmParams p)
 }
 
 // W [N][K] fp32 -> the fragment stream gemm_rows16_kernel reads: 1-KiB blocks ordered (wave, pass, k-step, column tile,
-// hi | lo), lane l of a block = 8 halves of column (4 pass + wave) 64 + 32 ct + (l & 31) at k = 16 s + 8 (l >> 5) ..
-__global__ __launch_bounds__(256) void pack_frag16_kernel(const float *__restrict__ W, int N, int K, int nks,
+// hi | lo), lane l of a block = 8 halves of column (W pass + wave) CHUNK + 32 ct + (l & 31) at k = 16 s + 8 (l >> 5) ..
+__global__ __launch_bounds__(256) void pack_frag16_kernel(const float *__restrict__ W, int N, int K, int nks, int waves, int ctn,
                                                           const unsigned *__restrict__ absmax, _Float16 *__restrict__ out)
 {
     const float sc = ldexpf(1.0f, tt_pow2_exponent(*absmax));
-    const int nchunks = N / 64;
-    const int total = nchunks * nks * 2 * 64; // (chunk, s, ct, lane)
+    const int chunk_cols = 32 * ctn, nchunks = N / chunk_cols;
+    const int total = nchunks * nks * ctn * 64; // (chunk, s, ct, lane)
     for (int t = blockIdx.x * 256 + threadIdx.x; t < total; t += gridDim.x * 256) {
-        const int l = t & 63, ct = (t >> 6) & 1;
-        int rest = t >> 7;
+        const int l = t & 63;
+        int rest = t >> 6;
+        const int ct = rest % ctn;
+        rest /= ctn;
         const int s = rest % nks, chunk = rest / nks;
-        const int w = chunk & 3, pass = chunk >> 2;
+        const int w = chunk % waves, pass = chunk / waves;
         int first = 0;
         for (int j = 0; j < w; ++j)
-            first += rs_chunks_of(nchunks, j);
-        const int col = chunk * 64 + 32 * ct + (l & 31), k0 = 16 * s + 8 * (l >> 5);
+            first += rs_chunks_of(nchunks, j, waves);
+        const int col = chunk * chunk_cols + 32 * ct + (l & 31), k0 = 16 * s + 8 * (l >> 5);
         h8 vh, vl;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -255,39 +273,46 @@ __global__ __launch_bounds__(256) void pack_frag16_kernel(const float *__restric
             vh[e] = hv;
             vl[e] = (_Float16)(x - (float)hv);
         }
-        _Float16 *blk = out + ((size_t)(((first + pass) * nks + s) * 2 + ct) * 2) * 512 + l * 8;
+        _Float16 *blk = out + ((size_t)(((first + pass) * nks + s) * ctn + ct) * 2) * 512 + l * 8;
         *(h8 *)blk = vh;
         *(h8 *)(blk + 512) = vl;
     }
 }
 
-template <int NKS>
+template <int NKS, bool WIDE>
 int launch_rows16(const SgemmParams &p, hipStream_t st)
 {
+    using C = RSCfg<NKS, WIDE>;
     static bool attr_done = false; // (idempotent: a race sets the same value twice)
     if (!attr_done) {
-        TT_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_rows16_kernel<NKS>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         RS_LDS));
+        TT_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_rows16_kernel<NKS, WIDE>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         C::LDS));
         attr_done = true;
     }
-    hipLaunchKernelGGL((gemm_rows16_kernel<NKS>), dim3((unsigned)((p.M + RS_ROWS - 1) / RS_ROWS)), dim3(256), RS_LDS, st, p);
+    hipLaunchKernelGGL((gemm_rows16_kernel<NKS, WIDE>), dim3((unsigned)((p.M + RS_ROWS - 1) / RS_ROWS)), dim3(C::WAVES * 64), C::LDS,
+                       st, p);
     TT_LAUNCH_CHECK();
     return TT_OK;
 }
+
+bool rows16_wide(int K) { return (K + 15) / 16 > 19; }
 
 } // namespace
 
 bool tt_gemm_rows16_supported(int N, int K, int64_t lda, int64_t ldc)
 {
     const int nks = (K + 15) / 16;
-    return N % 64 == 0 && N >= 256 && K % 4 == 0 && lda % 4 == 0 && ldc % 4 == 0 && (nks == 19 || nks == 16 || nks == 13);
+    if (K % 4 || lda % 4 || ldc % 4 || N < 256)
+        return false;
+    return rows16_wide(K) ? (nks == 32 && N % 32 == 0) : (N % 64 == 0 && (nks == 19 || nks == 16 || nks == 13));
 }
 
 int tt_pack_frag16(const float *W, int N, int K, const unsigned *absmax, void *out, hipStream_t st)
 {
     const int nks = (K + 15) / 16;
-    const int total = N / 64 * nks * 2 * 64;
-    hipLaunchKernelGGL(pack_frag16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, W, N, K, nks, absmax,
+    const int waves = rows16_wide(K) ? 8 : 4, ctn = rows16_wide(K) ? 1 : 2;
+    const int total = N / 32 * nks * 64;
+    hipLaunchKernelGGL(pack_frag16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, W, N, K, nks, waves, ctn, absmax,
                        (_Float16 *)out);
     TT_LAUNCH_CHECK();
     return TT_OK;
@@ -300,9 +325,10 @@ int tt_gemm_rows16(const SgemmParams &p, hipStream_t st)
     if (!tt_gemm_rows16_supported(p.N, p.K, p.lda, p.ldc) || !p.b_hi16 || p.accumulate || p.k_dyn || p.b_map)
         return TT_ERR_UNSUPPORTED;
     switch ((p.K + 15) / 16) {
-    case 19: return launch_rows16<19>(p, st); // E = 300 (GloVe 6B.300d: the north-star tower)
-    case 16: return launch_rows16<16>(p, st); // 256: a stacked layer's input
-    case 13: return launch_rows16<13>(p, st); // E = 200 (config.json's embedding width)
+    case 19: return launch_rows16<19, false>(p, st); // E = 300 (GloVe 6B.300d: the north-star tower)
+    case 16: return launch_rows16<16, false>(p, st); // 256: a stacked layer's input
+    case 13: return launch_rows16<13, false>(p, st); // E = 200 (config.json's embedding width)
+    case 32: return launch_rows16<32, true>(p, st);  // 512: a stacked bidirectional layer's input (config.json's default)
     }
     return TT_ERR_UNSUPPORTED;
 }
