@@ -580,7 +580,17 @@ TT_EXPORT int tt_encoder_backward_f32(const int64_t *ids, int B, int T, const fl
                 x.ldc = I;
                 x.slab_stride = 0;
                 x.accumulate = d;
-                rc = tt_sgemm(x, false, true, 1, st);
+                if (!force_f32) {
+                    // on the f16 pipes like every other product of the step: dGi scaled by its maximum (the column-sum
+                    // pass found it), W_ih by the power of two the forward pass derived (status word 40 + 2 l + d)
+                    x.a_absmax = mx_dgi;
+                    x.b_absmax = (const unsigned *)(ws + lo.flag) + 40 + 2 * l + d;
+                    x.a_exp = x.b_exp = 0;
+                    x.b_hi16 = x.b_lo16 = nullptr;
+                    x.ldb16 = 0;
+                    rc = tt_sgemm16(x, false, true, 1, st);
+                } else
+                    rc = tt_sgemm(x, false, true, 1, st);
                 if (rc != TT_OK)
                     return rc;
             }

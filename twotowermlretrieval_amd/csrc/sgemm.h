@@ -53,7 +53,7 @@ int tt_sgemm(const SgemmParams &p, bool a_t, bool b_t, int splits, hipStream_t s
 // The same products on the f16 matrix pipes: both operands are split into fp16 hi + lo parts while they are staged into LDS
 // and the product is taken as hi*hi + lo*hi + hi*lo on v_mfma_f32_32x32x16_f16 with fp32 accumulation -- every product good to
 // ~3 * 2^-24 relative, i.e. one fp32 rounding, at 3/16 of the fp32-MFMA time (csrc/gru16.hip has the error argument).
-// A_T = B_T = false: C = A * B^T, A rows optionally gathered through a_map;
+// A_T = B_T = false: C = A * B^T, A rows optionally gathered through a_map; A_T = false, B_T = true: C = A * B (B [K][N]);
 // ... and with both operands stored [K][rows] (C = A^T * B summed over their rows: the weight-gradient products over
 // all tokens), split-K like tt_sgemm.  Same four [row][k] LDS images; only the staging differs.
 int tt_sgemm16(const SgemmParams &p, bool a_t, bool b_t, int splits, hipStream_t st);

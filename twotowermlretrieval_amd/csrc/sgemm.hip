@@ -500,8 +500,8 @@ int tt_sgemm16(const SgemmParams &p, bool a_t, bool b_t, int splits, hipStream_t
 {
     if (p.M <= 0 || p.N <= 0 || p.K <= 0)
         return TT_OK;
-    if (a_t != b_t)
-        return tt_fail(TT_ERR_UNSUPPORTED, "tt_sgemm16: only A*B^T (both row operands) and A^T*B (both [K][rows]) are built");
+    if (a_t && !b_t)
+        return tt_fail(TT_ERR_UNSUPPORTED, "tt_sgemm16: A^T * B^T is not built");
     if ((!a_t && (p.K & 3)) || (a_t && (p.M & 3)) || (p.N & 3) || (p.lda & 3) || (p.ldb & 3) || (p.ldc & 3) ||
         ((uintptr_t)p.C & 15) || (p.bias && ((uintptr_t)p.bias & 15)))
         return tt_fail(TT_ERR_UNSUPPORTED, "tt_sgemm16: dims / leading dimensions must be multiples of 4 and C, bias 16-byte "
@@ -515,7 +515,9 @@ int tt_sgemm16(const SgemmParams &p, bool a_t, bool b_t, int splits, hipStream_t
         if (!p.b_absmax || (p.ldb16 & 31) || p.ldb16 < p.K)
             return tt_fail(TT_ERR_BAD_SHAPE, "tt_sgemm16: pre-split B needs b_absmax and ldb16 >= K, a multiple of 32");
         hipLaunchKernelGGL((sgemm16_kernel<false, false, true>), grid, dim3(256), 0, st, p);
-    } else if (!a_t)
+    } else if (!a_t && b_t) // C = A * B with B stored [K][N] (the input-gradient product dX = dGi * W_ih)
+        hipLaunchKernelGGL((sgemm16_kernel<false, true>), grid, dim3(256), 0, st, p);
+    else if (!a_t)
         hipLaunchKernelGGL((sgemm16_kernel<false, false>), grid, dim3(256), 0, st, p);
     else
         hipLaunchKernelGGL((sgemm16_kernel<true, true>), grid, dim3(256), 0, st, p);
