@@ -23,6 +23,7 @@ Fixtures:
                           autograd gradient of the table and of the GRU weights, 1-layer uni and 2-layer bidirectional
   g13_lstm_rnn.npz        RNN_TYPE = LSTM / RNN (model.py:30,59-62): forward outputs and autograd gradients of every tensor,
                           1-layer unidirectional and 2-layer bidirectional
+  g14_corpus_eval.json    CorpusEvaluator.evaluate (evaluators.py:83-209): Recall@k / Hit@k over seeded query samples, stub towers
   g11_hybrid.npz          SimpleHybridRetriever.fit/search blend alpha*dense + (1-alpha)*tfidf (simple_hybrid.py:28-67)
   g10_errors.json         error behaviour (all-zero row, empty row, interior zeros)
 """
@@ -450,9 +451,55 @@ def g10():
         json.dump(res, f, indent=1)
 
 
+
+def g14():
+    """CorpusEvaluator (evaluators.py:83-209) with stub towers returning fixed embeddings: the metric bookkeeping, the
+    candidate pool and the seeded query sample.  Texts are 'q<i>' / 'd<j>'; the stub tokenizer maps a text to one id."""
+    import random
+    import evaluators as refeval  # reference backend/evaluators.py
+    nq, nd, dim = 40, 120, 32
+    Qe = synth.unit_rows(1401, nq, dim)
+    De = synth.unit_rows(1402, nd, dim)
+    rs = np.random.RandomState(1403)
+    triplets = []
+    for i in range(nq):
+        for pos in rs.choice(nd, size=1 + i % 3, replace=False):
+            triplets.append((i, int(pos), int(rs.randint(nd))))
+    for i, p_, _ in triplets[::2]:                      # half the positives are made to rank high
+        De[p_] = 0.55 * Qe[i] + 0.45 * De[p_]
+    De /= np.linalg.norm(De, axis=1, keepdims=True)
+    De = De.astype(np.float32)
+    val_data = [(f"q{i}", f"d{p_}", f"d{n_}") for i, p_, n_ in triplets]
+
+    class Tok:
+        def encode(self, text):
+            return [1 + int(text[1:]) + (1000 if text[0] == "d" else 0)]
+
+    class Stub:
+        def eval(self):
+            pass
+
+        def encode_query(self, x):
+            return torch.from_numpy(Qe[x[:, 0].numpy() - 1])
+
+        def encode_document(self, x):
+            return torch.from_numpy(De[x[:, 0].numpy() - 1001])
+
+    cases = []
+    for seed, max_q, top_k in ((1234, 25, [1, 5, 10]), (7, 50, [1, 3]), (99, 8, [2, 10])):
+        random.seed(seed)
+        ev = refeval.CorpusEvaluator(top_k=top_k, max_candidates=1000, max_queries=max_q)
+        import io, contextlib
+        with contextlib.redirect_stdout(io.StringIO()):
+            m = ev.evaluate(Stub(), val_data, Tok(), torch.device("cpu"))
+        cases.append({"seed": seed, "max_queries": max_q, "top_k": top_k, "metrics": {k: float(v) for k, v in m.items()}})
+    doc = {"q": Qe.tolist(), "d": De.tolist(), "triplets": triplets, "cases": cases}
+    with open(HERE / "g14_corpus_eval.json", "w") as f:
+        json.dump(doc, f)
+
 if __name__ == "__main__":
     only = set(sys.argv[1:])
-    for fn in (g1, g2, g3, g4, g5, g6, g7, g8, g9, g10, g11, g12, g13):
+    for fn in (g1, g2, g3, g4, g5, g6, g7, g8, g9, g10, g11, g12, g13, g14):
         if only and fn.__name__ not in only:
             continue
         fn()

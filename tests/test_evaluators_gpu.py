@@ -136,3 +136,77 @@ def test_embed_corpus_pipeline_equals_batch_of_64_loop():
     b = embed_corpus(m, tok, docs, torch.device("cuda"), batch_size=300, prefetch=2)
     torch.cuda.synchronize()
     assert a.shape == b.shape == (1000, H) and torch.equal(a, b)
+
+
+class _TextStub:
+    """Towers for the G14 fixture: a text 'q<i>' / 'd<j>' is ONE token id, the embedding is the recorded row."""
+
+    def __init__(self, q, d):
+        self.q = torch.tensor(q, dtype=torch.float32).cuda()
+        self.d = torch.tensor(d, dtype=torch.float32).cuda()
+
+    def eval(self):
+        pass
+
+    def encode_query(self, x):
+        return self.q[x[:, 0] - 1]
+
+    def encode_document(self, x):
+        return self.d[x[:, 0] - 1001]
+
+
+class _TextTok:
+    def encode(self, text):
+        return [1 + int(text[1:]) + (1000 if text[0] == "d" else 0)]
+
+
+def test_corpus_evaluator_matches_reference_with_the_same_seed():
+    """backend/evaluators.py:83-209 run by tests/golden/gen_golden.py (g14) with stub towers: same triplets, same
+    random.seed -> the same sampled queries -> the same Recall@k / Hit@k."""
+    import random
+    from pathlib import Path
+    from twotowermlretrieval_amd.evaluators import CorpusEvaluator
+    g = json.loads((Path(__file__).parent / "golden" / "g14_corpus_eval.json").read_text())
+    val_data = [(f"q{i}", f"d{p}", f"d{n}") for i, p, n in g["triplets"]]
+    stub, tok = _TextStub(g["q"], g["d"]), _TextTok()
+    for case in g["cases"]:
+        random.seed(case["seed"])
+        ev = CorpusEvaluator(top_k=case["top_k"], max_candidates=1000, max_queries=case["max_queries"])
+        got = ev.evaluate(stub, val_data, tok, torch.device("cuda"))
+        assert set(got) == set(case["metrics"])
+        for name, want in case["metrics"].items():
+            assert abs(got[name] - want) < 1e-12, (case["seed"], name, got[name], want)
+
+
+def test_corpus_evaluator_candidate_sampling_and_empty_cases():
+    import random
+    from twotowermlretrieval_amd.evaluators import CorpusEvaluator
+    rs = np.random.RandomState(3)
+    q = synth.unit_rows(31, 6, 32)
+    d = synth.unit_rows(32, 50, 32)
+    d[:6] = q                                            # document i is query i's exact positive
+    stub, tok = _TextStub(q.tolist(), d.tolist()), _TextTok()
+    val = [(f"q{i}", f"d{i}", f"d{int(rs.randint(6, 50))}") for i in range(6)]
+    random.seed(0)
+    m = CorpusEvaluator(top_k=[1, 5], max_candidates=1000, max_queries=50).evaluate(stub, val, tok, torch.device("cuda"))
+    assert m == {"Recall@1": 1.0, "Recall@5": 1.0, "Hit@1": 1.0, "Hit@5": 1.0}
+    # fewer candidates than documents: positives that were not drawn do not count against the query (evaluators.py:188-192)
+    random.seed(1)
+    m2 = CorpusEvaluator(top_k=[1], max_candidates=4, max_queries=50).evaluate(stub, val, tok, torch.device("cuda"))
+    assert set(m2) == {"Recall@1", "Hit@1"} and 0.0 <= m2["Recall@1"] <= 1.0
+    assert CorpusEvaluator().evaluate(stub, [], tok, torch.device("cuda")) == {f"{n}@{k}": 0.0 for n in ("Recall", "Hit") for k in (1, 5, 10)}
+
+
+def test_test_evaluator_prints_the_ranked_documents(capsys):
+    import random
+    from twotowermlretrieval_amd.evaluators import TestEvaluator
+    q = synth.unit_rows(41, 3, 32)
+    d = synth.unit_rows(42, 20, 32)
+    d[:3] = q
+    stub, tok = _TextStub(q.tolist(), d.tolist()), _TextTok()
+    val = [(f"q{i}", f"d{i}", f"d{10 + i}") for i in range(3)]
+    random.seed(5)
+    assert TestEvaluator(num_examples=2, top_k=3).evaluate(stub, val, tok, torch.device("cuda")) is None
+    out = capsys.readouterr().out
+    assert out.count("--- Example") == 2 and out.count("[+]") == 2 and "found 1/1 ground truth positives in Top 3" in out
+    assert "(Score: 1.0000)" in out

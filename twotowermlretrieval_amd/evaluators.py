@@ -1,7 +1,8 @@
 """Metric shells of the reference's evaluators (backend/evaluators.py) on top of the HIP kernels.
 
-Only the arithmetic-heavy parts are reproduced -- the reference's Python bookkeeping around them
-(printing, random sampling of candidate documents) is out of scope:
+The three classes main.py imports (backend/main.py:29: BatchEvaluator, CorpusEvaluator, TestEvaluator) keep their
+constructor arguments, their evaluate(...) signatures and their use of `random` (same draws in the same order, so a
+seeded run samples the same queries as the reference); the arithmetic inside is the HIP path:
 
   * BatchEvaluator (evaluators.py:18-79): validation loss + Recall@{1,5,10} + MRR with the positive of
     query i at index i.  The reference builds the full [Nq,Nq] score matrix (:50) and SORTS every row
@@ -11,9 +12,15 @@ Only the arithmetic-heavy parts are reproduced -- the reference's Python bookkee
     embedding matrix, via the fused `score_topk`.
   * embed_documents (evaluators.py:162-175, 240-250; main.py:125-138): batches of strings ->
     [N,H] document embeddings through tokenizer.encode_batch + model.encode_document.
+  * CorpusEvaluator (evaluators.py:83-209): unique queries / documents of the validation triplets, candidate and query
+    sampling as in the reference, document embeddings in batches of 64, then ONE fused score + top-k over all sampled
+    queries (the reference: one matmul + topk per query, :185-186) and the same Recall@k / Hit@k bookkeeping.
+  * TestEvaluator (evaluators.py:212-283): the qualitative print-out (top-k documents per sampled query with their
+    scores and whether they are ground-truth positives), :269-272's matmul + topk replaced the same way.
 """
 from __future__ import annotations
 
+import random
 from typing import Dict, Iterable, List, Sequence, Tuple
 
 import numpy as np
@@ -162,3 +169,103 @@ def save_inference_artifacts(output_dir, model, config: Dict, tokenizer, documen
         pickle.dump(docs, f)
     np.save(out / "document_embeddings.npy", emb)
     return emb
+
+
+def _encode_texts(model, tokenizer, texts: Sequence[str], device: torch.device, which: str, batch_size: int = 64) -> torch.Tensor:
+    """texts -> [n,H] embeddings in batches of `batch_size` rows padded to the batch maximum (evaluators.py:162-175)."""
+    enc = model.encode_document if which == "doc" else model.encode_query
+    out = []
+    with torch.no_grad():
+        for i in range(0, len(texts), batch_size):
+            rows = [tokenizer.encode(t) for t in texts[i:i + batch_size]]
+            width = max((len(r) for r in rows), default=0)
+            ids = torch.zeros((len(rows), width), dtype=torch.long)
+            for j, r in enumerate(rows):
+                ids[j, :len(r)] = torch.as_tensor(r, dtype=torch.long)
+            out.append(enc(ids.to(device)))
+    return torch.cat(out) if out else torch.empty((0, 0), device=device)
+
+
+class CorpusEvaluator:
+    """Full-corpus evaluation with several positives per query (backend/evaluators.py:83-209)."""
+
+    def __init__(self, top_k: List[int] = [1, 5, 10], max_candidates: int = 1000, max_queries: int = 50):
+        self.top_k = top_k
+        self.max_candidates = max_candidates
+        self.max_queries = max_queries
+
+    def evaluate(self, model, val_data: List[Tuple[str, str, str]], tokenizer, device: torch.device) -> Dict[str, float]:
+        model.eval()
+        query_to_positives: Dict[str, set] = {}
+        all_docs = set()
+        for query, pos_doc, neg_doc in val_data:
+            query_to_positives.setdefault(query, set()).add(pos_doc)
+            all_docs.add(pos_doc)
+            all_docs.add(neg_doc)
+        unique_queries = list(query_to_positives.keys())
+        unique_docs = list(all_docs)
+        if len(unique_docs) > self.max_candidates:  # (same draw as the reference: evaluators.py:124-126)
+            unique_docs = random.sample(unique_docs, self.max_candidates)
+            print(f"  Using {self.max_candidates} candidate documents for evaluation")
+        print(f"\nCorpus evaluation: {len(unique_queries)} unique queries against {len(unique_docs)} documents...")
+        doc_embeddings = _encode_texts(model, tokenizer, unique_docs, device, "doc")
+        sample_queries = random.sample(unique_queries, min(self.max_queries, len(unique_queries)))  # evaluators.py:138
+        metrics: Dict[str, List[float]] = {f"Recall@{k}": [] for k in self.top_k}
+        metrics.update({f"Hit@{k}": [] for k in self.top_k})
+        if sample_queries and len(unique_docs):
+            doc_pos = {doc: i for i, doc in enumerate(unique_docs)}
+            # one query at a time through the tower, like the reference (a padded batch would feed the same rows: padding
+            # never reaches the recurrence), then one fused score + top-k for all of them
+            q_embs = torch.cat([_encode_texts(model, tokenizer, [q], device, "query") for q in sample_queries])
+            kmax = min(max(self.top_k), len(unique_docs))
+            _, top = score_topk(q_embs, doc_embeddings, kmax)
+            top = top.tolist()
+            for qi, query in enumerate(sample_queries):
+                known = query_to_positives[query]
+                available = [doc for doc in known if doc in doc_pos]
+                if not available:
+                    continue  # no positive among the candidates: the reference skips the query (:191-192)
+                pos_idx = {doc_pos[doc] for doc in available}
+                for k in self.top_k:
+                    found = len([i for i in top[qi][:k] if i in pos_idx])
+                    metrics[f"Recall@{k}"].append(found / len(available))
+                    metrics[f"Hit@{k}"].append(1 if found else 0)
+        return {name: (float(np.mean(vals)) if vals else 0.0) for name, vals in metrics.items()}
+
+
+class TestEvaluator:
+    """Qualitative print-out on the test triplets (backend/evaluators.py:212-283); returns nothing, like the reference."""
+
+    __test__ = False  # (not a pytest class)
+
+    def __init__(self, num_examples: int = 10, top_k: int = 5):
+        self.num_examples = num_examples
+        self.top_k = top_k
+
+    def evaluate(self, model, test_data: List[Tuple[str, str, str]], tokenizer, device: torch.device) -> None:
+        model.eval()
+        all_queries = {t[0] for t in test_data}
+        all_docs = {t[1] for t in test_data}.union({t[2] for t in test_data})
+        ground_truth: Dict[str, set] = {}
+        for query, pos_doc, _ in test_data:
+            ground_truth.setdefault(query, set()).add(pos_doc)
+        unique_queries, unique_docs = list(all_queries), list(all_docs)
+        print(f"\nTest evaluation: {len(unique_queries)} queries, {len(unique_docs)} documents...")
+        doc_embs = _encode_texts(model, tokenizer, unique_docs, device, "doc")
+        sample_queries = random.sample(unique_queries, min(self.num_examples, len(unique_queries)))
+        print("\n" + "=" * 80 + f"\nQUALITATIVE EXAMPLES (Top {self.top_k})\n" + "=" * 80)
+        if not sample_queries or not len(unique_docs):
+            return
+        q_embs = torch.cat([_encode_texts(model, tokenizer, [q], device, "query") for q in sample_queries])
+        vals, idx = score_topk(q_embs, doc_embs, min(self.top_k, len(unique_docs)))
+        vals, idx = vals.tolist(), idx.tolist()
+        for i, query in enumerate(sample_queries):
+            print(f"\n--- Example {i + 1}/{len(sample_queries)} ---\nQuery: {query}\n\nTop {self.top_k} retrieved documents:")
+            truth = ground_truth.get(query, set())
+            hits = 0
+            for rank, (score, di) in enumerate(zip(vals[i], idx[i])):
+                doc = unique_docs[di]
+                good = doc in truth
+                hits += int(good)
+                print(f"  {rank + 1}. {'[+]' if good else '[-]'} {doc[:100]}... (Score: {score:.4f})")
+            print(f"\nSummary: found {hits}/{len(truth)} ground truth positives in Top {self.top_k}.")
