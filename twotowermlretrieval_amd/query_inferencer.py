@@ -23,12 +23,17 @@ from .model import TwoTowerModel
 from .tokenizer import PretrainedTokenizer
 
 
+def load_config(path: str):
+    """Loads a JSON config file (query_inferencer.py:8-11, main.py:76-79)."""
+    with open(path, "r") as f:
+        return json.load(f)
+
+
 class QueryInferencer:
     def __init__(self, artifacts_path: str, device: Optional[torch.device] = None):
         self.artifacts_path = Path(artifacts_path)
         self.device = device or self._get_best_device()
-        with open(self.artifacts_path / "config.json", "r") as f:
-            self.config = json.load(f)
+        self.config = load_config(str(self.artifacts_path / "config.json"))
         self.tokenizer = PretrainedTokenizer(str(self.artifacts_path / "word_to_idx.pkl"))
         self.config["VOCAB_SIZE"] = self.tokenizer.vocab_size()
         if "EMBED_DIM" not in self.config:
