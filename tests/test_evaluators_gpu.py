@@ -73,6 +73,17 @@ def test_artifact_export_round_trip(tmp_path, oracle):
     qe = torch.from_numpy(inf.get_query_embedding(docs[3])).cuda()
     res = corpus_recall_hit(qe, D, positives=[3], top_k=(1, 5))
     assert set(res) == {"Recall@1", "Hit@1", "Recall@5", "Hit@5"} and 0.0 <= res["Recall@5"] <= 1.0
+    # the TF-IDF half of main.py:140-149: sklearn's vectorizer fitted on the same documents, matrix row i <-> documents[i]
+    tf = pickle.load(open(tmp_path / "tfidf_artifacts.pkl", "rb"))
+    assert set(tf) == {"vectorizer", "matrix"} and tf["matrix"].shape[0] == len(docs)
+    assert tf["vectorizer"].transform([docs[3]]).dot(tf["matrix"][3].T).toarray()[0, 0] > 0.99
+    # the reference's calling convention: fifth argument = datasets (split -> triplets), device taken from the model
+    datasets = {"train": [("q a", docs[0], docs[1]), ("q b", docs[2], docs[1])], "validation": [("q c", docs[5], docs[0])]}
+    emb2 = save_inference_artifacts(tmp_path / "run2", m, {"BATCH_SIZE": 16}, tok, datasets)
+    saved_docs = pickle.load(open(tmp_path / "run2" / "documents.pkl", "rb"))
+    assert sorted(saved_docs) == sorted({docs[0], docs[1], docs[2], docs[5]}) and emb2.shape == (4, H)
+    for i, d_ in enumerate(saved_docs):
+        np.testing.assert_allclose(emb2[i], loaded[docs.index(d_)], atol=1e-6)
 
 
 def test_hybrid_rerank_blend_and_keyword_mode(tmp_path):

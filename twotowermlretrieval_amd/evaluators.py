@@ -142,10 +142,14 @@ def corpus_recall_hit(query_emb: torch.Tensor, doc_embeddings: torch.Tensor, pos
     return res
 
 
-def save_inference_artifacts(output_dir, model, config: Dict, tokenizer, documents: Sequence[str], device) -> np.ndarray:
-    """The dense half of backend/main.py:92-138: model.pth, config.json (+VOCAB_SIZE, EMBED_DIM),
-    word_to_idx.pkl, documents.pkl and document_embeddings.npy ([N,H] fp32, C order, row i <-> documents[i]).
-    (The TF-IDF artifact of main.py:140-149 is CPU/sklearn work and out of scope.)"""
+def save_inference_artifacts(output_dir, model, config: Dict, tokenizer, documents, device=None, tfidf: bool = True) -> np.ndarray:
+    """backend/main.py:92-149: model.pth, config.json (+VOCAB_SIZE, EMBED_DIM), word_to_idx.pkl, documents.pkl,
+    document_embeddings.npy ([N,H] fp32, C order, row i <-> documents[i]) and tfidf_artifacts.pkl ({'vectorizer', 'matrix'}:
+    sklearn on the CPU, exactly the reference's call; skipped with tfidf=False or without sklearn).
+
+    `documents`: the reference's fifth argument -- `datasets`, a dict split -> [(query, pos_doc, neg_doc)] whose unique
+    documents are collected as main.py:115-121 does -- or a plain sequence of document strings.  `device`: where the towers
+    run; default: the device of the model's parameters (the reference reads the caller-set `model.device`)."""
     import json
     import pickle
     from pathlib import Path
@@ -158,7 +162,17 @@ def save_inference_artifacts(output_dir, model, config: Dict, tokenizer, documen
     (out / "config.json").write_text(json.dumps(cfg, indent=4))
     with open(out / "word_to_idx.pkl", "wb") as f:
         pickle.dump({w: i for w, i in tokenizer.word2idx.items()}, f)
-    docs = list(documents)
+    if isinstance(documents, dict):
+        all_docs = set()
+        for split_data in documents.values():
+            for _, pos_doc, neg_doc in split_data:
+                all_docs.add(pos_doc)
+                all_docs.add(neg_doc)
+        docs = list(all_docs)
+    else:
+        docs = list(documents)
+    if device is None:
+        device = getattr(model, "device", None) or next(model.parameters()).device
     model.eval()
     # same rows either way (rows are independent); the pipelined build is the fast path for a real corpus
     if len(docs) > 4096 and torch.device(device).type == "cuda":
@@ -168,6 +182,20 @@ def save_inference_artifacts(output_dir, model, config: Dict, tokenizer, documen
     with open(out / "documents.pkl", "wb") as f:
         pickle.dump(docs, f)
     np.save(out / "document_embeddings.npy", emb)
+    if tfidf and docs:
+        try:
+            from sklearn.feature_extraction.text import TfidfVectorizer
+        except ImportError:
+            TfidfVectorizer = None
+        if TfidfVectorizer is not None:
+            vec = TfidfVectorizer(stop_words="english", max_features=20000)  # main.py:141-142
+            try:
+                mat = vec.fit_transform(docs)
+            except ValueError:  # (only stop words / empty vocabulary: nothing to save)
+                mat = None
+            if mat is not None:
+                with open(out / "tfidf_artifacts.pkl", "wb") as f:
+                    pickle.dump({"vectorizer": vec, "matrix": mat}, f)
     return emb
 
 
