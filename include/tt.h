@@ -89,7 +89,7 @@ int tt_score_topk_partials_f32(const float *Q, int B, int d, const float *D, int
  * Screened exact search, the fast path at every batch size: SAME result as tt_score_topk_f32 (bit-exact
  * scores, same tie order), computed as an fp16-MFMA screen over an fp16 shadow copy of the corpus
  * with a rigorous error bound, followed by exact fp32 rescoring of the survivors
- * (csrc/screen.hip header; DESIGN.md "K4s", "K4t").  B <= 32 takes the streaming form (bound by HBM streaming
+ * (csrc/screen.hip header; DESIGN.md "K4s", "K4t").  B <= 64 takes the streaming form (bound by HBM streaming
  * of the shadow copy, N x 512 B), larger batches the shared-tile form (bound by the fp16 MFMA rate).  tt_index_build_f16 makes the shadow copy D16 [N,d]
  * (2 bytes/element) and stats[2] = {largest row L2 norm, largest |element|} (device floats; the
  * caller reads stats[0] once at index-build time and passes it as dmax_norm).  If the screen cannot

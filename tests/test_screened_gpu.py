@@ -42,9 +42,10 @@ def test_bit_exact_vs_oracle(tt, oracle, B, N, k):
 
 
 @pytest.mark.parametrize("B,N,k", [(1, 5000, 10), (7, 33333, 10), (16, 20000, 16), (17, 1000, 1), (32, 4097, 5),
-                                   (33, 9000, 50), (64, 700000, 64), (1, 300000, 10), (32, 31, 8)])
+                                   (33, 9000, 50), (64, 700000, 64), (1, 300000, 10), (32, 31, 8), (48, 120000, 10),
+                                   (64, 250000, 50), (40, 31, 8), (49, 65600, 3)])
 def test_small_batch_streaming_form_bit_exact_vs_oracle(tt, oracle, B, N, k):
-    """B <= 64 runs screen_stream_kernel (one wave per 32-query tile and document chunk)."""
+    """B <= 64 runs screen_stream_kernel (one wave per query tile -- 32 queries up to B = 32, 64 above -- and document chunk)."""
     Q = synth.unit_rows(300 + B, B, 256)
     D = synth.unit_rows(400 + N, N, 256)
     k = min(k, N)
@@ -183,7 +184,7 @@ def test_full_baseline_size_10m_screened_equals_exact_kernel(tt, oracle):
     torch.cuda.empty_cache()
 
 
-@pytest.mark.parametrize("B", [4, 80])
+@pytest.mark.parametrize("B", [4, 50, 80])
 def test_query_beyond_fp16_range_goes_to_the_exact_kernel(tt, oracle, B):
     """A query with an element fp16 cannot hold (|x| > 6e4) raises flag bit 2 for its 32-query tile in
     q_image_kernel; the exact kernel recomputes that tile on the device; the other tiles stay screened."""

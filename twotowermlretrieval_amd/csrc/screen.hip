@@ -578,15 +578,18 @@ constexpr int TDMA = 4;                  // DMA instructions per slab
 // chunk from L2 (44.2 -> 52.9 ms at B = 1024 with nt), nor for the shared-tile screen (two workgroups per chunk).
 constexpr int TSTREAM_AUX = 2;
 
-template <bool MAXONLY>
+// NQS = 16-query sets per wave: 2 (B <= 32), or 4 (33 <= B <= 64: ONE pass of the stream for 64 queries instead of the
+// shared-tile form's 1.03 ms; twice the MFMAs per tile, still a fifth of what the stream allows)
+template <bool MAXONLY, int NQS = 2>
 __global__ __launch_bounds__(TW * 64, 2) void screen_stream_kernel(ScreenParams p)
 {
+    constexpr int QPT = 16 * NQS; // queries per task
     extern __shared__ __attribute__((aligned(16))) char ring_all[]; // [TW][TSTAGE][TSLAB_BYTES]
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     char *const ring = ring_all + w * (TSTAGE * TSLAB_BYTES);
     const int task = blockIdx.x * TW + w;                 // = qtile * n_chunks + chunk
-    const int n_qtiles = (p.B + 31) / 32;
+    const int n_qtiles = (p.B + QPT - 1) / QPT;
     if (task >= n_qtiles * p.n_chunks)
         return; // wave-uniform; this kernel has no workgroup barrier
     const int qtile = task / p.n_chunks, chunk = task % p.n_chunks;
@@ -594,15 +597,16 @@ __global__ __launch_bounds__(TW * 64, 2) void screen_stream_kernel(ScreenParams 
     const int t1 = min(t0 + p.tiles_per_chunk, p.n_tiles);
     const int k = p.k;
     const int g = lane >> 4, n = lane & 15;
-    const int qbase = qtile * 32;
+    const int qbase = qtile * QPT;
 
     // ---- query operands: set c holds queries qbase + 16c + n; lane (n,g) keeps features 32s + 8g .. +7 ----
-    h8 qreg[2][8];
-    float eps2[2];
-    f32x4 negthr[2];
-    int cnt[2] = {0, 0};
+    h8 qreg[NQS][8];
+    float eps2[NQS];
+    f32x4 negthr[NQS];
+    int cnt[NQS];
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
+    for (int c = 0; c < NQS; ++c) {
+        cnt[c] = 0;
         const int qrow = qbase + 16 * c + n;
         const bool live = qrow < p.B;
         const h8 *src = p.qimg + ((size_t)(qbase / 16 + c) * 8) * 64 + lane;
@@ -621,7 +625,7 @@ __global__ __launch_bounds__(TW * 64, 2) void screen_stream_kernel(ScreenParams 
         negthr[c] = f32x4{c_init, c_init, c_init, c_init};
     }
 
-    SCand *const cwave = p.cand + (size_t)task * 32 * SCAP;
+    SCand *const cwave = p.cand + (size_t)task * QPT * SCAP;
 
     auto compact_where = [&](int c, unsigned qmask) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -636,7 +640,7 @@ __global__ __launch_bounds__(TW * 64, 2) void screen_stream_kernel(ScreenParams 
             bool have, ovf;
             screen_compact(cwave + (size_t)(16 * c + q) * SCAP, nq, k, slack, lane, n_new, tn, have, ovf);
             if (ovf && lane == 0)
-                atomicOr(p.flag + qtile, 1);
+                atomicOr(p.flag + ((qbase + 16 * c) >> 5), 1);
             if (n == q) {
                 cnt[c] = (n_new - g + 3) >> 2;
                 if (have)
@@ -680,7 +684,7 @@ __global__ __launch_bounds__(TW * 64, 2) void screen_stream_kernel(ScreenParams 
         const char *rd_row = ring + n * 128;
         const int rsw = n & 7;
         for (int tile = t0; tile < t1; ++tile) {
-            f32x4 acc[2][2]; // acc[u][c][r] = s16(doc tile*32 + 16u + 4g + r, query qbase + 16c + n) - thr
+            f32x4 acc[2][NQS]; // acc[u][c][r] = s16(doc tile*32 + 16u + 4g + r, query qbase + 16c + n) - thr
 #pragma unroll
             for (int kq = 0; kq < 4; ++kq) {
                 // slab (tile,kq) has landed once at most TSTAGE-2 younger slabs are pending (candidate stores
@@ -699,7 +703,7 @@ __global__ __launch_bounds__(TW * 64, 2) void screen_stream_kernel(ScreenParams 
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-                    for (int c = 0; c < 2; ++c)
+                    for (int c = 0; c < NQS; ++c)
 #pragma unroll
                         for (int u = 0; u < 2; ++u) {
                             const f32x4 cin = (kq == 0 && s2 == 0) ? negthr[c] : acc[u][c];
@@ -716,21 +720,22 @@ __global__ __launch_bounds__(TW * 64, 2) void screen_stream_kernel(ScreenParams 
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
                             if (tile_base + 16 * u + 4 * g + r >= p.N) {
-                                acc[u][0][r] = -INFINITY;
-                                acc[u][1][r] = -INFINITY;
+#pragma unroll
+                                for (int c = 0; c < NQS; ++c)
+                                    acc[u][c][r] = -INFINITY;
                             }
                 }
                 int mall = INT_MIN;
 #pragma unroll
                 for (int u = 0; u < 2; ++u)
 #pragma unroll
-                    for (int c = 0; c < 2; ++c)
+                    for (int c = 0; c < NQS; ++c)
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
                             mall = max(mall, __float_as_int(acc[u][c][r]));
                 if (__ballot(mall >= 0) != 0ull) {
 #pragma unroll
-                    for (int c = 0; c < 2; ++c) {
+                    for (int c = 0; c < NQS; ++c) {
                         const unsigned mine = (unsigned)(((16 * c + n) * SCAP + SQUART * g) * sizeof(SCand));
                         const float thr_c = -negthr[c][0];
 #pragma unroll
@@ -752,7 +757,7 @@ __global__ __launch_bounds__(TW * 64, 2) void screen_stream_kernel(ScreenParams 
                 }
             } else {
 #pragma unroll
-                for (int c = 0; c < 2; ++c) {
+                for (int c = 0; c < NQS; ++c) {
                     float m = -INFINITY;
 #pragma unroll
                     for (int u = 0; u < 2; ++u)
@@ -773,7 +778,7 @@ __global__ __launch_bounds__(TW * 64, 2) void screen_stream_kernel(ScreenParams 
     if (MAXONLY)
         return;
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
+    for (int c = 0; c < NQS; ++c) {
         int tot = cnt[c] + __shfl_xor(cnt[c], 16);
         tot += __shfl_xor(tot, 32);
         const unsigned long long over = __ballot(tot > k) & 0xffffull;
@@ -1135,7 +1140,8 @@ struct SPlan {
 };
 
 constexpr int64_t SAMPLE_MIN_N = 65536;
-constexpr int STREAM_MAX_B = 32; // measured: at B = 64 the shared-tile kernel (1.48 ms) beats two streaming passes (1.59 ms)
+constexpr int STREAM_MAX_B = 64; // one streaming pass: 32 queries per wave (2 sets) up to B = 32, 64 (4 sets) up to B = 64;
+                                 // beyond that the shared-tile kernel wins (B = 65 .. 128: 1.20 ms against two passes)
 
 int screen_cus()
 {
@@ -1153,7 +1159,7 @@ SPlan make_splan(int B, int64_t N, int k)
     SPlan pl;
     pl.stream = B <= STREAM_MAX_B;
     pl.nset = B <= SW * 16 ? 1 : (B <= SW * 32 ? 2 : 4);
-    pl.q_per_block = pl.stream ? 32 : SW * 16 * pl.nset;
+    pl.q_per_block = pl.stream ? (B <= 32 ? 32 : 64) : SW * 16 * pl.nset;
     pl.n_qgroups = (B + pl.q_per_block - 1) / pl.q_per_block;
     pl.n_tiles = (int)((N + 31) / 32);
     int want, max_chunks;
@@ -1338,7 +1344,12 @@ TT_EXPORT int tt_score_topk_screened_f32(const float *Q, int B, int d, const flo
                        pl.n_qgroups);
     TT_LAUNCH_CHECK();
     auto launch = [&](const ScreenParams &a, int blocks, bool maxonly) -> int {
-        if (pl.stream) {
+        if (pl.stream && pl.q_per_block == 64) {
+            if (maxonly)
+                hipLaunchKernelGGL((screen_stream_kernel<true, 4>), dim3(blocks), dim3(TW * 64), pl.lds, st, a);
+            else
+                hipLaunchKernelGGL((screen_stream_kernel<false, 4>), dim3(blocks), dim3(TW * 64), pl.lds, st, a);
+        } else if (pl.stream) {
             if (maxonly)
                 hipLaunchKernelGGL(screen_stream_kernel<true>, dim3(blocks), dim3(TW * 64), pl.lds, st, a);
             else
@@ -1362,7 +1373,10 @@ TT_EXPORT int tt_score_topk_screened_f32(const float *Q, int B, int d, const flo
         TT_LAUNCH_CHECK();
         return TT_OK;
     };
-    if (pl.stream) {
+    if (pl.stream && pl.q_per_block == 64) {
+        TT_HIP_CHECK(hipFuncSetAttribute((const void *)screen_stream_kernel<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds));
+        TT_HIP_CHECK(hipFuncSetAttribute((const void *)screen_stream_kernel<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds));
+    } else if (pl.stream) {
         TT_HIP_CHECK(hipFuncSetAttribute((const void *)screen_stream_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds));
         TT_HIP_CHECK(hipFuncSetAttribute((const void *)screen_stream_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds));
     } else {
