@@ -24,11 +24,11 @@
 //
 // Three kernels share that scheme and the finish kernel:
 //   q_image_kernel        once per search: queries -> f16 MFMA B-operand image, norms, initial flags
-//   screen_kernel<.,NSET> B > 32: one workgroup (8 waves, one per CU) = 128 NSET queries x a contiguous chunk of
+//   screen_kernel<.,NSET> B > 64: one workgroup (8 waves, one per CU) = 128 NSET queries x a contiguous chunk of
 //                         documents; each wave keeps 16 NSET queries in registers; document tiles (32 docs x 256
 //                         features f16 = 16 KiB) are DMA'd once per workgroup into an 8-deep LDS ring
 //                         (global_load_lds, XOR-swizzled source) and read by all 8 waves
-//   screen_stream_kernel  B <= 32: every wave an independent streaming engine with a private 4-slab ring; bound by
+//   screen_stream_kernel  B <= 64: every wave an independent streaming engine (32 or 64 queries) with a private 4-slab ring; bound by
 //                         HBM streaming of the fp16 copy (N * 512 B)
 // The accumulators start at minus the query's threshold, so "any candidate in this wave-tile?" is one integer max.
 #include "tt_common.h"
