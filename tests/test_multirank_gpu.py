@@ -61,6 +61,20 @@ def _worker(rank, world, port, tmp):
         v2, i2 = ix.search(Q.to(dev), k=10)     # and the synchronous form still works after pipelined steps
         torch.cuda.synchronize()
         assert torch.equal(v2, v) and torch.equal(i2, i)
+    # ---- index build across ranks: every rank embeds only its shard of the document list, then the usual sharded search
+    words = ["the", ",", ".", "of", "and"] + [f"w{i}" for i in range(5, 80)]
+    tok = tt.PretrainedTokenizer(word2idx={w: i for i, w in enumerate(words)})
+    rs = np.random.RandomState(77)
+    docs = [" ".join(words[rs.randint(5, 80)] for _ in range(rs.randint(3, 12))) for _ in range(301)]
+    torch.manual_seed(1)
+    tm = tt.TwoTowerModel({"VOCAB_SIZE": tok.vocab_size(), "EMBED_DIM": 20, "HIDDEN_DIM": 32}, synth.make_table(9, tok.vocab_size(), 20)).to(dev)
+    sx = tt.ShardedIndex.from_documents(tm, tok, docs, dev, shard_k=10)
+    assert sx._index.ntotal in (150, 151)
+    with torch.no_grad():
+        qv = tm.encode_query(tok.encode_batch([docs[5], docs[222]]).to(dev))
+    dv, di = sx.search(qv, k=3)
+    torch.cuda.synchronize()
+    res["doc_i"], res["doc_v"] = di.cpu().numpy(), dv.cpu().numpy()
     # ---- data-parallel step: equal batch shards, one all-reduce, same update on both ranks
     V, E, H = 60, 20, 32
     table = synth.make_table(3, V, E)
@@ -96,9 +110,23 @@ def test_two_ranks_on_one_gpu_sharded_search_and_dp_step(oracle, tmp_path):
             sv, si = oracle.score_topk(Qs, D, 10)
             for r in (r0, r1):
                 assert np.array_equal(r[f"pi{B}_{step}"], si) and np.array_equal(r[f"pv{B}_{step}"], sv), (B, step)
+    # the document-sharded build: both ranks return the same global rows, and they are what one process computes
+    assert np.array_equal(r0["doc_i"], r1["doc_i"]) and np.array_equal(r0["doc_v"], r1["doc_v"])
+    import twotowermlretrieval_amd as tt
+    from twotowermlretrieval_amd.evaluators import embed_corpus
+    words = ["the", ",", ".", "of", "and"] + [f"w{i}" for i in range(5, 80)]
+    tok = tt.PretrainedTokenizer(word2idx={w: i for i, w in enumerate(words)})
+    rs = np.random.RandomState(77)
+    docs = [" ".join(words[rs.randint(5, 80)] for _ in range(rs.randint(3, 12))) for _ in range(301)]
+    torch.manual_seed(1)
+    tm = tt.TwoTowerModel({"VOCAB_SIZE": tok.vocab_size(), "EMBED_DIM": 20, "HIDDEN_DIM": 32}, synth.make_table(9, tok.vocab_size(), 20)).cuda().eval()
+    with torch.no_grad():
+        full = embed_corpus(tm, tok, docs, torch.device("cuda"))
+        qv = tm.encode_query(tok.encode_batch([docs[5], docs[222]]).cuda())
+    fv, fi = tt.score_topk(qv, full, 3)
+    assert np.array_equal(r0["doc_i"], fi.cpu().numpy()) and np.array_equal(r0["doc_v"], fv.cpu().numpy())
     assert np.array_equal(r0["params"], r1["params"])       # same averaged gradient, same clip, same Adam step
     # single process on the full batch of 8 = the mean of the two rank means
-    import twotowermlretrieval_amd as tt
     V, E, H = 60, 20, 32
     torch.manual_seed(0)
     m = tt.TwoTowerModel({"VOCAB_SIZE": V, "EMBED_DIM": E, "HIDDEN_DIM": H}, synth.make_table(3, V, E)).cuda()

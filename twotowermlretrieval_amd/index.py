@@ -346,6 +346,21 @@ class ShardedIndex:
         lo, hi = shard_bounds(docs.shape[0], rank, world)
         return cls(docs[lo:hi], lo, group=group, **kw)
 
+    @classmethod
+    def from_documents(cls, model, tokenizer, documents, device, group=None, **kw) -> "ShardedIndex":
+        """Index build across ranks (third row: embarrassingly parallel over documents, no collective): every rank
+        holds the same document list (documents.pkl order, backend/main.py:134-136), embeds ONLY its contiguous shard
+        [lo, hi) with the document tower and keeps those rows; row i of the global index is documents[i] on every rank."""
+        import torch.distributed as dist
+        from .evaluators import embed_corpus
+        world = dist.get_world_size(group) if dist.is_initialized() else 1
+        rank = dist.get_rank(group) if dist.is_initialized() else 0
+        lo, hi = shard_bounds(len(documents), rank, world)
+        model.eval()
+        with torch.no_grad():
+            local = embed_corpus(model, tokenizer, documents[lo:hi], device)
+        return cls(local, lo, group=group, **kw)
+
     def _slot(self, B: int, kp: int, k: int, which: int) -> _Slot:
         key = (B, kp, k, self._coll.world)
         if key not in self._slots:
