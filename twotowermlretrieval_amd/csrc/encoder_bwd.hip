@@ -449,9 +449,29 @@ TT_EXPORT int tt_encoder_backward_f32(const int64_t *ids, int B, int T, const fl
             g.ldc = 2 * H;
             g.slab_stride = 0;
             g.accumulate = 0;
-            rc = tt_sgemm(g, true, true, 1, st);
-            if (rc != TT_OK)
-                return rc;
+            // The product sums over the B batch rows: with one k-range a 256 x 256 output is 4 workgroups walking B / 32
+            // tiles each (160 us at B = 1024).  Split it over 16 k-ranges into contiguous slabs, reduce in fixed order,
+            // then place the H x H block into its half of g_proj_w (row pitch 2H).
+            const int psplit = B >= 256 ? 16 : 1;
+            if (psplit > 1) {
+                float *ptmp = slabs + (size_t)psplit * H * H; // behind the slabs, inside the split-K scratch
+                g.C = slabs;
+                g.ldc = H;
+                g.slab_stride = (int64_t)H * H;
+                rc = tt_sgemm(g, true, true, psplit, st);
+                if (rc != TT_OK)
+                    return rc;
+                rc = tt_slab_reduce(slabs, psplit, (int64_t)H * H, ptmp, 0, st);
+                if (rc != TT_OK)
+                    return rc;
+                TT_HIP_CHECK(hipMemcpy2DAsync(g_proj_w + (size_t)d * H, sizeof(float) * 2 * H, ptmp, sizeof(float) * H,
+                                              sizeof(float) * H, H, hipMemcpyDeviceToDevice, st));
+                g.slab_stride = 0;
+            } else {
+                rc = tt_sgemm(g, true, true, 1, st);
+                if (rc != TT_OK)
+                    return rc;
+            }
             // d_hfin[d] = d_hid * proj_w[:, dH:(d+1)H]
             g.A = d_hid;
             g.B = proj_w + (size_t)d * H;
