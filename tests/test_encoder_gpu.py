@@ -76,6 +76,7 @@ def test_g3_normalize_off(golden):
     (41, 30, 200, 256, 2, True),    # config.json's own shape: token-stationary K1 with 13 k-steps, layer 2 on the tiled GEMM
     (67, 21, 300, 128, 1, False),   # 6 column chunks over 4 waves: two waves run a second pass
     (9, 70, 256, 256, 1, False),    # 16 k-steps: no refill-only ring turns
+    (2100, 5, 20, 32, 1, True),     # B >= 2048, bidirectional: the projection head as two accumulating GEMMs
 ])
 def test_random_batches_vs_oracle(oracle, B, T, E, H, layers, bi):
     V, seed = 500, 31 + B

@@ -644,8 +644,37 @@ static int encoder_forward(const char *who, const int64_t *ids, int B, int T, co
             TT_LAUNCH_CHECK();
         }
     }
-    hipLaunchKernelGGL(head_kernel, dim3(B), dim3(256), 0, st, (const float *)(ws + lo.hfin), B, H, ndir, proj_w,
-                       proj_b, normalize, train ? (float *)(ws + lo.hid) : (float *)nullptr, out);
+    if (ndir == 2 && B >= 2048) { // (below that the two launches cost what the per-row loop does: ~50 us at B = 512 .. 1024)
+        // Linear(2H, H) on cat(h_fwd, h_bwd) (model.py:65-69) as two accumulating GEMMs over the two halves of the weight
+        // (the head kernel's per-row scalar loop read all of proj_w once per batch row: 0.6 ms at B = 8192), then the head
+        // kernel only normalises
+        float *hid = (float *)(ws + lo.hid);
+        for (int d = 0; d < 2; ++d) {
+            SgemmParams g;
+            g.A = (const float *)(ws + lo.hfin) + (size_t)d * B * H;
+            g.B = proj_w + (size_t)d * H;
+            g.C = hid;
+            g.bias = d == 0 ? proj_b : nullptr;
+            g.a_map = g.b_map = nullptr;
+            g.m_dyn = g.k_dyn = nullptr;
+            g.M = B;
+            g.N = H;
+            g.K = H;
+            g.lda = H;
+            g.ldb = 2 * H;
+            g.ldc = H;
+            g.slab_stride = 0;
+            g.accumulate = d;
+            rc = tt_sgemm(g, false, false, 1, st);
+            if (rc != TT_OK)
+                return rc;
+        }
+        hipLaunchKernelGGL(head_kernel, dim3(B), dim3(256), 0, st, (const float *)hid, B, H, 1, proj_w, proj_b, normalize,
+                           (float *)nullptr, out);
+    } else {
+        hipLaunchKernelGGL(head_kernel, dim3(B), dim3(256), 0, st, (const float *)(ws + lo.hfin), B, H, ndir, proj_w,
+                           proj_b, normalize, train ? (float *)(ws + lo.hid) : (float *)nullptr, out);
+    }
     TT_LAUNCH_CHECK();
     return TT_OK;
 }
