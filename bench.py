@@ -119,17 +119,19 @@ def kernel_only_ms(q, docs, k, iters=5, warm=2):
     return main / iters, e0.elapsed_time(e1) / iters
 
 
-def screen_kernel_ms(index, q, k, iters=20, warm=5):
+def screen_kernel_ms(index, q, k, iters=20, warm=5, k_seed=0):
     """Average duration of screen_kernel<false> alone: HIP events recorded on the launch stream right
-    before and after that launch inside tt_score_topk_screened_f32 (prof_events)."""
+    before and after that launch inside tt_score_topk_screened_f32 (prof_events).  k_seed: the sharded step's form of the
+    search (list length k, thresholds seeded for the final k_seed: ShardedIndex._local_search)."""
     from twotowermlretrieval_amd import _lib
     L = _lib.lib()
     pairs = [_event_pair(L) for _ in range(iters)]
+    kw = dict(_seed_exchange=(lambda seed: None), _k_seed=k_seed) if 0 < k_seed < k else {}
     for _ in range(warm):
-        index.search(q, k)
+        index.search(q, k, **kw)
     torch.cuda.synchronize()
     for evs in pairs:  # back to back, no host synchronisation in between
-        index.search(q, k, _prof_events=evs)
+        index.search(q, k, _prof_events=evs, **kw)
     torch.cuda.synchronize()
     return sum(_pair_ms(L, evs) for evs in pairs) / iters
 
@@ -388,7 +390,7 @@ def main():
         n_shard = hi - lo
         kp = TOPK if world == 1 else SHARD_K
         flops = 2.0 * BATCH * n_shard * DIM
-        ms_s = screen_kernel_ms(local_index, q, kp)
+        ms_s = screen_kernel_ms(local_index, q, kp, k_seed=TOPK if world > 1 else 0)
         roof = {"bound": "mfma", "kernel": "screen_kernel<false> (f16 MFMA 16x16x32, fp32 accumulate)",
                 "achieved": round(flops / ms_s / 1e9, 2), "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(flops / ms_s / 1e9 / MFMA_F16_PEAK_TFLOPS, 4), "traffic": pmc_traffic("screen_b1024") if world == 1 else None,
@@ -431,7 +433,8 @@ def main():
                                    f"passages resident in HBM (BASELINE configs[3]; configs[1] batch), row-sharded "
                                    f"over {world} GPU(s), screened path (f16-MFMA filter + exact fp32 rescoring, "
                                    f"bit-identical to the fp32 kernel)"
-                                   + (f", per-shard top-{SHARD_K} + RCCL all-gather + merge" if world > 1 else ""),
+                                   + (f", per-shard lists of up to {SHARD_K} (every document above the shard's own "
+                                      f"top-{TOPK} threshold) + RCCL all-gather + merge" if world > 1 else ""),
                        "n_docs": N_DOCS, "dim": DIM, "batch": BATCH, "k": TOPK, "parallelism": f"rowshard{world}",
                        "collective": index.collective if world > 1 else None},
             "roofline": roof, "roofline_exact_f32": roof_f32, "roofline_hbm": roof_hbm,

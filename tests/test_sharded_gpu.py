@@ -120,3 +120,42 @@ def test_merge_reads_the_all_gather_buffer_in_place(oracle, B, kp, k, world):
     torch.cuda.synchronize()
     rv, ri = oracle.score_topk(Q, D, k)
     assert np.array_equal(oi.cpu().numpy(), ri) and np.array_equal(ov.cpu().numpy(), rv)
+
+
+def test_shard_lists_seeded_for_the_final_k_give_the_same_top_k():
+    """ShardedIndex seeds the screen with the k-th (not the shard_k-th) sample maximum (two-phase form of the screened
+    search): the per-shard list holds the shard's documents above ITS k-th-best threshold (up to shard_k, padded), and the
+    merged top-k equals the exact kernel's.  Also the raw two-phase call with k_seed = k against the plain call."""
+    import twotowermlretrieval_amd as tt
+    from twotowermlretrieval_amd import index as _index
+    old = _index.SCREEN_MIN_DOCS
+    _index.SCREEN_MIN_DOCS = 0
+    try:
+        for B, N in ((3, 90000), (200, 70000), (64, 20000), (40, 300)):
+            D = torch.from_numpy(synth.unit_rows(700 + B, N, 256)).cuda()
+            Q = torch.from_numpy(synth.unit_rows(800 + B, B, 256)).cuda()
+            sx = tt.ShardedIndex(D, 5, shard_k=50, screen=True)
+            sv, si = sx.search(Q, 10)
+            ev, ei = tt.score_topk(Q, D, 10, 5)
+            assert torch.equal(sv, ev) and torch.equal(si, ei)
+            pend = [sx.submit(Q, 10) for _ in range(3)]
+            for p_ in pend:
+                v_, i_ = p_.result()
+                assert torch.equal(v_, ev) and torch.equal(i_, ei)
+            # the shard list itself: its first 10 entries are the shard's exact top-10, the rest are real documents or padding
+            ix = tt.BruteForceIndex(D, idx_offset=5, screen=True)
+            lv, li = ix.search(Q, 50, _seed_exchange=lambda s_: None, _k_seed=10)
+            assert torch.equal(lv[:, :10], ev) and torch.equal(li[:, :10], ei)
+            # beyond the guaranteed top-10: every listed entry is a real (exact score, document) pair, best first, no
+            # duplicates (WHICH documents just below the threshold are listed depends on their fp16 screen scores)
+            live = li >= 0
+            assert bool((lv[~live] == float("-inf")).all())
+            exact = (Q @ D.t()).cpu().numpy()
+            lvh, lih = lv.cpu().numpy(), li.cpu().numpy()
+            for b in range(Q.shape[0]):
+                n_live = int(live[b].sum())
+                ids = lih[b, :n_live] - 5
+                assert len(set(ids.tolist())) == n_live and bool((np.diff(lvh[b, :n_live]) <= 0).all())
+                np.testing.assert_allclose(lvh[b, :n_live], exact[b, ids], atol=2e-6)
+    finally:
+        _index.SCREEN_MIN_DOCS = old

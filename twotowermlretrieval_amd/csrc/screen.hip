@@ -1289,28 +1289,39 @@ TT_EXPORT size_t tt_score_topk_screened_workspace_bytes(int B, int64_t N, int d,
     return make_splan(B, N, k).ws_bytes + tt_score_topk_workspace_bytes(B, N, d, k);
 }
 
-TT_EXPORT int tt_score_topk_screened_f32(const float *Q, int B, int d, const float *D32, const void *D16, int64_t N,
-                                         int k, float dmax_norm, int64_t idx_offset, float *out_val, int64_t *out_idx,
-                                         int32_t *fallback_flag, void *workspace, size_t workspace_bytes,
-                                         void *const *prof_events, tt_stream_t stream)
+namespace {
+__global__ void seed_fill_kernel(float *seed, int n)
 {
-    hipStream_t st = (hipStream_t)stream;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n)
+        seed[i] = -3.0e38f; // no sample pass for this corpus size: no information (the floor threshold applies)
+}
+
+// phase 0: the whole search.  phase 1: query image + sample pass; seed[q] <- the k_seed-th largest sample maximum (nothing
+// else).  phase 2: the screen with the caller's seed[] as thresholds (the workspace still holds phase 1's query image and
+// flags), finish, predicated exact kernels.
+int screened_impl(const char *who, int phase, const float *Q, int B, int d, const float *D32, const void *D16, int64_t N, int k,
+                  int k_seed, float dmax_norm, int64_t idx_offset, float *out_val, int64_t *out_idx, int32_t *fallback_flag,
+                  float *seed, void *workspace, size_t workspace_bytes, void *const *prof_events, hipStream_t st)
+{
     if (B <= 0 || N <= 0 || k <= 0)
-        return tt_fail(TT_ERR_BAD_SHAPE, "tt_score_topk_screened_f32: B=%d N=%lld k=%d", B, (long long)N, k);
+        return tt_fail(TT_ERR_BAD_SHAPE, "%s: B=%d N=%lld k=%d", who, B, (long long)N, k);
     if (d != 256)
-        return tt_fail(TT_ERR_UNSUPPORTED, "tt_score_topk_screened_f32: d=%d (supported: 256)", d);
+        return tt_fail(TT_ERR_UNSUPPORTED, "%s: d=%d (supported: 256)", who, d);
     if (k > 64)
-        return tt_fail(TT_ERR_UNSUPPORTED, "tt_score_topk_screened_f32: k=%d > 64", k);
+        return tt_fail(TT_ERR_UNSUPPORTED, "%s: k=%d > 64", who, k);
     if (N >= (int64_t)INT_MAX - 64)
-        return tt_fail(TT_ERR_UNSUPPORTED, "tt_score_topk_screened_f32: N too large; shard the corpus");
+        return tt_fail(TT_ERR_UNSUPPORTED, "%s: N too large; shard the corpus", who);
     if (!(dmax_norm >= 0.0f) || !(dmax_norm < 60000.0f))
-        return tt_fail(TT_ERR_UNSUPPORTED, "tt_score_topk_screened_f32: corpus norm %g outside the fp16 range", dmax_norm);
-    if (!Q || !D32 || !D16 || !out_val || !out_idx || !fallback_flag)
-        return tt_fail(TT_ERR_BAD_SHAPE, "tt_score_topk_screened_f32: null pointer");
+        return tt_fail(TT_ERR_UNSUPPORTED, "%s: corpus norm %g outside the fp16 range", who, dmax_norm);
+    if (!Q || !D16 || !fallback_flag || (phase != 1 && (!D32 || !out_val || !out_idx)) || (phase != 0 && !seed))
+        return tt_fail(TT_ERR_BAD_SHAPE, "%s: null pointer", who);
+    if (phase == 1 && (k_seed < 1 || k_seed > k))
+        return tt_fail(TT_ERR_BAD_SHAPE, "%s: k_seed=%d outside [1, k=%d]", who, k_seed, k);
     const SPlan pl = make_splan(B, N, k);
     const size_t need = pl.ws_bytes + tt_score_topk_workspace_bytes(B, N, d, k);
     if (!workspace || workspace_bytes < need || ((uintptr_t)workspace & 255))
-        return tt_fail(TT_ERR_WORKSPACE, "tt_score_topk_screened_f32: workspace %zu < %zu bytes", workspace_bytes, need);
+        return tt_fail(TT_ERR_WORKSPACE, "%s: workspace %zu < %zu bytes", who, workspace_bytes, need);
     char *ws = (char *)workspace;
     // (the fallback flags are initialised by q_image_kernel below -- a kernel, not hipMemsetAsync: a 16-byte-multiple
     //  memset node captured in a HIP graph came back with garbage from the second replay on; ROCm 7.2, found with
@@ -1339,10 +1350,12 @@ TT_EXPORT int tt_score_topk_screened_f32(const float *Q, int B, int d, const flo
     sp.qimg = (const h8 *)(ws + pl.qimg_off);
     sp.qnorm = (const float *)(ws + pl.qnorm_off);
     sp.dbg_thr = nullptr;
-    hipLaunchKernelGGL(q_image_kernel, dim3(pl.rows_pad / 32), dim3(128), 0, st, Q, B, (h8 *)(ws + pl.qimg_off),
-                       (float *)(ws + pl.qnorm_off), fallback_flag, (B + 31) / 32, (int *)(ws + pl.tailctr_off),
-                       pl.n_qgroups);
-    TT_LAUNCH_CHECK();
+    if (phase != 2) {
+        hipLaunchKernelGGL(q_image_kernel, dim3(pl.rows_pad / 32), dim3(128), 0, st, Q, B, (h8 *)(ws + pl.qimg_off),
+                           (float *)(ws + pl.qnorm_off), fallback_flag, (B + 31) / 32, (int *)(ws + pl.tailctr_off),
+                           pl.n_qgroups);
+        TT_LAUNCH_CHECK();
+    }
     auto launch = [&](const ScreenParams &a, int blocks, bool maxonly) -> int {
         if (pl.stream && pl.q_per_block == 64) {
             if (maxonly)
@@ -1387,7 +1400,13 @@ TT_EXPORT int tt_score_topk_screened_f32(const float *Q, int B, int d, const flo
         TT_HIP_CHECK(hipFuncSetAttribute(fns[f0], hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds));
         TT_HIP_CHECK(hipFuncSetAttribute(fns[f0 + 1], hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds));
     }
-    if (pl.sample) {
+    if (phase == 2) {
+        sp.thr0 = seed;
+        sp.thr0_stride = 1;
+    } else if (!pl.sample && phase == 1) {
+        hipLaunchKernelGGL(seed_fill_kernel, dim3((B + 255) / 256), dim3(256), 0, st, seed, B);
+        TT_LAUNCH_CHECK();
+    } else if (pl.sample) {
         ScreenParams ss = sp;
         ss.N = (int)pl.s_docs;
         ss.n_tiles = pl.s_tiles;
@@ -1399,12 +1418,14 @@ TT_EXPORT int tt_score_topk_screened_f32(const float *Q, int B, int d, const flo
         int rc = launch(ss, pl.s_blocks, true);
         if (rc != TT_OK)
             return rc;
-        rc = tt_kth_largest(ss.max_val, B, pl.s_tiles, k, (float *)(ws + pl.sthr_val_off), st);
+        rc = tt_kth_largest(ss.max_val, B, pl.s_tiles, phase == 1 ? k_seed : k, phase == 1 ? seed : (float *)(ws + pl.sthr_val_off), st);
         if (rc != TT_OK)
             return rc;
         sp.thr0 = (const float *)(ws + pl.sthr_val_off);
         sp.thr0_stride = 1;
     }
+    if (phase == 1)
+        return TT_OK;
     if (prof_events)
         TT_HIP_CHECK(hipEventRecord((hipEvent_t)prof_events[0], st));
     {
@@ -1436,6 +1457,34 @@ TT_EXPORT int tt_score_topk_screened_f32(const float *Q, int B, int d, const flo
     return tt_score_topk_f32_pred(Q, B, d, D32, N, k, idx_offset, out_val, out_idx, ws + pl.ws_bytes,
                                   workspace_bytes - pl.ws_bytes, fallback_flag, st);
 }
+} // namespace
+
+TT_EXPORT int tt_score_topk_screened_f32(const float *Q, int B, int d, const float *D32, const void *D16, int64_t N,
+                                         int k, float dmax_norm, int64_t idx_offset, float *out_val, int64_t *out_idx,
+                                         int32_t *fallback_flag, void *workspace, size_t workspace_bytes,
+                                         void *const *prof_events, tt_stream_t stream)
+{
+    return screened_impl("tt_score_topk_screened_f32", 0, Q, B, d, D32, D16, N, k, k, dmax_norm, idx_offset, out_val, out_idx,
+                         fallback_flag, nullptr, workspace, workspace_bytes, prof_events, (hipStream_t)stream);
+}
+
+TT_EXPORT int tt_score_topk_screened_seed_f32(const float *Q, int B, int d, const void *D16, int64_t N, int k, int k_seed,
+                                              float dmax_norm, int32_t *fallback_flag, float *seed, void *workspace,
+                                              size_t workspace_bytes, tt_stream_t stream)
+{
+    return screened_impl("tt_score_topk_screened_seed_f32", 1, Q, B, d, nullptr, D16, N, k, k_seed, dmax_norm, 0, nullptr, nullptr,
+                         fallback_flag, seed, workspace, workspace_bytes, nullptr, (hipStream_t)stream);
+}
+
+TT_EXPORT int tt_score_topk_screened_seeded_f32(const float *Q, int B, int d, const float *D32, const void *D16, int64_t N,
+                                                int k, float dmax_norm, int64_t idx_offset, float *out_val, int64_t *out_idx,
+                                                int32_t *fallback_flag, const float *seed, void *workspace,
+                                                size_t workspace_bytes, void *const *prof_events, tt_stream_t stream)
+{
+    return screened_impl("tt_score_topk_screened_seeded_f32", 2, Q, B, d, D32, D16, N, k, k, dmax_norm, idx_offset, out_val,
+                         out_idx, fallback_flag, (float *)seed, workspace, workspace_bytes, prof_events, (hipStream_t)stream);
+}
+
 
 // ------------------------------------------------------------------ test-only: observe the screen's raw scores
 // include/tt_debug.h.  Runs the REAL screen kernels (q_image_kernel + the MAXONLY form of screen_stream_kernel /

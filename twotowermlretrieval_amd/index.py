@@ -170,8 +170,12 @@ class BruteForceIndex:
     def ntotal(self) -> int:
         return self.docs.shape[0]
 
-    def search(self, q: torch.Tensor, k: int = 10, _prof_events=None, out=None) -> Tuple[torch.Tensor, torch.Tensor]:
-        """out: optional (vals f32 [B,k], idx int64 [B,k]) contiguous device tensors to write into (2-D q only)."""
+    def search(self, q: torch.Tensor, k: int = 10, _prof_events=None, out=None, _seed_exchange=None,
+               _k_seed: int = 0) -> Tuple[torch.Tensor, torch.Tensor]:
+        """out: optional (vals f32 [B,k], idx int64 [B,k]) contiguous device tensors to write into (2-D q only).
+        _seed_exchange (ShardedIndex): a callable that turns this shard's seed thresholds [B] f32 (the _k_seed-th largest
+        sample maximum per query) into the maximum over the ranks, in place, on the current stream; the screen then runs
+        with the GLOBAL seed and `out` holds this shard's documents above it (tt_score_topk_screened_seed(ed)_f32)."""
         B = 1 if q.dim() == 1 else q.shape[0]
         N, d = self.docs.shape
         L = _lib.lib()
@@ -201,6 +205,19 @@ class BruteForceIndex:
                 need = L.tt_score_topk_screened_workspace_bytes(B, N, d, k)
                 ws_s = torch.empty(need, dtype=torch.uint8, device=self.docs.device)
                 flags = torch.empty((B + 31) // 32, dtype=torch.int32, device=self.docs.device)
+                if _seed_exchange is not None:
+                    seed = torch.empty(B, dtype=torch.float32, device=self.docs.device)
+                    _lib.check(L.tt_score_topk_screened_seed_f32(q.data_ptr(), B, d, self.docs16.data_ptr(), N, k,
+                                                                 min(_k_seed or k, k), self.dmax_norm, flags.data_ptr(),
+                                                                 seed.data_ptr(), ws_s.data_ptr(), ws_s.numel(), _stream(q)))
+                    _seed_exchange(seed)
+                    _lib.check(L.tt_score_topk_screened_seeded_f32(q.data_ptr(), B, d, self._sdocs.data_ptr(),
+                                                                   self.docs16.data_ptr(), N, k, self.dmax_norm,
+                                                                   self.idx_offset, vals.data_ptr(), idx.data_ptr(),
+                                                                   flags.data_ptr(), seed.data_ptr(), ws_s.data_ptr(),
+                                                                   ws_s.numel(), _prof_events, _stream(q)))
+                    self.fallback_flags = flags
+                    return vals, idx
                 _lib.check(L.tt_score_topk_screened_f32(q.data_ptr(), B, d, self._sdocs.data_ptr(), self.docs16.data_ptr(),
                                                         N, k, self.dmax_norm, self.idx_offset, vals.data_ptr(),
                                                         idx.data_ptr(), flags.data_ptr(), ws_s.data_ptr(), ws_s.numel(),
@@ -279,6 +296,10 @@ def _exchange_and_merge(vals: torch.Tensor, idx: torch.Tensor, k: int, merge: Ca
     return merge(gv, gi, k)
 
 
+def _no_exchange(seed: torch.Tensor) -> None:
+    """(hook of BruteForceIndex.search's two-phase form: the seed thresholds could be combined across ranks here)"""
+
+
 class _Slot:
     """One set of exchange buffers of a ShardedIndex (two of them: a step's all-gather + merge overlaps the next
     step's search): send block [vals f32 [B,kp] | idx int64 [B,kp]], receive buffer of `world` such blocks, outputs."""
@@ -333,6 +354,18 @@ class ShardedIndex:
         self._n_submitted = 0
         self._xs: Optional[torch.cuda.Stream] = None
 
+    def _local_search(self, q: torch.Tensor, kp: int, k: int, sl: "_Slot") -> None:
+        """This shard's list for the exchange: up to kp = max(k, shard_k) entries, best first.  The screen is seeded for
+        the FINAL k, not for kp: the global top-k is contained in the union of the shards' top-k, so a shard only has to list
+        its documents above ITS k-th-best threshold -- the kp-th sample maximum is a much weaker seed, and on a small shard
+        the candidates that get through, not the matrix pipes, set the screen's pace (1.25M rows, kp = 50, k = 10:
+        0.785 -> 0.650 ms per step, tools/experiments/global_seed_time.py).  Entries beyond the shard's top-k may be missing
+        (padding: -inf / -1); the merge ignores padding."""
+        if kp > k:
+            self._index.search(q, kp, out=(sl.send_v, sl.send_i), _seed_exchange=_no_exchange, _k_seed=k)
+        else:
+            self._index.search(q, kp, out=(sl.send_v, sl.send_i))
+
     @property
     def collective(self) -> str:
         """Which transport the exchange uses (reported by bench.py)."""
@@ -383,7 +416,7 @@ class ShardedIndex:
         sl = self._slot(q.shape[0], kp, k, 0)
         cur = torch.cuda.current_stream(sl.send.device)
         cur.wait_event(sl.merged)  # a pipelined step may still own this slot
-        self._index.search(q, kp, out=(sl.send_v, sl.send_i))
+        self._local_search(q, kp, k, sl)
         self._exchange_merge(sl, q.shape[0], kp, k)
         sl.merged.record(cur)
         return sl.out_v.clone(), sl.out_i.clone()
@@ -402,7 +435,7 @@ class ShardedIndex:
             self._xs = torch.cuda.Stream(device=dev)
         cur = torch.cuda.current_stream(dev)
         cur.wait_event(sl.merged)            # the slot's previous exchange has read its send block
-        self._index.search(q, kp, out=(sl.send_v, sl.send_i))
+        self._local_search(q, kp, k, sl)
         sl.searched.record(cur)
         with torch.cuda.stream(self._xs):
             self._xs.wait_event(sl.searched)
