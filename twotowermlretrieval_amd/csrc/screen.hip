@@ -562,7 +562,7 @@ __global__ __launch_bounds__(SW * 64, 2) void screen_kernel(ScreenParams p)
 }
 
 // ------------------------------------------------------------------ small batches: streaming form
-// For B <= 32 the shared-tile kernel above would leave seven of a workgroup's eight waves without queries.  Here every
+// For B <= 64 the shared-tile kernel above would leave most of a workgroup's eight waves without queries.  Here every
 // WAVE is an independent streaming engine (the organisation of the exact kernel, score_topk.hip): it keeps one
 // 32-query tile as B operands (64 VGPRs), walks its own range of documents through a private 4-slab LDS ring
 // (slab = 32 documents x 64 features f16 = 4 KiB, 4 global_load_lds per slab, 3 slabs in flight, no barriers)

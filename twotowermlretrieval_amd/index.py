@@ -114,7 +114,7 @@ def score_all(q: torch.Tensor, docs: torch.Tensor) -> torch.Tensor:
 
 
 SCREEN_MIN_BATCH = 1     # the screened path wins at every batch size once the corpus is large enough to sample:
-                         # B <= 32 streaming form (half the bytes of the fp32 kernel), above it the shared-tile form
+                         # B <= 64 streaming form (half the bytes of the fp32 kernel), above it the shared-tile form
 SCREEN_PADDED_MIN_BATCH = 33  # d < 256 (zero-padded screen copy): only where the exact kernel is MFMA-bound
 SCREEN_MIN_DOCS = 65536  # below this there is no sample pass to seed thresholds and the exact kernel is faster
 
