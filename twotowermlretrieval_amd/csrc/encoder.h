@@ -204,6 +204,11 @@ struct GruBwdDir {
     const unsigned *wmax; // f16-split kernel: bit pattern of max|W_hh|
     float *dgi;           // [M][3H]
     float *dghn;          // GRU: dGh [M][3H] = [dr_pre, dz_pre, dn_pre * r]
+    // f16-split kernel: per-workgroup column sums of dGi | dGh ([row groups][2][3H]: the bias gradients, reduced in fixed order
+    // afterwards) and the bit patterns of max |dGi|, max |dGh| (atomicMax; zeroed by the caller): the scales of the
+    // weight-gradient products -- what two column-sum passes over the 2 x 218 MB computed before
+    float *bias_slab;
+    unsigned *mx_dgi, *mx_dghn;
     int col0, reverse;
 };
 

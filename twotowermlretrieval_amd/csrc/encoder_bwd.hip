@@ -339,6 +339,22 @@ __global__ __launch_bounds__(256) void table_scatter_kernel(const float *__restr
     }
 }
 
+// out_ih[c] = sum over row groups of slab[g][c], out_hh[c] = ... of slab[g][n + c], in row-group order
+__global__ __launch_bounds__(256) void bias_reduce_kernel(const float *__restrict__ slab, int ngroups, int n,
+                                                          float *__restrict__ out_ih, float *__restrict__ out_hh)
+{
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= 2 * n)
+        return;
+    float s = 0.0f;
+    for (int g = 0; g < ngroups; ++g)
+        s += slab[(size_t)g * 2 * n + c];
+    if (c < n)
+        out_ih[c] = s;
+    else
+        out_hh[c - n] = s;
+}
+
 constexpr int COLSUM_SLICES = 256; // N <= 3H <= 1536 columns: 256 x N floats fit the split-K slab buffer
 
 int colsum(const float *X, int64_t ld, int N, int M, const int *m_dyn, float *slabs, float *out, hipStream_t st,
@@ -496,6 +512,10 @@ TT_EXPORT int tt_encoder_backward_f32(const int64_t *ids, int B, int T, const fl
     const size_t lds = sizeof(float) * ENC_RB * (H3 + 4);
     static const bool force_f32 = [] { const char *e = getenv("TT_GRU_F32"); return e && e[0] == '1'; }();
     const bool use16 = rnn_type == CELL_GRU && gru16_supported(H) && !force_f32; // (gru16.hip)
+    const int n_rowgroups = (B + ENC_RB - 1) / ENC_RB;
+    // the recurrence kernel's bias partial sums live in the split-K scratch (free while it runs): they must fit
+    const size_t slab_floats = (size_t)ENC_SPLITK * (NG < 3 ? 3 : NG) * H * (size_t)((E > ndir * H ? E : ndir * H) > H ? (E > ndir * H ? E : ndir * H) : H);
+    const bool fused_bias = use16 && (size_t)n_rowgroups * 2 * H3 * ndir <= slab_floats;
     for (int l = num_layers - 1; l >= 0; --l) {
         const int I = l == 0 ? E : ndir * H;
         const bool top = l == num_layers - 1;
@@ -534,6 +554,10 @@ TT_EXPORT int tt_encoder_backward_f32(const int64_t *ids, int B, int T, const fl
             bp.dir[d].dghn = (float *)(ws + lo.dghn[d]);
             bp.dir[d].col0 = d * H;
             bp.dir[d].reverse = d;
+            // f16-split recurrence: bias sums per row group and the operand maxima come out of the kernel itself
+            bp.dir[d].bias_slab = fused_bias ? slabs + (size_t)d * n_rowgroups * 2 * H3 : nullptr;
+            bp.dir[d].mx_dgi = (unsigned *)(ws + lo.flag) + 48 + 2 * (2 * l + d);
+            bp.dir[d].mx_dghn = bp.dir[d].mx_dgi + 1;
         }
         if (ndir == 1)
             bp.dir[1] = bp.dir[0];
@@ -546,6 +570,16 @@ TT_EXPORT int tt_encoder_backward_f32(const int64_t *ids, int B, int T, const fl
         }
         if (rc != TT_OK)
             return rc;
+        if (fused_bias) {
+            // the recurrence kernel left one partial sum per row group in the split-K scratch: reduce them (row-group order:
+            // deterministic) for BOTH directions before the first weight-gradient product reuses that scratch
+            for (int d = 0; d < ndir; ++d) {
+                float *const *g = grads + ((size_t)l * ndir + d) * 4;
+                hipLaunchKernelGGL(bias_reduce_kernel, dim3((2 * H3 + 255) / 256), dim3(256), 0, st,
+                                   (const float *)(slabs + (size_t)d * n_rowgroups * 2 * H3), n_rowgroups, H3, g[2], g[3]);
+            }
+            TT_LAUNCH_CHECK();
+        }
 
         for (int d = 0; d < ndir; ++d) {
             const float *const *w = weights + ((size_t)l * ndir + d) * 4;
@@ -556,10 +590,13 @@ TT_EXPORT int tt_encoder_backward_f32(const int64_t *ids, int B, int T, const fl
             // or the same sums (LSTM / RNN: one pre-activation per gate)
             unsigned *mx_dgi = force_f32 ? nullptr : (unsigned *)(ws + lo.flag) + 48 + 2 * (2 * l + d);
             unsigned *mx_dghn = force_f32 ? nullptr : mx_dgi + 1;
-            rc = colsum(dgi, H3, H3, MT, m_valid, slabs, g[2], st, mx_dgi);
-            if (rc != TT_OK)
-                return rc;
-            if (rnn_type == CELL_GRU) {
+            if (!fused_bias) {
+                rc = colsum(dgi, H3, H3, MT, m_valid, slabs, g[2], st, mx_dgi);
+                if (rc != TT_OK)
+                    return rc;
+            }
+            if (fused_bias) {
+            } else if (rnn_type == CELL_GRU) {
                 rc = colsum(dghn, H3, H3, MT, m_valid, slabs, g[3], st, mx_dghn);
                 if (rc != TT_OK)
                     return rc;

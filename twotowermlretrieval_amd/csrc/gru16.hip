@@ -352,10 +352,13 @@ struct B16 {
     static constexpr int A_BYTES = 2 * IMG; // hi, lo (single buffer: two barriers per step)
     static constexpr int RM_BYTES = 2 * NW * 16 * 4; // per-wave row maxima, double-buffered
     static constexpr int LDS_CAP = ((160 * 1024 - A_BYTES - RM_BYTES) / NW) / 1024;
-    static constexpr int R = H == 256 ? 17 : 16;
+#ifndef TT_B16_R
+#define TT_B16_R 15
+#endif
+    static constexpr int R = H == 256 ? TT_B16_R : 16; // (15: room for the bias sums and the operand maxima kept in registers)
     static constexpr int NL = NF - R < LDS_CAP ? NF - R : LDS_CAP;
     static constexpr int NS = NF - R - NL;
-    static constexpr int NR = NS == 0 ? 1 : 6;
+    static constexpr int NR = NS == 0 ? 1 : (NS % 6 == 0 ? 6 : (NS % 5 == 0 ? 5 : (NS % 4 == 0 ? 4 : 3)));
     static constexpr int LDS_BYTES = A_BYTES + RM_BYTES + NW * NL * 1024;
     static_assert(NS % NR == 0, "the ring must come round once per step");
     static_assert(NF <= 96, "plan tables are sized for H <= 256");
@@ -475,6 +478,8 @@ __global__ __launch_bounds__(B16<H>::NW * 64) void gru_bwd16_kernel(GruBwdParams
     Stash cur_st, next_st;
     load_stash(steps - 1, cur_st);
     int rb = 0;
+    float bsum[4][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}}; // column sums over this lane's rows and all steps: dr, dz, dn, dn r
+    float mx_i = 0.0f, mx_h = 0.0f;                        // max |dGi|, max |dGh| over the same elements
 
     for (int s = steps - 1; s >= 0; --s) {
         float direct[2][4];
@@ -512,6 +517,13 @@ __global__ __launch_bounds__(B16<H>::NW * 64) void gru_bwd16_kernel(GruBwdParams
                     gh[0] = dr_pre;
                     gh[H] = dz_pre;
                     gh[2 * H] = dghn_v;
+                    bsum[0][ct] += dr_pre;
+                    bsum[1][ct] += dz_pre;
+                    bsum[2][ct] += dn_pre;
+                    bsum[3][ct] += dghn_v;
+                    const float m2 = fmaxf(fabsf(dr_pre), fabsf(dz_pre));
+                    mx_i = fmaxf(mx_i, fmaxf(m2, fabsf(dn_pre)));
+                    mx_h = fmaxf(mx_h, fmaxf(m2, fabsf(dghn_v)));
                 }
                 gv[0][ct][e] = dr_pre;
                 gv[1][ct][e] = dz_pre;
@@ -612,6 +624,37 @@ __global__ __launch_bounds__(B16<H>::NW * 64) void gru_bwd16_kernel(GruBwdParams
                 if (act[e])
                     dh[ct][e] = direct[ct][e] + acc[ct][e] * down[e];
         cur_st = next_st;
+    }
+    // bias gradients of this row group (rows live in the four kq lane groups) and the operand maxima
+    if (d.bias_slab) {
+        float *slab = d.bias_slab + (size_t)blockIdx.x * 2 * H3;
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float v = bsum[g][ct];
+                v += __shfl_xor(v, 16);
+                v += __shfl_xor(v, 32);
+                bsum[g][ct] = v;
+            }
+            if (kq == 0) {
+                slab[unit[ct]] = bsum[0][ct];              // d b_ih = colsum(dGi) = [dr, dz, dn]
+                slab[H + unit[ct]] = bsum[1][ct];
+                slab[2 * H + unit[ct]] = bsum[2][ct];
+                slab[H3 + unit[ct]] = bsum[0][ct];         // d b_hh = colsum(dGh) = [dr, dz, dn r]
+                slab[H3 + H + unit[ct]] = bsum[1][ct];
+                slab[H3 + 2 * H + unit[ct]] = bsum[3][ct];
+            }
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            mx_i = fmaxf(mx_i, __shfl_xor(mx_i, off));
+            mx_h = fmaxf(mx_h, __shfl_xor(mx_h, off));
+        }
+        if (lane == 0) { // non-negative floats order like their bit patterns
+            atomicMax(d.mx_dgi, __float_as_uint(mx_i));
+            atomicMax(d.mx_dghn, __float_as_uint(mx_h));
+        }
     }
 }
 
