@@ -239,3 +239,42 @@ def test_g12_trainable_embedding_table_matches_reference_autograd(golden, tag):
     seen = np.zeros(V, dtype=bool)
     seen[np.unique(g[f"{tag}_ids"])] = True
     assert not has_grad[~seen].any()                         # ids that never occur get no gradient
+
+
+@pytest.mark.parametrize("layers,bi,drop", [(1, False, 0.0), (2, True, 0.0), (2, True, 0.3)])
+def test_direct_train_step_equals_the_autograd_path_bit_for_bit(layers, bi, drop):
+    """train_step's autograd-free shortcut (gradients written straight into the optimizer's flat buffer) against the same
+    step through torch.autograd: same kernels on the same inputs -> identical parameters after three steps."""
+    import copy
+    import twotowermlretrieval_amd as tt
+    V, E, H, B = 80, 20, 32, 24
+    cfg = {"VOCAB_SIZE": V, "EMBED_DIM": E, "HIDDEN_DIM": H, "NUM_LAYERS": layers, "BIDIRECTIONAL": bi, "DROPOUT": drop}
+    torch.manual_seed(3)
+    m1 = tt.TwoTowerModel(cfg, synth.make_table(4, V, E)).cuda().train()
+    m2 = copy.deepcopy(m1)
+    o1 = tt.FusedClipAdam(m1.parameters(), lr=1e-2, max_norm=1.0)
+    o2 = tt.FusedClipAdam(m2.parameters(), lr=1e-2, max_norm=1.0)
+    losses = []
+    for step in range(3):
+        ids = [torch.from_numpy(synth.make_ids(60 + 3 * step + s, B, T, V)).cuda() for s, T in enumerate((6, 11, 9))]
+        torch.manual_seed(100 + step)          # the dropout seeds are drawn from torch's CPU generator
+        l1 = tt.train_step(m1, o1, *ids, margin=0.5, direct=True)
+        torch.manual_seed(100 + step)
+        l2 = tt.train_step(m2, o2, *ids, margin=0.5, direct=False)
+        losses.append((float(l1.item()), float(l2.item())))
+    torch.cuda.synchronize()
+    assert all(a == b for a, b in losses), losses
+    assert torch.equal(o1.flat_params, o2.flat_params)
+    assert torch.equal(o1.exp_avg, o2.exp_avg) and torch.equal(o1.exp_avg_sq, o2.exp_avg_sq)
+
+
+def test_direct_train_step_reports_bad_input_like_the_reference():
+    import twotowermlretrieval_amd as tt
+    V, E, H = 50, 20, 32
+    m = tt.TwoTowerModel({"VOCAB_SIZE": V, "EMBED_DIM": E, "HIDDEN_DIM": H}, synth.make_table(1, V, E)).cuda().train()
+    opt = tt.FusedClipAdam(m.parameters(), lr=1e-3)
+    ids = [torch.from_numpy(synth.make_ids(7 + s, 4, T, V)).cuda() for s, T in enumerate((5, 6, 7))]
+    ids[1][2] = 0                               # an all-padding row: "Length of all samples has to be greater than 0"
+    with pytest.raises(RuntimeError):
+        tt.train_step(m, opt, *ids, margin=0.5)
+    torch.cuda.synchronize()

@@ -270,13 +270,15 @@ class RNNEncoder(nn.Module):
         return out, ws, status
 
     def _run_backward(self, ids: torch.Tensor, ws: torch.Tensor, d_out: torch.Tensor, dropout_p: float = 0.0,
-                      dropout_seed: int = 0):
+                      dropout_seed: int = 0, into: Optional[list] = None):
+        """into: contiguous float32 tensors, one per _flat_params() entry, that receive the gradients (the C entry point
+        OVERWRITES its gradient buffers): trainer.train_step hands over the optimizer's gradient views."""
         L = _lib.lib()
         B, T = ids.shape
         V, E = self.embedding.weight.shape
         H = self.hidden_dim
         params = self._flat_params()
-        grads = [torch.empty_like(p, memory_format=torch.contiguous_format) for p in params]
+        grads = into if into is not None else [torch.empty_like(p, memory_format=torch.contiguous_format) for p in params]
         table = self.embedding.weight
         g_table = torch.empty_like(table, memory_format=torch.contiguous_format) if table.requires_grad else None
         nq = 4 * self.num_layers * (2 if self.bidirectional else 1)
