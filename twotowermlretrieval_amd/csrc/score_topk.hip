@@ -40,6 +40,8 @@ constexpr int SLAB_BYTES = 32 * 128; // 32 docs x 32 f32
 constexpr int NSTAGE = 4;            // ring depth (slabs); NSTAGE-1 in flight
 constexpr int WPB = 4;               // waves per block
 constexpr int DMA_PER_SLAB = 4;      // global_load_lds_dwordx4 per slab per wave
+constexpr int PACE_R = 16;            // pacing counter slots per chunk (> pace_lag + 1)
+constexpr int PACE_POLLS = 400;       // bound of one wait (~0.3 us per poll)
 
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void gbl_void;
@@ -62,6 +64,17 @@ struct ScoreParams {
     // of the launch with equal shares).  tail_ctr == nullptr: everything static.
     int static_tiles, tail_g, tail_blocks;
     int *tail_ctr;
+    // Several query tiles (K4 only): the n_qtiles waves of a chunk sit on one XCD and read the same documents, but nothing
+    // keeps them within an L2's reach of each other (32 waves over 160 MB each: 10x the corpus fetched at B = 1024).
+    // pace[chunk][PACE_R]: a wave adds 1 to slot b % PACE_R when it has finished its b-th block of pace_g tiles and does
+    // not start block b + pace_lag before all n_qtiles waves have (a HINT: the wait is bounded, and a wave that ran into
+    // the bound stops waiting for good, so nothing depends on the other waves being resident).  grp_blk[chunk][grp_maxseg]:
+    // the pool blocks the chunk's waves take, drawn by whichever of them gets there first (0 = not drawn, -1 = being
+    // drawn, else block + 1), so that the pool is walked in step as well.  Both nullptr: every wave for itself.
+    int *pace;
+    int pace_g, pace_lag;
+    int *grp_blk;
+    int grp_maxseg;
     float *pval;   // [n_qtiles*32][n_chunks][k]
     int64_t *pidx; // same shape, global indices (idx_offset applied), -1 = empty
     int64_t idx_offset;
@@ -243,6 +256,30 @@ __global__ __launch_bounds__(WPB * 64, 2) void score_topk_kernel(ScoreParams p)
         }
     };
 
+    // ---- pacing (see ScoreParams::pace) ------------------------------------
+    constexpr bool PACED = !MAXONLY && !NT; // (NT is the one-query-tile build)
+    int *const pace = (PACED && p.pace) ? p.pace + (size_t)chunk * PACE_R : nullptr;
+    bool waits = pace != nullptr; // false once a wait ran into its bound
+    int gb = 0;                   // blocks of pace_g tiles this wave has finished
+    int in_blk = 0;               // tiles of the current block done
+    int seg = 0;                  // pool blocks this wave has taken
+    auto pace_gate = [&](int b) { // all n_qtiles waves of the chunk have finished their block b?
+        const int need = p.n_qtiles * (b / PACE_R + 1);
+        const int *slot = pace + (b % PACE_R);
+        for (int polls = 0;; ++polls) {
+            int v;
+            // scalar load past the scalar cache: its own counter (lgkmcnt), so the LDS-DMA ring stays in flight
+            asm volatile("s_load_dword %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(slot) : "memory");
+            if (v >= need)
+                return;
+            if (polls == PACE_POLLS) {
+                waits = false;
+                return;
+            }
+            __builtin_amdgcn_s_sleep(8);
+        }
+    };
+
     // ---- DMA state -------------------------------------------------------
     // DMA instruction jj moves docs 8jj..8jj+7 of the tile: lane -> (doc 8jj + lane>>3,
     // physical 16-B chunk lane&7).  Logical chunk = physical ^ ((doc>>1)&7) (source swizzle).
@@ -284,6 +321,8 @@ __global__ __launch_bounds__(WPB * 64, 2) void score_topk_kernel(ScoreParams p)
         int stage = 0;
 
         for (int tile = t0; tile < t1; ++tile) {
+            if (PACED && waits && in_blk == 0 && gb >= p.pace_lag)
+                pace_gate(gb - p.pace_lag);
             f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
@@ -346,14 +385,46 @@ __global__ __launch_bounds__(WPB * 64, 2) void score_topk_kernel(ScoreParams p)
                 if (full)
                     compact_where(full);
             }
+            if (PACED && pace && (++in_blk == p.pace_g || tile == t1 - 1)) {
+                // block done (counted whether or not this wave still waits for the others: they may wait for it)
+                if (lane == 0)
+                    asm volatile("global_atomic_add %0, %1, off" ::"v"(pace + (gb % PACE_R)), "v"(1) : "memory");
+                ++gb;
+                in_blk = 0;
+            }
         }
     }
     if (MAXONLY || !p.tail_ctr)
         break;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the over-prefetch of the segment's end has landed: the ring is free
     int blk = 0;
-    if (lane == 0)
+    if (PACED && p.grp_blk) {
+        // the chunk's waves take the same pool blocks in the same order: the first to get here draws for all of them
+        if (seg >= p.grp_maxseg)
+            break;
+        if (lane == 0) {
+            int *slot = p.grp_blk + (size_t)chunk * p.grp_maxseg + seg;
+            int v = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (v == 0) {
+                int expected = 0;
+                if (__hip_atomic_compare_exchange_strong(slot, &expected, -1, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                         __HIP_MEMORY_SCOPE_AGENT)) {
+                    v = atomicAdd(p.tail_ctr, 1) + 1;
+                    __hip_atomic_store(slot, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else {
+                    v = expected;
+                }
+            }
+            while (v < 0) { // the drawing wave is between its two atomics: it waits for nobody
+                __builtin_amdgcn_s_sleep(2);
+                v = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            blk = v - 1;
+        }
+        ++seg;
+    } else if (lane == 0) {
         blk = atomicAdd(p.tail_ctr + qtile, 1);
+    }
     blk = __builtin_amdgcn_readfirstlane(blk);
     if (blk >= p.tail_blocks)
         break;
@@ -952,6 +1023,11 @@ struct Plan {
     bool prepass;  // sample pass first: its k-th scores seed the main pass's thresholds
     // workspace layout (byte offsets)
     size_t cand_off, pval_off, pidx_off, pre_val_off, pre_idx_off, tailctr_off, ws_bytes;
+    // three or more query tiles on the 32-query kernel: pacing counters and the chunks' pool draws behind the pool counter(s)
+    bool paced;
+    int pace_g, pace_lag;
+    int grp_maxseg;
+    size_t pace_off, grp_off, ctr_bytes; // ctr_bytes: pool counter(s) + pacing + draws, zeroed together before the main pass
 };
 
 int device_cus()
@@ -963,6 +1039,12 @@ int device_cus()
         cus = 256; // MI355X; keeps the workspace query usable without a device
     }
     return cus;
+}
+
+bool tt_score_pacing() // TT_SCORE_PACE=0: every wave for itself (measurement)
+{
+    static const bool on = [] { const char *e = getenv("TT_SCORE_PACE"); return !e || atoi(e) != 0; }();
+    return on;
 }
 
 Pass make_pass(int B, int64_t N, int slots, int qt, bool tail = false)
@@ -1045,6 +1127,34 @@ Plan make_plan(int B, int64_t N, int k, int d)
     off = tt_align_up(off + rows * k * sizeof(int64_t), 256);
     pl.tailctr_off = off;
     off = tt_align_up(off + (size_t)pl.main.n_qtiles * sizeof(int), 256);
+    pl.paced = qt == 32 && pl.main.n_qtiles >= 3; // (two query tiles: +0.7 % with it, 1.7x fetched either way)
+    {
+        // the chunks of one XCD (an eighth of them) share its 4 MiB L2: a chunk's waves must stay within its part of
+        // ~3 MiB of each other, i.e. (pace_lag + 1) * pace_g tiles
+        static const int env_g = [] { const char *e = getenv("TT_SCORE_PACE_G"); return e ? atoi(e) : 0; }();
+        static const int env_lag = [] { const char *e = getenv("TT_SCORE_PACE_LAG"); return e ? atoi(e) : 0; }();
+        const int64_t per_xcd = (pl.main.n_chunks + 7) / 8;
+        const int64_t window = (3 << 20) / (per_xcd * TILE_DOCS * d * 4); // tiles
+        pl.pace_lag = env_lag > 0 ? env_lag : 2;
+        int g = (int)(window / (pl.pace_lag + 1));
+        pl.pace_g = env_g > 0 ? env_g : (g < 1 ? 1 : (g > 8 ? 8 : g));
+        if (pl.pace_lag > PACE_R - 2)
+            pl.pace_lag = PACE_R - 2;
+    }
+    pl.grp_maxseg = 0;
+    pl.pace_off = pl.grp_off = off;
+    if (pl.paced) {
+        off = tt_align_up(off + (size_t)pl.main.n_chunks * PACE_R * sizeof(int), 256);
+        pl.grp_off = off;
+        if (pl.main.tail_blocks > 0) {
+            // a chunk's waves may take up to 4x their even share of the pool (>= 16 blocks); n_chunks * grp_maxseg >=
+            // tail_blocks, so every block is drawn by a chunk that still may
+            const int even = (pl.main.tail_blocks + pl.main.n_chunks - 1) / pl.main.n_chunks;
+            pl.grp_maxseg = 4 * even > 16 ? 4 * even : 16;
+            off = tt_align_up(off + (size_t)pl.main.n_chunks * pl.grp_maxseg * sizeof(int), 256);
+        }
+    }
+    pl.ctr_bytes = off - pl.tailctr_off;
     pl.ws_bytes = off;
     return pl;
 }
@@ -1142,6 +1252,10 @@ ScoreParams pass_params(const Pass &ps, const float *Q, int B, const float *D, i
     sp.tail_g = 1;
     sp.tail_blocks = 0;
     sp.tail_ctr = nullptr;
+    sp.pace = nullptr;
+    sp.pace_g = sp.pace_lag = 1;
+    sp.grp_blk = nullptr;
+    sp.grp_maxseg = 0;
     sp.pval = (float *)(ws + pl.pval_off);
     sp.pidx = (int64_t *)(ws + pl.pidx_off);
     sp.idx_offset = idx_offset;
@@ -1203,8 +1317,18 @@ int score_partials(const float *Q, int B, int d, const float *D, int64_t N, int 
         sp.tail_g = pl.main.tail_g;
         sp.tail_blocks = pl.main.tail_blocks;
         sp.tail_ctr = (int *)(ws + pl.tailctr_off);
-        TT_RC_CHECK(tt_zero_async(sp.tail_ctr, sizeof(int) * pl.main.n_qtiles, st));
     }
+    if (pl.paced && !run_if && tt_score_pacing()) {
+        sp.pace = (int *)(ws + pl.pace_off);
+        sp.pace_g = pl.pace_g;
+        sp.pace_lag = pl.pace_lag;
+        if (sp.tail_ctr) {
+            sp.grp_blk = (int *)(ws + pl.grp_off);
+            sp.grp_maxseg = pl.grp_maxseg;
+        }
+    }
+    if (sp.tail_ctr || sp.pace)
+        TT_RC_CHECK(tt_zero_async(ws + pl.tailctr_off, pl.ctr_bytes, st));
     if (prof_events)
         TT_HIP_CHECK(hipEventRecord((hipEvent_t)prof_events[0], st));
     const int rc = launch_score(d, sp, pl, st, false);
