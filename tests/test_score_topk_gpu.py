@@ -60,6 +60,19 @@ def test_bit_exact_vs_oracle(tt, oracle, B, N, d, k):
         assert (i[:, N:] == -1).all() and np.isneginf(v[:, N:]).all()
 
 
+@pytest.mark.parametrize("B,N,d,k", [(160, 1_500_000, 64, 10), (100, 400_000, 64, 50), (96, 3_000_000, 32, 10)])
+def test_paced_chunks_and_shared_pool_draws_vs_oracle(tt, oracle, B, N, d, k):
+    # three or more query tiles: the waves of a document chunk pace each other and (first and third shape: chunks long
+    # enough for a pool) take the same pool blocks in the same order -- every tile must still be scored exactly once
+    # for every query tile
+    Q = synth.unit_rows(31 + B, B, d)
+    D = synth.unit_rows(32 + B, N, d)
+    v, i = run(tt, Q, D, k)
+    ov, oi = oracle.score_topk(Q, D, k)
+    assert np.array_equal(i, oi)
+    assert np.array_equal(v, ov)
+
+
 def test_non_unit_and_large_magnitudes(tt, oracle):
     rs = np.random.RandomState(5)
     Q = (rs.standard_normal((6, 256)) * 37.0).astype(np.float32)
