@@ -41,7 +41,10 @@ struct EncLayout {
     size_t total;
 };
 
-constexpr int ENC_SPLITK = 32;
+#ifndef TT_ENC_SPLITK
+#define TT_ENC_SPLITK 64
+#endif
+constexpr int ENC_SPLITK = TT_ENC_SPLITK;
 
 // The mask is a counter-based hash of (seed, layer, padded element index): no storage, the backward
 // pass regenerates it.  Identical to oracle/tt_oracle.c:o_dropout_scale.
