@@ -229,5 +229,5 @@ struct GruBwdParams {
 bool gru16_supported(int H);
 int gru16_pack(const float *W_hh, int H, unsigned *absmax, void *wp16, hipStream_t st);
 int gru16_launch(const GruParams &gp, int ndir, hipStream_t st);
-int gru16_pack_t(const float *W_hh, int H, unsigned *absmax, void *wtp16, hipStream_t st);
+int gru16_pack_t(const float *W_hh, int H, const unsigned *absmax, void *wtp16, hipStream_t st);
 int gru16_bwd_launch(const GruBwdParams &bp, int ndir, hipStream_t st);

@@ -534,9 +534,9 @@ TT_EXPORT int tt_encoder_backward_f32(const int64_t *ids, int B, int T, const fl
         bp.T = T;
         for (int d = 0; d < ndir; ++d) {
             const float *const *w = weights + ((size_t)l * ndir + d) * 4;
-            unsigned *wmax = (unsigned *)(ws + lo.flag) + 32 + 2 * l + d; // the forward's status block: slots 32.. are free
+            // max |W_hh| of this layer and direction: the training forward left it in its status block (encoder.hip)
+            const unsigned *wmax = (const unsigned *)(ws + lo.flag) + 16 + 2 * l + d;
             if (use16) {
-                TT_RC_CHECK(tt_zero_async(wmax, sizeof(unsigned), st));
                 rc = gru16_pack_t(w[1], H, wmax, ws + lo.wtp[d], st);
                 if (rc != TT_OK)
                     return rc;

@@ -690,9 +690,9 @@ int gru16_launch(const GruParams &gp, int ndir, hipStream_t st)
     return tt_fail(TT_ERR_UNSUPPORTED, "gru16_launch: H=%d", gp.H);
 }
 
-int gru16_pack_t(const float *W_hh, int H, unsigned *absmax /*zeroed by the caller on the stream*/, void *wtp16, hipStream_t st)
+// absmax: max |W_hh| as the forward's gru16_pack left it (same weights, same workspace)
+int gru16_pack_t(const float *W_hh, int H, const unsigned *absmax, void *wtp16, hipStream_t st)
 {
-    TT_RC_CHECK(tt_absmax(W_hh, (int64_t)3 * H * H, absmax, st));
     hipLaunchKernelGGL(pack_whh16_t_kernel, dim3(96), dim3(256), 0, st, W_hh, H, (const unsigned *)absmax, (_Float16 *)wtp16);
     TT_LAUNCH_CHECK();
     return TT_OK;
