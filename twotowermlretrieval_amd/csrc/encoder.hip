@@ -64,9 +64,8 @@ int enc_cus()
     return cus;
 }
 
-// Single block: tok_off = exclusive scan of len; perm = rows sorted by length, longest first.
-__global__ __launch_bounds__(1024) void prep_scan_sort_kernel(const int32_t *__restrict__ len, int B, int T,
-                                                              int32_t *__restrict__ tok_off, int32_t *__restrict__ perm)
+// Single block of 1024 threads: tok_off = exclusive scan of len; perm = rows sorted by length, longest first.
+__device__ __forceinline__ void scan_sort_block(const int32_t *len, int B, int T, int32_t *tok_off, int32_t *perm)
 {
     __shared__ int hist[SORT_BINS];
     __shared__ int wsum[16];
@@ -137,6 +136,81 @@ __global__ __launch_bounds__(1024) void prep_scan_sort_kernel(const int32_t *__r
     }
     for (int b = tid; b < B; b += 1024)
         perm[atomicAdd(&hist[bin_of(len[b])], 1)] = b;
+}
+
+__global__ __launch_bounds__(1024) void prep_scan_sort_kernel(const int32_t *__restrict__ len, int B, int T,
+                                                              int32_t *__restrict__ tok_off, int32_t *__restrict__ perm)
+{
+    scan_sort_block(len, B, T, tok_off, perm);
+}
+
+// The whole prep in ONE workgroup for small batches (B <= 1024 rows, B*T <= 8192 ids: every query-tower call): clears the
+// 64-word status block, lengths + input flags, scan + sort, packed ids and the caller's status word -- five dependent
+// launches of ~5 us each otherwise.  Thread = id (8 per thread, all loads in flight at once; a row per wave with its loads
+// one after the other was slower than the five launches); a row's non-zero count is the popcount of the wave's ballot
+// over the row's lanes, added to an LDS counter by the row's first lane in the wave.
+constexpr int PREP_FUSED_PER = 8;
+constexpr int64_t PREP_FUSED_MAX_IDS = 1024 * PREP_FUSED_PER;
+__global__ __launch_bounds__(1024) void prep_fused_kernel(const int64_t *__restrict__ ids, int B, int T, int64_t V,
+                                                          int32_t *len, int32_t *flag, int32_t *tok_off, int32_t *perm,
+                                                          int32_t *__restrict__ packed, int32_t *__restrict__ status)
+{
+    __shared__ int cnt[1024];
+    __shared__ int st_bits;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int n = B * T;
+    cnt[tid] = 0;
+    if (tid == 0)
+        st_bits = 0;
+    __syncthreads();
+    int64_t id[PREP_FUSED_PER];
+#pragma unroll
+    for (int i = 0; i < PREP_FUSED_PER; ++i) {
+        const int idx = i * 1024 + tid;
+        id[i] = idx < n ? ids[idx] : 0;
+    }
+    int bad = 0;
+#pragma unroll
+    for (int i = 0; i < PREP_FUSED_PER; ++i) {
+        const int idx = i * 1024 + tid;
+        const bool live = idx < n;
+        bad |= live && (id[i] < 0 || id[i] >= V);
+        const unsigned long long nz = __ballot(live && id[i] != 0);
+        if (live) {
+            const int row = idx / T, first = row * T, base = idx - lane; // the wave covers ids [base, base + 64)
+            const int lo = max(first - base, 0), hi = min(first + T - base, 64);
+            if (lane == lo) { // the row's first lane in this wave
+                const unsigned long long m = (hi >= 64 ? ~0ull : ((1ull << hi) - 1)) & ~((1ull << lo) - 1);
+                const int c = __popcll(nz & m);
+                if (c)
+                    atomicAdd(&cnt[row], c);
+            }
+        }
+    }
+    if (__ballot(bad) != 0ull && lane == 0)
+        atomicOr(&st_bits, 2); // id outside [0,V): nn.Embedding raises IndexError
+    __syncthreads();
+    if (tid < B) {
+        len[tid] = cnt[tid];
+        if (cnt[tid] == 0)
+            atomicOr(&st_bits, 1); // zero-length row: pack_padded_sequence raises (model.py:55-57)
+    }
+    __syncthreads(); // (workgroup-scope fence: the lengths are visible to every thread of the block)
+    if (tid < 64)
+        flag[tid] = tid == 0 ? st_bits : 0;
+    if (tid == 0 && status)
+        status[0] = st_bits;
+    scan_sort_block(len, B, T, tok_off, perm);
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < PREP_FUSED_PER; ++i) {
+        const int idx = i * 1024 + tid;
+        if (idx < n) {
+            const int row = idx / T, t = idx - row * T;
+            if (t < cnt[row])
+                packed[tok_off[row] + t] = (int32_t)(id[i] < 0 || id[i] >= V ? 0 : id[i]); // flagged, never dereferenced
+        }
+    }
 }
 
 __global__ __launch_bounds__(256) void prep_pack_ids_kernel(const int64_t *__restrict__ ids, int B, int T,
@@ -520,13 +594,18 @@ static int encoder_forward(const char *who, const int64_t *ids, int B, int T, co
     int32_t *perm = (int32_t *)(ws + lo.perm), *idsp = (int32_t *)(ws + lo.ids), *flag = (int32_t *)(ws + lo.flag);
     const int ndir = lo.ndir;
 
-    TT_RC_CHECK(tt_zero_async(flag, 256, st));
-    hipLaunchKernelGGL(prep_len_kernel, dim3((B + 3) / 4), dim3(256), 0, st, ids, B, T, V, len, flag);
-    hipLaunchKernelGGL(prep_scan_sort_kernel, dim3(1), dim3(1024), 0, st, len, B, T, tok_off, perm);
-    hipLaunchKernelGGL(prep_pack_ids_kernel, dim3(B), dim3(256), 0, st, ids, B, T, len, tok_off, V, idsp);
-    TT_LAUNCH_CHECK();
-    if (status)
-        TT_HIP_CHECK(hipMemcpyAsync(status, flag, sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+    if (B <= 1024 && (int64_t)B * T <= PREP_FUSED_MAX_IDS) {
+        hipLaunchKernelGGL(prep_fused_kernel, dim3(1), dim3(1024), 0, st, ids, B, T, V, len, flag, tok_off, perm, idsp, status);
+        TT_LAUNCH_CHECK();
+    } else {
+        TT_RC_CHECK(tt_zero_async(flag, 256, st));
+        hipLaunchKernelGGL(prep_len_kernel, dim3((B + 3) / 4), dim3(256), 0, st, ids, B, T, V, len, flag);
+        hipLaunchKernelGGL(prep_scan_sort_kernel, dim3(1), dim3(1024), 0, st, len, B, T, tok_off, perm);
+        hipLaunchKernelGGL(prep_pack_ids_kernel, dim3(B), dim3(256), 0, st, ids, B, T, len, tok_off, V, idsp);
+        TT_LAUNCH_CHECK();
+        if (status)
+            TT_HIP_CHECK(hipMemcpyAsync(status, flag, sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+    }
 
     const size_t lds = sizeof(float) * 2 * ENC_RB * (H + 4);
     const bool force_f32 = enc_force_f32();
