@@ -114,10 +114,22 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(float *__restrict__ p, f
                                                         float *__restrict__ total_norm_out)
 {
     __shared__ float s_coef;
+    __shared__ double s_red[4];
+    {
+        // every block sums the partials in the SAME fixed order (thread t: t, t + 256, ...; xor tree; the four waves in
+        // order), so all of them clip by bit-identical coefficients; one thread walking all of them took 30 us per step
+        double s = 0.0;
+        for (int i = threadIdx.x; i < npartial; i += 256)
+            s += partial[i];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1)
+            s += __shfl_xor(s, off);
+        if ((threadIdx.x & 63) == 0)
+            s_red[threadIdx.x >> 6] = s;
+    }
+    __syncthreads();
     if (threadIdx.x == 0) {
-        double ss = 0.0;
-        for (int i = 0; i < npartial; ++i)
-            ss += partial[i];
+        const double ss = ((s_red[0] + s_red[1]) + s_red[2]) + s_red[3];
         const float total = (float)sqrt(ss);
         float coef = 1.0f;
         if (max_norm > 0.0f) {
