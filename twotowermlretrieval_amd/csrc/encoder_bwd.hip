@@ -339,20 +339,32 @@ __global__ __launch_bounds__(256) void table_scatter_kernel(const float *__restr
     }
 }
 
-// out_ih[c] = sum over row groups of slab[g][c], out_hh[c] = ... of slab[g][n + c], in row-group order
+// out_ih[c] = sum over row groups of slab[g][c], out_hh[c] = ... of slab[g][n + c].  A block takes 32 columns x 8 parts:
+// part p adds its eighth of the row groups in order, the 8 partial sums are combined in part order (fixed order, so the
+// result does not depend on the launch; one thread walking all groups of a column was 64 dependent loads, 12-19 us).
 __global__ __launch_bounds__(256) void bias_reduce_kernel(const float *__restrict__ slab, int ngroups, int n,
                                                           float *__restrict__ out_ih, float *__restrict__ out_hh)
 {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= 2 * n)
-        return;
+    __shared__ float part[8][32];
+    const int col = threadIdx.x & 31, p = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + col;
+    const int per = (ngroups + 7) / 8;
     float s = 0.0f;
-    for (int g = 0; g < ngroups; ++g)
-        s += slab[(size_t)g * 2 * n + c];
-    if (c < n)
-        out_ih[c] = s;
-    else
-        out_hh[c - n] = s;
+    if (c < 2 * n)
+        for (int g = p * per; g < min((p + 1) * per, ngroups); ++g)
+            s += slab[(size_t)g * 2 * n + c];
+    part[p][col] = s;
+    __syncthreads();
+    if (p == 0 && c < 2 * n) {
+        float t = part[0][col];
+#pragma unroll
+        for (int q = 1; q < 8; ++q)
+            t += part[q][col];
+        if (c < n)
+            out_ih[c] = t;
+        else
+            out_hh[c - n] = t;
+    }
 }
 
 constexpr int COLSUM_SLICES = 256; // N <= 3H <= 1536 columns: 256 x N floats fit the split-K slab buffer
@@ -575,7 +587,7 @@ TT_EXPORT int tt_encoder_backward_f32(const int64_t *ids, int B, int T, const fl
             // deterministic) for BOTH directions before the first weight-gradient product reuses that scratch
             for (int d = 0; d < ndir; ++d) {
                 float *const *g = grads + ((size_t)l * ndir + d) * 4;
-                hipLaunchKernelGGL(bias_reduce_kernel, dim3((2 * H3 + 255) / 256), dim3(256), 0, st,
+                hipLaunchKernelGGL(bias_reduce_kernel, dim3((2 * H3 + 31) / 32), dim3(256), 0, st,
                                    (const float *)(slabs + (size_t)d * n_rowgroups * 2 * H3), n_rowgroups, H3, g[2], g[3]);
             }
             TT_LAUNCH_CHECK();

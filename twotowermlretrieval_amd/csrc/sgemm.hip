@@ -454,6 +454,33 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float *__restrict__ x
         atomicMax(out, __float_as_uint(fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3]))));
 }
 
+// four consecutive elements per thread (n % 4 == 0, 16-byte aligned slabs / out): 16-byte loads, 8 slabs in flight
+__global__ __launch_bounds__(256) void slab_reduce4_kernel(const float *__restrict__ slabs, int nslab, int64_t n4,
+                                                           float *out, int accumulate)
+{
+    const f32x4 *src = (const f32x4 *)slabs;
+    f32x4 *dst = (f32x4 *)out;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        f32x4 s = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll 8
+        for (int z = 0; z < nslab; ++z) {
+            const f32x4 v = src[(size_t)z * n4 + i];
+            s.x += v.x;
+            s.y += v.y;
+            s.z += v.z;
+            s.w += v.w;
+        }
+        if (accumulate) {
+            const f32x4 o = dst[i];
+            s.x += o.x;
+            s.y += o.y;
+            s.z += o.z;
+            s.w += o.w;
+        }
+        dst[i] = s;
+    }
+}
+
 __global__ void slab_reduce_kernel(const float *__restrict__ slabs, int nslab, int64_t n, float *out, int accumulate)
 {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -573,6 +600,13 @@ int tt_slab_reduce(const float *slabs, int nslab, int64_t n, float *out, int acc
         return TT_OK;
     if (n <= 8192 && nslab >= 64) {
         hipLaunchKernelGGL(slab_reduce_wide_kernel, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, st, slabs, nslab, (int)n,
+                           out, accumulate);
+        TT_LAUNCH_CHECK();
+        return TT_OK;
+    }
+    if ((n & 3) == 0 && ((((uintptr_t)slabs) | ((uintptr_t)out)) & 15) == 0 && n >= 65536) { // (same sums, same order)
+        int blocks4 = (int)((n / 4 + 255) / 256);
+        hipLaunchKernelGGL(slab_reduce4_kernel, dim3(blocks4 > 2048 ? 2048 : blocks4), dim3(256), 0, st, slabs, nslab, n / 4,
                            out, accumulate);
         TT_LAUNCH_CHECK();
         return TT_OK;
