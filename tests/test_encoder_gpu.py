@@ -380,3 +380,49 @@ def test_prepared_weights_inside_a_hip_graph_and_deepcopy():
         assert torch.equal(out, want)
         twin = copy.deepcopy(enc)             # the cache (and the module-level lock) must not break copying
         assert torch.equal(twin(ids), want)
+
+
+@pytest.mark.parametrize("B,T", [(8, 12), (40, 300)])  # the one-workgroup prep (<= 8192 ids) and the four-kernel prep
+def test_status_word_is_written_not_accumulated(B, T):
+    """include/tt.h: `status` is WRITTEN on the stream.  The Python host hands the call an uninitialised word, so a stale
+    value must never survive: poison it, run clean ids (-> 0), a zero-length row (-> exactly 1), an id >= V (-> exactly 2)."""
+    import ctypes as C
+    import twotowermlretrieval_amd as tt
+    from twotowermlretrieval_amd import _lib
+    from twotowermlretrieval_amd.model import _ptr_array, _stream
+    V, E, H = 50, 16, 32
+    torch.manual_seed(3)
+    enc = tt.RNNEncoder(V, E, H).cuda().eval()
+    L = _lib.lib()
+    rs = np.random.RandomState(B)
+    base = rs.randint(1, V, size=(B, T)).astype(np.int64)
+    quads = [w.detach().contiguous() for quad in enc.rnn.quads() for w in quad]
+    wptr = _ptr_array(quads)
+    table = enc.embedding.weight.detach()
+    need = L.tt_encoder_workspace_bytes(B, T, E, H, 1, 0, enc._cell, 0, 0)
+    ws = torch.empty(max(need, 256), dtype=torch.uint8, device="cuda")
+    out = torch.empty((B, H), dtype=torch.float32, device="cuda")
+
+    def run(ids_np):
+        ids = torch.from_numpy(ids_np).cuda()
+        status = torch.full((1,), 0x7FFFFFFF, dtype=torch.int32, device="cuda")
+        with torch.cuda.device(0):
+            _lib.check(L.tt_encoder_forward_f32(ids.data_ptr(), B, T, table.data_ptr(), V, E, H, 1, 0, enc._cell, wptr, None,
+                                                None, 1, 0, 0.0, 0, out.data_ptr(), ws.data_ptr(), ws.numel(),
+                                                status.data_ptr(), _stream(ids.device)))
+        torch.cuda.synchronize()
+        return int(status.item())
+
+    assert run(base) == 0
+    empty_row = base.copy()
+    empty_row[B // 2] = 0
+    assert run(empty_row) == 1
+    bad_id = base.copy()
+    bad_id[1, T - 1] = V
+    assert run(bad_id) == 2
+    # and through the module: the reference's exceptions, from a word nobody zeroed
+    with pytest.raises(RuntimeError):
+        enc(torch.from_numpy(empty_row).cuda())
+    with pytest.raises(IndexError):
+        enc(torch.from_numpy(bad_id).cuda())
+    assert torch.isfinite(enc(torch.from_numpy(base).cuda())).all()

@@ -241,7 +241,9 @@ class RNNEncoder(nn.Module):
         # overwritten by the next call's kernels while this call's are still queued.
         ws = torch.empty(max(need, 256), dtype=torch.uint8, device=ids.device)
         out = torch.empty((B, H), dtype=torch.float32, device=ids.device)
-        status = torch.zeros(1, dtype=torch.int32, device=ids.device)
+        # (not zeroed: every call that returns TT_OK WRITES the word on the stream -- include/tt.h, `status` -- and a call that
+        #  does not raises below before anyone reads it; the fill was one more ~5 us launch in front of every tower call)
+        status = torch.empty(1, dtype=torch.int32, device=ids.device)
         quads = [w.detach().contiguous() for quad in self.rnn.quads() for w in quad]
         wptr = _ptr_array(quads)
         pw = self.projection.weight.detach().contiguous() if self.projection is not None else None
