@@ -126,7 +126,8 @@ def screen_kernel_ms(index, q, k, iters=20, warm=5, k_seed=0):
     from twotowermlretrieval_amd import _lib
     L = _lib.lib()
     pairs = [_event_pair(L) for _ in range(iters)]
-    kw = dict(_seed_exchange=(lambda seed: None), _k_seed=k_seed) if 0 < k_seed < k else {}
+    from twotowermlretrieval_amd.index import _local_seed
+    kw = dict(_seed_union=_local_seed, _k_seed=k_seed) if 0 < k_seed < k else {}
     for _ in range(warm):
         index.search(q, k, **kw)
     torch.cuda.synchronize()
@@ -227,9 +228,11 @@ def _time_gpu(fn, iters, warm):
     return (time.perf_counter() - t0) / iters
 
 
-def encoder_legs(dev):
-    """Tower forward (B=512), index build (B=8192) and the train step (512 triplets) on this rank's GPU.
-    Returns (encoder dict, train dict, inputs for the CPU legs)."""
+def make_encoder_inputs(dev, with_index_batch=True):
+    """The synthetic inputs of the encoder / train legs, also used by tests/test_bench_size_gpu.py to check
+    these very launches against the oracle: embedding table randn * 0.3 [V,E] (CPU tensor), the two-tower model with
+    torch.manual_seed(0) default init on `dev`, Zipf(1.07) id batches q / p / n (B=512) and the index-build batch
+    (B=8192), each with its count of non-zero tokens."""
     import numpy as np
     import twotowermlretrieval_amd as tt
     rs = np.random.RandomState(0)
@@ -241,7 +244,18 @@ def encoder_legs(dev):
     q, qt = make_ids(rs, B, 6, 1, 30, ENC_V)
     p, pt = make_ids(rs, B, 70, 10, 250, ENC_V)
     n, nt = make_ids(rs, B, 70, 10, 250, ENC_V)
-    big, bt = make_ids(rs, 8192, 70, 10, 250, ENC_V)
+    big, bt = make_ids(rs, 8192, 70, 10, 250, ENC_V) if with_index_batch else (None, 0)
+    return {"table": table, "model": m, "B": B, "q": q, "p": p, "n": n, "big": big, "qt": qt, "pt": pt, "nt": nt, "bt": bt}
+
+
+def encoder_legs(dev):
+    """Tower forward (B=512), index build (B=8192) and the train step (512 triplets) on this rank's GPU.
+    Returns (encoder dict, train dict, inputs for the CPU legs)."""
+    import twotowermlretrieval_amd as tt
+    inp = make_encoder_inputs(dev)
+    table, m, B = inp["table"], inp["model"], inp["B"]
+    q, p, n, big = inp["q"], inp["p"], inp["n"], inp["big"]
+    qt, pt, nt, bt = inp["qt"], inp["pt"], inp["nt"], inp["bt"]
     qd, pd, nd, bigd = q.to(dev), p.to(dev), n.to(dev), big.to(dev)
     m.eval()
     with torch.no_grad():

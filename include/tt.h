@@ -114,18 +114,31 @@ int tt_score_topk_screened_f32(const float *Q, int B, int d, const float *D32, c
  * The same search in two calls around an exchange of the seed thresholds -- for a ROW-SHARDED corpus, where a
  * shard's own sample gives a much weaker seed than the whole corpus would: ≈ 8 candidates per workgroup-tile on a 1.25M-row
  * shard against 1 on 10M rows, and the append path, not the matrix pipes, then sets the pace of the screen.
- *   tt_score_topk_screened_seed_f32    query image + sample pass; seed[q] = the k_seed-th largest sample maximum of THIS shard
- *                                      (k_seed = the k of the FINAL answer, <= k = the per-shard list length)
- *   [caller]                           seed[q] <- max over the ranks (one all-reduce of B floats): some rank holds k_seed
- *                                      documents scoring at least that much, so it bounds the GLOBAL k_seed-th score from below
- *   tt_score_topk_screened_seeded_f32  the screen with thresholds seed[q] - 2 eps_q, pooling + exact rescoring, predicated exact
- *                                      kernels; writes this shard's documents above the global threshold (up to k, best first,
- *                                      the rest padded with -inf / -1): merged over the shards they contain the exact global top-k_seed
+ *   tt_score_topk_screened_seed_f32       query image + sample pass; seed[q] = the k_seed-th largest sample maximum of THIS
+ *                                         shard (k_seed = the k of the FINAL answer, <= k = the per-shard list length)
+ *   tt_score_topk_screened_seed_list_f32  the same pass, but seed_list[q][0..k_seed) = this shard's k_seed LARGEST sample
+ *                                         maxima (unordered; -3e38 / -inf entries where the shard has no such sample)
+ *   [caller]                              ONE all-gather of the ranks' seed lists (k_seed floats per query and rank: 40 KB per
+ *                                         rank at B = 1024, k_seed = 10 -- tt_allgather_topk moves any byte block), then
+ *   tt_seed_union_f32                     seed[q] = the k_seed-th largest of the world * k_seed gathered values.  They are
+ *                                         approximate scores of DISTINCT documents (one per 32-document sample tile, the shards'
+ *                                         rows are disjoint), so k_seed documents of the whole corpus reach seed[q]: it bounds the
+ *                                         GLOBAL k_seed-th best approximate score from below -- the seed the unsharded search
+ *                                         would take from a sample of the same total size
+ *   tt_score_topk_screened_seeded_f32     the screen with thresholds seed[q] - 2 eps_q, pooling + exact rescoring, predicated exact
+ *                                         kernels; writes this shard's documents above the global threshold (up to k, best first,
+ *                                         the rest padded with -inf / -1): merged over the shards they contain the exact global
+ *                                         top-k_seed (any valid lower bound works as seed[]: a single shard's own, or the union's)
  * Both calls take the SAME (B, N, k), flags and workspace; nothing else may use the workspace in between.
  */
 int tt_score_topk_screened_seed_f32(const float *Q, int B, int d, const void *D16, int64_t N, int k, int k_seed, float dmax_norm,
                                     int32_t *fallback_flag, float *seed /*[B] out*/, void *workspace, size_t workspace_bytes,
                                     tt_stream_t stream);
+int tt_score_topk_screened_seed_list_f32(const float *Q, int B, int d, const void *D16, int64_t N, int k, int k_seed,
+                                         float dmax_norm, int32_t *fallback_flag, float *seed_list /*[B][k_seed] out*/,
+                                         void *workspace, size_t workspace_bytes, tt_stream_t stream);
+int tt_seed_union_f32(const float *lists /*[world][B][k_seed]*/, int world, int B, int k_seed, float *seed /*[B] out*/,
+                      tt_stream_t stream);
 int tt_score_topk_screened_seeded_f32(const float *Q, int B, int d, const float *D32, const void *D16, int64_t N, int k,
                                       float dmax_norm, int64_t idx_offset, float *out_val, int64_t *out_idx,
                                       int32_t *fallback_flag, const float *seed /*[B]*/, void *workspace, size_t workspace_bytes,

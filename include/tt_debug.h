@@ -15,7 +15,7 @@ extern "C" {
 /*
  * Observe the approximate scores of the screened search (tt_score_topk_screened_f32, replacing
  * backend/evaluators.py:185-186) as the REAL screen kernels compute them, so that the error bound the filter rests on
- *     |s16 - s| <= eps_q = 1.05e-3 |q| Dmax + 1e-6 (|q| + Dmax)          (csrc/screen.hip: screen_eps)
+ *     |s16 - s| <= eps_q = 1.10e-3 |q| Dmax + 1e-6 (|q| + Dmax)          (csrc/screen.hip: screen_eps)
  * can be checked on the hardware (tests/test_screen_bound_gpu.py).  Runs q_image_kernel and the MAXONLY form of
  *   form 0: screen_stream_kernel with two query sets (B <= 32 in the product; 33..64 run it with four),  form 1 / 2 / 4: screen_kernel<., NSET = form>
  * over the whole fp16 corpus D16 [N,256] and writes out_t [B][ceil(N/32)]: per (query, 32-document tile) the maximum

@@ -1,3 +1,5 @@
+import json
+import os
 import sys
 from pathlib import Path
 
@@ -10,9 +12,59 @@ for p in (str(ROOT), str(GOLDEN)):
     if p not in sys.path:
         sys.path.insert(0, p)
 
+# Floating-point tolerances of the encoder / training parity tests, set from what the kernels measure (profiles/
+# r03_tolerance_report.json, written by these helpers): outputs of unit-norm rows 2e-6 absolute (observed <= 4e-7),
+# gradients 2e-5 of the tensor's largest element (observed <= 3e-6).  A product that lost the `lo` halves of the fp16
+# hi/lo split errs by ~5e-4 relative per product and fails both (tools/mutation_guard.py).  north_star's 1e-5 stays
+# only where the cosine tolerance itself is the statement under test (tests/test_score_topk_gpu.py, g6).
+FWD_ATOL = 2e-6
+GRAD_TOL = 2e-5
+
+_observed = {}
+
+
+def _record(kind, err, tol):
+    name = os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0]
+    cur = _observed.get((name, kind))
+    if cur is None or err > cur[0]:
+        _observed[(name, kind)] = (float(err), float(tol))
+
+
+def assert_fwd_close(got, want, atol=FWD_ATOL, what=""):
+    """Encoder outputs: max absolute error (rows are unit-norm or O(1))."""
+    got, want = np.asarray(got), np.asarray(want)
+    assert got.shape == want.shape, (got.shape, want.shape)
+    err = float(np.abs(got.astype(np.float64) - want.astype(np.float64)).max()) if got.size else 0.0
+    _record("fwd" + what, err, atol)
+    assert np.isfinite(got).all() and err <= atol, f"{what}: max abs error {err:.3e} > {atol:.1e}"
+
+
+def assert_grad_close(got, want, tol=GRAD_TOL, what="", floor=1e-30):
+    """Gradients: max error as a fraction of the tensor's largest element."""
+    got, want = np.asarray(got), np.asarray(want)
+    assert got.shape == want.shape, (got.shape, want.shape)
+    scale = max(float(np.abs(want).max()), floor)
+    err = float(np.abs(got.astype(np.float64) - want.astype(np.float64)).max()) / scale
+    _record("grad", err, tol)
+    assert np.isfinite(got).all() and err <= tol, f"{what}: max error / max|g| = {err:.3e} > {tol:.1e}"
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """Largest observed error per test, next to the tolerance it was held to (scratch: gpurun_out/)."""
+    if not _observed:
+        return
+    out = ROOT / "gpurun_out"
+    try:
+        out.mkdir(exist_ok=True)
+        rows = [{"test": t, "kind": k, "max_err": e, "tol": tol, "ratio": e / tol} for (t, k), (e, tol) in sorted(_observed.items())]
+        tag = os.environ.get("TT_TOL_REPORT", "tolerance_report")
+        (out / f"{tag}.json").write_text(json.dumps(rows, indent=1))
+    except OSError:
+        pass
 
 
 @pytest.fixture(scope="session")

@@ -8,6 +8,7 @@ import pytest
 import torch
 
 import synth
+from conftest import assert_fwd_close
 
 pytestmark = pytest.mark.gpu
 
@@ -64,7 +65,7 @@ def test_artifact_export_round_trip(tmp_path, oracle):
     # the exported rows are what the oracle computes for the same padded batches
     quads = [tuple(p.detach().cpu().numpy() for p in quad) for quad in m.doc_encoder.rnn.quads()]
     ids = tok.encode_batch(docs[:16]).numpy()
-    np.testing.assert_allclose(loaded[:16], oracle.encoder_forward(ids, table, quads, H), atol=1e-5)
+    assert_fwd_close(loaded[:16], oracle.encoder_forward(ids, table, quads, H))
     # the inferencer loads the directory; a document's own text retrieves it
     inf = tt.QueryInferencer(str(tmp_path))
     D = torch.from_numpy(loaded).cuda()

@@ -6,6 +6,7 @@ import numpy as np
 import pytest
 import torch
 
+from conftest import assert_fwd_close
 from test_inferencer_gpu import _artifacts
 
 pytestmark = pytest.mark.gpu
@@ -20,7 +21,7 @@ def test_hybrid_blend_matches_reference_simple_hybrid(tmp_path, golden):
     inf = QueryInferencer(str(_artifacts(tmp_path, g)))
     # the reference embeds the corpus with the SAME (query) encoder (simple_hybrid.py:37-41)
     emb = inf.get_query_embeddings(docs)
-    np.testing.assert_allclose(emb.cpu().numpy(), g["doc_emb"], atol=1e-5, rtol=0)
+    assert_fwd_close(emb.cpu().numpy(), g["doc_emb"])
     tfidf = TfidfVectorizer(stop_words="english", max_features=10000)  # simple_hybrid.py:24
     mat = tfidf.fit_transform(docs)
     hs = HybridSearcher(inf, docs, emb, tfidf_vectorizer=tfidf, doc_tfidf_matrix=mat, n_candidates=len(docs),
@@ -57,7 +58,7 @@ def test_simple_hybrid_retriever_drop_in_matches_reference(tmp_path, golden):
     for ai, alpha in enumerate(g["alphas"]):
         r = SimpleHybridRetriever(art, alpha=float(alpha))
         r.fit(docs)
-        np.testing.assert_allclose(r.doc_embeddings.cpu().numpy(), g["doc_emb"], atol=1e-5, rtol=0)
+        assert_fwd_close(r.doc_embeddings.cpu().numpy(), g["doc_emb"])
         for qi, q in enumerate(g["queries"]):
             want = g["combined"][ai, qi]
             res = r.search(str(q), top_k=10)

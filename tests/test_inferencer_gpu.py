@@ -8,6 +8,7 @@ import pytest
 import torch
 
 import synth
+from conftest import assert_fwd_close
 
 pytestmark = pytest.mark.gpu
 
@@ -39,7 +40,7 @@ def test_query_inferencer_matches_reference(tmp_path, golden):
     for q, want in zip(g["queries"], g["embs"]):
         e = inf.get_query_embedding(str(q))
         assert e.shape == want.shape and e.dtype == np.float32
-        np.testing.assert_allclose(e, want, atol=1e-5, rtol=0)
+        assert_fwd_close(e, want)
         assert abs(np.linalg.norm(e) - 1.0) < 1e-5          # the reference's own self-check (:98)
     z = inf.get_query_embedding("")
     assert z.shape == g["empty"].shape and not z.any()       # un-tokenisable query -> zero vector (:66-69)
@@ -47,7 +48,7 @@ def test_query_inferencer_matches_reference(tmp_path, golden):
     with pytest.raises(RuntimeError, match="Length of all samples"):
         inf.get_query_embedding("the the")                   # ids [0,0]: the reference raises too
     batch = inf.get_query_embeddings([str(q) for q in g["queries"]] + [""])
-    np.testing.assert_allclose(batch[:-1].cpu().numpy(), g["embs"], atol=1e-5, rtol=0)
+    assert_fwd_close(batch[:-1].cpu().numpy(), g["embs"])
     assert not batch[-1].any()
 
 

@@ -78,11 +78,18 @@ def _worker(rank, world, port, tmp):
     # ---- data-parallel step: equal batch shards, one all-reduce, same update on both ranks
     V, E, H = 60, 20, 32
     table = synth.make_table(3, V, E)
-    torch.manual_seed(0)
+    torch.manual_seed(rank)               # the ranks start from DIFFERENT weights; rank 0's are broadcast
     m = tt.TwoTowerModel({"VOCAB_SIZE": V, "EMBED_DIM": E, "HIDDEN_DIM": H}, table).to(dev)
     tr = tt.trainer.DataParallelTrainer(m, lr=1e-3, margin=0.5)
-    tr.broadcast_parameters()
     ids = [torch.from_numpy(synth.make_ids(40 + s, 8, T, V)) for s, T in enumerate((5, 9, 7))]
+    # an eval forward BEFORE the broadcast leaves kernel-form weights in the encoders' caches; the broadcast writes the
+    # optimizer's flat buffer (the parameters are views of it), and the next eval forward must see rank 0's weights
+    m.eval()
+    with torch.no_grad():
+        res["eval_before"] = m.encode_document(ids[1].to(dev)).cpu().numpy()
+    tr.broadcast_parameters()
+    with torch.no_grad():
+        res["eval_after"] = m.encode_document(ids[1].to(dev)).cpu().numpy()
     lo, hi = rank * 4, rank * 4 + 4
     loss = tr.step(*(x[lo:hi].to(dev) for x in ids))
     torch.cuda.synchronize()
@@ -126,6 +133,9 @@ def test_two_ranks_on_one_gpu_sharded_search_and_dp_step(oracle, tmp_path):
     fv, fi = tt.score_topk(qv, full, 3)
     assert np.array_equal(r0["doc_i"], fi.cpu().numpy()) and np.array_equal(r0["doc_v"], fv.cpu().numpy())
     assert np.array_equal(r0["params"], r1["params"])       # same averaged gradient, same clip, same Adam step
+    # the broadcast reached the encoders' cached kernel-form weights: rank 1 now computes what rank 0 computes
+    assert np.array_equal(r0["eval_before"], r0["eval_after"]) and np.array_equal(r1["eval_after"], r0["eval_after"])
+    assert np.abs(r1["eval_before"] - r1["eval_after"]).max() > 1e-3
     # single process on the full batch of 8 = the mean of the two rank means
     V, E, H = 60, 20, 32
     torch.manual_seed(0)

@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 
 import synth
-from conftest import GOLDEN
+from conftest import GOLDEN, assert_grad_close
 
 ATOL = 2e-6
 
@@ -87,8 +87,7 @@ def test_g4_triplet_loss_and_grads(oracle, golden, tag, margin):
             names += [prefix + "projection.weight", prefix + "projection.bias"]
         for name, got in zip(names, tot):
             want = g[f"{mt}_grad_{name}"]
-            scale = max(np.abs(want).max(), 1e-6)
-            assert np.abs(got - want).max() / scale < 2e-4, name
+            assert_grad_close(got, want, what=name, floor=1e-6)
 
 
 def test_g5_clip_adam(oracle, golden):
@@ -231,7 +230,7 @@ def test_g12_trainable_embedding_table_gradient(oracle, golden, tag):
     want = g[f"{tag}_grad_embedding.weight"]
     assert not gt[0].any() and not want[0].any()            # padding_idx: row 0 gets no gradient
     assert (ids == 0).any() and np.abs(want).max() > 0.1
-    np.testing.assert_allclose(gt, want, atol=2e-4 * np.abs(want).max(), rtol=0)
+    assert_grad_close(gt, want, what='embedding.weight')
     names = []
     for layer in range(layers):
         for d in range(2 if bi else 1):
@@ -239,7 +238,7 @@ def test_g12_trainable_embedding_table_gradient(oracle, golden, tag):
             names += [f"rnn.{n}{sfx}" for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
     for name, got in zip(names, [x for quad in grads for x in quad]):
         w = g[f"{tag}_grad_{name}"]
-        np.testing.assert_allclose(got, w, atol=2e-4 * max(np.abs(w).max(), 1e-6), rtol=0, err_msg=name)
+        assert_grad_close(got, w, what=name, floor=1e-6)
 
 
 @pytest.mark.parametrize("cell", ["LSTM", "RNN"])
@@ -271,4 +270,4 @@ def test_g13_lstm_and_vanilla_rnn_towers(oracle, golden, cell, tag):
     for name, got in zip(names, flat):
         w = g[f"{key}_grad_{name}"]
         assert got.shape == w.shape, name
-        np.testing.assert_allclose(got, w, atol=2e-4 * max(np.abs(w).max(), 1e-6), rtol=0, err_msg=name)
+        assert_grad_close(got, w, what=name, floor=1e-6)

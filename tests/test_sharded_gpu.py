@@ -144,7 +144,7 @@ def test_shard_lists_seeded_for_the_final_k_give_the_same_top_k():
                 assert torch.equal(v_, ev) and torch.equal(i_, ei)
             # the shard list itself: its first 10 entries are the shard's exact top-10, the rest are real documents or padding
             ix = tt.BruteForceIndex(D, idx_offset=5, screen=True)
-            lv, li = ix.search(Q, 50, _seed_exchange=lambda s_: None, _k_seed=10)
+            lv, li = ix.search(Q, 50, _seed_union=_index._local_seed, _k_seed=10)
             assert torch.equal(lv[:, :10], ev) and torch.equal(li[:, :10], ei)
             # beyond the guaranteed top-10: every listed entry is a real (exact score, document) pair, best first, no
             # duplicates (WHICH documents just below the threshold are listed depends on their fp16 screen scores)

@@ -1,12 +1,14 @@
 """GPU parity tests for the training path: K6 triplet loss, K7 encoder backward (BPTT), K8 fused
 clip+Adam -- against the reference's own autograd outputs (tests/golden/g4_triplet.npz,
-g5_clip_adam.npz) and the CPU oracle.  Gradient tolerance: 5e-4 of the tensor's max magnitude
-(fp32 summation order over thousands of tokens; observed ~1e-5)."""
+g5_clip_adam.npz) and the CPU oracle.  Gradient tolerance: conftest.GRAD_TOL = 2e-5 of the tensor's largest
+element (observed <= 3e-6: fp32 summation order); outputs conftest.FWD_ATOL = 2e-6.  Dropping the `lo` halves of the
+fp16 hi/lo split fails these (tools/mutation_guard.py)."""
 import numpy as np
 import pytest
 import torch
 
 import synth
+from conftest import assert_fwd_close, assert_grad_close
 
 pytestmark = pytest.mark.gpu
 
@@ -53,8 +55,8 @@ def test_g4_full_backward_matches_reference_autograd(golden, tag, margin):
     q, p, n = (dev(g[f"{tag}_{k}"]) for k in "qpn")
     m.zero_grad()
     eq, ep, en = m.encode_query(q), m.encode_document(p), m.encode_document(n)
-    np.testing.assert_allclose(eq.detach().cpu().numpy(), g[f"{mt}_emb_q"], atol=1e-5)
-    np.testing.assert_allclose(en.detach().cpu().numpy(), g[f"{mt}_emb_n"], atol=1e-5)
+    assert_fwd_close(eq.detach().cpu().numpy(), g[f"{mt}_emb_q"])
+    assert_fwd_close(en.detach().cpu().numpy(), g[f"{mt}_emb_n"])
     loss = triplet_loss_cosine((eq, ep, en), margin=margin)
     loss.backward()
     assert abs(loss.item() - float(g[f"{mt}_loss"])) < 2e-6
@@ -65,8 +67,7 @@ def test_g4_full_backward_matches_reference_autograd(golden, tag, margin):
             continue
         want = g[f"{mt}_grad_{name}"]
         got = prm.grad.cpu().numpy()
-        scale = max(np.abs(want).max(), 1e-6)
-        assert np.abs(got - want).max() / scale < 5e-4, name
+        assert_grad_close(got, want, what=name, floor=1e-6)
         checked += 1
     assert checked == (8 if tag == "uni" else 36)  # 8 / 36 trainable tensors
 
@@ -96,8 +97,7 @@ def test_encoder_backward_vs_oracle(oracle, B, T, E, H, layers, bi):
     flat_want = [x for quad in og for x in quad] + ([gpw, gpb] if bi else [])
     flat_got = [p.grad.cpu().numpy() for p in enc._flat_params()]
     for i, (got, want) in enumerate(zip(flat_got, flat_want)):
-        scale = max(np.abs(want).max(), 1e-6)
-        assert np.abs(got - want).max() / scale < 5e-4, i
+        assert_grad_close(got, want, what=str(i), floor=1e-6)
 
 
 def test_g5_fused_clip_adam_matches_torch_sequence(golden):
@@ -182,7 +182,7 @@ def test_inter_layer_dropout_forward_and_backward_vs_oracle(oracle, layers, bi, 
     enc.eval()
     with torch.no_grad():
         y_eval = enc(dev(ids)).cpu().numpy()
-    np.testing.assert_allclose(y_eval, oracle.encoder_forward(ids, table, quads, H, layers, bi, pw, pb), atol=1e-5)
+    assert_fwd_close(y_eval, oracle.encoder_forward(ids, table, quads, H, layers, bi, pw, pb))
     # train mode: same seed draw as the autograd node will make
     enc.train()
     torch.manual_seed(4242)
@@ -190,15 +190,14 @@ def test_inter_layer_dropout_forward_and_backward_vs_oracle(oracle, layers, bi, 
     torch.manual_seed(4242)
     y = enc(dev(ids))
     want = oracle.encoder_forward(ids, table, quads, H, layers, bi, pw, pb, True, p, mask_seed)
-    np.testing.assert_allclose(y.detach().cpu().numpy(), want, atol=1e-5)
+    assert_fwd_close(y.detach().cpu().numpy(), want)
     assert np.abs(want - y_eval).max() > 1e-3
     d_out = np.random.RandomState(5).standard_normal((B, H)).astype(np.float32)
     y.backward(dev(d_out))
     og, gpw, gpb = oracle.encoder_backward(ids, table, quads, H, d_out, layers, bi, pw, pb, True, p, mask_seed)
     flat_want = [x for quad in og for x in quad] + ([gpw, gpb] if bi else [])
     for i, (prm, w) in enumerate(zip(enc._flat_params(), flat_want)):
-        scale = max(np.abs(w).max(), 1e-6)
-        assert np.abs(prm.grad.cpu().numpy() - w).max() / scale < 5e-4, i
+        assert_grad_close(prm.grad.cpu().numpy(), w, what=str(i), floor=1e-6)
 
 
 @pytest.mark.parametrize("tag", ["uni", "bi"])
@@ -221,13 +220,13 @@ def test_g12_trainable_embedding_table_matches_reference_autograd(golden, tag):
     opt = FusedClipAdam(enc.parameters(), lr=1e-2, max_norm=1.0)   # (re-points .data / .grad at its flat buffers)
     ids = dev(g[f"{tag}_ids"])
     y = enc(ids)
-    np.testing.assert_allclose(y.detach().cpu().numpy(), g[f"{tag}_out"], atol=1e-5, rtol=0)
+    assert_fwd_close(y.detach().cpu().numpy(), g[f"{tag}_out"])
     (y * dev(g[f"{tag}_c"])).sum().backward()
     torch.cuda.synchronize()
     for name, prm in enc.named_parameters():
         want = g[f"{tag}_grad_{name}"]
         got = prm.grad.cpu().numpy()
-        np.testing.assert_allclose(got, want, atol=5e-4 * max(np.abs(want).max(), 1e-6), rtol=0, err_msg=name)
+        assert_grad_close(got, want, what=name, floor=1e-6)
     gt = enc.embedding.weight.grad.cpu().numpy()
     assert not gt[0].any()                                   # padding_idx
     before = enc.embedding.weight.detach().clone()

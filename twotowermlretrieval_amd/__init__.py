@@ -1,8 +1,7 @@
 """MI355X-native (gfx950) implementation of the two-tower retrieval hot path of
 jpe17/TwoTowerMLRetrieval: fused brute-force scoring + top-k, GRU encoder towers,
 triplet-loss training.  Python host over a C-ABI HIP library (libtt.so, include/tt.h)."""
-from .data import TripletDataset, collate_fn
-from . import collective, data, evaluators, hybrid, model, query_inferencer, tokenizer, trainer
+from . import collective, evaluators, hybrid, model, query_inferencer, tokenizer, trainer
 from .index import (BruteForceIndex, GraphedSearch, PendingSearch, ShardedIndex, StreamedIndex, score_all, score_rank, score_topk, shard_bounds,
                     topk_merge)
 from .model import RNNEncoder, TwoTowerModel, triplet_loss_cosine
@@ -13,5 +12,5 @@ from .trainer import DataParallelTrainer, FusedClipAdam, train_step
 __all__ = ["BruteForceIndex", "GraphedSearch", "ShardedIndex", "PendingSearch", "StreamedIndex", "score_topk", "topk_merge", "score_rank", "score_all", "shard_bounds",
            "RNNEncoder", "TwoTowerModel", "triplet_loss_cosine", "QueryInferencer", "PretrainedTokenizer",
            "FusedClipAdam", "DataParallelTrainer", "train_step", "model", "trainer", "tokenizer", "query_inferencer",
-           "evaluators", "hybrid", "collective", "data", "TripletDataset", "collate_fn"]
+           "evaluators", "hybrid", "collective"]
 __version__ = "0.1.0"

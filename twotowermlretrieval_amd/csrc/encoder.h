@@ -41,6 +41,12 @@ struct EncLayout {
     size_t total;
 };
 
+// Word of the 256-byte status block (EncLayout::flag) that holds the bit pattern of max |x| over the embedding vectors of
+// the call's valid tokens: written by the training forward (K1's fill, or tt_absmax_rows), read by the backward as the X
+// scale of dW_ih = dGi^T X.  (Other words: 0 error flags, 16.. max|W_hh| forward, 32.. backward, 40.. max|W_ih|, 48..63
+// max|dGi| / max|dGh|.)
+constexpr int ENC_FLAG_XMAX = 8;
+
 #ifndef TT_ENC_SPLITK
 #define TT_ENC_SPLITK 64
 #endif

@@ -664,18 +664,25 @@ static int encoder_forward(const char *who, const int64_t *ids, int B, int T, co
             }
             if (!force_f32) {
                 // K1 on the f16 pipes (fp16 hi/lo split, fp32-grade; sgemm.h): W_ih is scaled by the power of two
-                // that puts its largest element in [2^13, 2^14); layer 0's A rows are embedding vectors, taken as they
-                // are (|x| < 65504), deeper layers' are hidden states in (-1, 1) (times 1/(1-p) under dropout): 2^6
+                // that puts its largest element in [2^13, 2^14); deeper layers' A rows are hidden states in (-1, 1) (times
+                // 1/(1-p) under dropout): 2^6; layer 0's are embedding vectors of ANY magnitude: the token-stationary
+                // kernel scales every row by its own power of two (the tiled kernel, for the shapes that one does not take,
+                // takes them as they are: fp32-grade for |x|max in ~[0.1, 6e4])
                 g.a_absmax = nullptr;
                 g.a_exp = l == 0 ? 0 : 6;
                 g.b_absmax = wih_max;
                 g.b_exp = 0;
                 g.b_hi16 = w16;
+                unsigned *xmax = (train && l == 0) ? (unsigned *)flag + ENC_FLAG_XMAX : nullptr; // for the backward's dW_ih
                 if (enc_rows16(NGH, I)) { // token-stationary form (gemm_rows16.hip): W_ih as a fragment stream
                     g.b_lo16 = nullptr;
                     g.ldb16 = 0;
+                    g.a_row_scale = l == 0;
+                    g.a_absmax_out = d == 0 ? xmax : nullptr;
                     rc = tt_gemm_rows16(g, st);
                 } else {
+                    if (xmax && d == 0)
+                        TT_RC_CHECK(tt_absmax_rows(table, E, E, idsp, (int)lo.MT, tok_off + B, xmax, st));
                     const int Kp = (I + 31) / 32 * 32;
                     g.b_lo16 = w16 + (size_t)NGH * Kp * sizeof(uint16_t);
                     g.ldb16 = Kp;

@@ -383,7 +383,7 @@ int colsum(const float *X, int64_t ld, int N, int M, const int *m_dyn, float *sl
 // power of two that *a_absmax (max |A|, from the colsum pass over the same matrix) implies; B scaled by 2^b_exp.
 int gemm_tn(const float *A, int64_t lda, int Mo, const float *Bsrc, int64_t ldb, const int32_t *b_map, int No,
             int Ktok, const int *k_dyn, float *slabs, float *out, hipStream_t st, const unsigned *a_absmax = nullptr,
-            int b_exp = 0)
+            int b_exp = 0, const unsigned *b_absmax = nullptr)
 {
     SgemmParams g;
     g.A = A;
@@ -403,7 +403,7 @@ int gemm_tn(const float *A, int64_t lda, int Mo, const float *Bsrc, int64_t ldb,
     g.slab_stride = (int64_t)Mo * No;
     g.accumulate = 0;
     g.a_absmax = a_absmax;
-    g.b_absmax = nullptr;
+    g.b_absmax = a_absmax ? b_absmax : nullptr;
     g.a_exp = 0;
     g.b_exp = b_exp;
     g.b_hi16 = g.b_lo16 = nullptr;
@@ -616,9 +616,11 @@ TT_EXPORT int tt_encoder_backward_f32(const int64_t *ids, int B, int T, const fl
                 TT_HIP_CHECK(hipMemcpyAsync(g[3], g[2], sizeof(float) * H3, hipMemcpyDeviceToDevice, st));
             }
             // W_ih <- dGi^T X   (X = gathered table rows for layer 0, the layer below's output above)
-            // (f16-split products: embedding rows as they are, hidden states (|h| < 1, times 1/(1-p) when dropped) 2^6)
+            // (f16-split products: embedding rows scaled by the power of two of the batch's largest |x|, which the training
+            //  forward left in the status block; hidden states (|h| < 1, times 1/(1-p) when dropped) 2^6)
             if (l == 0)
-                rc = gemm_tn(dgi, H3, H3, table, E, idsp, E, MT, m_valid, slabs, g[0], st, mx_dgi, 0);
+                rc = gemm_tn(dgi, H3, H3, table, E, idsp, E, MT, m_valid, slabs, g[0], st, mx_dgi, 0,
+                             (const unsigned *)(ws + lo.flag) + ENC_FLAG_XMAX);
             else
                 rc = gemm_tn(dgi, H3, H3, (const float *)(ws + (drop ? lo.xd[l] : lo.x[l])), I, nullptr, I, MT, m_valid,
                              slabs, g[0], st, mx_dgi, 6);

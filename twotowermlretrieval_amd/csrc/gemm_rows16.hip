@@ -41,7 +41,7 @@ struct RSCfg {
     static constexpr int FRAGS = 2 * CT;                 // 1-KiB fragments per k-step: hi, lo of each tile
     static constexpr int LDH = WIDE ? NKS * 16 + 8 : 312; // halves per image row: 156 / 260 dwords = 28 / 4 mod 32 banks
     static constexpr int IMG = RS_ROWS * LDH * 2;        // bytes per image (hi | lo)
-    static constexpr int LDS = 2 * IMG;                  // 79 872 B (two per CU) / 133 120 B (one per CU)
+    static constexpr int LDS = 2 * IMG + RS_ROWS * 4;    // + per-token "down" factors: 80 128 B (two per CU) / 133 376 B (one per CU)
     static constexpr int TPR = WAVES * 64 / RS_ROWS;     // threads per token row in the fill
     static constexpr int NJ = (NKS * 4 + TPR - 1) / TPR; // 16-byte pieces per thread
 };
@@ -81,15 +81,15 @@ __global__ __launch_bounds__(WIDE ? 512 : 256, WIDE ? 1 : 2) void gemm_rows16_ke
         return;
     const int ea = p.a_absmax ? tt_pow2_exponent(*p.a_absmax) : p.a_exp;
     const int eb = p.b_absmax ? tt_pow2_exponent(*p.b_absmax) : p.b_exp;
-    const float sa = ldexpf(1.0f, ea), down = ldexpf(1.0f, -(ea + eb)), up = ldexpf(1.0f, ea + eb);
     const int i = lane & 31, h = lane >> 5;
+    float *const tdown = (float *)(lds + 2 * C::IMG); // [RS_ROWS]: 2^-(e_row + e_B), what a token's accumulators are multiplied by
     const int nchunks = p.N / C::CHUNK, npass = rs_chunks_of(nchunks, w, C::WAVES);
     int first = 0; // this wave's first pass in the (wave-major) fragment stream
     for (int j = 0; j < w; ++j)
         first += rs_chunks_of(nchunks, j, C::WAVES);
-    // The bias is the accumulators' starting value (times the operand scales), fetched one pass ahead: a load issued in
-    // the epilogue would have to be waited for with vmcnt(0), draining the fragment ring at every pass boundary.
-    float bnext[C::CT]; // [ct]: column (W pass + w) CHUNK + 32 ct + i
+    // The bias (added when a pass's accumulators are scaled back) is fetched one pass ahead: a load issued in the epilogue
+    // would have to be waited for with vmcnt(0), draining the fragment ring at every pass boundary.
+    float bnext[C::CT], bcur[C::CT]; // [ct]: column (W pass + w) CHUNK + 32 ct + i
     auto load_bias = [&](int pass) {
 #pragma unroll
         for (int ct = 0; ct < C::CT; ++ct)
@@ -120,11 +120,31 @@ __global__ __launch_bounds__(WIDE ? 512 : 256, WIDE ? 1 : 2) void gemm_rows16_ke
         if (row < M)
             src = p.A + (size_t)(p.a_map ? (int64_t)p.a_map[row] : (int64_t)row) * p.lda;
         f32x4v v[C::NJ];
+        float mx = 0.0f;
 #pragma unroll
         for (int j = 0; j < C::NJ; ++j) {
             v[j] = (f32x4v){0, 0, 0, 0};
             if (src && 4 * (q + C::TPR * j) < p.K)
                 v[j] = *(const f32x4v *)(src + 4 * (q + C::TPR * j));
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                mx = fmaxf(mx, fabsf(v[j][e]));
+        }
+        // the row's largest element: its TPR threads are adjacent lanes
+#pragma unroll
+        for (int off = 1; off < C::TPR; off <<= 1)
+            mx = fmaxf(mx, __shfl_xor(mx, off));
+        const int ea_row = p.a_row_scale ? tt_pow2_exponent(__float_as_uint(mx)) : ea;
+        const float sa = ldexpf(1.0f, ea_row);
+        if (q == 0)
+            tdown[r] = ldexpf(1.0f, -(ea_row + eb));
+        if (p.a_absmax_out) { // one atomic per wave (non-negative floats order like their bit patterns)
+            float mw = mx;
+#pragma unroll
+            for (int off = C::TPR; off < 64; off <<= 1)
+                mw = fmaxf(mw, __shfl_xor(mw, off));
+            if (lane == 0)
+                atomicMax(p.a_absmax_out, __float_as_uint(mw));
         }
         char *dst = lds + r * (C::LDH * 2) + q * 8;
 #pragma unroll
@@ -154,7 +174,7 @@ __global__ __launch_bounds__(WIDE ? 512 : 256, WIDE ? 1 : 2) void gemm_rows16_ke
         for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int e = 0; e < 16; ++e)
-                acc[a][b][e] = bnext[a] * up;
+                acc[a][b][e] = 0.0f;
     h8 ahi[2][2], alo[2][2]; // [parity of the k-step][rt]
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt) {
@@ -169,6 +189,9 @@ __global__ __launch_bounds__(WIDE ? 512 : 256, WIDE ? 1 : 2) void gemm_rows16_ke
     const int mrem = M - row0 - 4 * h; // token offset t of this lane's base row is stored iff t < mrem
     for (int pass = 0; pass < npass; ++pass) {
         const int sbase = pass * NKS * C::FRAGS * 1024; // byte offset of this pass in the wave's stream
+#pragma unroll
+        for (int ct = 0; ct < C::CT; ++ct)
+            bcur[ct] = bnext[ct];
         static_for<0, PER>([&](auto sc) {
             constexpr int s = decltype(sc)::value;
             // A double buffer: k-step s of a pass reads buffer s & 1 and fetches k-step s + 1 into the other one.  The
@@ -198,6 +221,7 @@ __global__ __launch_bounds__(WIDE ? 512 : 256, WIDE ? 1 : 2) void gemm_rows16_ke
 #pragma unroll
                     for (int rt = 0; rt < 2; ++rt)
                         acc[ct][rt] = RS_MFMA(b[2 * ct], ahi[par][rt], acc[ct][rt]);
+#if !(TT_MUTATE_DROP_LO & 4)
 #pragma unroll
                 for (int ct = 0; ct < C::CT; ++ct)
 #pragma unroll
@@ -208,6 +232,7 @@ __global__ __launch_bounds__(WIDE ? 512 : 256, WIDE ? 1 : 2) void gemm_rows16_ke
 #pragma unroll
                     for (int rt = 0; rt < 2; ++rt)
                         acc[ct][rt] = RS_MFMA(b[2 * ct + 1], ahi[par][rt], acc[ct][rt]);
+#endif
             }
             // refill the slot just consumed (or, on a refill-only turn, the slot of this turn) with the k-step RS_NR
             // turns on: k-step s + RS_NR of this pass, or k-step s + RS_NR - PER of the next one
@@ -234,15 +259,20 @@ __global__ __launch_bounds__(WIDE ? 512 : 256, WIDE ? 1 : 2) void gemm_rows16_ke
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-            for (int ct = 0; ct < C::CT; ++ct)
+            for (int rq = 0; rq < 4; ++rq) {
+                // registers 4 rq .. 4 rq + 3 hold tokens 4 h + rt 32 + 8 rq + (0..3): their four down factors in one read
+                const f32x4v dn = *(const f32x4v *)(tdown + 4 * h + rt * 32 + 8 * rq);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int t = rt * 32 + 8 * (r >> 2) + (r & 3);
-                    const float v = acc[ct][rt][r] * down;
-                    acc[ct][rt][r] = bnext[ct] * up; // (the next pass's, if there is one)
-                    if (t < mrem)
-                        cp[(size_t)t * p.ldc + 32 * ct] = v;
-                }
+                for (int ct = 0; ct < C::CT; ++ct)
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) {
+                        const int r = 4 * rq + rr, t = rt * 32 + 8 * rq + rr;
+                        const float v = fmaf(acc[ct][rt][r], dn[rr], bcur[ct]);
+                        acc[ct][rt][r] = 0.0f;
+                        if (t < mrem)
+                            cp[(size_t)t * p.ldc + 32 * ct] = v;
+                    }
+            }
     }
 }
 

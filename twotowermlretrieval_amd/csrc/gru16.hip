@@ -276,10 +276,12 @@ __global__ __launch_bounds__(G16<H>::NW * 64) void gru_seq16_kernel(GruParams p)
             constexpr int t0 = 2 * pair, t1 = 2 * pair + 1;
             acc[t0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[s2 & 1], b[0], acc[t0], 0, 0, 0);
             acc[t1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[s2 & 1], b[1], acc[t1], 0, 0, 0);
+#if !(TT_MUTATE_DROP_LO & 1)
             acc[t0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo[s2 & 1], b[0], acc[t0], 0, 0, 0);
             acc[t1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo[s2 & 1], b[1], acc[t1], 0, 0, 0);
             acc[t0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[s2 & 1], b[2], acc[t0], 0, 0, 0);
             acc[t1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[s2 & 1], b[3], acc[t1], 0, 0, 0);
+#endif
             // refill the ring slots this group consumed: the fragment NR streamed fragments further on (the next
             // step's first ones near the end of this step -- W_hh does not change)
             static_for<0, 4>([&](auto ic) {
@@ -603,10 +605,12 @@ __global__ __launch_bounds__(B16<H>::NW * 64) void gru_bwd16_kernel(GruBwdParams
             });
             acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[q & 1], b[0], acc[0], 0, 0, 0);
             acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[q & 1], b[1], acc[1], 0, 0, 0);
+#if !(TT_MUTATE_DROP_LO & 2)
             acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo[q & 1], b[0], acc[0], 0, 0, 0);
             acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo[q & 1], b[1], acc[1], 0, 0, 0);
             acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[q & 1], b[2], acc[0], 0, 0, 0);
             acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[q & 1], b[3], acc[1], 0, 0, 0);
+#endif
             static_for<0, 4>([&](auto ic) {
                 constexpr int i = decltype(ic)::value, f = f0 + i;
                 constexpr int kind = P::value.kind[f], idx = P::value.idx[f];

@@ -843,18 +843,31 @@ __device__ __forceinline__ unsigned order_key(float f)
     return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
 }
 
+__device__ __forceinline__ float order_key_to_float(unsigned key)
+{
+    return __uint_as_float((key & 0x80000000u) ? (key & 0x7fffffffu) : ~key);
+}
+
+// top_out (nullable): [rows][k], receives the row's k largest values, UNORDERED (the values above the k-th in arrival
+// order, then copies of the k-th; -inf padding when M < k) -- what a shard contributes to the union seed of a sharded
+// search (tt_score_topk_screened_seed_list_f32).
 __global__ __launch_bounds__(256) void kth_largest_kernel(const float *__restrict__ vals, int M, int k,
-                                                          float *__restrict__ out, const int *run_if)
+                                                          float *__restrict__ out, const int *run_if,
+                                                          float *__restrict__ top_out)
 {
     if (run_if && run_if[blockIdx.x >> 5] == 0)
         return;
     __shared__ int hist[256];
     __shared__ int sel[2];
+    __shared__ int wpos;
     const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const float *v = vals + (size_t)row * M;
     if (M < k) {
-        if (tid == 0)
+        if (tid == 0 && out)
             out[row] = -INFINITY;
+        if (top_out)
+            for (int i = tid; i < k; i += 256)
+                top_out[(size_t)row * k + i] = i < M ? v[i] : -INFINITY;
         return;
     }
     unsigned prefix = 0u, mask = 0u;
@@ -919,8 +932,29 @@ __global__ __launch_bounds__(256) void kth_largest_kernel(const float *__restric
         k_rem -= sel[1];
         __syncthreads();
     }
-    if (tid == 0)
-        out[row] = __uint_as_float((prefix & 0x80000000u) ? (prefix & 0x7fffffffu) : ~prefix);
+    const float kth = order_key_to_float(prefix);
+    if (tid == 0 && out)
+        out[row] = kth;
+    if (top_out) {
+        // k - k_rem values are strictly above the k-th (k_rem = the k-th's rank among its equals): they go first, in
+        // arrival order; the remaining k_rem slots are copies of the k-th
+        if (tid == 0)
+            wpos = 0;
+        __syncthreads();
+        float *dst = top_out + (size_t)row * k;
+        if (in_regs) {
+#pragma unroll
+            for (int i = 0; i < KTH_REG; ++i)
+                if (tid + 256 * i < M && keys[i] > prefix)
+                    dst[atomicAdd(&wpos, 1)] = order_key_to_float(keys[i]);
+        } else {
+            for (int m = tid; m < M; m += 256)
+                if (order_key(v[m]) > prefix)
+                    dst[atomicAdd(&wpos, 1)] = v[m];
+        }
+        for (int i = k - k_rem + tid; i < k; i += 256)
+            dst[i] = kth;
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -1319,7 +1353,7 @@ int score_partials(const float *Q, int B, int d, const float *D, int64_t N, int 
         if (rc != TT_OK)
             return rc;
         hipLaunchKernelGGL(kth_largest_kernel, dim3(B), dim3(256), 0, st, (const float *)pp.pval, pl.pre.n_chunks, k,
-                           (float *)(ws + pl.pre_val_off), run_if);
+                           (float *)(ws + pl.pre_val_off), run_if, (float *)nullptr);
         TT_LAUNCH_CHECK();
         thr0 = (const float *)(ws + pl.pre_val_off);
     }
@@ -1432,7 +1466,50 @@ int tt_score_topk_f32_pred(const float *Q, int B, int d, const float *D, int64_t
 // k-th largest of each row of vals [B][M] -> out [B] (internal: threshold seeding of both search paths)
 int tt_kth_largest(const float *vals, int B, int M, int k, float *out, hipStream_t st)
 {
-    hipLaunchKernelGGL(kth_largest_kernel, dim3(B), dim3(256), 0, st, vals, M, k, out, (const int *)nullptr);
+    hipLaunchKernelGGL(kth_largest_kernel, dim3(B), dim3(256), 0, st, vals, M, k, out, (const int *)nullptr, (float *)nullptr);
+    TT_LAUNCH_CHECK();
+    return TT_OK;
+}
+
+// the k largest of each row of vals [B][M] -> list [B][k], unordered (-inf padding when M < k)
+int tt_k_largest_list(const float *vals, int B, int M, int k, float *list, hipStream_t st)
+{
+    hipLaunchKernelGGL(kth_largest_kernel, dim3(B), dim3(256), 0, st, vals, M, k, (float *)nullptr, (const int *)nullptr, list);
+    TT_LAUNCH_CHECK();
+    return TT_OK;
+}
+
+namespace {
+// Union seed of a row-sharded search: lists [world][B][ks] (every shard's ks largest sample maxima per query, as the
+// all-gather left them) -> seed[q] = the ks-th largest of the world * ks values of query q.  Those are approximate scores
+// of world * ks DISTINCT documents (one per 32-document sample tile, the shards' rows are disjoint), so ks documents of the
+// whole corpus score at least seed[q]: a valid lower bound of the global ks-th best approximate score A_ks, and a much
+// tighter one than any single shard's ks-th sample maximum.  One wave per query, rank by counting (world * ks <= 512).
+__global__ __launch_bounds__(64) void seed_union_kernel(const float *__restrict__ lists, int world, int B, int ks,
+                                                        float *__restrict__ seed)
+{
+    const int q = blockIdx.x, lane = threadIdx.x;
+    const int M = world * ks;
+    __shared__ float v[512];
+    for (int i = lane; i < M; i += 64)
+        v[i] = lists[((size_t)(i / ks) * B + q) * ks + (i % ks)];
+    __syncthreads();
+    for (int i = lane; i < M; i += 64) {
+        const float x = v[i];
+        int before = 0; // entries ranking before entry i in (value desc, position asc) order
+        for (int j = 0; j < M; ++j)
+            before += (v[j] > x) || (v[j] == x && j < i);
+        if (before == ks - 1)
+            seed[q] = x; // exactly one entry has this rank (NaNs do not occur: the lists hold MFMA sums of finite inputs)
+    }
+}
+} // namespace
+
+TT_EXPORT int tt_seed_union_f32(const float *lists, int world, int B, int k_seed, float *seed, tt_stream_t stream)
+{
+    if (!lists || !seed || world < 1 || B <= 0 || k_seed < 1 || (int64_t)world * k_seed > 512)
+        return tt_fail(TT_ERR_BAD_SHAPE, "tt_seed_union_f32: world=%d B=%d k_seed=%d (world * k_seed <= 512)", world, B, k_seed);
+    hipLaunchKernelGGL(seed_union_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, lists, world, B, k_seed, seed);
     TT_LAUNCH_CHECK();
     return TT_OK;
 }

@@ -6,7 +6,7 @@
 //
 //   1. screen   approximate scores s16 = <fp16(q), fp16(d)> with fp32 accumulation on
 //               v_mfma_f32_16x16x32_f16 against an fp16 shadow copy of the corpus.  For every pair
-//                   |s16 - s| <= eps_q  with  eps_q = 1.05e-3 |q| Dmax + 1e-6 (|q| + Dmax)
+//                   |s16 - s| <= eps_q  with  eps_q = 1.10e-3 |q| Dmax + 1e-6 (|q| + Dmax)
 //               (fp16 rounding 2^-11 per operand, exact products, fp32 summation of 256 terms on
 //               both sides, fp16 underflow; Dmax = largest document L2 norm; derivation in
 //               DESIGN.md).  A document can be in the exact top-k only if
@@ -43,6 +43,7 @@ int tt_score_topk_f32_pred(const float *Q, int B, int d, const float *D, int64_t
                            const int *run_if, hipStream_t st);
 
 int tt_kth_largest(const float *vals, int B, int M, int k, float *out, hipStream_t st);
+int tt_k_largest_list(const float *vals, int B, int M, int k, float *list, hipStream_t st);
 
 namespace {
 
@@ -68,9 +69,13 @@ struct SCand {
     int x;
 };
 
+// The derivation gives (2^-10 + 2^-22 + 2 * 1.53e-5 + threshold-in-accumulator terms) = 1.023e-3 (DESIGN 4 "K4s"); the worst
+// input family the hardware test can build reaches 0.892 of 1.05e-3 (tests/test_screen_bound_gpu.py).  1.10e-3 leaves 7.5 % over
+// the derivation instead of 2.6 %: a violation has no fallback (a true top-k document would be lost silently), and the
+// wider slack costs about one more survivor per query.
 __device__ __forceinline__ float screen_eps(float qnorm, float dmax)
 {
-    return 1.05e-3f * qnorm * dmax + 1e-6f * (qnorm + dmax);
+    return 1.10e-3f * qnorm * dmax + 1e-6f * (qnorm + dmax);
 }
 
 __device__ __forceinline__ SCand scand_load_l2(const SCand *p)
@@ -1298,7 +1303,8 @@ __global__ void seed_fill_kernel(float *seed, int n)
 }
 
 // phase 0: the whole search.  phase 1: query image + sample pass; seed[q] <- the k_seed-th largest sample maximum (nothing
-// else).  phase 2: the screen with the caller's seed[] as thresholds (the workspace still holds phase 1's query image and
+// else); phase 3: the same, but seed[q][0..k_seed) <- the k_seed LARGEST sample maxima, unordered (a shard's share of the
+// union seed: tt_seed_union_f32).  phase 2: the screen with the caller's seed[] as thresholds (the workspace still holds phase 1's query image and
 // flags), finish, predicated exact kernels.
 int screened_impl(const char *who, int phase, const float *Q, int B, int d, const float *D32, const void *D16, int64_t N, int k,
                   int k_seed, float dmax_norm, int64_t idx_offset, float *out_val, int64_t *out_idx, int32_t *fallback_flag,
@@ -1314,9 +1320,10 @@ int screened_impl(const char *who, int phase, const float *Q, int B, int d, cons
         return tt_fail(TT_ERR_UNSUPPORTED, "%s: N too large; shard the corpus", who);
     if (!(dmax_norm >= 0.0f) || !(dmax_norm < 60000.0f))
         return tt_fail(TT_ERR_UNSUPPORTED, "%s: corpus norm %g outside the fp16 range", who, dmax_norm);
-    if (!Q || !D16 || !fallback_flag || (phase != 1 && (!D32 || !out_val || !out_idx)) || (phase != 0 && !seed))
+    const bool seed_only = phase == 1 || phase == 3;
+    if (!Q || !D16 || !fallback_flag || (!seed_only && (!D32 || !out_val || !out_idx)) || (phase != 0 && !seed))
         return tt_fail(TT_ERR_BAD_SHAPE, "%s: null pointer", who);
-    if (phase == 1 && (k_seed < 1 || k_seed > k))
+    if (seed_only && (k_seed < 1 || k_seed > k))
         return tt_fail(TT_ERR_BAD_SHAPE, "%s: k_seed=%d outside [1, k=%d]", who, k_seed, k);
     const SPlan pl = make_splan(B, N, k);
     const size_t need = pl.ws_bytes + tt_score_topk_workspace_bytes(B, N, d, k);
@@ -1403,8 +1410,9 @@ int screened_impl(const char *who, int phase, const float *Q, int B, int d, cons
     if (phase == 2) {
         sp.thr0 = seed;
         sp.thr0_stride = 1;
-    } else if (!pl.sample && phase == 1) {
-        hipLaunchKernelGGL(seed_fill_kernel, dim3((B + 255) / 256), dim3(256), 0, st, seed, B);
+    } else if (!pl.sample && seed_only) {
+        const int n = phase == 3 ? B * k_seed : B;
+        hipLaunchKernelGGL(seed_fill_kernel, dim3((n + 255) / 256), dim3(256), 0, st, seed, n);
         TT_LAUNCH_CHECK();
     } else if (pl.sample) {
         ScreenParams ss = sp;
@@ -1418,13 +1426,16 @@ int screened_impl(const char *who, int phase, const float *Q, int B, int d, cons
         int rc = launch(ss, pl.s_blocks, true);
         if (rc != TT_OK)
             return rc;
-        rc = tt_kth_largest(ss.max_val, B, pl.s_tiles, phase == 1 ? k_seed : k, phase == 1 ? seed : (float *)(ws + pl.sthr_val_off), st);
+        if (phase == 3)
+            rc = tt_k_largest_list(ss.max_val, B, pl.s_tiles, k_seed, seed, st);
+        else
+            rc = tt_kth_largest(ss.max_val, B, pl.s_tiles, phase == 1 ? k_seed : k, phase == 1 ? seed : (float *)(ws + pl.sthr_val_off), st);
         if (rc != TT_OK)
             return rc;
         sp.thr0 = (const float *)(ws + pl.sthr_val_off);
         sp.thr0_stride = 1;
     }
-    if (phase == 1)
+    if (seed_only)
         return TT_OK;
     if (prof_events)
         TT_HIP_CHECK(hipEventRecord((hipEvent_t)prof_events[0], st));
@@ -1474,6 +1485,14 @@ TT_EXPORT int tt_score_topk_screened_seed_f32(const float *Q, int B, int d, cons
 {
     return screened_impl("tt_score_topk_screened_seed_f32", 1, Q, B, d, nullptr, D16, N, k, k_seed, dmax_norm, 0, nullptr, nullptr,
                          fallback_flag, seed, workspace, workspace_bytes, nullptr, (hipStream_t)stream);
+}
+
+TT_EXPORT int tt_score_topk_screened_seed_list_f32(const float *Q, int B, int d, const void *D16, int64_t N, int k, int k_seed,
+                                                   float dmax_norm, int32_t *fallback_flag, float *seed_list, void *workspace,
+                                                   size_t workspace_bytes, tt_stream_t stream)
+{
+    return screened_impl("tt_score_topk_screened_seed_list_f32", 3, Q, B, d, nullptr, D16, N, k, k_seed, dmax_norm, 0, nullptr,
+                         nullptr, fallback_flag, seed_list, workspace, workspace_bytes, nullptr, (hipStream_t)stream);
 }
 
 TT_EXPORT int tt_score_topk_screened_seeded_f32(const float *Q, int B, int d, const float *D32, const void *D16, int64_t N,

@@ -33,6 +33,13 @@ struct SgemmParams {
     // call instead of once per workgroup that touches a tile of it.  Null: B is split on the fly like A.
     const void *b_hi16, *b_lo16;
     int64_t ldb16;
+    // tt_gemm_rows16 only.  a_row_scale != 0: every A row (an embedding vector gathered through a_map) is scaled by ITS OWN
+    // power of two (row maximum -> [2^13, 2^14)) before the split, undone on that row's accumulators: fp32-grade for tables of
+    // any magnitude, and -- unlike a batch-wide scale -- a row's result does not depend on which other rows share the launch.
+    // a_absmax_out (nullable): receives atomicMax of the bit pattern of max |A element| over the rows of this launch (the
+    // weight-gradient product over the same rows takes its X scale from it).
+    int a_row_scale = 0;
+    unsigned *a_absmax_out = nullptr;
 };
 
 // exponent e with max|x| 2^e in [2^13, 2^14) (0 for an all-zero or non-finite tensor)
@@ -71,6 +78,9 @@ int tt_gemm_rows16(const SgemmParams &p, hipStream_t st);
 
 // bit pattern of max |x| over n floats -> *out (atomicMax; the caller zeroes *out on the stream first)
 int tt_absmax(const float *x, int64_t n, unsigned *out, hipStream_t st);
+
+// the same over the gathered rows x[map[r]][0..K), r < min(M, *m_dyn) (K, ld multiples of 4)
+int tt_absmax_rows(const float *x, int64_t ld, int K, const int32_t *map, int M, const int *m_dyn, unsigned *out, hipStream_t st);
 
 // out[i] (+)= sum_z slabs[z][i], fixed order (deterministic split-K reduction)
 int tt_slab_reduce(const float *slabs, int nslab, int64_t n, float *out, int accumulate, hipStream_t st);

@@ -358,6 +358,7 @@ __global__ __launch_bounds__(256) void sgemm16_kernel(SgemmParams p)
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt)
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[nt], ah[mt], acc[mt][nt], 0, 0, 0);
+#if !(TT_MUTATE_DROP_LO & 8)
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -368,6 +369,7 @@ __global__ __launch_bounds__(256) void sgemm16_kernel(SgemmParams p)
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt)
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[nt], ah[mt], acc[mt][nt], 0, 0, 0);
+#endif
         }
         __syncthreads();
     }
@@ -443,6 +445,30 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float *__restrict__ x
     } else {
         for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride)
             m = fmaxf(m, fabsf(x[i]));
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1)
+        m = fmaxf(m, __shfl_xor(m, off));
+    if ((threadIdx.x & 63) == 0)
+        part[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        atomicMax(out, __float_as_uint(fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3]))));
+}
+
+// the same over the rows map[0 .. min(M, *m_dyn)) of a [.][ld] table, K (a multiple of 4) elements each: the embedding vectors
+// of a packed batch (shapes the token-stationary K1, which finds this maximum on the way, does not take)
+__global__ __launch_bounds__(256) void absmax_rows_kernel(const float *__restrict__ x, int64_t ld, int K, const int32_t *__restrict__ map,
+                                                          int M, const int *__restrict__ m_dyn, unsigned *__restrict__ out)
+{
+    __shared__ float part[4];
+    const int m_eff = m_dyn ? min(M, *m_dyn) : M;
+    const int kq = K >> 2;
+    float m = 0.0f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < (int64_t)m_eff * kq; i += (int64_t)gridDim.x * 256) {
+        const int row = (int)(i / kq), c = (int)(i % kq);
+        const f32x4 v = *(const f32x4 *)(x + (size_t)map[row] * ld + 4 * c);
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1)
@@ -590,6 +616,17 @@ int tt_absmax(const float *x, int64_t n, unsigned *out, hipStream_t st)
         return TT_OK;
     const int64_t want = (n + 1023) / 1024; // one 16-byte load per thread and pass
     hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)(want > 64 ? 64 : want)), dim3(256), 0, st, x, n, out);
+    TT_LAUNCH_CHECK();
+    return TT_OK;
+}
+
+int tt_absmax_rows(const float *x, int64_t ld, int K, const int32_t *map, int M, const int *m_dyn, unsigned *out, hipStream_t st)
+{
+    if (M <= 0 || K <= 0 || (K & 3) || (ld & 3))
+        return TT_OK;
+    const int64_t want = ((int64_t)M * (K >> 2) + 1023) / 1024;
+    hipLaunchKernelGGL(absmax_rows_kernel, dim3((unsigned)(want > 64 ? 64 : (want < 1 ? 1 : want))), dim3(256), 0, st, x, ld, K, map, M,
+                       m_dyn, out);
     TT_LAUNCH_CHECK();
     return TT_OK;
 }

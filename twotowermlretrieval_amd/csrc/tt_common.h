@@ -40,4 +40,13 @@ static inline size_t tt_align_up(size_t x, size_t a) { return (x + a - 1) / a * 
 // (tools/experiments/encoder_graph_flags.py; small stand-alone graphs do not show it: memset_graph.hip).
 int tt_zero_async(void *p, size_t bytes, hipStream_t st);
 
+// MUTATION SWITCH, never set in the product build (tools/mutation_guard.py builds the variants): a bit mask of f16-split
+// kernels whose `lo` products (hi*lo and lo*hi) are compiled out, which turns "fp32-grade" into plain fp16 (2^-11 per
+// product).  The parity tests' tolerances must be tight enough to FAIL on every one of them.
+//   1 = K2 gru_seq16 (forward recurrence)   2 = K7 gru_bwd16 (backward recurrence)
+//   4 = K1 gemm_rows16 (input projection)   8 = sgemm16 (weight gradients, input gradients, tiled K1)
+#ifndef TT_MUTATE_DROP_LO
+#define TT_MUTATE_DROP_LO 0
+#endif
+
 #define TT_WAVE 64

@@ -21,7 +21,7 @@ import torch
 from . import _lib
 
 __all__ = ["GraphedSearch", "score_topk", "topk_merge", "score_rank", "score_all", "BruteForceIndex", "ShardedIndex", "PendingSearch", "StreamedIndex",
-           "shard_bounds"]
+           "shard_bounds", "seed_union"]
 
 
 def _stream(t: torch.Tensor) -> int:
@@ -170,12 +170,13 @@ class BruteForceIndex:
     def ntotal(self) -> int:
         return self.docs.shape[0]
 
-    def search(self, q: torch.Tensor, k: int = 10, _prof_events=None, out=None, _seed_exchange=None,
+    def search(self, q: torch.Tensor, k: int = 10, _prof_events=None, out=None, _seed_union=None,
                _k_seed: int = 0) -> Tuple[torch.Tensor, torch.Tensor]:
         """out: optional (vals f32 [B,k], idx int64 [B,k]) contiguous device tensors to write into (2-D q only).
-        _seed_exchange (ShardedIndex): a callable that turns this shard's seed thresholds [B] f32 (the _k_seed-th largest
-        sample maximum per query) into the maximum over the ranks, in place, on the current stream; the screen then runs
-        with the GLOBAL seed and `out` holds this shard's documents above it (tt_score_topk_screened_seed(ed)_f32)."""
+        _seed_union (ShardedIndex): a callable that turns this shard's seed list [B, _k_seed] f32 (its _k_seed largest
+        sample maxima per query, tt_score_topk_screened_seed_list_f32) into the seed thresholds [B] f32 -- the _k_seed-th
+        largest of the UNION of the ranks' lists (one all-gather + tt_seed_union_f32) -- on the current stream; the screen
+        then runs with that global seed and `out` holds this shard's documents above it."""
         B = 1 if q.dim() == 1 else q.shape[0]
         N, d = self.docs.shape
         L = _lib.lib()
@@ -205,12 +206,15 @@ class BruteForceIndex:
                 need = L.tt_score_topk_screened_workspace_bytes(B, N, d, k)
                 ws_s = torch.empty(need, dtype=torch.uint8, device=self.docs.device)
                 flags = torch.empty((B + 31) // 32, dtype=torch.int32, device=self.docs.device)
-                if _seed_exchange is not None:
-                    seed = torch.empty(B, dtype=torch.float32, device=self.docs.device)
-                    _lib.check(L.tt_score_topk_screened_seed_f32(q.data_ptr(), B, d, self.docs16.data_ptr(), N, k,
-                                                                 min(_k_seed or k, k), self.dmax_norm, flags.data_ptr(),
-                                                                 seed.data_ptr(), ws_s.data_ptr(), ws_s.numel(), _stream(q)))
-                    _seed_exchange(seed)
+                if _seed_union is not None:
+                    ks = min(_k_seed or k, k)
+                    lst = torch.empty((B, ks), dtype=torch.float32, device=self.docs.device)
+                    _lib.check(L.tt_score_topk_screened_seed_list_f32(q.data_ptr(), B, d, self.docs16.data_ptr(), N, k, ks,
+                                                                      self.dmax_norm, flags.data_ptr(), lst.data_ptr(),
+                                                                      ws_s.data_ptr(), ws_s.numel(), _stream(q)))
+                    seed = _seed_union(lst)
+                    if seed.shape != (B,) or seed.dtype != torch.float32 or not seed.is_contiguous():
+                        raise ValueError("_seed_union must return a contiguous float32 [B] tensor")
                     _lib.check(L.tt_score_topk_screened_seeded_f32(q.data_ptr(), B, d, self._sdocs.data_ptr(),
                                                                    self.docs16.data_ptr(), N, k, self.dmax_norm,
                                                                    self.idx_offset, vals.data_ptr(), idx.data_ptr(),
@@ -296,13 +300,26 @@ def _exchange_and_merge(vals: torch.Tensor, idx: torch.Tensor, k: int, merge: Ca
     return merge(gv, gi, k)
 
 
-def _no_exchange(seed: torch.Tensor) -> None:
-    """(hook of BruteForceIndex.search's two-phase form: the seed thresholds could be combined across ranks here)"""
+def seed_union(lists: torch.Tensor, world: int) -> torch.Tensor:
+    """lists [world, B, ks] f32 (every rank's ks largest sample maxima per query) -> seed [B]: the ks-th largest of each
+    query's world * ks values (tt_seed_union_f32), on the current stream."""
+    world_, B, ks = lists.shape
+    assert world_ == world and lists.is_contiguous() and lists.dtype == torch.float32
+    seed = torch.empty(B, dtype=torch.float32, device=lists.device)
+    with torch.cuda.device(lists.device):
+        _lib.check(_lib.lib().tt_seed_union_f32(lists.data_ptr(), world, B, ks, seed.data_ptr(), _stream(lists)))
+    return seed
+
+
+def _local_seed(lst: torch.Tensor) -> torch.Tensor:
+    """No exchange: the union over one shard is that shard's own ks-th largest sample maximum."""
+    return seed_union(lst.unsqueeze(0), 1)
 
 
 class _Slot:
-    """One set of exchange buffers of a ShardedIndex (two of them: a step's all-gather + merge overlaps the next
-    step's search): send block [vals f32 [B,kp] | idx int64 [B,kp]], receive buffer of `world` such blocks, outputs."""
+    """One set of exchange buffers of a ShardedIndex (three per shape: two that submit() alternates between -- a step's
+    all-gather + merge overlaps the next step's search -- and one of search()'s own): send block [vals f32 [B,kp] |
+    idx int64 [B,kp]], receive buffer of `world` such blocks, outputs."""
 
     def __init__(self, B: int, kp: int, k: int, world: int, dev):
         self.nv = (B * kp * 4 + 7) // 8 * 8           # idx block 8-byte aligned
@@ -316,10 +333,14 @@ class _Slot:
         self.searched = torch.cuda.Event()
         self.merged = torch.cuda.Event()
 
+    def tensors(self):
+        return (self.send, self.recv, self.out_v, self.out_i)
+
 
 class PendingSearch:
     """Result of ShardedIndex.submit(): result() makes the CURRENT stream wait for the exchange + merge (no host
-    synchronisation) and returns (values, indices) views valid until two more submits on the same index."""
+    synchronisation) and returns (values, indices) views valid until two more submits of the same shape on the same
+    index (search() has a slot of its own and never overwrites them)."""
 
     def __init__(self, slot: _Slot):
         self._slot = slot
@@ -354,15 +375,39 @@ class ShardedIndex:
         self._n_submitted = 0
         self._xs: Optional[torch.cuda.Stream] = None
 
-    def _local_search(self, q: torch.Tensor, kp: int, k: int, sl: "_Slot") -> None:
+    def _local_search(self, q: torch.Tensor, kp: int, k: int, sl: "_Slot", comm_stream=None) -> None:
         """This shard's list for the exchange: up to kp = max(k, shard_k) entries, best first.  The screen is seeded for
-        the FINAL k, not for kp: the global top-k is contained in the union of the shards' top-k, so a shard only has to list
-        its documents above ITS k-th-best threshold -- the kp-th sample maximum is a much weaker seed, and on a small shard
-        the candidates that get through, not the matrix pipes, set the screen's pace (1.25M rows, kp = 50, k = 10:
-        0.785 -> 0.650 ms per step, tools/experiments/global_seed_time.py).  Entries beyond the shard's top-k may be missing
-        (padding: -inf / -1); the merge ignores padding."""
-        if kp > k:
-            self._index.search(q, kp, out=(sl.send_v, sl.send_i), _seed_exchange=_no_exchange, _k_seed=k)
+        the FINAL k with the UNION seed: every rank lists its k largest sample maxima per query, ONE small all-gather
+        (k floats per query and rank: 40 KB per rank at B = 1024), and seed[q] = the k-th largest of the union -- k distinct
+        documents of the whole corpus reach it, so it bounds the global k-th score from below as well as the unsharded
+        search's own sample would (a shard's own k-th sample maximum is much weaker, and on a small shard the candidates
+        that get through, not the matrix pipes, set the screen's pace: 1.25M rows, emulated 8 shards, 0.640 -> 0.582 ms).
+        The shard then owes the exchange only its documents above that global threshold: entries beyond them are padding
+        (-inf / -1), which the merge ignores; the merged top-k is exact (two real-kernel ranks vs the oracle,
+        tests/test_multirank_gpu.py).
+        comm_stream: the stream the seed all-gather is issued on (submit(): the index's exchange stream, so that ALL
+        collectives of this index go out on one stream in one order); None = the caller's."""
+        coll, world = self._coll, self._coll.world
+
+        def union(lst: torch.Tensor) -> torch.Tensor:
+            if world == 1:
+                return _local_seed(lst)
+            recv = torch.empty((world,) + tuple(lst.shape), dtype=torch.float32, device=lst.device)
+            send_b, recv_b = lst.view(-1).view(torch.uint8), recv.view(-1).view(torch.uint8)
+            if comm_stream is None:
+                coll.all_gather_blocks(send_b, recv_b)
+            else:
+                cur = torch.cuda.current_stream(lst.device)
+                comm_stream.wait_stream(cur)
+                with torch.cuda.stream(comm_stream):
+                    lst.record_stream(comm_stream)
+                    recv.record_stream(comm_stream)
+                    coll.all_gather_blocks(send_b, recv_b)
+                cur.wait_stream(comm_stream)
+            return seed_union(recv, world)
+
+        if self._index.docs16 is not None:
+            self._index.search(q, kp, out=(sl.send_v, sl.send_i), _seed_union=union, _k_seed=k)
         else:
             self._index.search(q, kp, out=(sl.send_v, sl.send_i))
 
@@ -394,10 +439,20 @@ class ShardedIndex:
             local = embed_corpus(model, tokenizer, documents[lo:hi], device)
         return cls(local, lo, group=group, **kw)
 
+    _MAX_SLOT_SHAPES = 8
+
     def _slot(self, B: int, kp: int, k: int, which: int) -> _Slot:
+        """which: 0 / 1 = the two slots submit() alternates between, 2 = search()'s own (a search() between a submit() and
+        its .result() must not overwrite that PendingSearch's outputs).  Slot sets are kept per (B, kp, k) shape; when
+        more than _MAX_SLOT_SHAPES shapes have been seen the oldest set is retired, after its queued exchanges have
+        completed (its buffers are used on the exchange stream, which the caching allocator does not know about)."""
         key = (B, kp, k, self._coll.world)
         if key not in self._slots:
-            self._slots = {key: [_Slot(B, kp, k, self._coll.world, self._index.docs.device) for _ in range(2)]}
+            while len(self._slots) >= self._MAX_SLOT_SHAPES:
+                old = self._slots.pop(next(iter(self._slots)))
+                for sl in old:
+                    sl.merged.synchronize()
+            self._slots[key] = [_Slot(B, kp, k, self._coll.world, self._index.docs.device) for _ in range(3)]
         return self._slots[key][which]
 
     def _exchange_merge(self, sl: _Slot, B: int, kp: int, k: int) -> None:
@@ -413,9 +468,9 @@ class ShardedIndex:
             v, i = self.search(q.unsqueeze(0), k)
             return v[0], i[0]
         kp = max(k, self.shard_k)
-        sl = self._slot(q.shape[0], kp, k, 0)
+        sl = self._slot(q.shape[0], kp, k, 2)
         cur = torch.cuda.current_stream(sl.send.device)
-        cur.wait_event(sl.merged)  # a pipelined step may still own this slot
+        cur.wait_event(sl.merged)  # (a search() on another stream may still own the slot)
         self._local_search(q, kp, k, sl)
         self._exchange_merge(sl, q.shape[0], kp, k)
         sl.merged.record(cur)
@@ -435,10 +490,12 @@ class ShardedIndex:
             self._xs = torch.cuda.Stream(device=dev)
         cur = torch.cuda.current_stream(dev)
         cur.wait_event(sl.merged)            # the slot's previous exchange has read its send block
-        self._local_search(q, kp, k, sl)
+        self._local_search(q, kp, k, sl, comm_stream=self._xs if self._coll.world > 1 else None)
         sl.searched.record(cur)
         with torch.cuda.stream(self._xs):
             self._xs.wait_event(sl.searched)
+            for t in sl.tensors():           # allocated on the caller's stream, used on the exchange stream
+                t.record_stream(self._xs)
             self._exchange_merge(sl, B, kp, k)
             sl.merged.record(self._xs)
         return PendingSearch(sl)

@@ -190,8 +190,12 @@ class RNNEncoder(nn.Module):
                 raise TypeError("parameters must be float32")
 
     def invalidate_prepared(self) -> None:
-        """Drop the cached kernel-form weights.  Needed only after writing the weights through raw pointers: in-place torch
-        ops, load_state_dict, .to() and FusedClipAdam are noticed by themselves (tensor version counters / addresses)."""
+        """Drop the cached kernel-form weights.  The cache is keyed on every weight's (address, tensor version counter), so
+        in-place torch ops ON THE PARAMETER (`w.mul_()`, `w.copy_()` under no_grad), load_state_dict, .to() and
+        FusedClipAdam.step / DataParallelTrainer.broadcast_parameters are noticed by themselves.  NOT noticed -- call this
+        afterwards: writes through `w.data` (`w.data.copy_(...)` leaves the counter alone), through another view of the same
+        storage (an optimizer's flat buffer: FusedClipAdam.mark_params_changed does the bump for its own), or through raw
+        pointers."""
         self._prep = {}
 
     def _prepared_weights(self, device: torch.device, quads, wptr) -> Optional[torch.Tensor]:

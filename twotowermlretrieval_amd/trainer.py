@@ -93,10 +93,15 @@ class _FlatClipAdam:
         self.step_count += 1
         self._step_fn(self.flat_params, self.flat_grads, self.exp_avg, self.exp_avg_sq, self.step_count, self.lr,
                       self.betas, self.eps, self.max_norm, 1.0 / self.world, self.total_norm, self._scratch)
-        # the kernel wrote the parameters through raw pointers: tell torch (and RNNEncoder's cache of kernel-form
-        # weights, keyed on these counters) that they changed
-        torch.autograd.graph.increment_version(self.params)
+        self.mark_params_changed()
         return self.total_norm
+
+    def mark_params_changed(self) -> None:
+        """Call after ANY write to `flat_params` that did not go through the parameters themselves (this class's own step,
+        a broadcast into the flat buffer, a checkpoint copied into it): the parameters are views whose version counters are
+        separate from the flat buffer's, and RNNEncoder keys its cache of kernel-form weights on those counters -- without
+        the bump an eval forward would keep serving the weights of before the write."""
+        torch.autograd.graph.increment_version(self.params)
 
 
 class FusedClipAdam(_FlatClipAdam):
@@ -276,6 +281,7 @@ class DataParallelTrainer:
         import torch.distributed as dist
         if dist.is_initialized() and dist.get_world_size(self.optimizer.group) > 1:
             dist.broadcast(self.optimizer.flat_params, src=src, group=self.optimizer.group)
+        self.optimizer.mark_params_changed()  # (the broadcast wrote the flat buffer, not the parameter tensors)
 
     def step(self, queries, pos_docs, neg_docs) -> torch.Tensor:
         self.model.train()
