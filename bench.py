@@ -13,13 +13,16 @@ global top-10 on every rank (strong scaling: the corpus is fixed, the shard shri
 Rank 0 prints ONE JSON line.
 
 Extra legs on rank 0 (untimed w.r.t. `value`): `roofline` (the step's dominant kernel,
-screen_kernel<false>, timed alone with HIP events recorded around its launch), `roofline_exact_f32`
-(the plain fp32-MFMA kernel on the same batch), `roofline_hbm` (a serving-size batch, B=32: the
-streaming form of the screen, bound by HBM streaming of the fp16 shadow corpus),
-`roofline_hbm_exact_f32` (the fp32 kernel at B=32), `encoder` / `train` (SURVEY 8d's secondary metrics: tower
-tokens/s, index-build tokens/s, training triplets/s on synthetic MS-MARCO-shaped batches, each with its fp32-MFMA
-fraction), and at N=1 `cpu_baseline` (the reference's torch CPU idiom on a bounded sample; `cpu_baseline.legs` holds
-the other rows of BASELINE.md section 2: B=64 scoring, doc-tower forward, train step).
+screen_kernel<false>, timed alone with HIP events recorded around its launch) and, nested under `roofline.legs` so that
+the driver's record carries them: `mfma_exact_f32` (the plain fp32-MFMA kernel on the same batch), `hbm_screen` (a
+serving-size batch, B=32: the streaming form of the screen, bound by HBM streaming of the fp16 shadow corpus -- the
+regime north_star's ">= 70 % of HBM" is graded in), `hbm_exact_f32` (the fp32 kernel at B=32), `encoder` / `train`
+(SURVEY 8d's secondary metrics: tower tokens/s, index-build tokens/s, training triplets/s on synthetic
+MS-MARCO-shaped batches, each with its fp32-MFMA fraction), `encoder_corpus` (the same search over a corpus of
+document-tower outputs with query-tower outputs as queries: queries/s, what the filter let through, fallback count);
+and at N=1 `cpu_baseline` (the reference's torch CPU idioms: `value` = the bench batch on a 1M-document sample scaled
+x10; `cpu_baseline.legs` holds BASELINE.md section 2's rows run at their own sizes, incl. B=64 over all 10M documents,
+the 512-passage doc-tower forward and the 512-triplet train step).
 """
 from __future__ import annotations
 
@@ -163,32 +166,42 @@ def pmc_traffic(name: str):
 
 
 def cpu_baseline(q_gpu, docs_gpu, enc_inputs=None):
-    """The reference's torch CPU idioms (oracle/torch_ref.py) on this box's host cores, bounded samples."""
+    """The reference's torch CPU idioms (oracle/torch_ref.py) on this box's host cores: BASELINE.md section 2's rows at
+    their own sizes.  `value` is the bench batch (B=1024) on the first 1M documents scaled x10 -- the full 10M x 1024 score
+    matrix would be 41 GB, which BASELINE.md excludes; every other row is RUN at the size it names."""
     from oracle import torch_ref
     n_s = 1_000_000
     cores = min(len(os.sched_getaffinity(0)), 64)
     torch.set_num_threads(cores)
     qs = q_gpu.cpu()
-    ds = docs_gpu[:n_s].cpu()
-    t = torch_ref.time_scoring_idiom(qs, ds, TOPK, warmup=1, reps=3)
+    dfull = docs_gpu.cpu()                      # 10.24 GB of host memory
+    ds = dfull[:n_s]
+    t = torch_ref.time_scoring_idiom(qs, ds, TOPK, warmup=1, reps=5)
     scale = N_DOCS / n_s
     out = {"value": round(BATCH / (t * scale), 2), "unit": "queries/s", "cores": cores, "kind": "port",
            "sample": f"B={BATCH} queries x first {n_s} of the {N_DOCS} docs, torch.matmul+torch.topk on CPU "
-                     f"(reference idiom evaluators.py:185-186), median of 3 = {t:.3f} s, time scaled x{scale:.0f}"}
-    legs = {}
-    t64 = torch_ref.time_scoring_idiom(qs[:64].contiguous(), ds, TOPK, warmup=1, reps=3)
-    legs["scoring_b64"] = {"value": round(64 / (t64 * scale), 2), "unit": "queries/s",
-                           "sample": f"B=64 x first {n_s} docs, median of 3 = {t64:.3f} s, time scaled x{scale:.0f}"}
+                     f"(reference idiom evaluators.py:185-186), median of 5 = {t:.3f} s, time scaled x{scale:.0f} "
+                     f"(the full pass would materialise a 41 GB score matrix: BASELINE.md section 2 skips it)"}
+    legs = {"scoring_b1024_n1m": {"value": round(BATCH / t, 1), "unit": "queries/s",
+                                  "sample": f"B={BATCH} x N={n_s}, as run (no scaling), median of 5 = {t:.3f} s"}}
+    q64 = qs[:64].contiguous()
+    t64 = torch_ref.time_scoring_idiom(q64, ds, TOPK, warmup=1, reps=5)
+    legs["scoring_b64_n1m"] = {"value": round(64 / t64, 1), "unit": "queries/s",
+                               "sample": f"B=64 x N={n_s}, as run, median of 5 = {t64:.3f} s"}
+    t64f = torch_ref.time_scoring_idiom(q64, dfull, TOPK, warmup=1, reps=3)
+    legs["scoring_b64_n10m"] = {"value": round(64 / t64f, 2), "unit": "queries/s",
+                                "sample": f"B=64 x N={dfull.shape[0]} (2.6 GB score matrix), as run, median of 3 = {t64f:.3f} s"}
+    del dfull, ds
     if enc_inputs is not None:
         table, q_ids, p_ids, n_ids = enc_inputs
-        nb = 64  # bounded sample: 64 rows of each 512-row batch (the reference's BATCH_SIZE)
+        nb = q_ids.shape[0]  # the whole 512-row batches of the GPU legs
         qt, dt = torch_ref.TorchTower(table, ENC_H, seed=0), torch_ref.TorchTower(table, ENC_H, seed=1)
-        qc, pc, nc = q_ids[:nb].cpu(), p_ids[:nb].cpu(), n_ids[:nb].cpu()
-        tf = torch_ref.time_tower_forward(dt, pc, warmup=1, reps=3)
+        qc, pc, nc = q_ids.cpu(), p_ids.cpu(), n_ids.cpu()
+        tf = torch_ref.time_tower_forward(dt, pc, warmup=1, reps=5)
         ptok = int((pc != 0).sum())
         legs["doc_tower_forward"] = {"value": round(ptok / tf), "unit": "tokens/s",
                                      "sample": f"{nb} passages ({ptok} tokens), nn.Embedding + nn.GRU + F.normalize "
-                                               f"(model.py:48-75), median of 3 = {tf:.3f} s"}
+                                               f"(model.py:48-75), median of 5 = {tf:.3f} s"}
         tt_ = torch_ref.time_train_step(qt, dt, qc, pc, nc, margin=0.5, lr=5e-5, warmup=1, reps=3)
         legs["train_step"] = {"value": round(nb / tt_, 1), "unit": "triplets/s",
                               "sample": f"{nb} triplets per step (main.py:244-259: 3 forwards, loss, backward, "
@@ -215,6 +228,76 @@ def make_ids(rs, B, mean, lo, hi, V):
         z[0] = max(z[0], 1)
         ids[b, :L[b]] = z
     return torch.from_numpy(ids), int((ids != 0).sum())
+
+
+def make_ids_bulk(rs, B, mean, lo, hi, V):
+    """make_ids's distribution drawn in one vectorised call per batch (millions of passages: the per-row loop is ~25 us a row)."""
+    import numpy as np
+    L = np.clip(rs.poisson(mean, B), lo, hi).astype(np.int64)
+    T = int(L.max())
+    z = (rs.zipf(1.07, int(L.sum())) % V).astype(np.int64)
+    start = np.concatenate([[0], np.cumsum(L)[:-1]])
+    z[start] = np.maximum(z[start], 1)                      # first token of every row non-zero
+    ids = np.zeros((B, T), dtype=np.int64)
+    rows = np.repeat(np.arange(B), L)
+    cols = np.arange(int(L.sum())) - np.repeat(start, L)
+    ids[rows, cols] = z
+    return torch.from_numpy(ids)
+
+
+def encoder_corpus_leg(dev, model, n_docs=2_097_152, seed=11):
+    """The screened search on embeddings the ENCODER produces (north_star: "synthetic MS-MARCO-shaped queries/passages"):
+    corpus = document-tower outputs for n_docs synthetic Zipf passages (model.py:71-74: unit rows, but anisotropic --
+    nothing like the isotropic randn rows of the headline corpus), queries = query-tower outputs.  Reports queries/s at
+    B = 1024 and B = 32, what the fp16 filter let through (pooled candidates / survivors per query), the exact-kernel
+    fallback count, and checks the results bit for bit against the plain fp32 kernel (K4)."""
+    import numpy as np
+    import twotowermlretrieval_amd as tt
+    rs = np.random.RandomState(seed)
+    model.eval()
+    D = torch.empty((n_docs, ENC_H), dtype=torch.float32, device=dev)
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        for lo in range(0, n_docs, 8192):
+            n = min(8192, n_docs - lo)
+            D[lo:lo + n] = model.encode_document(make_ids_bulk(rs, n, 70, 10, 250, ENC_V).to(dev))
+        q = model.encode_query(make_ids_bulk(rs, BATCH, 6, 1, 30, ENC_V).to(dev))
+    torch.cuda.synchronize()
+    t_build = time.perf_counter() - t0
+    ix = tt.BruteForceIndex(D, screen=True)
+    assert ix.docs16 is not None
+    ix.keep_stats = True
+    # how far from isotropic: mean pairwise cosine of a sample, spread of one query's scores over the corpus
+    samp = D[torch.randint(0, n_docs, (2048,), device=dev)]
+    mean_cos = float(((samp @ samp.t()).sum() - 2048) / (2048 * 2047))
+    sc = q[:64] @ D[:262144].t()
+    out = {"docs": n_docs, "corpus": "doc-tower outputs (1-layer GRU, random init, Zipf(1.07) passages ~Poisson(70))",
+           "queries": "query-tower outputs (~Poisson(6) tokens)", "mean_pairwise_cos": round(mean_cos, 4),
+           "score_std_per_query": round(float(sc.std(dim=1).mean()), 5), "index_build_s_incl_host_id_generation": round(t_build, 2)}
+    for B in (BATCH, 32):
+        qb = q[:B].contiguous()
+        t = time_search(ix, qb, TOPK)
+        v, i = ix.search(qb, TOPK)
+        st = ix.search_stats().to(torch.float32)
+        flags = int(ix.fallback_flags.ne(0).sum().item())
+        ev, ei = tt.score_topk(qb, D, TOPK)
+        ms_k = screen_kernel_ms(ix, qb, TOPK, iters=10, warm=2)
+        leg = {"queries_per_s": round(B / t * 1e3, 1), "search_ms": round(t, 4), "screen_kernel_ms": round(ms_k, 4),
+               "pooled_per_query_mean": round(float(st[:, 0].mean()), 1), "pooled_per_query_max": int(st[:, 0].max()),
+               "survivors_per_query_mean": round(float(st[:, 1].mean()), 1), "survivors_per_query_max": int(st[:, 1].max()),
+               "exact_fallback_tiles": flags, "identical_to_exact_f32": bool(torch.equal(v, ev) and torch.equal(i, ei))}
+        if B == 32:
+            byts = n_docs * DIM * 2 + 32 * DIM * 4
+            leg.update({"bound": "hbm", "achieved": round(byts / ms_k / 1e6, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                        "frac": round(byts / ms_k / 1e6 / HBM_PEAK_GBPS, 4)})
+        else:
+            fl = 2.0 * B * n_docs * DIM
+            leg.update({"bound": "mfma", "achieved": round(fl / ms_k / 1e9, 2), "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(fl / ms_k / 1e9 / MFMA_F16_PEAK_TFLOPS, 4)})
+        out[f"b{B}"] = leg
+    del ix, D
+    torch.cuda.empty_cache()
+    return out
 
 
 def _time_gpu(fn, iters, warm):
@@ -285,9 +368,9 @@ def encoder_legs(dev):
                      "input checking",
              "TFLOPs": round(tf, 2), "frac_f32_mfma": round(tf / MFMA_F32_PEAK_TFLOPS, 4),
              "frac_f16_mfma_3x": round(3.0 * tf / MFMA_F16_PEAK_TFLOPS, 4)}
-    del m, opt
+    del opt
     torch.cuda.empty_cache()
-    return enc, train, (table, q, p, n)
+    return enc, train, (table, q, p, n), m
 
 
 def launch_ranks(n: int) -> int:
@@ -325,7 +408,8 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the encoder / train legs")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the encoder / train / encoder-corpus legs")
+    ap.add_argument("--no-encoder-corpus", action="store_true", help="skip the encoder-produced-corpus leg (~20 s)")
     a = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
@@ -447,18 +531,29 @@ def main():
                                    f"passages resident in HBM (BASELINE configs[3]; configs[1] batch), row-sharded "
                                    f"over {world} GPU(s), screened path (f16-MFMA filter + exact fp32 rescoring, "
                                    f"bit-identical to the fp32 kernel)"
-                                   + (f", per-shard lists of up to {SHARD_K} (every document above the shard's own "
-                                      f"top-{TOPK} threshold) + RCCL all-gather + merge" if world > 1 else ""),
+                                   + (f", union seed (all-gather of every rank's {TOPK} largest sample maxima per query), "
+                                      f"per-shard lists of up to {SHARD_K} (the shard's documents above the global "
+                                      f"threshold) + RCCL all-gather + merge" if world > 1 else ""),
                        "n_docs": N_DOCS, "dim": DIM, "batch": BATCH, "k": TOPK, "parallelism": f"rowshard{world}",
                        "collective": index.collective if world > 1 else None},
-            "roofline": roof, "roofline_exact_f32": roof_f32, "roofline_hbm": roof_hbm,
-            "roofline_hbm_exact_f32": roof_hbm_f32,
+            "roofline": roof,
         }
+        # every other leg rides INSIDE `roofline` (the driver's record keeps `roofline` and `cpu_baseline` whole):
+        #   hbm_screen      north_star's ">= 70 % of HBM" regime: the streaming screen at B = 32 over the fp16 shadow corpus
+        #   hbm_exact_f32   the plain fp32 kernel at B = 32 (N x 1024 bytes)
+        #   mfma_exact_f32  the plain fp32 kernel on the bench batch (the strict-precision reading of the step)
+        #   encoder_corpus  the same index over embeddings the encoder produces (anisotropic), with the filter's statistics
+        #   encoder, train  SURVEY 8d's secondary metrics (tower / index-build tokens/s, training triplets/s)
+        roof["legs"] = {"hbm_screen": roof_hbm, "hbm_exact_f32": roof_hbm_f32, "mfma_exact_f32": roof_f32}
         enc_inputs = None
         if not a.no_secondary:
             del index, local_index
             torch.cuda.empty_cache()
-            line["encoder"], line["train"], enc_inputs = encoder_legs(dev)
+            roof["legs"]["encoder"], roof["legs"]["train"], enc_inputs, model = encoder_legs(dev)
+            if not a.no_encoder_corpus:
+                roof["legs"]["encoder_corpus"] = encoder_corpus_leg(dev, model)
+            del model
+            torch.cuda.empty_cache()
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(q, docs, enc_inputs)
         print(json.dumps(line), flush=True)

@@ -105,6 +105,10 @@ int tt_index_build_f16(const float *D, int64_t N, int d, void *D16, float *stats
 int tt_index_build_from_bf16(const void *D_bf16, int64_t N, int d, float *D32, void *D16, float *stats,
                              int reset_stats, tt_stream_t stream);
 size_t tt_score_topk_screened_workspace_bytes(int B, int64_t N, int d, int k);
+/* Byte offset, inside the workspace of a finished screened search of this (B, N, k), of its per-query statistics:
+ * int32 [B][2] = (candidates pooled over the whole corpus, survivors rescored exactly).  Diagnostic: how much the filter
+ * let through on the caller's data; read it after the call, before the workspace is reused. */
+size_t tt_score_topk_screened_stats_offset(int B, int64_t N, int d, int k);
 int tt_score_topk_screened_f32(const float *Q, int B, int d, const float *D32, const void *D16, int64_t N, int k,
                                float dmax_norm, int64_t idx_offset, float *out_val, int64_t *out_idx,
                                int32_t *fallback_flag, void *workspace, size_t workspace_bytes,

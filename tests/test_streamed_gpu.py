@@ -26,3 +26,45 @@ def test_streamed_equals_oracle_on_widened_corpus(oracle, B, N, block, k, screen
     assert abs(ix.dmax_norm - float(D.to(torch.float32).norm(dim=1).max())) < 1e-5
     rv, ri = ix.resident().search(torch.from_numpy(Q).cuda(), k)                    # widened once into HBM: same answer
     assert torch.equal(ri, i) and torch.equal(rv, v)
+
+
+def test_streamed_index_at_shard_scale_4m_rows(oracle):
+    """configs[4] near its own size: a 4.2M-row bf16 corpus (2.1 GB) in PINNED host memory, streamed
+    in 1M-row blocks (the last one ragged).  streamed == resident (widened once into HBM) == the plain fp32 kernel for every
+    query of a large and of a serving-size batch, and == the CPU oracle over all rows for four of them."""
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+    import twotowermlretrieval_amd as tt
+    dev = torch.device("cuda:0")
+    N = 4_200_003
+    host = torch.empty((N, 256), dtype=torch.bfloat16).pin_memory()
+    g = torch.Generator(device=dev).manual_seed(17)
+    for lo in range(0, N, 1_000_000):
+        hi = min(N, lo + 1_000_000)
+        x = torch.randn((hi - lo, 256), device=dev, generator=g)
+        x /= x.norm(dim=1, keepdim=True)
+        host[lo:hi].copy_(x.to(torch.bfloat16))
+    torch.cuda.synchronize()
+    Q = torch.randn((200, 256), device=dev, generator=g)
+    Q /= Q.norm(dim=1, keepdim=True)
+    Q[3] = host[4_100_000].to(dev).to(torch.float32)          # a document of the LAST (ragged) block as a query
+    Q[3] /= Q[3].norm()
+    ix = tt.StreamedIndex(host, block_docs=1 << 20, idx_offset=7)
+    assert ix.host.is_pinned() and ix._d16[0] is not None
+    res = ix.resident()
+    full32 = res.docs                                          # the corpus widened to fp32 (exact), resident
+    for B in (200, 32):
+        q = Q[:B].contiguous()
+        sv, si = ix.search(q, 10)
+        rv, ri = res.search(q, 10)
+        ev, ei = tt.score_topk(q, full32, 10, idx_offset=7)
+        torch.cuda.synchronize()
+        assert torch.equal(si, ri) and torch.equal(sv, rv), B
+        assert torch.equal(si, ei) and torch.equal(sv, ev), B
+    assert int(si[3, 0]) == 4_100_000 + 7
+    rows = [0, 3, 17, 31]
+    d_np = full32.cpu().numpy()
+    with ThreadPoolExecutor(min(4, len(os.sched_getaffinity(0)))) as ex:
+        got = list(ex.map(lambda r: oracle.score_topk(Q[r:r + 1].cpu().numpy(), d_np, 10, idx_offset=7), rows))
+    for r, (ov, oi) in zip(rows, got):
+        assert np.array_equal(si[r].cpu().numpy(), oi[0]) and np.array_equal(sv[r].cpu().numpy(), ov[0]), r

@@ -29,6 +29,7 @@ SIGNATURES = {
     "tt_index_build_f16": (_i, [_vp, _i64, _i, _vp, _vp, _vp]),
     "tt_index_build_from_bf16": (_i, [_vp, _i64, _i, _vp, _vp, _vp, _i, _vp]),
     "tt_score_topk_screened_workspace_bytes": (_sz, [_i, _i64, _i, _i]),
+    "tt_score_topk_screened_stats_offset": (_sz, [_i, _i64, _i, _i]),
     "tt_score_topk_screened_seed_f32": (_i, [_vp, _i, _i, _vp, _i64, _i, _i, _f, _vp, _vp, _vp, _sz, _vp]),
     "tt_score_topk_screened_seed_list_f32": (_i, [_vp, _i, _i, _vp, _i64, _i, _i, _f, _vp, _vp, _vp, _sz, _vp]),
     "tt_seed_union_f32": (_i, [_vp, _i, _i, _i, _vp, _vp]),

@@ -36,14 +36,36 @@ struct Rccl {
     bool ok = false;
 };
 
+// The RCCL library itself: a mapped object whose BASENAME is librccl.so or librccl.so.<version> -- not a plugin that merely
+// carries the name (librccl-net.so, librccl_tuner.so ...: binding one of those leaves every symbol below unresolved).
 int find_loaded_rccl(struct dl_phdr_info *info, size_t, void *data)
 {
     const char *name = info->dlpi_name;
-    if (name && strstr(name, "librccl")) {
+    if (!name)
+        return 0;
+    const char *base = strrchr(name, '/');
+    base = base ? base + 1 : name;
+    if (strncmp(base, "librccl.so", 10) == 0 && (base[10] == '\0' || base[10] == '.')) {
         strncpy((char *)data, name, 511);
         return 1;
     }
     return 0;
+}
+
+bool bind_rccl(Rccl &x)
+{
+#define TT_SYM(field, name) *(void **)(&x.field) = dlsym(x.handle, name)
+    TT_SYM(GetUniqueId, "ncclGetUniqueId");
+    TT_SYM(CommInitRank, "ncclCommInitRank");
+    TT_SYM(CommDestroy, "ncclCommDestroy");
+    TT_SYM(CommCount, "ncclCommCount");
+    TT_SYM(CommUserRank, "ncclCommUserRank");
+    TT_SYM(AllGather, "ncclAllGather");
+    TT_SYM(AllReduce, "ncclAllReduce");
+    TT_SYM(GetErrorString, "ncclGetErrorString");
+#undef TT_SYM
+    return x.GetUniqueId && x.CommInitRank && x.CommDestroy && x.CommCount && x.CommUserRank && x.AllGather && x.AllReduce &&
+           x.GetErrorString;
 }
 
 // Resolved once per process (function-local static: thread-safe initialisation, immutable afterwards).
@@ -55,28 +77,22 @@ const Rccl &rccl()
         dl_iterate_phdr(find_loaded_rccl, loaded);
         if (loaded[0])
             x.handle = dlopen(loaded, RTLD_NOW | RTLD_NOLOAD);
-        if (!x.handle)
-            x.handle = dlopen("librccl.so.1", RTLD_NOW);
-        if (!x.handle)
-            x.handle = dlopen("librccl.so", RTLD_NOW);
-        if (!x.handle)
-            return x;
-        if (loaded[0])
+        if (x.handle && loaded[0]) {
             strncpy(x.path, loaded, sizeof(x.path) - 1);
-        else
-            strncpy(x.path, "librccl.so.1 (opened by libtt.so)", sizeof(x.path) - 1);
-#define TT_SYM(field, name) *(void **)(&x.field) = dlsym(x.handle, name)
-        TT_SYM(GetUniqueId, "ncclGetUniqueId");
-        TT_SYM(CommInitRank, "ncclCommInitRank");
-        TT_SYM(CommDestroy, "ncclCommDestroy");
-        TT_SYM(CommCount, "ncclCommCount");
-        TT_SYM(CommUserRank, "ncclCommUserRank");
-        TT_SYM(AllGather, "ncclAllGather");
-        TT_SYM(AllReduce, "ncclAllReduce");
-        TT_SYM(GetErrorString, "ncclGetErrorString");
-#undef TT_SYM
-        x.ok = x.GetUniqueId && x.CommInitRank && x.CommDestroy && x.CommCount && x.CommUserRank && x.AllGather &&
-               x.AllReduce && x.GetErrorString;
+            x.ok = bind_rccl(x);
+        }
+        if (!x.ok) { // nothing mapped (a C host that has not touched RCCL yet), or the mapped object lacks the symbols
+            for (const char *cand : {"librccl.so.1", "librccl.so"}) {
+                void *h = dlopen(cand, RTLD_NOW);
+                if (!h)
+                    continue;
+                x.handle = h;
+                snprintf(x.path, sizeof(x.path), "%s (opened by libtt.so)", cand);
+                x.ok = bind_rccl(x);
+                if (x.ok)
+                    break;
+            }
+        }
         return x;
     }();
     return r;

@@ -811,6 +811,7 @@ struct FinishParams {
     float *out_val;
     int64_t *out_idx;
     int q_per_block; // candidate layout [query group][chunk][q_per_block][SCAP]: 512 (shared tiles) or 32 (streaming)
+    int *stats;      // [B][2]: pooled candidates, survivors (>= A_k - 2 eps) of each query -- what the filter let through
 };
 
 __device__ __forceinline__ bool before_f(float sa, int ia, float sb, int ib) { return sa > sb || (sa == sb && ia < ib); }
@@ -1017,6 +1018,10 @@ __global__ __launch_bounds__(256) void screen_finish_kernel(FinishParams p)
         }
         sv_v[tid] = acc;
     }
+    if (tid == 0) {
+        p.stats[2 * row] = n_pool;
+        p.stats[2 * row + 1] = n_surv;
+    }
     if (__syncthreads_or(too_many) && tid == 0)
         atomicOr(p.flag + (row >> 5), 4);
     // ---- exact top-k of the survivors: every thread ranks its own survivor against all others ----
@@ -1140,7 +1145,7 @@ struct SPlan {
     bool sample;
     int s_tiles, s_chunks, s_tiles_per_chunk, s_blocks;
     int64_t s_docs;
-    size_t cand_off, pcnt_off, smax_val_off, sthr_val_off, qimg_off, qnorm_off, ws_bytes, lds;
+    size_t cand_off, pcnt_off, smax_val_off, sthr_val_off, qimg_off, qnorm_off, stats_off, ws_bytes, lds;
     int rows_pad; // n_qgroups * q_per_block
 };
 
@@ -1244,6 +1249,8 @@ SPlan make_splan(int B, int64_t N, int k)
     off = tt_align_up(off + rows * sizeof(float), 256);
     pl.tailctr_off = off;
     off = tt_align_up(off + (size_t)pl.n_qgroups * sizeof(int), 256);
+    pl.stats_off = off;
+    off = tt_align_up(off + rows * 2 * sizeof(int), 256);
     pl.ws_bytes = off;
     pl.lds = pl.stream ? (size_t)TW * TSTAGE * TSLAB_BYTES : (size_t)SRING * STILE_BYTES;
     return pl;
@@ -1292,6 +1299,17 @@ TT_EXPORT size_t tt_score_topk_screened_workspace_bytes(int B, int64_t N, int d,
     if (B <= 0 || N <= 0)
         return 0;
     return make_splan(B, N, k).ws_bytes + tt_score_topk_workspace_bytes(B, N, d, k);
+}
+
+// Where a finished screened search left its per-query statistics in the caller's workspace: int32 [B][2] = (pooled
+// candidates, survivors within 2 eps of the k-th best approximate score) -- how much the filter let through on THIS data
+// (bench.py reports it for encoder-produced corpora; queries recomputed by the exact fallback keep the screen's counts).
+TT_EXPORT size_t tt_score_topk_screened_stats_offset(int B, int64_t N, int d, int k)
+{
+    (void)d;
+    if (B <= 0 || N <= 0)
+        return 0;
+    return make_splan(B, N, k).stats_off;
 }
 
 namespace {
@@ -1462,6 +1480,7 @@ int screened_impl(const char *who, int phase, const float *Q, int B, int d, cons
     fp.idx_offset = idx_offset;
     fp.out_val = out_val;
     fp.out_idx = out_idx;
+    fp.stats = (int *)(ws + pl.stats_off);
     hipLaunchKernelGGL(screen_finish_kernel, dim3(B), dim3(256), (size_t)(2 * pl.n_chunks + 1) * sizeof(int), st, fp);
     TT_LAUNCH_CHECK();
     // exact kernel, a no-op unless a workgroup raised the flag; then it rewrites every output row

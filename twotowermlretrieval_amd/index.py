@@ -135,6 +135,8 @@ class BruteForceIndex:
         self.docs16: Optional[torch.Tensor] = None
         self.dmax_norm = float("nan")
         self.fallback_flags = torch.zeros(1, dtype=torch.int32, device=self.docs.device)  # per 32-query tile
+        self.keep_stats = False   # True: the most recent screened search's workspace is kept for search_stats()
+        self._last_ws = None
         N, d = self.docs.shape
         self._sdocs = self.docs  # what the screened path scores against: [N,256] fp32
         if screen and N > 0 and (d == 256 or (d < 256 and d % 4 == 0)):
@@ -164,11 +166,22 @@ class BruteForceIndex:
         self.docs, self.docs16, self.dmax_norm, self.idx_offset = docs32, docs16, float(dmax_norm), int(idx_offset)
         self._sdocs = docs32
         self.fallback_flags = torch.zeros(1, dtype=torch.int32, device=docs32.device)
+        self.keep_stats, self._last_ws = False, None
         return self
 
     @property
     def ntotal(self) -> int:
         return self.docs.shape[0]
+
+    def search_stats(self) -> Optional[torch.Tensor]:
+        """int32 [B,2] = (pooled candidates, survivors rescored exactly) per query of the most recent screened search made
+        with keep_stats = True, or None.  Diagnostic: what the fp16 filter let through on this corpus."""
+        if self._last_ws is None:
+            return None
+        ws, B, k = self._last_ws
+        with torch.cuda.device(self.docs.device):
+            off = _lib.lib().tt_score_topk_screened_stats_offset(B, self.docs.shape[0], 256, k)
+        return ws[off:off + 8 * B].view(torch.int32).view(B, 2).clone()
 
     def search(self, q: torch.Tensor, k: int = 10, _prof_events=None, out=None, _seed_union=None,
                _k_seed: int = 0) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -206,6 +219,8 @@ class BruteForceIndex:
                 need = L.tt_score_topk_screened_workspace_bytes(B, N, d, k)
                 ws_s = torch.empty(need, dtype=torch.uint8, device=self.docs.device)
                 flags = torch.empty((B + 31) // 32, dtype=torch.int32, device=self.docs.device)
+                if self.keep_stats:
+                    self._last_ws = (ws_s, B, k)
                 if _seed_union is not None:
                     ks = min(_k_seed or k, k)
                     lst = torch.empty((B, ks), dtype=torch.float32, device=self.docs.device)
