@@ -211,7 +211,11 @@ int tt_score_all_f32(const float *Q, int B, int d, const float *D, int64_t N, fl
  * Lengths are computed on the device; nothing synchronises with the host.  Data errors cannot be
  * returned synchronously, so they are reported through `status` (device int32, nullable), written
  * on the stream: bit 0 = a row with no non-zero id (the reference raises RuntimeError), bit 1 = an
- * id outside [0,V) (IndexError).  Such rows produce finite garbage, never a fault.
+ * id outside [0,V) (IndexError).  Such rows produce finite garbage, never a fault.  bit 2 = the column-split GRU
+ * recurrence (H = 256, B <= 1024: a row group's gate columns on four workgroups that hand the hidden state to each other
+ * every step, csrc/gru16x4.hip) gave up waiting for a partner workgroup: its waits are bounded, so a workgroup that is
+ * never scheduled ends the call with this bit instead of a hang; the outputs are then invalid (TT_GRU_SPLIT=0 in the
+ * environment selects the one-workgroup kernel, whose results are bit-identical).
  * train != 0 keeps the activations the backward pass needs inside the workspace: the SAME workspace
  * (sized with train = 1) must then be passed, untouched, to tt_encoder_backward_f32.
  * Supported: H multiple of 32 in [32,512], E multiple of 4, 1 <= num_layers <= 4.

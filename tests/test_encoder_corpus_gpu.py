@@ -1,8 +1,8 @@
 """The screened search on embeddings the ENCODER produces (backend/model.py:71-74, backend/evaluators.py:185-186).
 
 Every other search test (and the headline bench corpus) uses isotropic randn unit rows -- the friendliest distribution a
-threshold screen can meet.  Tower outputs are anisotropic: with random-init GRU weights all rows share a large common component,
-scores crowd together and the 2-eps slack of the fp16 filter covers far more documents.  Here: 200 k document-tower outputs of
+threshold screen can meet.  Tower outputs are anisotropic: with random-init GRU weights the rows share a common component (mean
+pairwise cosine ~0.14 instead of 0), so scores crowd together and the 2-eps slack of the fp16 filter covers more documents.  Here: 200 k document-tower outputs of
 Zipf passages, 160 query-tower outputs, both screen forms, bit-identical to the CPU oracle (values and indices), with what the
 filter let through and the exact-kernel fallback count asserted."""
 import os
@@ -42,7 +42,7 @@ def test_screened_search_over_encoder_outputs_is_bit_identical_to_the_oracle(ora
     # the corpus really is anisotropic (isotropic unit rows in 256-d: mean cosine 0, score std 1/16)
     samp = D[:2048]
     mean_cos = float(((samp @ samp.t()).sum() - 2048) / (2048 * 2047))
-    assert mean_cos > 0.2, mean_cos
+    assert mean_cos > 0.05, mean_cos     # (2048 isotropic unit rows: 0 +- 0.0014; these: ~0.14)
     ix = tt.BruteForceIndex(D, screen=True)
     assert ix.docs16 is not None
     ix.keep_stats = True

@@ -438,3 +438,70 @@ def test_status_word_is_written_not_accumulated(B, T):
     with pytest.raises(IndexError):
         enc(torch.from_numpy(bad_id).cuda())
     assert torch.isfinite(enc(torch.from_numpy(base).cuda())).all()
+
+
+def _with_split(flag, fn):
+    """Run fn with the column-split recurrence (gru16x4.hip) on or off: libtt reads TT_GRU_SPLIT at every call."""
+    import os
+    old = os.environ.get("TT_GRU_SPLIT")
+    os.environ["TT_GRU_SPLIT"] = "1" if flag else "0"
+    try:
+        return fn()
+    finally:
+        if old is None:
+            os.environ.pop("TT_GRU_SPLIT", None)
+        else:
+            os.environ["TT_GRU_SPLIT"] = old
+
+
+@pytest.mark.parametrize("B,T,layers,bi", [(70, 40, 1, False), (5, 250, 1, False), (1024, 33, 1, False), (1, 7, 1, False),
+                                          (300, 21, 2, True), (512, 12, 1, True), (17, 9, 3, False)])
+def test_column_split_recurrence_is_bit_identical_to_the_one_cu_kernel(B, T, layers, bi):
+    """gru_seq16x4_kernel (a row group's gate columns on four CUs, hidden state handed over through tagged granules every
+    step) against gru_seq16_kernel: same products in the same order -> the SAME BITS, in eval mode and, in train mode, for
+    every gradient (the backward reads the stash the forward kernel wrote).  Ragged lengths, one-row batches, 64 teams
+    (every CU taken), both directions in one launch, stacked layers."""
+    V, E, H, seed = 400, 300, 256, 900 + B
+    enc, table, sd = make_encoder(V, E, H, seed, layers, bi)
+    ids = torch.from_numpy(synth.make_ids(seed + 5, B, T, V, zero_inside=0.05)).cuda()
+    enc.cache_prepared = False
+    with torch.no_grad():
+        one = _with_split(False, lambda: enc(ids).clone())
+        four = _with_split(True, lambda: enc(ids).clone())
+    torch.cuda.synchronize()
+    assert torch.equal(one, four)
+    assert torch.isfinite(four).all() and float(four.norm(dim=1).min()) > 0.99
+    if B <= 300:
+        enc.train()
+        d_out = torch.from_numpy(np.random.RandomState(seed).standard_normal((B, H)).astype(np.float32)).cuda()
+
+        def grads(flag):
+            enc.zero_grad()
+            y = _with_split(flag, lambda: enc(ids))
+            _with_split(flag, lambda: y.backward(d_out))
+            return [p.grad.clone() for p in enc._flat_params()], y.detach().clone()
+        g1, y1 = grads(False)
+        g4, y4 = grads(True)
+        torch.cuda.synchronize()
+        assert torch.equal(y1, y4) and all(torch.equal(a, b) for a, b in zip(g1, g4))
+
+
+def test_column_split_recurrence_with_both_towers_in_flight():
+    """The train step launches the query tower and the 2B-row document tower on two streams: 32 + 64 teams = 384 workgroups
+    for 256 CUs, so members of some teams wait for a CU while their partners already sweep for them.  Three steps with the
+    split kernels must leave the same parameters, bit for bit, as three steps with the one-CU kernels."""
+    import copy
+    import twotowermlretrieval_amd as tt
+    V, E, H, B = 500, 300, 256, 512
+    torch.manual_seed(5)
+    m1 = tt.TwoTowerModel({"VOCAB_SIZE": V, "EMBED_DIM": E, "HIDDEN_DIM": H}, synth.make_table(4, V, E)).cuda().train()
+    m2 = copy.deepcopy(m1)
+    o1 = tt.FusedClipAdam(m1.parameters(), lr=1e-3, max_norm=1.0)
+    o2 = tt.FusedClipAdam(m2.parameters(), lr=1e-3, max_norm=1.0)
+    for step in range(3):
+        ids = [torch.from_numpy(synth.make_ids(60 + 3 * step + s, B, T, V)).cuda() for s, T in enumerate((9, 60, 70))]
+        l1 = _with_split(False, lambda: tt.train_step(m1, o1, *ids, margin=0.5))
+        l2 = _with_split(True, lambda: tt.train_step(m2, o2, *ids, margin=0.5))
+        torch.cuda.synchronize()
+        assert float(l1.item()) == float(l2.item()), step
+    assert torch.equal(o1.flat_params, o2.flat_params)

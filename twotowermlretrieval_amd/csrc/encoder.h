@@ -27,6 +27,7 @@ struct EncLayout {
     size_t gi[2];                                // scratch: input projections [MT][ng H] per direction
     size_t wp[2];                                // scratch: W_hh packed for the MFMA B operand
     size_t wih16[2];                             // scratch: W_ih split into fp16 hi | lo images [ng H][Kp] each
+    size_t xch;                                  // column-split recurrence (gru16x4.hip): the teams' hand-off granules; 0 = none
     size_t fwd_end;
     // backward scratch (train only)
     size_t d_hfin;                               // [ndir][B][H]
@@ -66,6 +67,11 @@ __host__ __device__ static inline float tt_dropout_scale(uint64_t seed, int laye
     const uint32_t thresh = t >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)t;
     return u >= thresh ? 1.0f / (1.0f - p) : 0.0f;
 }
+
+// csrc/gru16x4.hip: the GRU recurrence (H = 256) with a row group's gate columns split over four CUs; bit-identical to
+// gru16_launch.  gru16x4_xch_bytes: hand-off scratch for B rows (0 when H != 256; host-only arithmetic, no GPU call).
+size_t gru16x4_xch_bytes(int B, int H, int ndir);
+bool gru16x4_usable(int B, int H, int ndir); // this device has a CU for every member of every team (and TT_GRU_SPLIT != 0)
 
 static inline EncLayout enc_layout(int B, int T, int E, int H, int L, int bidir, int train, int dropout = 0,
                                    int cell = CELL_GRU)
@@ -110,6 +116,10 @@ static inline EncLayout enc_layout(int B, int T, int E, int H, int L, int bidir,
             const int in_w = E > lo.ndir * H ? E : lo.ndir * H;
             lo.wih16[d] = d < lo.ndir ? take((size_t)2 * sizeof(uint16_t) * ng * H * ((in_w + 31) / 32 * 32)) : 0;
         }
+    }
+    {
+        const size_t xb = cell == CELL_GRU ? gru16x4_xch_bytes(B, H, lo.ndir) : 0;
+        lo.xch = xb ? take(xb) : 0;
     }
     lo.fwd_end = off;
     lo.d_hfin = lo.d_hid = lo.slabs = 0;
@@ -237,3 +247,4 @@ int gru16_pack(const float *W_hh, int H, unsigned *absmax, void *wp16, hipStream
 int gru16_launch(const GruParams &gp, int ndir, hipStream_t st);
 int gru16_pack_t(const float *W_hh, int H, const unsigned *absmax, void *wtp16, hipStream_t st);
 int gru16_bwd_launch(const GruBwdParams &bp, int ndir, hipStream_t st);
+int gru16x4_launch(const GruParams &gp, int ndir, void *xch, int32_t *status, hipStream_t st);

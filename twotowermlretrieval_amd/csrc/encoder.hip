@@ -711,7 +711,12 @@ static int encoder_forward(const char *who, const int64_t *ids, int B, int T, co
         }
         if (ndir == 1)
             gp.dir[1] = gp.dir[0];
-        if (use16) {
+        if (use16 && lo.xch && gru16x4_usable(B, H, ndir)) {
+            // a row group's gate columns on four CUs (gru16x4.hip): same bits out, ~half the time per step
+            rc = gru16x4_launch(gp, ndir, ws + lo.xch, status, st);
+            if (rc != TT_OK)
+                return rc;
+        } else if (use16) {
             rc = gru16_launch(gp, ndir, st);
             if (rc != TT_OK)
                 return rc;

@@ -114,6 +114,9 @@ def _or_all(status_tensors) -> int:
 
 
 def _raise_status(status: int) -> None:
+    if status & 4:
+        raise RuntimeError("libtt: the column-split GRU recurrence gave up waiting for a partner workgroup (bounded hand-off "
+                           "sweep, csrc/gru16x4.hip); the call's outputs are invalid.  TT_GRU_SPLIT=0 selects the one-CU kernel")
     if status & 2:
         raise IndexError("index out of range in self")  # nn.Embedding's message (tests/golden/g10_errors.json)
     if status & 1:
