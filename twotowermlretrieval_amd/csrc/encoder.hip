@@ -64,10 +64,17 @@ int enc_cus()
     return cus;
 }
 
-// Single block of 1024 threads: tok_off = exclusive scan of len; perm = rows sorted by length, longest first.
-__device__ __forceinline__ void scan_sort_block(const int32_t *len, int B, int T, int32_t *tok_off, int32_t *perm)
+// Single block of 1024 threads: tok_off = exclusive scan of len; perm = rows sorted by length, longest first, rows of equal
+// length (bin) in ASCENDING ROW ORDER: the counting sort's scatter hands out a bin's slots by LDS atomics in whatever order
+// the waves arrive, so it goes into `tmp` (>= B ints of scratch the caller does not need yet) and every row is then placed at
+// its bin's start + the number of smaller row numbers in that bin.  perm decides which rows share a 16-row recurrence
+// workgroup, and the backward kernels sum the bias gradients per workgroup: with an arbitrary order inside a bin those sums
+// (not the weight gradients, which are token-parallel) changed in their last bits from one run to the next.
+__device__ __forceinline__ void scan_sort_block(const int32_t *len, int B, int T, int32_t *tok_off, int32_t *perm,
+                                                int32_t *tmp)
 {
     __shared__ int hist[SORT_BINS];
+    __shared__ int hstart[SORT_BINS];
     __shared__ int wsum[16];
     __shared__ int carry;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -130,18 +137,30 @@ __device__ __forceinline__ void scan_sort_block(const int32_t *len, int B, int T
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             hist[tid * 4 + i] = run;
+            hstart[tid * 4 + i] = run;
             run += loc[i];
         }
         __syncthreads();
     }
     for (int b = tid; b < B; b += 1024)
-        perm[atomicAdd(&hist[bin_of(len[b])], 1)] = b;
+        tmp[atomicAdd(&hist[bin_of(len[b])], 1)] = b;
+    __syncthreads(); // (hist[bin] is now the END of the bin's segment; tmp is visible to the whole block)
+    for (int i = tid; i < B; i += 1024) {
+        const int b = tmp[i];
+        const int bin = bin_of(len[b]);
+        const int s0 = hstart[bin], s1 = hist[bin];
+        int rank = s0;
+        for (int jj = s0; jj < s1; ++jj)
+            rank += tmp[jj] < b;
+        perm[rank] = b;
+    }
 }
 
 __global__ __launch_bounds__(1024) void prep_scan_sort_kernel(const int32_t *__restrict__ len, int B, int T,
-                                                              int32_t *__restrict__ tok_off, int32_t *__restrict__ perm)
+                                                              int32_t *__restrict__ tok_off, int32_t *__restrict__ perm,
+                                                              int32_t *tmp)
 {
-    scan_sort_block(len, B, T, tok_off, perm);
+    scan_sort_block(len, B, T, tok_off, perm, tmp);
 }
 
 // The whole prep in ONE workgroup for small batches (B <= 1024 rows, B*T <= 8192 ids: every query-tower call): clears the
@@ -200,7 +219,7 @@ __global__ __launch_bounds__(1024) void prep_fused_kernel(const int64_t *__restr
         flag[tid] = tid == 0 ? st_bits : 0;
     if (tid == 0 && status)
         status[0] = st_bits;
-    scan_sort_block(len, B, T, tok_off, perm);
+    scan_sort_block(len, B, T, tok_off, perm, packed); // (the packed ids are written below: until then their buffer is scratch)
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < PREP_FUSED_PER; ++i) {
@@ -600,7 +619,7 @@ static int encoder_forward(const char *who, const int64_t *ids, int B, int T, co
     } else {
         TT_RC_CHECK(tt_zero_async(flag, 256, st));
         hipLaunchKernelGGL(prep_len_kernel, dim3((B + 3) / 4), dim3(256), 0, st, ids, B, T, V, len, flag);
-        hipLaunchKernelGGL(prep_scan_sort_kernel, dim3(1), dim3(1024), 0, st, len, B, T, tok_off, perm);
+        hipLaunchKernelGGL(prep_scan_sort_kernel, dim3(1), dim3(1024), 0, st, len, B, T, tok_off, perm, idsp);
         hipLaunchKernelGGL(prep_pack_ids_kernel, dim3(B), dim3(256), 0, st, ids, B, T, len, tok_off, V, idsp);
         TT_LAUNCH_CHECK();
         if (status)
