@@ -440,27 +440,32 @@ def test_status_word_is_written_not_accumulated(B, T):
     assert torch.isfinite(enc(torch.from_numpy(base).cuda())).all()
 
 
-def _with_split(flag, fn):
-    """Run fn with the column-split recurrence (gru16x4.hip) on or off: libtt reads TT_GRU_SPLIT at every call."""
+def _with_split(flag, fn, bwd=None):
+    """Run fn with the column-split recurrences (gru16x4.hip) on or off: libtt reads TT_GRU_SPLIT (both directions of time) and
+    TT_GRU_SPLIT_BWD (the reverse-time one alone) at every call."""
     import os
-    old = os.environ.get("TT_GRU_SPLIT")
-    os.environ["TT_GRU_SPLIT"] = "1" if flag else "0"
+    keys = {"TT_GRU_SPLIT": "1" if flag else "0", "TT_GRU_SPLIT_BWD": "1" if (flag if bwd is None else bwd) else "0"}
+    old = {k: os.environ.get(k) for k in keys}
+    os.environ.update(keys)
     try:
         return fn()
     finally:
-        if old is None:
-            os.environ.pop("TT_GRU_SPLIT", None)
-        else:
-            os.environ["TT_GRU_SPLIT"] = old
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
 
 
 @pytest.mark.parametrize("B,T,layers,bi", [(70, 40, 1, False), (5, 250, 1, False), (1024, 33, 1, False), (1, 7, 1, False),
                                           (300, 21, 2, True), (512, 12, 1, True), (17, 9, 3, False)])
-def test_column_split_recurrence_is_bit_identical_to_the_one_cu_kernel(B, T, layers, bi):
+def test_column_split_recurrence_vs_the_one_cu_kernels(B, T, layers, bi):
     """gru_seq16x4_kernel (a row group's gate columns on four CUs, hidden state handed over through tagged granules every
-    step) against gru_seq16_kernel: same products in the same order -> the SAME BITS, in eval mode and, in train mode, for
-    every gradient (the backward reads the stash the forward kernel wrote).  Ragged lengths, one-row batches, 64 teams
-    (every CU taken), both directions in one launch, stacked layers."""
+    step) against gru_seq16_kernel: same products in the same order -> the SAME BITS, in eval mode and in train mode, stash
+    included: with the split forward and the one-CU backward every gradient is bit-identical to the all-one-CU run.
+    gru_bwd16x4_kernel splits the REDUCTION (four partial chains per column, summed in member order): its gradients agree
+    with the one-CU backward to the tests' gradient tolerance and are the same bits on every run.  Ragged lengths, one-row
+    batches, 64 teams (every CU taken), both directions in one launch, stacked layers."""
     V, E, H, seed = 400, 300, 256, 900 + B
     enc, table, sd = make_encoder(V, E, H, seed, layers, bi)
     ids = torch.from_numpy(synth.make_ids(seed + 5, B, T, V, zero_inside=0.05)).cuda()
@@ -471,37 +476,46 @@ def test_column_split_recurrence_is_bit_identical_to_the_one_cu_kernel(B, T, lay
     torch.cuda.synchronize()
     assert torch.equal(one, four)
     assert torch.isfinite(four).all() and float(four.norm(dim=1).min()) > 0.99
-    if B <= 300:
-        enc.train()
-        d_out = torch.from_numpy(np.random.RandomState(seed).standard_normal((B, H)).astype(np.float32)).cuda()
+    enc.train()
+    d_out = torch.from_numpy(np.random.RandomState(seed).standard_normal((B, H)).astype(np.float32)).cuda()
 
-        def grads(flag):
-            enc.zero_grad()
-            y = _with_split(flag, lambda: enc(ids))
-            _with_split(flag, lambda: y.backward(d_out))
-            return [p.grad.clone() for p in enc._flat_params()], y.detach().clone()
-        g1, y1 = grads(False)
-        g4, y4 = grads(True)
+    def grads(flag, bwd):
+        enc.zero_grad()
+        y = _with_split(flag, lambda: enc(ids), bwd)
+        _with_split(flag, lambda: y.backward(d_out), bwd)
         torch.cuda.synchronize()
-        assert torch.equal(y1, y4) and all(torch.equal(a, b) for a, b in zip(g1, g4))
+        return [p.grad.clone() for p in enc._flat_params()], y.detach().clone()
+    g1, y1 = grads(False, False)
+    g4f, y4f = grads(True, False)      # split forward, one-CU backward: the stash is the same bits
+    assert torch.equal(y1, y4f) and all(torch.equal(a, b) for a, b in zip(g1, g4f))
+    g4, y4 = grads(True, True)         # both split
+    g4b, _ = grads(True, True)
+    assert torch.equal(y1, y4) and all(torch.equal(a, b) for a, b in zip(g4, g4b))
+    for a, b in zip(g4, g1):
+        assert_grad_close(a.cpu().numpy(), b.cpu().numpy())
 
 
 def test_column_split_recurrence_with_both_towers_in_flight():
     """The train step launches the query tower and the 2B-row document tower on two streams: 32 + 64 teams = 384 workgroups
-    for 256 CUs, so members of some teams wait for a CU while their partners already sweep for them.  Three steps with the
-    split kernels must leave the same parameters, bit for bit, as three steps with the one-CU kernels."""
+    for 256 CUs, so members of some teams wait for a CU while their partners already sweep for them.  Three steps: with the
+    split forward alone the parameters are the one-CU run's bit for bit; with both recurrences split the run repeats itself
+    bit for bit and its last gradient agrees with the one-CU run's to the gradient tolerance."""
     import copy
     import twotowermlretrieval_amd as tt
     V, E, H, B = 500, 300, 256, 512
     torch.manual_seed(5)
-    m1 = tt.TwoTowerModel({"VOCAB_SIZE": V, "EMBED_DIM": E, "HIDDEN_DIM": H}, synth.make_table(4, V, E)).cuda().train()
-    m2 = copy.deepcopy(m1)
-    o1 = tt.FusedClipAdam(m1.parameters(), lr=1e-3, max_norm=1.0)
-    o2 = tt.FusedClipAdam(m2.parameters(), lr=1e-3, max_norm=1.0)
-    for step in range(3):
-        ids = [torch.from_numpy(synth.make_ids(60 + 3 * step + s, B, T, V)).cuda() for s, T in enumerate((9, 60, 70))]
-        l1 = _with_split(False, lambda: tt.train_step(m1, o1, *ids, margin=0.5))
-        l2 = _with_split(True, lambda: tt.train_step(m2, o2, *ids, margin=0.5))
-        torch.cuda.synchronize()
-        assert float(l1.item()) == float(l2.item()), step
-    assert torch.equal(o1.flat_params, o2.flat_params)
+    m0 = tt.TwoTowerModel({"VOCAB_SIZE": V, "EMBED_DIM": E, "HIDDEN_DIM": H}, synth.make_table(4, V, E)).cuda().train()
+    runs = {}
+    for name, (flag, bwd) in {"one": (False, False), "fwd": (True, False), "both": (True, True), "both2": (True, True)}.items():
+        m = copy.deepcopy(m0)
+        o = tt.FusedClipAdam(m.parameters(), lr=1e-5, max_norm=1.0)
+        losses = []
+        for step in range(3):
+            ids = [torch.from_numpy(synth.make_ids(60 + 3 * step + s, B, T, V)).cuda() for s, T in enumerate((9, 60, 70))]
+            losses.append(float(_with_split(flag, lambda: tt.train_step(m, o, *ids, margin=0.5), bwd).item()))
+            torch.cuda.synchronize()
+        runs[name] = (losses, o.flat_params.clone(), o.flat_grads.clone())
+    assert runs["one"][0] == runs["fwd"][0] and torch.equal(runs["one"][1], runs["fwd"][1])
+    assert runs["both"][0] == runs["both2"][0] and torch.equal(runs["both"][1], runs["both2"][1])
+    np.testing.assert_allclose(runs["both"][0], runs["one"][0], atol=2e-6)
+    assert_grad_close(runs["both"][2].cpu().numpy(), runs["one"][2].cpu().numpy())

@@ -37,6 +37,7 @@ struct EncLayout {
     size_t dghn[2];                              // GRU: dGh = [dr_pre, dz_pre, dn_pre * r], [MT][3H] (the hidden-side pre-activation gradients)
     size_t dx[2];                                // ping-pong [MT][ndir*H]: gradient w.r.t. a layer's input
     size_t wtp[2];                               // W_hh packed for dh_prev = dGh * W_hh
+    size_t xchb;                                 // column-split backward recurrence: hand-off granules; 0 = none
     size_t slabs;                                // split-K partial products
     size_t dx0;                                  // train == 2 (trainable table): gradient w.r.t. the gathered vectors [MT][E]
     size_t total;
@@ -47,6 +48,9 @@ struct EncLayout {
 // scale of dW_ih = dGi^T X.  (Other words: 0 error flags, 16.. max|W_hh| forward, 32.. backward, 40.. max|W_ih|, 48..63
 // max|dGi| / max|dGh|.)
 constexpr int ENC_FLAG_XMAX = 8;
+// Words 2..3 (8-byte aligned): the forward call's `status` pointer, left there by the training forward so that the backward
+// call -- which has no status argument of its own -- can raise bit 2 if its column-split recurrence gives up (gru16x4.hip).
+constexpr int ENC_FLAG_STATUS_PTR = 2;
 
 #ifndef TT_ENC_SPLITK
 #define TT_ENC_SPLITK 64
@@ -71,7 +75,9 @@ __host__ __device__ static inline float tt_dropout_scale(uint64_t seed, int laye
 // csrc/gru16x4.hip: the GRU recurrence (H = 256) with a row group's gate columns split over four CUs; bit-identical to
 // gru16_launch.  gru16x4_xch_bytes: hand-off scratch for B rows (0 when H != 256; host-only arithmetic, no GPU call).
 size_t gru16x4_xch_bytes(int B, int H, int ndir);
+size_t gru16x4_bwd_xch_bytes(int B, int H, int ndir);
 bool gru16x4_usable(int B, int H, int ndir); // this device has a CU for every member of every team (and TT_GRU_SPLIT != 0)
+bool gru16x4_bwd_usable(int B, int H, int ndir); // ... and TT_GRU_SPLIT_BWD != 0
 
 static inline EncLayout enc_layout(int B, int T, int E, int H, int L, int bidir, int train, int dropout = 0,
                                    int cell = CELL_GRU)
@@ -122,7 +128,7 @@ static inline EncLayout enc_layout(int B, int T, int E, int H, int L, int bidir,
         lo.xch = xb ? take(xb) : 0;
     }
     lo.fwd_end = off;
-    lo.d_hfin = lo.d_hid = lo.slabs = 0;
+    lo.d_hfin = lo.d_hid = lo.slabs = lo.xchb = 0;
     for (int d = 0; d < 2; ++d)
         lo.dgi[d] = lo.dghn[d] = lo.dx[d] = lo.wtp[d] = lo.prevmap[d] = 0;
     if (train) {
@@ -138,6 +144,10 @@ static inline EncLayout enc_layout(int B, int T, int E, int H, int L, int bidir,
         if (L > 1)
             for (int i = 0; i < 2; ++i)
                 lo.dx[i] = take(seq);
+        {
+            const size_t xb = cell == CELL_GRU ? gru16x4_bwd_xch_bytes(B, H, lo.ndir) : 0;
+            lo.xchb = xb ? take(xb) : 0;
+        }
         const size_t in_max = (size_t)(E > lo.ndir * H ? E : lo.ndir * H);
         lo.slabs = take(sizeof(float) * ENC_SPLITK * (ng < 3 ? 3 : ng) * H * (in_max > (size_t)H ? in_max : (size_t)H));
     }
@@ -248,3 +258,5 @@ int gru16_launch(const GruParams &gp, int ndir, hipStream_t st);
 int gru16_pack_t(const float *W_hh, int H, const unsigned *absmax, void *wtp16, hipStream_t st);
 int gru16_bwd_launch(const GruBwdParams &bp, int ndir, hipStream_t st);
 int gru16x4_launch(const GruParams &gp, int ndir, void *xch, int32_t *status, hipStream_t st);
+// the reverse-time recurrence on four CUs per row group (reduction split; deterministic, not bit-identical to gru16_bwd_launch)
+int gru16x4_bwd_launch(const GruBwdParams &bp, int ndir, void *xch, int32_t *const *status_pp, hipStream_t st);

@@ -489,6 +489,8 @@ __global__ __launch_bounds__(256) void head_kernel(const float *__restrict__ hfi
         out[(size_t)b * H + u] = normalize ? hid[u] / nrm : hid[u];
 }
 
+__global__ void store_ptr_kernel(int32_t **slot, int32_t *value) { *slot = value; }
+
 } // namespace
 
 int enc_check_shape(const char *who, int B, int T, int E, int H, int L, int64_t V)
@@ -626,6 +628,10 @@ static int encoder_forward(const char *who, const int64_t *ids, int B, int T, co
             TT_HIP_CHECK(hipMemcpyAsync(status, flag, sizeof(int32_t), hipMemcpyDeviceToDevice, st));
     }
 
+    if (train) { // the backward call finds this call's status word through the workspace (encoder.h: ENC_FLAG_STATUS_PTR)
+        hipLaunchKernelGGL(store_ptr_kernel, dim3(1), dim3(1), 0, st, (int32_t **)(flag + ENC_FLAG_STATUS_PTR), status);
+        TT_LAUNCH_CHECK();
+    }
     const size_t lds = sizeof(float) * 2 * ENC_RB * (H + 4);
     const bool force_f32 = enc_force_f32();
     const bool use16 = rnn_type == CELL_GRU && gru16_supported(H) && !force_f32;

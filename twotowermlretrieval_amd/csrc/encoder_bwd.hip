@@ -573,7 +573,11 @@ TT_EXPORT int tt_encoder_backward_f32(const int64_t *ids, int B, int T, const fl
         }
         if (ndir == 1)
             bp.dir[1] = bp.dir[0];
-        if (use16) {
+        if (use16 && fused_bias && lo.xchb && gru16x4_bwd_usable(B, H, ndir)) {
+            // a row group's reduction over the gate columns on four CUs (gru16x4.hip); the forward call left its status
+            // pointer in the flag block
+            rc = gru16x4_bwd_launch(bp, ndir, ws + lo.xchb, (int32_t *const *)((int32_t *)(ws + lo.flag) + ENC_FLAG_STATUS_PTR), st);
+        } else if (use16) {
             rc = gru16_bwd_launch(bp, ndir, st);
         } else {
             rc = rnn_type == CELL_LSTM ? launch_bwd_seq<CELL_LSTM>(bp, B, H, ndir, lds, st)

@@ -41,6 +41,62 @@ __device__ __forceinline__ h8 frag_load(__amdgpu_buffer_rsrc_t rsrc, int lane_of
     return __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane_off, byte_off, 0));
 }
 
+// Which XCD this workgroup runs on (hardware register, 0-7).
+__device__ __forceinline__ unsigned xcc_id()
+{
+    unsigned x;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+    return x & 0xfu;
+}
+
+// Progressive back-off of a sweep that did not find its tags: the first retries come quickly (partners in step arrive
+// within a microsecond), later ones seldom -- a member whose partner has no CU yet would otherwise pull 24 KB through
+// the fabric every microsecond for as long as it waits.
+__device__ __forceinline__ void sweep_backoff(unsigned spins)
+{
+    if (spins < 8)
+        __builtin_amdgcn_s_sleep(1);
+    else if (spins < 32)
+        __builtin_amdgcn_s_sleep(8);
+    else
+        __builtin_amdgcn_s_sleep(64);
+}
+
+constexpr int X4_HEADER = 256; // per team, behind its granule slots: one {XCC id, tag} granule per member
+
+// Do the four members of this team share an XCD (= one L2)?  Every member publishes its XCC id (sc1: placement-independent)
+// and reads all four; all members compute the same answer from the same four words.  If they do, the step granules are
+// written with PLAIN stores: the line stays in the XCD's L2, where the partners' sc1 loads (which bypass only their own L1)
+// find it -- no trip through the fabric.  If they do not, the stores are sc1 (write-through) and every read comes from
+// memory: slower, equally correct.  Returns 1 / 0, or -1 when a partner did not show up within the budget.
+__device__ __forceinline__ int team_shares_xcd(__amdgpu_buffer_rsrc_t xsrc, int header_off, int m, int tid, unsigned spin_max, int *lds_word)
+{
+    if (tid == 0) {
+        const unsigned long long g = ((unsigned long long)0x5843u << 32) | (xcc_id() + 1u); // tag 'XC', value id + 1 (never 0)
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(__attribute__((ext_vector_type(2))) unsigned, g), xsrc,
+                                              header_off + 8 * m, 0, 16);
+        int res = -1;
+        for (unsigned spins = 0; spins <= spin_max; ++spins) {
+            unsigned id[4];
+            bool ok = true;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const __attribute__((ext_vector_type(2))) unsigned v = __builtin_amdgcn_raw_buffer_load_b64(xsrc, header_off + 8 * q, 0, 16);
+                id[q] = v.x;
+                ok = ok && v.y == 0x5843u;
+            }
+            if (ok) {
+                res = (id[0] == id[1] && id[1] == id[2] && id[2] == id[3]) ? 1 : 0;
+                break;
+            }
+            sweep_backoff(spins);
+        }
+        *lds_word = res;
+    }
+    __syncthreads();
+    return *lds_word;
+}
+
 struct GruSplitParams {
     GruParams g;
     char *xch;         // [dir][team] x X4_TEAM_BYTES, zeroed before the launch (tag 0 = nothing published)
@@ -108,13 +164,20 @@ __global__ __launch_bounds__(256, 1) void gru_seq16x4_kernel(GruSplitParams sp)
                 wreg[s2][g][part] = frag_load(wsrc, loff, (12 * s2 + 4 * g + 2 * part) * 1024);
 
     // ---- the team's granule slots ----
-    char *const xteam = sp.xch + ((size_t)blockIdx.y * sp.nteams + team) * X4_TEAM_BYTES;
-    const __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc((void *)xteam, 0, (int)X4_TEAM_BYTES, 0x00020000);
+    char *const xteam = sp.xch + ((size_t)blockIdx.y * sp.nteams + team) * (X4_TEAM_BYTES + X4_HEADER);
+    const __amdgpu_buffer_rsrc_t xsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void *)xteam, 0, (int)X4_TEAM_BYTES + X4_HEADER, 0x00020000);
     // send: lanes j and j ^ 1 hold units (2 q, 2 q + 1) of rows 4 kq .. 4 kq + 3; the even lane publishes rows e = 0, 1, the
     // odd lane rows e = 2, 3, each as ONE 16-byte store {unit 2q | tag | unit 2q+1 | tag}
     const bool odd = j & 1;
     const int send_row = kq * 4 + (odd ? 2 : 0);
     const int send_off = (send_row * 64 + 16 * w + (j & ~1)) * 8; // + 512 for the second row
+    const int same_xcd = team_shares_xcd(xsrc, (int)X4_TEAM_BYTES, m, tid, sp.spin_max, &abort_flag + 1);
+    if (same_xcd < 0) {
+        if (tid == 0 && sp.status)
+            atomicOr(sp.status, 4);
+        steps = 0; // (h_final = 0 is written below; the status bit tells the caller the outputs are invalid)
+    }
     // (the resident fragments have landed: without this the compiler keeps vmcnt waits for them INSIDE the step loop, where
     //  they would also wait for the next step's prefetched projections and this step's stores)
     __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
@@ -179,6 +242,7 @@ __global__ __launch_bounds__(256, 1) void gru_seq16x4_kernel(GruSplitParams sp)
 
         char *nimg = lds + (cur ^ 1) * 2 * X4_IMG;
         unsigned pk[4]; // fp16 hi | lo << 16 of this lane's four new states
+        float sv_r[4], sv_z[4], sv_n[4], sv_g[4]; // what the training stash keeps of this step (stored BEHIND the hand-off)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const float r = tt_fast_sigmoid(giv[0][e] + acc[0][e] * down);
@@ -186,18 +250,12 @@ __global__ __launch_bounds__(256, 1) void gru_seq16x4_kernel(GruSplitParams sp)
             const float ghn = acc[2][e] * down;
             const float n = tt_fast_tanh(giv[2][e] + r * ghn);
             const float hn = (hreg[e] - n) * z + n;
-            if (act[e]) {
+            if (act[e])
                 hreg[e] = hn;
-                if (d.out_seq)
-                    d.out_seq[tok[e] * p.out_ld + d.out_col0 + unit] = hn;
-                if (d.gates) {
-                    float *gs = d.gates + tok[e] * 4 * H + unit;
-                    gs[0] = r;
-                    gs[H] = z;
-                    gs[2 * H] = n;
-                    gs[3 * H] = ghn;
-                }
-            }
+            sv_r[e] = r;
+            sv_z[e] = z;
+            sv_n[e] = n;
+            sv_g[e] = ghn;
             const float hs = hreg[e] * (float)(1 << X4_H_SHIFT);
             const _Float16 hi = (_Float16)hs;
             const _Float16 lo = (_Float16)(hs - (float)hi);
@@ -214,8 +272,13 @@ __global__ __launch_bounds__(256, 1) void gru_seq16x4_kernel(GruSplitParams sp)
             const u32x4 v0 = odd ? (u32x4){g0, tag, pk[2], tag} : (u32x4){pk[0], tag, g0, tag};
             const u32x4 v1 = odd ? (u32x4){g1, tag, pk[3], tag} : (u32x4){pk[1], tag, g1, tag};
             const int sbase = (par * 4 + m) * X4_REGION + send_off;
-            __builtin_amdgcn_raw_buffer_store_b128(v0, xsrc, sbase, 0, 16);       // aux 16 = sc1
-            __builtin_amdgcn_raw_buffer_store_b128(v1, xsrc, sbase + 512, 0, 16); // the next row
+            if (same_xcd) { // the partners read this XCD's L2
+                __builtin_amdgcn_raw_buffer_store_b128(v0, xsrc, sbase, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(v1, xsrc, sbase + 512, 0, 0); // the next row
+            } else {
+                __builtin_amdgcn_raw_buffer_store_b128(v0, xsrc, sbase, 0, 16);      // aux 16 = sc1 (write-through)
+                __builtin_amdgcn_raw_buffer_store_b128(v1, xsrc, sbase + 512, 0, 16);
+            }
             // ---- sweep the other three members' granules until every tag is this step's ----
             u32x4 got[3][2];
             bool ok = false;
@@ -241,7 +304,7 @@ __global__ __launch_bounds__(256, 1) void gru_seq16x4_kernel(GruSplitParams sp)
                     }
                     break;
                 }
-                __builtin_amdgcn_s_sleep(1);
+                sweep_backoff(spins);
             }
             // chunk (tid + 256 c) of a member's region: row = chunk >> 5, units 2 (chunk & 31), + 1
 #pragma unroll
@@ -257,6 +320,22 @@ __global__ __launch_bounds__(256, 1) void gru_seq16x4_kernel(GruSplitParams sp)
                 }
             }
         }
+        // The step's bulk stores go out only now: vector memory operations complete in issue order, so in front of the
+        // hand-off they would stand between the sweep's loads and the registers those loads fill (20 stores per lane).
+        // From here they drain under the next step's MFMAs.
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (act[e]) {
+                if (d.out_seq)
+                    d.out_seq[tok[e] * p.out_ld + d.out_col0 + unit] = hreg[e];
+                if (d.gates) {
+                    float *gs = d.gates + tok[e] * 4 * H + unit;
+                    gs[0] = sv_r[e];
+                    gs[H] = sv_z[e];
+                    gs[2 * H] = sv_n[e];
+                    gs[3 * H] = sv_g[e];
+                }
+            }
         __syncthreads();
         if (abort_flag)
             break;
@@ -273,6 +352,377 @@ __global__ __launch_bounds__(256, 1) void gru_seq16x4_kernel(GruSplitParams sp)
     for (int e = 0; e < 4; ++e)
         if (rid_e[e] >= 0)
             d.h_final[(size_t)rid_e[e] * H + unit] = hreg[e];
+}
+
+// ------------------------------------------------------------------ reverse-time recurrence on four CUs (training)
+// dh_{t-1} = dh_t z + dGh W_hh, dGh = [dr_pre, dz_pre, dn_pre r] (16 rows x 3H).  Splitting the OUTPUT columns (as the forward
+// kernel does) would need all 768 columns of dGh on every member: 72 KB of granules to receive per member and step.  The gate
+// derivatives of a unit only need that unit's dh, so the team splits the REDUCTION instead: member m owns units
+// [64 m, 64 m + 64), forms dGh for them (192 of the 768 columns, lane-local from the stash), multiplies that slice by ITS
+// 192 ROWS of W_hh (fp16 hi/lo, 196 KB, resident in VGPRs) into a partial dh for ALL 256 units, keeps the 64 columns that
+// are its own and publishes the other three 16 x 64 fp32 blocks to their owners as {value, tag} granules: 24 KB out and
+// 24 KB in per member and step -- the forward kernel's volume -- straight from and into registers (no LDS staging).
+// dh_own = dh z + (partial of member 0 + 1 + 2 + 3, always in that order): deterministic, and every partial carries its own
+// per-row power-of-two scale (the row's largest |dGh| among the member's 192 columns), so the fp16 hi/lo split is at least as
+// tight as in gru_bwd16_kernel, which scales a row by its maximum over all 768.  NOT bit-identical to that kernel (four
+// partial chains of 6 k-steps instead of one of 24): checked against the oracle at the tests' gradient tolerance instead.
+constexpr int XB_LDG = 192 + 8;            // fp16 elements per row of a dGh image (own 3 x 64 columns)
+constexpr int XB_IMG = 16 * XB_LDG * 2;    // bytes of one (hi or lo) image
+constexpr int XB_RM = 2 * 4 * 16 * 4;      // per-wave row maxima, double-buffered
+constexpr int XB_LDS = 2 * XB_IMG + XB_RM; // + 16 for the abort word
+constexpr int XB_REGION = 16 * 64 * 8;     // one (dest, src) block of one parity
+constexpr size_t XB_TEAM_BYTES = 2 * 4 * 4 * (size_t)XB_REGION; // [parity][dest][src]
+
+struct GruSplitBwdParams {
+    GruBwdParams g;
+    char *xch;                  // [dir][team] x XB_TEAM_BYTES, zeroed before the launch
+    int32_t *const *status_pp;  // device word holding the forward call's status pointer (may hold null): bit 2 on a time-out
+    int nteams;
+    unsigned spin_max;
+};
+
+__global__ __launch_bounds__(256, 1) void gru_bwd16x4_kernel(GruSplitBwdParams sp)
+{
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    int &abort_flag = *(int *)(lds + XB_LDS);
+    const GruBwdParams &p = sp.g;
+    const int chunk = blockIdx.x >> 5, r32 = blockIdx.x & 31;
+    const int m = r32 >> 3, team = chunk * 8 + (r32 & 7);
+    if (team >= sp.nteams)
+        return;
+    const GruBwdDir d = p.dir[blockIdx.y];
+    constexpr int H = X4_H, H3 = 3 * X4_H;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 15, kq = lane >> 4;
+    const int row0 = team * ENC_RB;
+    const int ul = 16 * w + j;          // this lane's unit within the member
+    const int unit = 64 * m + ul;
+
+    int len_e[4], off_e[4], rid_e[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int br = row0 + kq * 4 + e;
+        rid_e[e] = br < p.B ? p.perm[br] : -1;
+        len_e[e] = rid_e[e] >= 0 ? p.len[rid_e[e]] : 0;
+        off_e[e] = rid_e[e] >= 0 ? p.tok_off[rid_e[e]] : 0;
+    }
+    int steps = max(max(len_e[0], len_e[1]), max(len_e[2], len_e[3]));
+    steps = max(steps, __shfl_xor(steps, 16));
+    steps = max(steps, __shfl_xor(steps, 32));
+    float dh[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+        dh[e] = (d.d_hfin && rid_e[e] >= 0) ? d.d_hfin[(size_t)rid_e[e] * H + unit] : 0.0f;
+    const int exw = tt_pow2_exponent(*d.wmax);
+
+    char *const img = lds;                            // [hi, lo][16][XB_LDG] fp16: this member's dGh columns [g][64]
+    float *const rmax = (float *)(lds + 2 * XB_IMG);  // [2][4 waves][16 rows]
+    if (tid == 0)
+        abort_flag = 0;
+
+    // ---- this wave's 48 fragments of W_hh: rows = the member's 192 gate rows (k-steps 8 g + 2 m + {0, 1} of gru16_pack_t's
+    // order), columns = the 16 units [64 o + 16 w, + 16) of every member o.  Packed order: wave pw of 32 output units,
+    // fragment f = 4 s + 2 part + t: (pw, t) = (2 o + (w >> 1), w & 1) ----
+    h8 wreg[4][6][2]; // [dest member][k-step of the member's 192 rows][hi, lo]
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+        const __amdgpu_buffer_rsrc_t wsrc = __builtin_amdgcn_make_buffer_rsrc(
+            (void *)((const char *)d.wtp + (size_t)(2 * o + (w >> 1)) * 96 * 1024), 0, 96 * 1024, 0x00020000);
+        const int loff = lane * 16 + (w & 1) * 1024;
+#pragma unroll
+        for (int s2 = 0; s2 < 6; ++s2) {
+            const int sg = 8 * (s2 >> 1) + 2 * m + (s2 & 1);
+#pragma unroll
+            for (int part = 0; part < 2; ++part)
+                wreg[o][s2][part] = frag_load(wsrc, loff + (4 * sg + 2 * part) * 1024, 0);
+        }
+    }
+
+    char *const xteam = sp.xch + ((size_t)blockIdx.y * sp.nteams + team) * (XB_TEAM_BYTES + X4_HEADER);
+    const __amdgpu_buffer_rsrc_t xsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void *)xteam, 0, (int)XB_TEAM_BYTES + X4_HEADER, 0x00020000);
+    // granule (row, col) of a block sits at (row 64 + col) 8; lanes j, j ^ 1 pair up: the even lane moves rows e = 0, 1 of
+    // columns (ul, ul + 1), the odd lane rows e = 2, 3 of (ul - 1, ul), 16 bytes at a time
+    const bool odd = j & 1;
+    const int pair_off = ((kq * 4 + (odd ? 2 : 0)) * 64 + (ul & ~1)) * 8; // + 512 for the second row
+
+    struct Stash {
+        float r[4], z[4], n[4], ghn[4], hp[4], dsv[4];
+    };
+    auto load_stash = [&](int s, Stash &st) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const bool a = s >= 0 && s < len_e[e];
+            const int t = d.reverse ? len_e[e] - 1 - s : s;
+            const size_t tok = (size_t)(off_e[e] + (a ? t : 0));
+            const size_t ptok = d.reverse ? tok + 1 : tok - 1;
+            st.r[e] = st.z[e] = st.n[e] = st.ghn[e] = st.hp[e] = st.dsv[e] = 0.0f;
+            if (a) {
+                const float *gs = d.gates + tok * 4 * H + unit;
+                st.r[e] = gs[0];
+                st.z[e] = gs[H];
+                st.n[e] = gs[2 * H];
+                st.ghn[e] = gs[3 * H];
+                if (s > 0)
+                    st.hp[e] = d.hseq[ptok * p.ld + d.col0 + unit];
+                if (d.d_seq)
+                    st.dsv[e] = d.d_seq[tok * p.ld + d.col0 + unit];
+            }
+        }
+    };
+    const int same_xcd = team_shares_xcd(xsrc, (int)XB_TEAM_BYTES, m, tid, sp.spin_max, &abort_flag + 1);
+    if (same_xcd < 0) {
+        if (tid == 0) {
+            abort_flag = 1; // (poisons the bias sums below)
+            int32_t *stw = sp.status_pp ? *sp.status_pp : nullptr;
+            if (stw)
+                atomicOr(stw, 4);
+        }
+        steps = 0;
+    }
+    Stash cur_st, next_st;
+    load_stash(steps - 1, cur_st);
+    __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): fragments and the first stash are in (no such waits inside the loop)
+    __syncthreads();
+    int rb = 0;
+    float bsum[4] = {0, 0, 0, 0}; // column sums over this lane's rows and all steps: dr, dz, dn, dn r
+    float mx_i = 0.0f, mx_h = 0.0f;
+    unsigned it = 0;              // steps done: tag = it + 1, parity = it & 1
+
+    for (int s = steps - 1; s >= 0; --s, ++it) {
+        float direct[4], gv[3][4], mrow[4], dnp[4] = {0, 0, 0, 0};
+        bool act[4];
+        size_t tokv[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            act[e] = s < len_e[e];
+            const int t = d.reverse ? len_e[e] - 1 - s : s;
+            const size_t tok = (size_t)(off_e[e] + (act[e] ? t : 0));
+            tokv[e] = tok;
+            float dr_pre = 0.0f, dz_pre = 0.0f, dghn_v = 0.0f;
+            direct[e] = 0.0f;
+            if (act[e]) {
+                const float r = cur_st.r[e], z = cur_st.z[e], n = cur_st.n[e], ghn = cur_st.ghn[e], hp = cur_st.hp[e];
+                float dsv = cur_st.dsv[e];
+                if (d.d_seq && p.drop_p > 0.0f)
+                    dsv *= tt_dropout_scale(p.drop_seed, p.drop_layer, ((uint64_t)rid_e[e] * p.T + t) * p.ld + d.col0 + unit,
+                                            p.drop_p);
+                const float dhv = dh[e] + dsv;
+                const float dn_pre = dhv * (1.0f - z) * (1.0f - n * n);
+                dz_pre = dhv * (hp - n) * z * (1.0f - z);
+                dr_pre = dn_pre * ghn * r * (1.0f - r);
+                dghn_v = dn_pre * r;
+                direct[e] = dhv * z;
+                dnp[e] = dn_pre;
+                bsum[0] += dr_pre;
+                bsum[1] += dz_pre;
+                bsum[2] += dn_pre;
+                bsum[3] += dghn_v;
+                const float m2 = fmaxf(fabsf(dr_pre), fabsf(dz_pre));
+                mx_i = fmaxf(mx_i, fmaxf(m2, fabsf(dn_pre)));
+                mx_h = fmaxf(mx_h, fmaxf(m2, fabsf(dghn_v)));
+            }
+            gv[0][e] = dr_pre;
+            gv[1][e] = dz_pre;
+            gv[2][e] = dghn_v;
+            mrow[e] = fmaxf(fmaxf(fabsf(dr_pre), fabsf(dz_pre)), fabsf(dghn_v));
+        }
+        // row maxima over the member's 192 columns: 16 lanes of a kq group -> one LDS word per wave and row
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+#pragma unroll
+            for (int off = 1; off < 16; off <<= 1)
+                mrow[e] = fmaxf(mrow[e], __shfl_xor(mrow[e], off));
+            if (j == 0)
+                rmax[(rb * 4 + w) * 16 + kq * 4 + e] = mrow[e];
+        }
+        load_stash(s - 1, next_st); // in flight during the MFMAs and the hand-off below
+        __syncthreads();            // B1: row maxima visible; every wave is done reading the previous step's images
+        if (abort_flag) // (set, if at all, before its wave reached B1: every wave reads the same value here)
+            break;
+        float down[4]; // rows 4 kq + e: the rows of this lane's values AND of its accumulators (the MFMA's C layout)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float mm = 0.0f;
+#pragma unroll
+            for (int ww = 0; ww < 4; ++ww)
+                mm = fmaxf(mm, rmax[(rb * 4 + ww) * 16 + kq * 4 + e]);
+            const int er = tt_pow2_exponent(__float_as_uint(mm));
+            const float upr = ldexpf(1.0f, er);
+            down[e] = ldexpf(1.0f, -(er + exw));
+            _Float16 *dst = (_Float16 *)img + (kq * 4 + e) * XB_LDG;
+#pragma unroll
+            for (int g = 0; g < 3; ++g) {
+                const float x = gv[g][e] * upr;
+                const _Float16 hi = (_Float16)x;
+                dst[g * 64 + ul] = hi;
+                dst[XB_IMG / 2 + g * 64 + ul] = (_Float16)(x - (float)hi);
+            }
+        }
+        rb ^= 1;
+        __syncthreads(); // B2: the dGh images are complete
+
+        f32x4v acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}}; // [dest member]
+        const char *arow = img + j * (XB_LDG * 2) + kq * 16;
+        h8 a_hi[2], a_lo[2];
+        a_hi[0] = *(const h8 *)(arow);
+        a_lo[0] = *(const h8 *)(arow + XB_IMG);
+#pragma unroll
+        for (int s2 = 0; s2 < 6; ++s2) {
+            if (s2 + 1 < 6) {
+                a_hi[(s2 + 1) & 1] = *(const h8 *)(arow + (s2 + 1) * 64);
+                a_lo[(s2 + 1) & 1] = *(const h8 *)(arow + XB_IMG + (s2 + 1) * 64);
+            }
+#pragma unroll
+            for (int o = 0; o < 4; ++o)
+                acc[o] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[s2 & 1], wreg[o][s2][0], acc[o], 0, 0, 0);
+#if !(TT_MUTATE_DROP_LO & 2)
+#pragma unroll
+            for (int o = 0; o < 4; ++o)
+                acc[o] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo[s2 & 1], wreg[o][s2][0], acc[o], 0, 0, 0);
+#pragma unroll
+            for (int o = 0; o < 4; ++o)
+                acc[o] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[s2 & 1], wreg[o][s2][1], acc[o], 0, 0, 0);
+#endif
+        }
+        // partial dh of this member for every unit: acc[o][e] = rows 4 kq + e, unit 64 o + 16 w + j
+        float part[4][4];
+#pragma unroll
+        for (int o = 0; o < 4; ++o)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                part[o][e] = acc[o][e] * down[e];
+        float sum[4] = {0, 0, 0, 0};
+        if (s > 0) { // (the partials of the last step would only feed a dh nobody reads)
+            const unsigned tag = it + 1u;
+            const int par = (int)(it & 1u);
+            // ---- publish the three foreign blocks: [parity][dest o][src m] ----
+#pragma unroll
+            for (int oo = 1; oo < 4; ++oo) {
+                const int o = (m + oo) & 3;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    v[e] = o == 0 ? part[0][e] : (o == 1 ? part[1][e] : (o == 2 ? part[2][e] : part[3][e]));
+                const unsigned p0 = __float_as_uint(v[0]), p1 = __float_as_uint(v[1]), p2 = __float_as_uint(v[2]), p3 = __float_as_uint(v[3]);
+                const unsigned g0 = __shfl_xor(odd ? p0 : p2, 1), g1 = __shfl_xor(odd ? p1 : p3, 1);
+                const u32x4 v0 = odd ? (u32x4){g0, tag, p2, tag} : (u32x4){p0, tag, g0, tag};
+                const u32x4 v1 = odd ? (u32x4){g1, tag, p3, tag} : (u32x4){p1, tag, g1, tag};
+                const int base = ((par * 4 + o) * 4 + m) * XB_REGION + pair_off;
+                if (same_xcd) {
+                    __builtin_amdgcn_raw_buffer_store_b128(v0, xsrc, base, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(v1, xsrc, base + 512, 0, 0);
+                } else {
+                    __builtin_amdgcn_raw_buffer_store_b128(v0, xsrc, base, 0, 16); // aux 16 = sc1 (write-through)
+                    __builtin_amdgcn_raw_buffer_store_b128(v1, xsrc, base + 512, 0, 16);
+                }
+            }
+            // ---- sweep the three blocks addressed to this member until every tag is this step's ----
+            u32x4 got[3][2];
+            unsigned spins = 0;
+            while (true) {
+                bool ok = true;
+#pragma unroll
+                for (int oo = 0; oo < 3; ++oo) {
+                    const int src = (m + 1 + oo) & 3;
+                    const int base = ((par * 4 + m) * 4 + src) * XB_REGION + pair_off;
+                    got[oo][0] = __builtin_amdgcn_raw_buffer_load_b128(xsrc, base, 0, 16);
+                    got[oo][1] = __builtin_amdgcn_raw_buffer_load_b128(xsrc, base + 512, 0, 16);
+                    ok = ok && got[oo][0].y == tag && got[oo][0].w == tag && got[oo][1].y == tag && got[oo][1].w == tag;
+                }
+                if (__all(ok))
+                    break;
+                if (++spins > sp.spin_max) {
+                    if (lane == 0) {
+                        abort_flag = 1;
+                        int32_t *stw = sp.status_pp ? *sp.status_pp : nullptr; // the forward call's status word, if it had one
+                        if (stw)
+                            atomicOr(stw, 4);
+                    }
+                    break;
+                }
+                sweep_backoff(spins);
+            }
+            // un-pair: this lane's column is the even (x) or the odd (z) word; the neighbour holds its other two rows
+            float theirs[4][4]; // [member][e]; entry m = this member's own partial
+#pragma unroll
+            for (int oo = 0; oo < 3; ++oo) {
+                const int src = (m + 1 + oo) & 3;
+                const unsigned mine0 = odd ? got[oo][0].z : got[oo][0].x, mine1 = odd ? got[oo][1].z : got[oo][1].x; // rows (2,3) | (0,1)
+                const unsigned nb0 = odd ? got[oo][0].x : got[oo][0].z, nb1 = odd ? got[oo][1].x : got[oo][1].z;     // the neighbour's column
+                const unsigned h0 = __shfl_xor(nb0, 1), h1 = __shfl_xor(nb1, 1); // my column, the neighbour's rows
+                const float r0 = __uint_as_float(odd ? h0 : mine0), r1 = __uint_as_float(odd ? h1 : mine1);
+                const float r2 = __uint_as_float(odd ? mine0 : h0), r3 = __uint_as_float(odd ? mine1 : h1);
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (q == src) {
+                        theirs[q][0] = r0;
+                        theirs[q][1] = r1;
+                        theirs[q][2] = r2;
+                        theirs[q][3] = r3;
+                    }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (q == m) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        theirs[q][e] = part[q][e];
+                }
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                sum[e] = ((theirs[0][e] + theirs[1][e]) + theirs[2][e]) + theirs[3][e]; // members 0, 1, 2, 3: a fixed order
+        }
+        // the step's gradient rows go out BEHIND the hand-off (in front of it, 24 stores per lane would complete before the
+        // sweep's loads could: vector memory operations finish in issue order); they drain under the next step's work
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (act[e]) {
+                float *go = d.dgi + tokv[e] * H3 + unit;
+                go[0] = gv[0][e];
+                go[H] = gv[1][e];
+                go[2 * H] = dnp[e];
+                float *gh = d.dghn + tokv[e] * H3 + unit;
+                gh[0] = gv[0][e];
+                gh[H] = gv[1][e];
+                gh[2 * H] = gv[2][e];
+            }
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (act[e])
+                dh[e] = direct[e] + sum[e];
+        cur_st = next_st;
+    }
+    __syncthreads();
+    // bias gradients of this member's units for the row group, and the operand maxima
+    if (d.bias_slab) {
+        float *slab = d.bias_slab + (size_t)team * 2 * H3;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float v = bsum[g];
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            bsum[g] = abort_flag ? __uint_as_float(0x7fc00000u) : v; // a team that gave up poisons its sums: NaN gradients, not wrong ones
+        }
+        if (kq == 0) {
+            slab[unit] = bsum[0];
+            slab[H + unit] = bsum[1];
+            slab[2 * H + unit] = bsum[2];
+            slab[H3 + unit] = bsum[0];
+            slab[H3 + H + unit] = bsum[1];
+            slab[H3 + 2 * H + unit] = bsum[3];
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            mx_i = fmaxf(mx_i, __shfl_xor(mx_i, off));
+            mx_h = fmaxf(mx_h, __shfl_xor(mx_h, off));
+        }
+        if (lane == 0) {
+            atomicMax(d.mx_dgi, __float_as_uint(mx_i));
+            atomicMax(d.mx_dghn, __float_as_uint(mx_h));
+        }
+    }
 }
 
 int device_cus()
@@ -300,7 +750,7 @@ size_t gru16x4_xch_bytes(int B, int H, int ndir)
 {
     if (H != X4_H || B <= 0 || B > 1024) // (more than 64 row groups never fit one workgroup per CU four times over)
         return 0;
-    return (size_t)ndir * ((B + ENC_RB - 1) / ENC_RB) * X4_TEAM_BYTES;
+    return (size_t)ndir * ((B + ENC_RB - 1) / ENC_RB) * (X4_TEAM_BYTES + X4_HEADER);
 }
 
 // one workgroup per CU at most, so that every member of every team is resident (one wave per SIMD with the whole
@@ -313,6 +763,40 @@ bool gru16x4_usable(int B, int H, int ndir)
     return (nteams + 7) / 8 * 32 * ndir <= device_cus();
 }
 
+size_t gru16x4_bwd_xch_bytes(int B, int H, int ndir)
+{
+    if (H != X4_H || B <= 0 || B > 1024)
+        return 0;
+    return (size_t)ndir * ((B + ENC_RB - 1) / ENC_RB) * (XB_TEAM_BYTES + X4_HEADER);
+}
+
+// TT_GRU_SPLIT_BWD=0 keeps the backward recurrence on gru_bwd16_kernel while the forward one is split (A/B; the tests that
+// pin the split forward's stash bit for bit against the one-CU kernel's)
+bool gru16x4_bwd_usable(int B, int H, int ndir)
+{
+    const char *e = getenv("TT_GRU_SPLIT_BWD");
+    return !(e && e[0] == '0') && gru16x4_usable(B, H, ndir);
+}
+
+int gru16x4_bwd_launch(const GruBwdParams &bp, int ndir, void *xch, int32_t *const *status_pp, hipStream_t st)
+{
+    GruSplitBwdParams sp;
+    sp.g = bp;
+    sp.xch = (char *)xch;
+    sp.status_pp = status_pp;
+    sp.nteams = (bp.B + ENC_RB - 1) / ENC_RB;
+    sp.spin_max = 1u << 17;
+    TT_RC_CHECK(tt_zero_async(xch, gru16x4_bwd_xch_bytes(bp.B, bp.H, ndir), st));
+    static bool attr_done = false;
+    if (!attr_done) {
+        TT_HIP_CHECK(hipFuncSetAttribute((const void *)gru_bwd16x4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, XB_LDS + 16));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(gru_bwd16x4_kernel, dim3((sp.nteams + 7) / 8 * 32, ndir), dim3(256), XB_LDS + 16, st, sp);
+    TT_LAUNCH_CHECK();
+    return TT_OK;
+}
+
 int gru16x4_launch(const GruParams &gp, int ndir, void *xch, int32_t *status, hipStream_t st)
 {
     GruSplitParams sp;
@@ -320,7 +804,7 @@ int gru16x4_launch(const GruParams &gp, int ndir, void *xch, int32_t *status, hi
     sp.xch = (char *)xch;
     sp.status = status;
     sp.nteams = (gp.B + ENC_RB - 1) / ENC_RB;
-    sp.spin_max = 1u << 19; // ~0.5 s of sweeps: a partner that is merely waiting for a CU arrives long before that
+    sp.spin_max = 1u << 17; // ~0.3 s of backed-off sweeps: a partner that is merely waiting for a CU arrives long before that
     TT_RC_CHECK(tt_zero_async(xch, gru16x4_xch_bytes(gp.B, gp.H, ndir), st));
     static bool attr_done = false;
     if (!attr_done) {
