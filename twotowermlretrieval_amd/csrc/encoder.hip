@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void prep_len_kernel(const int64_t *__restrict
     }
 }
 
-constexpr int SORT_BINS = 4096;
+constexpr int SORT_BINS = 256; // length classes of the row sort (8 ballots per row; [16][256] per-wave counts in LDS)
 
 int enc_cus()
 {
@@ -64,17 +64,18 @@ int enc_cus()
     return cus;
 }
 
-// Single block of 1024 threads: tok_off = exclusive scan of len; perm = rows sorted by length, longest first, rows of equal
-// length (bin) in ASCENDING ROW ORDER: the counting sort's scatter hands out a bin's slots by LDS atomics in whatever order
-// the waves arrive, so it goes into `tmp` (>= B ints of scratch the caller does not need yet) and every row is then placed at
-// its bin's start + the number of smaller row numbers in that bin.  perm decides which rows share a 16-row recurrence
-// workgroup, and the backward kernels sum the bias gradients per workgroup: with an arbitrary order inside a bin those sums
-// (not the weight gradients, which are token-parallel) changed in their last bits from one run to the next.
-__device__ __forceinline__ void scan_sort_block(const int32_t *len, int B, int T, int32_t *tok_off, int32_t *perm,
-                                                int32_t *tmp)
+// Single block of 1024 threads: tok_off = exclusive scan of len; perm = rows sorted by length, longest first (a counting
+// sort over SORT_BINS length classes), rows of one class in ASCENDING ROW ORDER.  The order inside a class matters: perm
+// decides which rows share a 16-row recurrence workgroup, and the backward kernels sum the bias gradients per workgroup, so
+// a scatter that hands out a class's slots by LDS atomics -- in whatever order the waves arrive -- made those sums (not the
+// weight gradients, which are token-parallel) differ in their last bits from one run to the next.  Here the scatter is
+// STABLE: rows are taken 1024 at a time; inside a wave a row's rank among the rows of its class is a popcount over the
+// lanes below it (the class's lane mask: one ballot per class bit), the waves' counts per class are laid out in wave order
+// by a 16-step scan, and a row lands at class start + rows of earlier chunks and waves + its rank.  No atomics, no second pass.
+__device__ __forceinline__ void scan_sort_block(const int32_t *len, int B, int T, int32_t *tok_off, int32_t *perm)
 {
-    __shared__ int hist[SORT_BINS];
-    __shared__ int hstart[SORT_BINS];
+    __shared__ int hist[SORT_BINS];      // class sizes, then the running start of each class
+    __shared__ int whist[16][SORT_BINS]; // per wave and class: count in the current chunk, then that wave's base slot
     __shared__ int wsum[16];
     __shared__ int carry;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -84,12 +85,12 @@ __device__ __forceinline__ void scan_sort_block(const int32_t *len, int B, int T
         carry = 0;
     __syncthreads();
     const int nb = min(T + 1, SORT_BINS);
-    auto bin_of = [&](int l) { return nb - 1 - (int)((int64_t)l * nb / (T + 1)); }; // long rows -> low bins
+    auto bin_of = [&](int l) { return nb - 1 - (int)((int64_t)l * nb / (T + 1)); }; // long rows -> low classes
     for (int base = 0; base < B; base += 1024) {
         const int b = base + tid;
         const int v = b < B ? len[b] : 0;
         if (b < B)
-            atomicAdd(&hist[bin_of(v)], 1);
+            atomicAdd(&hist[bin_of(v)], 1); // (a count: the order of the adds does not matter)
         int x = v; // inclusive wave scan
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
@@ -112,14 +113,9 @@ __device__ __forceinline__ void scan_sort_block(const int32_t *len, int B, int T
     }
     if (tid == 0)
         tok_off[B] = carry;
-    // exclusive scan of the histogram (4 bins per thread)
+    // exclusive scan of the class sizes (SORT_BINS = 256: one class per thread of the first four waves)
     {
-        int loc[4], s = 0;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            loc[i] = hist[tid * 4 + i];
-            s += loc[i];
-        }
+        const int s = tid < SORT_BINS ? hist[tid] : 0;
         int x = s;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
@@ -133,34 +129,48 @@ __device__ __forceinline__ void scan_sort_block(const int32_t *len, int B, int T
         int pre = 0;
         for (int w = 0; w < wave; ++w)
             pre += wsum[w];
-        int run = pre + x - s;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            hist[tid * 4 + i] = run;
-            hstart[tid * 4 + i] = run;
-            run += loc[i];
-        }
+        if (tid < SORT_BINS)
+            hist[tid] = pre + x - s;
         __syncthreads();
     }
-    for (int b = tid; b < B; b += 1024)
-        tmp[atomicAdd(&hist[bin_of(len[b])], 1)] = b;
-    __syncthreads(); // (hist[bin] is now the END of the bin's segment; tmp is visible to the whole block)
-    for (int i = tid; i < B; i += 1024) {
-        const int b = tmp[i];
-        const int bin = bin_of(len[b]);
-        const int s0 = hstart[bin], s1 = hist[bin];
-        int rank = s0;
-        for (int jj = s0; jj < s1; ++jj)
-            rank += tmp[jj] < b;
-        perm[rank] = b;
+    for (int base = 0; base < B; base += 1024) {
+        for (int i = tid; i < 16 * SORT_BINS; i += 1024)
+            (&whist[0][0])[i] = 0;
+        __syncthreads();
+        const int b = base + tid;
+        const bool valid = b < B;
+        const int bin = valid ? bin_of(len[b]) : 0;
+        unsigned long long mask = __ballot(valid); // lanes of this wave in the same class as this one
+#pragma unroll
+        for (int bit = 0; bit < 8; ++bit) {
+            const unsigned long long bb = __ballot(valid && ((bin >> bit) & 1));
+            mask &= ((bin >> bit) & 1) ? bb : ~bb;
+        }
+        const int rank = __popcll(mask & ((1ull << lane) - 1ull));
+        if (valid && rank == 0)
+            whist[wave][bin] = __popcll(mask);
+        __syncthreads();
+        if (tid < SORT_BINS) {
+            int run = hist[tid];
+#pragma unroll
+            for (int w = 0; w < 16; ++w) {
+                const int c = whist[w][tid];
+                whist[w][tid] = run;
+                run += c;
+            }
+            hist[tid] = run;
+        }
+        __syncthreads();
+        if (valid)
+            perm[whist[wave][bin] + rank] = b;
+        __syncthreads();
     }
 }
 
 __global__ __launch_bounds__(1024) void prep_scan_sort_kernel(const int32_t *__restrict__ len, int B, int T,
-                                                              int32_t *__restrict__ tok_off, int32_t *__restrict__ perm,
-                                                              int32_t *tmp)
+                                                              int32_t *__restrict__ tok_off, int32_t *__restrict__ perm)
 {
-    scan_sort_block(len, B, T, tok_off, perm, tmp);
+    scan_sort_block(len, B, T, tok_off, perm);
 }
 
 // The whole prep in ONE workgroup for small batches (B <= 1024 rows, B*T <= 8192 ids: every query-tower call): clears the
@@ -219,7 +229,7 @@ __global__ __launch_bounds__(1024) void prep_fused_kernel(const int64_t *__restr
         flag[tid] = tid == 0 ? st_bits : 0;
     if (tid == 0 && status)
         status[0] = st_bits;
-    scan_sort_block(len, B, T, tok_off, perm, packed); // (the packed ids are written below: until then their buffer is scratch)
+    scan_sort_block(len, B, T, tok_off, perm);
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < PREP_FUSED_PER; ++i) {
@@ -621,7 +631,7 @@ static int encoder_forward(const char *who, const int64_t *ids, int B, int T, co
     } else {
         TT_RC_CHECK(tt_zero_async(flag, 256, st));
         hipLaunchKernelGGL(prep_len_kernel, dim3((B + 3) / 4), dim3(256), 0, st, ids, B, T, V, len, flag);
-        hipLaunchKernelGGL(prep_scan_sort_kernel, dim3(1), dim3(1024), 0, st, len, B, T, tok_off, perm, idsp);
+        hipLaunchKernelGGL(prep_scan_sort_kernel, dim3(1), dim3(1024), 0, st, len, B, T, tok_off, perm);
         hipLaunchKernelGGL(prep_pack_ids_kernel, dim3(B), dim3(256), 0, st, ids, B, T, len, tok_off, V, idsp);
         TT_LAUNCH_CHECK();
         if (status)

@@ -97,6 +97,17 @@ __device__ __forceinline__ int team_shares_xcd(__amdgpu_buffer_rsrc_t xsrc, int 
     return *lds_word;
 }
 
+// lane ^ 1 and a 16-lane rotate as DPP moves (VALU, no LDS crossbar round trip as __shfl_xor's ds_bpermute)
+__device__ __forceinline__ unsigned swap1(unsigned x)
+{
+    return (unsigned)__builtin_amdgcn_mov_dpp((int)x, 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, true);
+}
+template <int N>
+__device__ __forceinline__ float row_ror(float x) // lane i of a 16-lane row takes lane (i + N) % 16's value
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0x120 + N, 0xF, 0xF, true));
+}
+
 struct GruSplitParams {
     GruParams g;
     char *xch;         // [dir][team] x X4_TEAM_BYTES, zeroed before the launch (tag 0 = nothing published)
@@ -268,7 +279,7 @@ __global__ __launch_bounds__(256, 1) void gru_seq16x4_kernel(GruSplitParams sp)
             const unsigned tag = (unsigned)s + 1u;
             const int par = s & 1;
             // ---- publish: swap halves with the neighbour lane, then two 16-byte write-through stores ----
-            const unsigned g0 = __shfl_xor(odd ? pk[0] : pk[2], 1), g1 = __shfl_xor(odd ? pk[1] : pk[3], 1);
+            const unsigned g0 = swap1(odd ? pk[0] : pk[2]), g1 = swap1(odd ? pk[1] : pk[3]);
             const u32x4 v0 = odd ? (u32x4){g0, tag, pk[2], tag} : (u32x4){pk[0], tag, g0, tag};
             const u32x4 v1 = odd ? (u32x4){g1, tag, pk[3], tag} : (u32x4){pk[1], tag, g1, tag};
             const int sbase = (par * 4 + m) * X4_REGION + send_off;
@@ -368,7 +379,7 @@ __global__ __launch_bounds__(256, 1) void gru_seq16x4_kernel(GruSplitParams sp)
 // partial chains of 6 k-steps instead of one of 24): checked against the oracle at the tests' gradient tolerance instead.
 constexpr int XB_LDG = 192 + 8;            // fp16 elements per row of a dGh image (own 3 x 64 columns)
 constexpr int XB_IMG = 16 * XB_LDG * 2;    // bytes of one (hi or lo) image
-constexpr int XB_RM = 2 * 4 * 16 * 4;      // per-wave row maxima, double-buffered
+constexpr int XB_RM = 2 * 16 * 4 * 4;      // row maxima [buffer][row][wave], double-buffered
 constexpr int XB_LDS = 2 * XB_IMG + XB_RM; // + 16 for the abort word
 constexpr int XB_REGION = 16 * 64 * 8;     // one (dest, src) block of one parity
 constexpr size_t XB_TEAM_BYTES = 2 * 4 * 4 * (size_t)XB_REGION; // [parity][dest][src]
@@ -383,11 +394,15 @@ struct GruSplitBwdParams {
 
 __global__ __launch_bounds__(256, 1) void gru_bwd16x4_kernel(GruSplitBwdParams sp)
 {
+    // One wave per SIMD: every instruction of the step is on the critical path (nothing else issues while it does), so the
+    // step is written for instruction count -- 32-bit element offsets from uniform base pointers, unconditional loads of a
+    // valid address + selects instead of exec-masked blocks, member indices RELATIVE to this member (compile-time register
+    // indices), one exec-masked block of stores per row.
     extern __shared__ __attribute__((aligned(16))) char lds[];
     int &abort_flag = *(int *)(lds + XB_LDS);
     const GruBwdParams &p = sp.g;
     const int chunk = blockIdx.x >> 5, r32 = blockIdx.x & 31;
-    const int m = r32 >> 3, team = chunk * 8 + (r32 & 7);
+    const int m = __builtin_amdgcn_readfirstlane(r32 >> 3), team = chunk * 8 + (r32 & 7);
     if (team >= sp.nteams)
         return;
     const GruBwdDir d = p.dir[blockIdx.y];
@@ -417,16 +432,17 @@ __global__ __launch_bounds__(256, 1) void gru_bwd16x4_kernel(GruSplitBwdParams s
     const int exw = tt_pow2_exponent(*d.wmax);
 
     char *const img = lds;                            // [hi, lo][16][XB_LDG] fp16: this member's dGh columns [g][64]
-    float *const rmax = (float *)(lds + 2 * XB_IMG);  // [2][4 waves][16 rows]
+    float *const rmax = (float *)(lds + 2 * XB_IMG);  // [2][16 rows][4 waves]
     if (tid == 0)
         abort_flag = 0;
 
     // ---- this wave's 48 fragments of W_hh: rows = the member's 192 gate rows (k-steps 8 g + 2 m + {0, 1} of gru16_pack_t's
-    // order), columns = the 16 units [64 o + 16 w, + 16) of every member o.  Packed order: wave pw of 32 output units,
-    // fragment f = 4 s + 2 part + t: (pw, t) = (2 o + (w >> 1), w & 1) ----
-    h8 wreg[4][6][2]; // [dest member][k-step of the member's 192 rows][hi, lo]
+    // order), columns = the 16 units [64 o + 16 w, + 16) of member o = (m + oo) & 3, oo = 0 (own) .. 3.  Packed order: wave
+    // pw of 32 output units, fragment f = 4 s + 2 part + t: (pw, t) = (2 o + (w >> 1), w & 1) ----
+    h8 wreg[4][6][2]; // [oo][k-step of the member's 192 rows][hi, lo]
 #pragma unroll
-    for (int o = 0; o < 4; ++o) {
+    for (int oo = 0; oo < 4; ++oo) {
+        const int o = (m + oo) & 3;
         const __amdgpu_buffer_rsrc_t wsrc = __builtin_amdgcn_make_buffer_rsrc(
             (void *)((const char *)d.wtp + (size_t)(2 * o + (w >> 1)) * 96 * 1024), 0, 96 * 1024, 0x00020000);
         const int loff = lane * 16 + (w & 1) * 1024;
@@ -435,7 +451,7 @@ __global__ __launch_bounds__(256, 1) void gru_bwd16x4_kernel(GruSplitBwdParams s
             const int sg = 8 * (s2 >> 1) + 2 * m + (s2 & 1);
 #pragma unroll
             for (int part = 0; part < 2; ++part)
-                wreg[o][s2][part] = frag_load(wsrc, loff + (4 * sg + 2 * part) * 1024, 0);
+                wreg[oo][s2][part] = frag_load(wsrc, loff + (4 * sg + 2 * part) * 1024, 0);
         }
     }
 
@@ -447,30 +463,6 @@ __global__ __launch_bounds__(256, 1) void gru_bwd16x4_kernel(GruSplitBwdParams s
     const bool odd = j & 1;
     const int pair_off = ((kq * 4 + (odd ? 2 : 0)) * 64 + (ul & ~1)) * 8; // + 512 for the second row
 
-    struct Stash {
-        float r[4], z[4], n[4], ghn[4], hp[4], dsv[4];
-    };
-    auto load_stash = [&](int s, Stash &st) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const bool a = s >= 0 && s < len_e[e];
-            const int t = d.reverse ? len_e[e] - 1 - s : s;
-            const size_t tok = (size_t)(off_e[e] + (a ? t : 0));
-            const size_t ptok = d.reverse ? tok + 1 : tok - 1;
-            st.r[e] = st.z[e] = st.n[e] = st.ghn[e] = st.hp[e] = st.dsv[e] = 0.0f;
-            if (a) {
-                const float *gs = d.gates + tok * 4 * H + unit;
-                st.r[e] = gs[0];
-                st.z[e] = gs[H];
-                st.n[e] = gs[2 * H];
-                st.ghn[e] = gs[3 * H];
-                if (s > 0)
-                    st.hp[e] = d.hseq[ptok * p.ld + d.col0 + unit];
-                if (d.d_seq)
-                    st.dsv[e] = d.d_seq[tok * p.ld + d.col0 + unit];
-            }
-        }
-    };
     const int same_xcd = team_shares_xcd(xsrc, (int)XB_TEAM_BYTES, m, tid, sp.spin_max, &abort_flag + 1);
     if (same_xcd < 0) {
         if (tid == 0) {
@@ -481,6 +473,31 @@ __global__ __launch_bounds__(256, 1) void gru_bwd16x4_kernel(GruSplitBwdParams s
         }
         steps = 0;
     }
+
+    // token of row e at step s: off + (s or len - 1 - s) while the row is live, the row's first token otherwise (a valid
+    // address: what is loaded there is discarded by a select).  Everything below indexes with 32-bit element offsets from
+    // the uniform base pointers (the host takes this kernel only when the largest array is below 4 GB).
+    const unsigned ld = (unsigned)p.ld, cu = (unsigned)d.col0 + (unsigned)unit;
+    struct Stash {
+        float r[4], z[4], n[4], ghn[4], hp[4], dsv[4];
+    };
+    auto load_stash = [&](int s, Stash &st) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const bool a = s >= 0 && s < len_e[e];
+            const int t = d.reverse ? len_e[e] - 1 - s : s;
+            const unsigned tok = (unsigned)(off_e[e] + (a ? t : 0));
+            const unsigned ptok = (a && s > 0) ? (d.reverse ? tok + 1u : tok - 1u) : tok;
+            const unsigned go = tok * (4u * H) + (unsigned)unit;
+            st.r[e] = d.gates[go];
+            st.z[e] = d.gates[go + H];
+            st.n[e] = d.gates[go + 2 * H];
+            st.ghn[e] = d.gates[go + 3 * H];
+            const float hpv = d.hseq[ptok * ld + cu];
+            st.hp[e] = s > 0 ? hpv : 0.0f;
+            st.dsv[e] = d.d_seq ? d.d_seq[tok * ld + cu] : 0.0f;
+        }
+    };
     Stash cur_st, next_st;
     load_stash(steps - 1, cur_st);
     __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): fragments and the first stash are in (no such waits inside the loop)
@@ -491,51 +508,47 @@ __global__ __launch_bounds__(256, 1) void gru_bwd16x4_kernel(GruSplitBwdParams s
     unsigned it = 0;              // steps done: tag = it + 1, parity = it & 1
 
     for (int s = steps - 1; s >= 0; --s, ++it) {
-        float direct[4], gv[3][4], mrow[4], dnp[4] = {0, 0, 0, 0};
+        float direct[4], gv[3][4], dnp[4], mrow[4];
         bool act[4];
-        size_t tokv[4];
+        unsigned tokv[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             act[e] = s < len_e[e];
             const int t = d.reverse ? len_e[e] - 1 - s : s;
-            const size_t tok = (size_t)(off_e[e] + (act[e] ? t : 0));
-            tokv[e] = tok;
-            float dr_pre = 0.0f, dz_pre = 0.0f, dghn_v = 0.0f;
-            direct[e] = 0.0f;
-            if (act[e]) {
-                const float r = cur_st.r[e], z = cur_st.z[e], n = cur_st.n[e], ghn = cur_st.ghn[e], hp = cur_st.hp[e];
-                float dsv = cur_st.dsv[e];
-                if (d.d_seq && p.drop_p > 0.0f)
-                    dsv *= tt_dropout_scale(p.drop_seed, p.drop_layer, ((uint64_t)rid_e[e] * p.T + t) * p.ld + d.col0 + unit,
-                                            p.drop_p);
-                const float dhv = dh[e] + dsv;
-                const float dn_pre = dhv * (1.0f - z) * (1.0f - n * n);
-                dz_pre = dhv * (hp - n) * z * (1.0f - z);
-                dr_pre = dn_pre * ghn * r * (1.0f - r);
-                dghn_v = dn_pre * r;
-                direct[e] = dhv * z;
-                dnp[e] = dn_pre;
-                bsum[0] += dr_pre;
-                bsum[1] += dz_pre;
-                bsum[2] += dn_pre;
-                bsum[3] += dghn_v;
-                const float m2 = fmaxf(fabsf(dr_pre), fabsf(dz_pre));
-                mx_i = fmaxf(mx_i, fmaxf(m2, fabsf(dn_pre)));
-                mx_h = fmaxf(mx_h, fmaxf(m2, fabsf(dghn_v)));
-            }
-            gv[0][e] = dr_pre;
-            gv[1][e] = dz_pre;
-            gv[2][e] = dghn_v;
-            mrow[e] = fmaxf(fmaxf(fabsf(dr_pre), fabsf(dz_pre)), fabsf(dghn_v));
+            tokv[e] = (unsigned)(off_e[e] + (act[e] ? t : 0));
+            const float r = cur_st.r[e], z = cur_st.z[e], n = cur_st.n[e], ghn = cur_st.ghn[e], hp = cur_st.hp[e];
+            float dsv = cur_st.dsv[e];
+            if (d.d_seq && p.drop_p > 0.0f) // (uniform)
+                dsv *= tt_dropout_scale(p.drop_seed, p.drop_layer, ((uint64_t)(rid_e[e] < 0 ? 0 : rid_e[e]) * p.T + t) * p.ld + cu,
+                                        p.drop_p);
+            const float dhv = dh[e] + dsv;
+            const float dn_pre = dhv * (1.0f - z) * (1.0f - n * n);
+            const float dz_pre = dhv * (hp - n) * z * (1.0f - z);
+            const float dr_pre = dn_pre * ghn * r * (1.0f - r);
+            const float dghn_v = dn_pre * r;
+            gv[0][e] = act[e] ? dr_pre : 0.0f;
+            gv[1][e] = act[e] ? dz_pre : 0.0f;
+            gv[2][e] = act[e] ? dghn_v : 0.0f;
+            dnp[e] = act[e] ? dn_pre : 0.0f;
+            direct[e] = dhv * z;
+            bsum[0] += gv[0][e];
+            bsum[1] += gv[1][e];
+            bsum[2] += dnp[e];
+            bsum[3] += gv[2][e];
+            const float m2 = fmaxf(fabsf(gv[0][e]), fabsf(gv[1][e]));
+            mx_i = fmaxf(mx_i, fmaxf(m2, fabsf(dnp[e])));
+            mrow[e] = fmaxf(m2, fabsf(gv[2][e]));
+            mx_h = fmaxf(mx_h, mrow[e]);
         }
         // row maxima over the member's 192 columns: 16 lanes of a kq group -> one LDS word per wave and row
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-#pragma unroll
-            for (int off = 1; off < 16; off <<= 1)
-                mrow[e] = fmaxf(mrow[e], __shfl_xor(mrow[e], off));
+            mrow[e] = fmaxf(mrow[e], row_ror<1>(mrow[e])); // after rotations by 1, 2, 4, 8 every lane of the row holds its maximum
+            mrow[e] = fmaxf(mrow[e], row_ror<2>(mrow[e]));
+            mrow[e] = fmaxf(mrow[e], row_ror<4>(mrow[e]));
+            mrow[e] = fmaxf(mrow[e], row_ror<8>(mrow[e]));
             if (j == 0)
-                rmax[(rb * 4 + w) * 16 + kq * 4 + e] = mrow[e];
+                rmax[(rb * 16 + kq * 4 + e) * 4 + w] = mrow[e];
         }
         load_stash(s - 1, next_st); // in flight during the MFMAs and the hand-off below
         __syncthreads();            // B1: row maxima visible; every wave is done reading the previous step's images
@@ -544,26 +557,24 @@ __global__ __launch_bounds__(256, 1) void gru_bwd16x4_kernel(GruSplitBwdParams s
         float down[4]; // rows 4 kq + e: the rows of this lane's values AND of its accumulators (the MFMA's C layout)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            float mm = 0.0f;
-#pragma unroll
-            for (int ww = 0; ww < 4; ++ww)
-                mm = fmaxf(mm, rmax[(rb * 4 + ww) * 16 + kq * 4 + e]);
+            const f32x4v rm = *(const f32x4v *)(rmax + (rb * 16 + kq * 4 + e) * 4); // the four waves' maxima of this row
+            const float mm = fmaxf(fmaxf(rm[0], rm[1]), fmaxf(rm[2], rm[3]));
             const int er = tt_pow2_exponent(__float_as_uint(mm));
             const float upr = ldexpf(1.0f, er);
             down[e] = ldexpf(1.0f, -(er + exw));
-            _Float16 *dst = (_Float16 *)img + (kq * 4 + e) * XB_LDG;
+            _Float16 *dst = (_Float16 *)img + (kq * 4 + e) * XB_LDG + ul;
 #pragma unroll
             for (int g = 0; g < 3; ++g) {
                 const float x = gv[g][e] * upr;
                 const _Float16 hi = (_Float16)x;
-                dst[g * 64 + ul] = hi;
-                dst[XB_IMG / 2 + g * 64 + ul] = (_Float16)(x - (float)hi);
+                dst[g * 64] = hi;
+                dst[XB_IMG / 2 + g * 64] = (_Float16)(x - (float)hi);
             }
         }
         rb ^= 1;
         __syncthreads(); // B2: the dGh images are complete
 
-        f32x4v acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}}; // [dest member]
+        f32x4v acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}}; // [oo]: destination member (m + oo) & 3
         const char *arow = img + j * (XB_LDG * 2) + kq * 16;
         h8 a_hi[2], a_lo[2];
         a_hi[0] = *(const h8 *)(arow);
@@ -575,42 +586,39 @@ __global__ __launch_bounds__(256, 1) void gru_bwd16x4_kernel(GruSplitBwdParams s
                 a_lo[(s2 + 1) & 1] = *(const h8 *)(arow + XB_IMG + (s2 + 1) * 64);
             }
 #pragma unroll
-            for (int o = 0; o < 4; ++o)
-                acc[o] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[s2 & 1], wreg[o][s2][0], acc[o], 0, 0, 0);
+            for (int oo = 0; oo < 4; ++oo)
+                acc[oo] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[s2 & 1], wreg[oo][s2][0], acc[oo], 0, 0, 0);
 #if !(TT_MUTATE_DROP_LO & 2)
 #pragma unroll
-            for (int o = 0; o < 4; ++o)
-                acc[o] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo[s2 & 1], wreg[o][s2][0], acc[o], 0, 0, 0);
+            for (int oo = 0; oo < 4; ++oo)
+                acc[oo] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo[s2 & 1], wreg[oo][s2][0], acc[oo], 0, 0, 0);
 #pragma unroll
-            for (int o = 0; o < 4; ++o)
-                acc[o] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[s2 & 1], wreg[o][s2][1], acc[o], 0, 0, 0);
+            for (int oo = 0; oo < 4; ++oo)
+                acc[oo] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[s2 & 1], wreg[oo][s2][1], acc[oo], 0, 0, 0);
 #endif
         }
-        // partial dh of this member for every unit: acc[o][e] = rows 4 kq + e, unit 64 o + 16 w + j
+        // partial dh of this member: part[oo][e] = rows 4 kq + e, unit 16 w + j of member (m + oo) & 3
         float part[4][4];
 #pragma unroll
-        for (int o = 0; o < 4; ++o)
+        for (int oo = 0; oo < 4; ++oo)
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-                part[o][e] = acc[o][e] * down[e];
+                part[oo][e] = acc[oo][e] * down[e];
         float sum[4] = {0, 0, 0, 0};
         if (s > 0) { // (the partials of the last step would only feed a dh nobody reads)
             const unsigned tag = it + 1u;
             const int par = (int)(it & 1u);
-            // ---- publish the three foreign blocks: [parity][dest o][src m] ----
+            // ---- publish the three foreign blocks: [parity][dest][src = m] ----
 #pragma unroll
             for (int oo = 1; oo < 4; ++oo) {
                 const int o = (m + oo) & 3;
-                float v[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    v[e] = o == 0 ? part[0][e] : (o == 1 ? part[1][e] : (o == 2 ? part[2][e] : part[3][e]));
-                const unsigned p0 = __float_as_uint(v[0]), p1 = __float_as_uint(v[1]), p2 = __float_as_uint(v[2]), p3 = __float_as_uint(v[3]);
-                const unsigned g0 = __shfl_xor(odd ? p0 : p2, 1), g1 = __shfl_xor(odd ? p1 : p3, 1);
+                const unsigned p0 = __float_as_uint(part[oo][0]), p1 = __float_as_uint(part[oo][1]);
+                const unsigned p2 = __float_as_uint(part[oo][2]), p3 = __float_as_uint(part[oo][3]);
+                const unsigned g0 = swap1(odd ? p0 : p2), g1 = swap1(odd ? p1 : p3);
                 const u32x4 v0 = odd ? (u32x4){g0, tag, p2, tag} : (u32x4){p0, tag, g0, tag};
                 const u32x4 v1 = odd ? (u32x4){g1, tag, p3, tag} : (u32x4){p1, tag, g1, tag};
                 const int base = ((par * 4 + o) * 4 + m) * XB_REGION + pair_off;
-                if (same_xcd) {
+                if (same_xcd) { // the partners read this XCD's L2
                     __builtin_amdgcn_raw_buffer_store_b128(v0, xsrc, base, 0, 0);
                     __builtin_amdgcn_raw_buffer_store_b128(v1, xsrc, base + 512, 0, 0);
                 } else {
@@ -624,12 +632,12 @@ __global__ __launch_bounds__(256, 1) void gru_bwd16x4_kernel(GruSplitBwdParams s
             while (true) {
                 bool ok = true;
 #pragma unroll
-                for (int oo = 0; oo < 3; ++oo) {
-                    const int src = (m + 1 + oo) & 3;
+                for (int oo = 1; oo < 4; ++oo) {
+                    const int src = (m + oo) & 3;
                     const int base = ((par * 4 + m) * 4 + src) * XB_REGION + pair_off;
-                    got[oo][0] = __builtin_amdgcn_raw_buffer_load_b128(xsrc, base, 0, 16);
-                    got[oo][1] = __builtin_amdgcn_raw_buffer_load_b128(xsrc, base + 512, 0, 16);
-                    ok = ok && got[oo][0].y == tag && got[oo][0].w == tag && got[oo][1].y == tag && got[oo][1].w == tag;
+                    got[oo - 1][0] = __builtin_amdgcn_raw_buffer_load_b128(xsrc, base, 0, 16);
+                    got[oo - 1][1] = __builtin_amdgcn_raw_buffer_load_b128(xsrc, base + 512, 0, 16);
+                    ok = ok && got[oo - 1][0].y == tag && got[oo - 1][0].w == tag && got[oo - 1][1].y == tag && got[oo - 1][1].w == tag;
                 }
                 if (__all(ok))
                     break;
@@ -645,53 +653,47 @@ __global__ __launch_bounds__(256, 1) void gru_bwd16x4_kernel(GruSplitBwdParams s
                 sweep_backoff(spins);
             }
             // un-pair: this lane's column is the even (x) or the odd (z) word; the neighbour holds its other two rows
-            float theirs[4][4]; // [member][e]; entry m = this member's own partial
-#pragma unroll
-            for (int oo = 0; oo < 3; ++oo) {
-                const int src = (m + 1 + oo) & 3;
-                const unsigned mine0 = odd ? got[oo][0].z : got[oo][0].x, mine1 = odd ? got[oo][1].z : got[oo][1].x; // rows (2,3) | (0,1)
-                const unsigned nb0 = odd ? got[oo][0].x : got[oo][0].z, nb1 = odd ? got[oo][1].x : got[oo][1].z;     // the neighbour's column
-                const unsigned h0 = __shfl_xor(nb0, 1), h1 = __shfl_xor(nb1, 1); // my column, the neighbour's rows
-                const float r0 = __uint_as_float(odd ? h0 : mine0), r1 = __uint_as_float(odd ? h1 : mine1);
-                const float r2 = __uint_as_float(odd ? mine0 : h0), r3 = __uint_as_float(odd ? mine1 : h1);
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    if (q == src) {
-                        theirs[q][0] = r0;
-                        theirs[q][1] = r1;
-                        theirs[q][2] = r2;
-                        theirs[q][3] = r3;
-                    }
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                if (q == m) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        theirs[q][e] = part[q][e];
-                }
+            float th[4][4]; // [oo][e]: the partial of member (m + oo) & 3 for this lane's unit
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-                sum[e] = ((theirs[0][e] + theirs[1][e]) + theirs[2][e]) + theirs[3][e]; // members 0, 1, 2, 3: a fixed order
+                th[0][e] = part[0][e];
+#pragma unroll
+            for (int oo = 1; oo < 4; ++oo) {
+                const u32x4 a0 = got[oo - 1][0], a1 = got[oo - 1][1];
+                const unsigned mine0 = odd ? a0.z : a0.x, mine1 = odd ? a1.z : a1.x; // rows (2, 3) | (0, 1) of my column
+                const unsigned h0 = swap1(odd ? a0.x : a0.z), h1 = swap1(odd ? a1.x : a1.z); // my column, the neighbour's rows
+                th[oo][0] = __uint_as_float(odd ? h0 : mine0);
+                th[oo][1] = __uint_as_float(odd ? h1 : mine1);
+                th[oo][2] = __uint_as_float(odd ? mine0 : h0);
+                th[oo][3] = __uint_as_float(odd ? mine1 : h1);
+            }
+            // members 0, 1, 2, 3 -- always in that order, whoever this member is: oo = (q - m) & 3 of absolute member q
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float t;
+                switch (m) { // (uniform)
+                case 0: t = ((th[0][e] + th[1][e]) + th[2][e]) + th[3][e]; break;
+                case 1: t = ((th[3][e] + th[0][e]) + th[1][e]) + th[2][e]; break;
+                case 2: t = ((th[2][e] + th[3][e]) + th[0][e]) + th[1][e]; break;
+                default: t = ((th[1][e] + th[2][e]) + th[3][e]) + th[0][e]; break;
+                }
+                sum[e] = t;
+            }
         }
         // the step's gradient rows go out BEHIND the hand-off (in front of it, 24 stores per lane would complete before the
         // sweep's loads could: vector memory operations finish in issue order); they drain under the next step's work
 #pragma unroll
         for (int e = 0; e < 4; ++e)
             if (act[e]) {
-                float *go = d.dgi + tokv[e] * H3 + unit;
-                go[0] = gv[0][e];
-                go[H] = gv[1][e];
-                go[2 * H] = dnp[e];
-                float *gh = d.dghn + tokv[e] * H3 + unit;
-                gh[0] = gv[0][e];
-                gh[H] = gv[1][e];
-                gh[2 * H] = gv[2][e];
-            }
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-            if (act[e])
+                const unsigned go = tokv[e] * (unsigned)H3 + (unsigned)unit;
+                d.dgi[go] = gv[0][e];
+                d.dgi[go + H] = gv[1][e];
+                d.dgi[go + 2 * H] = dnp[e];
+                d.dghn[go] = gv[0][e];
+                d.dghn[go + H] = gv[1][e];
+                d.dghn[go + 2 * H] = gv[2][e];
                 dh[e] = direct[e] + sum[e];
+            }
         cur_st = next_st;
     }
     __syncthreads();
