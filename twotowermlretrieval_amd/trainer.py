@@ -180,38 +180,47 @@ def _train_step_direct(model: TwoTowerModel, optimizer, queries, pos_docs, neg_d
             finally:
                 enc.check_inputs = check
             fw.append((out, ws, status, p_drop, seed))
-    for s, f in zip(streams, fw):
-        cur.wait_stream(s)
-        f[0].record_stream(cur)
+    # The document tower's stream carries the step's critical path from here on: the loss, the document backward and the
+    # optimizer are enqueued on IT (a hop to the caller's stream and back cost ~20 us each way on that path: event wait +
+    # launch); the query tower's stream joins for the loss and again before the optimizer.
+    s_doc, s_qry = streams
     pn, q = fw[0][0], fw[1][0]
     p, n = pn[:B], pn[B:]
     H = q.shape[1]
-    loss = torch.empty((), dtype=torch.float32, device=dev)
-    dq = torch.empty_like(q)
-    dpn = torch.empty_like(pn)
-    rows = torch.empty(B, dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
-        _lib.check(_lib.lib().tt_triplet_loss_f32(q.data_ptr(), p.data_ptr(), n.data_ptr(), B, H, float(margin), loss.data_ptr(),
-                                                  dq.data_ptr(), dpn[:B].data_ptr(), dpn[B:].data_ptr(), rows.data_ptr(),
-                                                  cur.cuda_stream))
+    s_doc.wait_stream(s_qry)
+    with torch.cuda.stream(s_doc):
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        dq = torch.empty_like(q)
+        dpn = torch.empty_like(pn)
+        rows = torch.empty(B, dtype=torch.float32, device=dev)
+        for t in (q, loss, dq, dpn, rows):
+            t.record_stream(s_doc)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().tt_triplet_loss_f32(q.data_ptr(), p.data_ptr(), n.data_ptr(), B, H, float(margin), loss.data_ptr(),
+                                                      dq.data_ptr(), dpn[:B].data_ptr(), dpn[B:].data_ptr(), rows.data_ptr(),
+                                                      s_doc.cuda_stream))
+    s_qry.wait_stream(s_doc)
     for enc, ids, s, f, d_out, grads in zip(encs, ids_of, streams, fw, (dpn, dq), into):
-        s.wait_stream(cur)
         with torch.cuda.stream(s):
             d_out.record_stream(s)
             enc._run_backward(ids.contiguous(), f[1], d_out, f[3], f[4], into=grads)
-    for s in streams:
-        cur.wait_stream(s)
+    s_doc.wait_stream(s_qry)
     for p_, gv in zip(optimizer.params, optimizer._views):
         p_.grad = gv
-    # The towers' status words (zero-length rows / ids out of range raise as in the reference) are read HERE: the read makes
-    # the host wait for the forward passes, and at this point the GPU is busy with the backward kernels, so the wait costs
-    # nothing; read right after the forwards it left the GPU idle for the ~0.1 ms the host needs to issue the loss and the
-    # backward launches.  The optimizer step is not enqueued for a bad batch: the weights stay untouched (the gradient buffer
-    # holds garbage, which the next step overwrites).
-    for enc, f in zip(encs, fw):
-        if enc.check_inputs:
-            _raise_status(int(f[2].item()))
-    optimizer.step()
+    with torch.cuda.stream(s_doc):
+        # The towers' status words (zero-length rows / ids out of range raise as in the reference; a column-split recurrence
+        # that gave up) are read HERE, behind the backward kernels: the read is the one host synchronisation of the step, and
+        # the optimizer step is not enqueued for a bad batch -- the weights stay untouched (the gradient buffer holds garbage,
+        # which the next step overwrites).
+        for enc, f in zip(encs, fw):
+            if enc.check_inputs:
+                _raise_status(int(f[2].item()))
+        for t in (optimizer.flat_params, optimizer.flat_grads, optimizer.exp_avg, optimizer.exp_avg_sq, optimizer.total_norm,
+                  optimizer._scratch):
+            t.record_stream(s_doc)
+        optimizer.step()
+    cur.wait_stream(s_doc)
+    loss.record_stream(cur)
     return loss
 
 
