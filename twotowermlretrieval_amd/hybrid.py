@@ -70,7 +70,10 @@ class SimpleHybridRetriever:
     scores of EVERY document, combined = alpha * dense + (1 - alpha) * tfidf, descending argsort, top_k (doc, score)
     pairs.  As in the reference the corpus is embedded with the SAME (query) encoder (:37-41) and the vectorizer is
     TfidfVectorizer(stop_words='english', max_features=10000) (:24).  The dense scores come from the HIP path
-    (query tower + tt_score_all_f32); the TF-IDF half is sklearn on the CPU, as in the reference."""
+    (query tower + tt_score_all_f32); the TF-IDF half is sklearn on the CPU, as in the reference.
+    RESTRICTION: the dense term is the dot product of the tower outputs, which equals the reference's
+    sklearn `cosine_similarity` only for unit rows, i.e. with NORMALIZE_OUTPUT = true (the reference's default and the
+    only configuration G11 pins); with NORMALIZE_OUTPUT = false the blend differs from the reference's."""
 
     def __init__(self, artifacts_path: str, alpha: float = 0.5, device=None):
         from sklearn.feature_extraction.text import TfidfVectorizer
