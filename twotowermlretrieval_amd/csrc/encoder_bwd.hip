@@ -408,6 +408,18 @@ int gemm_tn(const float *A, int64_t lda, int Mo, const float *Bsrc, int64_t ldb,
     g.b_exp = b_exp;
     g.b_hi16 = g.b_lo16 = nullptr;
     g.ldb16 = 0;
+    if (a_absmax && tt_wgrad16_supported(Mo, No, lda, ldb) && !((uintptr_t)A & 15) && !((uintptr_t)Bsrc & 15)) {
+        // 256-row output tiles with the whole K slab in one workgroup per CU (wgrad16.hip)
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+            cus <= 0) {
+            (void)hipGetLastError();
+            cus = 256;
+        }
+        const int ns = tt_wgrad16_slabs(Mo, No, cus, ENC_SPLITK);
+        TT_RC_CHECK(tt_wgrad16(g, ns, st));
+        return tt_slab_reduce(slabs, ns, (int64_t)Mo * No, out, 0, st);
+    }
     int rc = a_absmax ? tt_sgemm16(g, true, true, ENC_SPLITK, st) : tt_sgemm(g, true, true, ENC_SPLITK, st);
     if (rc != TT_OK)
         return rc;

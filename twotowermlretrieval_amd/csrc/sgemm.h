@@ -76,6 +76,13 @@ bool tt_gemm_rows16_supported(int N, int K, int64_t lda, int64_t ldc);
 int tt_pack_frag16(const float *W, int N, int K, const unsigned *absmax, void *out, hipStream_t st);
 int tt_gemm_rows16(const SgemmParams &p, hipStream_t st);
 
+// The weight-gradient products C[M][N] = A^T B summed over tokens (csrc/wgrad16.hip): p as for tt_sgemm16's (a_t, b_t) = (true,
+// true) form with C = the split-K slabs [z][M][N] (ldc = N, slab_stride = M N); writes nslabs slabs = tt_wgrad16_slabs(...),
+// which the caller reduces (tt_slab_reduce).  tt_wgrad16_supported: M a multiple of 256 (and TT_WGRAD_TILED unset).
+bool tt_wgrad16_supported(int M, int N, int64_t lda, int64_t ldb);
+int tt_wgrad16_slabs(int M, int N, int cus, int max_slabs);
+int tt_wgrad16(const SgemmParams &p, int nslabs, hipStream_t st);
+
 // bit pattern of max |x| over n floats -> *out (atomicMax; the caller zeroes *out on the stream first)
 int tt_absmax(const float *x, int64_t n, unsigned *out, hipStream_t st);
 
