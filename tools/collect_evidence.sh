@@ -1,6 +1,7 @@
 #!/bin/bash
 # Evidence of one build (run on the MI355X box from the repo root):  bash tools/collect_evidence.sh TAG
 #   gpurun_out/TAG_bench_kernel_stats.csv   rocprofv3 --kernel-trace --stats over `bench.py --steps 5 --warmup 2 --no-cpu-baseline`
+#                                           (tools/rocpd_stats.py: one row per kernel, grid and duration cluster)
 #   gpurun_out/TAG_bench_profiled.json      the bench line of that same run
 #   gpurun_out/TAG_pmc_summary.txt          FETCH_SIZE / WRITE_SIZE per launch (separate --pmc passes, --kernel-trace only) over
 #                                           tools/screen_probe.py (B=1024; B=32) and tools/pmc_probe.py (K4 at B=32 and B=1024)
