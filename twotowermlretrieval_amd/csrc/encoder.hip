@@ -180,9 +180,12 @@ __global__ __launch_bounds__(1024) void prep_scan_sort_kernel(const int32_t *__r
 // over the row's lanes, added to an LDS counter by the row's first lane in the wave.
 constexpr int PREP_FUSED_PER = 8;
 constexpr int64_t PREP_FUSED_MAX_IDS = 1024 * PREP_FUSED_PER;
+// pm_fwd / pm_rev (training; nullable): packed index of the token one step earlier / later in its row, `none` where there is
+// none (the backward's "previous token" maps: they only depend on the lengths, so the prep makes them).
 __global__ __launch_bounds__(1024) void prep_fused_kernel(const int64_t *__restrict__ ids, int B, int T, int64_t V,
                                                           int32_t *len, int32_t *flag, int32_t *tok_off, int32_t *perm,
-                                                          int32_t *__restrict__ packed, int32_t *__restrict__ status)
+                                                          int32_t *__restrict__ packed, int32_t *__restrict__ status,
+                                                          int32_t *__restrict__ pm_fwd, int32_t *__restrict__ pm_rev, int none)
 {
     __shared__ int cnt[1024];
     __shared__ int st_bits;
@@ -229,6 +232,9 @@ __global__ __launch_bounds__(1024) void prep_fused_kernel(const int64_t *__restr
         flag[tid] = tid == 0 ? st_bits : 0;
     if (tid == 0 && status)
         status[0] = st_bits;
+    __syncthreads();
+    if (tid == 0) // the backward call finds this call's status word through the workspace (encoder.h: ENC_FLAG_STATUS_PTR)
+        *(int32_t **)(flag + ENC_FLAG_STATUS_PTR) = status;
     scan_sort_block(len, B, T, tok_off, perm);
     __syncthreads();
 #pragma unroll
@@ -236,22 +242,40 @@ __global__ __launch_bounds__(1024) void prep_fused_kernel(const int64_t *__restr
         const int idx = i * 1024 + tid;
         if (idx < n) {
             const int row = idx / T, t = idx - row * T;
-            if (t < cnt[row])
-                packed[tok_off[row] + t] = (int32_t)(id[i] < 0 || id[i] >= V ? 0 : id[i]); // flagged, never dereferenced
+            if (t < cnt[row]) {
+                const int o = tok_off[row] + t;
+                packed[o] = (int32_t)(id[i] < 0 || id[i] >= V ? 0 : id[i]); // flagged, never dereferenced
+                if (pm_fwd)
+                    pm_fwd[o] = t > 0 ? o - 1 : none;
+                if (pm_rev)
+                    pm_rev[o] = t < cnt[row] - 1 ? o + 1 : none;
+            }
         }
     }
 }
 
+// (last kernel of the four-kernel prep: block 0 also hands the status word to the caller and leaves the caller's status
+//  pointer in the flag block -- a device-to-device copy and a one-thread kernel before)
 __global__ __launch_bounds__(256) void prep_pack_ids_kernel(const int64_t *__restrict__ ids, int B, int T,
                                                             const int32_t *__restrict__ len,
                                                             const int32_t *__restrict__ tok_off, int64_t V,
-                                                            int32_t *__restrict__ packed)
+                                                            int32_t *__restrict__ packed, int32_t *flag, int32_t *status,
+                                                            int32_t *__restrict__ pm_fwd, int32_t *__restrict__ pm_rev, int none)
 {
     const int b = blockIdx.x;
     const int L = len[b], o = tok_off[b];
+    if (b == 0 && threadIdx.x == 0) {
+        if (status)
+            status[0] = flag[0];
+        *(int32_t **)(flag + ENC_FLAG_STATUS_PTR) = status;
+    }
     for (int t = threadIdx.x; t < L; t += 256) {
         int64_t id = ids[(size_t)b * T + t];
         packed[o + t] = (int32_t)(id < 0 || id >= V ? 0 : id); // out-of-range ids are flagged, never dereferenced
+        if (pm_fwd)
+            pm_fwd[o + t] = t > 0 ? o + t - 1 : none;
+        if (pm_rev)
+            pm_rev[o + t] = t < L - 1 ? o + t + 1 : none;
     }
 }
 
@@ -499,8 +523,6 @@ __global__ __launch_bounds__(256) void head_kernel(const float *__restrict__ hfi
         out[(size_t)b * H + u] = normalize ? hid[u] / nrm : hid[u];
 }
 
-__global__ void store_ptr_kernel(int32_t **slot, int32_t *value) { *slot = value; }
-
 } // namespace
 
 int enc_check_shape(const char *who, int B, int T, int E, int H, int L, int64_t V)
@@ -625,23 +647,22 @@ static int encoder_forward(const char *who, const int64_t *ids, int B, int T, co
     int32_t *perm = (int32_t *)(ws + lo.perm), *idsp = (int32_t *)(ws + lo.ids), *flag = (int32_t *)(ws + lo.flag);
     const int ndir = lo.ndir;
 
+    // (training: the backward's "previous token" maps are made here -- they depend on the lengths only)
+    int32_t *pm_fwd = train ? (int32_t *)(ws + lo.prevmap[0]) : nullptr;
+    int32_t *pm_rev = (train && ndir == 2) ? (int32_t *)(ws + lo.prevmap[1]) : nullptr;
     if (B <= 1024 && (int64_t)B * T <= PREP_FUSED_MAX_IDS) {
-        hipLaunchKernelGGL(prep_fused_kernel, dim3(1), dim3(1024), 0, st, ids, B, T, V, len, flag, tok_off, perm, idsp, status);
+        hipLaunchKernelGGL(prep_fused_kernel, dim3(1), dim3(1024), 0, st, ids, B, T, V, len, flag, tok_off, perm, idsp, status,
+                           pm_fwd, pm_rev, (int)lo.MT);
         TT_LAUNCH_CHECK();
     } else {
         TT_RC_CHECK(tt_zero_async(flag, 256, st));
         hipLaunchKernelGGL(prep_len_kernel, dim3((B + 3) / 4), dim3(256), 0, st, ids, B, T, V, len, flag);
         hipLaunchKernelGGL(prep_scan_sort_kernel, dim3(1), dim3(1024), 0, st, len, B, T, tok_off, perm);
-        hipLaunchKernelGGL(prep_pack_ids_kernel, dim3(B), dim3(256), 0, st, ids, B, T, len, tok_off, V, idsp);
+        hipLaunchKernelGGL(prep_pack_ids_kernel, dim3(B), dim3(256), 0, st, ids, B, T, len, tok_off, V, idsp, flag, status,
+                           pm_fwd, pm_rev, (int)lo.MT);
         TT_LAUNCH_CHECK();
-        if (status)
-            TT_HIP_CHECK(hipMemcpyAsync(status, flag, sizeof(int32_t), hipMemcpyDeviceToDevice, st));
     }
 
-    if (train) { // the backward call finds this call's status word through the workspace (encoder.h: ENC_FLAG_STATUS_PTR)
-        hipLaunchKernelGGL(store_ptr_kernel, dim3(1), dim3(1), 0, st, (int32_t **)(flag + ENC_FLAG_STATUS_PTR), status);
-        TT_LAUNCH_CHECK();
-    }
     const size_t lds = sizeof(float) * 2 * ENC_RB * (H + 4);
     const bool force_f32 = enc_force_f32();
     const bool use16 = rnn_type == CELL_GRU && gru16_supported(H) && !force_f32;

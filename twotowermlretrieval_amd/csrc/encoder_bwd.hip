@@ -24,11 +24,15 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float fast_tanh_b(float x) { return tt_fast_tanh(x); } // the forward's tanh: tanh(c_t) is the value h_t used
 
 // d_hid = backward of y = hid / max(|hid|, 1e-12) (or identity)
+// (block 0 also clears `zero_words`: the 16 scale words of this call's f16-split weight-gradient products, which the kernels
+//  behind this one raise with atomicMax -- a separate launch before)
 __global__ __launch_bounds__(256) void head_bwd_kernel(const float *__restrict__ hid, const float *__restrict__ d_out,
-                                                       int H, int normalize, float *__restrict__ d_hid)
+                                                       int H, int normalize, float *__restrict__ d_hid, unsigned *zero_words)
 {
     __shared__ float red[8];
     const int b = blockIdx.x, tid = threadIdx.x;
+    if (b == 0 && tid < 16)
+        zero_words[tid] = 0u;
     const float *x = hid + (size_t)b * H, *dy = d_out + (size_t)b * H;
     if (!normalize) {
         for (int u = tid; u < H; u += 256)
@@ -98,18 +102,6 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ X
             mx = fmaxf(mx, __shfl_xor(mx, off));
         if ((threadIdx.x & 63) == 0 && mx > 0.0f)
             atomicMax(absmax, __float_as_uint(mx));
-    }
-}
-
-__global__ __launch_bounds__(256) void prevmap_kernel(const int32_t *__restrict__ len, const int32_t *__restrict__ tok_off,
-                                                      int none, int32_t *__restrict__ fwd, int32_t *__restrict__ rev)
-{
-    const int b = blockIdx.x;
-    const int L = len[b], o = tok_off[b];
-    for (int t = threadIdx.x; t < L; t += 256) {
-        fwd[o + t] = t > 0 ? o + t - 1 : none;
-        if (rev)
-            rev[o + t] = t < L - 1 ? o + t + 1 : none;
     }
 }
 
@@ -462,11 +454,10 @@ TT_EXPORT int tt_encoder_backward_f32(const int64_t *ids, int B, int T, const fl
 
     // scale words of the f16-split weight-gradient products (max |dGi|, max |dGh_n| per layer and direction), written
     // by the colsum passes: words 48..63 of the forward's status block
-    TT_RC_CHECK(tt_zero_async((unsigned *)(ws + lo.flag) + 48, 16 * sizeof(unsigned), st));
 
     // ---- head ------------------------------------------------------------------
     hipLaunchKernelGGL(head_bwd_kernel, dim3(B), dim3(256), 0, st, (const float *)(ws + lo.hid), d_out, H, normalize,
-                       bidirectional ? d_hid : d_hfin);
+                       bidirectional ? d_hid : d_hfin, (unsigned *)(ws + lo.flag) + 48);
     TT_LAUNCH_CHECK();
     if (bidirectional) {
         rc = colsum(d_hid, H, H, B, nullptr, slabs, g_proj_b, st);
@@ -528,10 +519,7 @@ TT_EXPORT int tt_encoder_backward_f32(const int64_t *ids, int B, int T, const fl
         }
     }
 
-    // ---- "previous token" maps --------------------------------------------------
-    hipLaunchKernelGGL(prevmap_kernel, dim3(B), dim3(256), 0, st, len, tok_off, MT, (int32_t *)(ws + lo.prevmap[0]),
-                       ndir == 2 ? (int32_t *)(ws + lo.prevmap[1]) : (int32_t *)nullptr);
-    TT_LAUNCH_CHECK();
+    // (the "previous token" maps were made by the training forward's prep: csrc/encoder.hip)
 
     const size_t lds = sizeof(float) * ENC_RB * (H3 + 4);
     static const bool force_f32 = [] { const char *e = getenv("TT_GRU_F32"); return e && e[0] == '1'; }();
