@@ -119,6 +119,8 @@ def kernel_only_ms(q, docs, k, iters=5, warm=2):
     e1.record()
     torch.cuda.synchronize()
     main = sum(_pair_ms(L, evs) for evs in pairs)
+    off = L.tt_score_topk_pace_timeouts_offset(B, N, d, k)
+    kernel_only_ms.pace_timeouts = int(ws[off:off + 4].view(torch.int32).item()) if off != C.c_size_t(-1).value else None
     return main / iters, e0.elapsed_time(e1) / iters
 
 
@@ -501,7 +503,8 @@ def main():
                     "achieved": round(flops / ms / 1e9, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(flops / ms / 1e9 / MFMA_F32_PEAK_TFLOPS, 4), "traffic": pmc_traffic("b1024") if world == 1 else None,
                     "kernel_ms": round(ms, 4), "with_sample_pass_ms": round(ms_br, 4), "batch": BATCH,
-                    "docs_per_gpu": n_shard, "qps": round(BATCH / ms_br * 1e3, 1)}
+                    "docs_per_gpu": n_shard, "qps": round(BATCH / ms_br * 1e3, 1),
+                    "pace_timeouts_last_launch": getattr(kernel_only_ms, "pace_timeouts", None)}
         qb = q[:32].contiguous()
         ms32, ms32_br = kernel_only_ms(qb, docs, TOPK)
         byts = n_shard * DIM * 4 + 32 * DIM * 4 + 32 * TOPK * 12

@@ -67,6 +67,10 @@ int tt_event_elapsed_ms(void *start, void *stop, float *ms); /* blocks until `st
  * N < 2^31 - 64 per call (shard larger corpora; idx_offset makes indices global).
  * Inputs must be finite (a NaN score is never selected).
  */
+/* Diagnostic: byte offset, in the workspace of a finished exact search of this shape, of an int32 counting the waves whose
+ * chunk-pacing wait timed out (the pacing counters are coherent only among waves on one XCD: a launch whose chunks straddle
+ * XCDs -- partition modes, tiny grids -- still returns exact results, each wave ~0.15 ms late once); (size_t)-1 = shape not paced. */
+size_t tt_score_topk_pace_timeouts_offset(int B, int64_t N, int d, int k);
 size_t tt_score_topk_workspace_bytes(int B, int64_t N, int d, int k);
 int tt_score_topk_f32(const float *Q, int B, int d, const float *D, int64_t N, int k,
                       int64_t idx_offset, float *out_val, int64_t *out_idx, void *workspace,

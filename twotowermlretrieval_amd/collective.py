@@ -75,7 +75,14 @@ class RcclComm:
 
 
 class Collective:
-    """all-gather of equal byte blocks / in-place summing all-reduce of a flat fp32 buffer on the CURRENT stream."""
+    """all-gather of equal byte blocks / in-place summing all-reduce of a flat fp32 buffer on the CURRENT stream.
+
+    CONSTRUCTION IS A COLLECTIVE: with an nccl group the constructor runs two all-reduces and a 16-byte all-gather (the
+    transport self-test), so every object that owns one -- `ShardedIndex`, `FusedClipAdam(group=...)`,
+    `DataParallelTrainer` -- must be constructed by ALL ranks of the group, in the SAME ORDER, or the job deadlocks; the same
+    holds for their searches / steps, as for any collective.  The C-ABI calls share torch.distributed's communicator: RCCL
+    executes what is enqueued on one communicator in issue order whatever the stream, so the host must issue collectives in the
+    same order on every rank (ShardedIndex puts all of an index's collectives on ONE exchange stream for that reason)."""
 
     def __init__(self, group=None, device: Optional[torch.device] = None, comm: Optional[RcclComm] = None):
         import torch.distributed as dist

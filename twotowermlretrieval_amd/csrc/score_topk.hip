@@ -73,6 +73,9 @@ struct ScoreParams {
     // drawn, else block + 1), so that the pool is walked in step as well.  Both nullptr: every wave for itself.
     int *pace;
     int pace_g, pace_lag;
+    int *pace_timeouts; // one word behind the pacing slots: how many waves gave up a pacing wait (the counters are only
+                        // coherent among waves that share an XCD's L2: a chunk that straddles XCDs times out once per wave
+                        // -- correct results, ~0.15 ms late; tt_score_topk_pace_timeouts_offset lets a bench report it)
     int *grp_blk;
     int grp_maxseg;
     float *pval;   // [n_qtiles*32][n_chunks][k]
@@ -274,6 +277,8 @@ __global__ __launch_bounds__(WPB * 64, 2) void score_topk_kernel(ScoreParams p)
                 return;
             if (polls == PACE_POLLS) {
                 waits = false;
+                if (lane == 0)
+                    atomicAdd(p.pace_timeouts, 1);
                 return;
             }
             __builtin_amdgcn_s_sleep(8);
@@ -1197,7 +1202,7 @@ Plan make_plan(int B, int64_t N, int k, int d)
     pl.grp_maxseg = 0;
     pl.pace_off = pl.grp_off = off;
     if (pl.paced) {
-        off = tt_align_up(off + (size_t)pl.main.n_chunks * PACE_R * sizeof(int), 256);
+        off = tt_align_up(off + ((size_t)pl.main.n_chunks * PACE_R + 1) * sizeof(int), 256); // + the time-out count
         pl.grp_off = off;
         if (pl.main.tail_blocks > 0) {
             // a chunk's waves may take up to 4x their even share of the pool (>= 16 blocks); n_chunks * grp_maxseg >=
@@ -1306,6 +1311,7 @@ ScoreParams pass_params(const Pass &ps, const float *Q, int B, const float *D, i
     sp.tail_blocks = 0;
     sp.tail_ctr = nullptr;
     sp.pace = nullptr;
+    sp.pace_timeouts = nullptr;
     sp.pace_g = sp.pace_lag = 1;
     sp.grp_blk = nullptr;
     sp.grp_maxseg = 0;
@@ -1373,6 +1379,7 @@ int score_partials(const float *Q, int B, int d, const float *D, int64_t N, int 
     }
     if (pl.paced && !run_if && tt_score_pacing()) {
         sp.pace = (int *)(ws + pl.pace_off);
+        sp.pace_timeouts = sp.pace + (size_t)pl.main.n_chunks * PACE_R;
         sp.pace_g = pl.pace_g;
         sp.pace_lag = pl.pace_lag;
         if (sp.tail_ctr) {
@@ -1391,6 +1398,16 @@ int score_partials(const float *Q, int B, int d, const float *D, int64_t N, int 
 }
 
 } // namespace
+
+// Byte offset, in the workspace of a finished tt_score_topk(_partials)_f32 call of this shape, of an int32 that counts the waves
+// whose pacing wait ran into its bound (0 when the launch was not paced): (size_t)-1 if the shape is never paced.
+TT_EXPORT size_t tt_score_topk_pace_timeouts_offset(int B, int64_t N, int d, int k)
+{
+    if (B <= 0 || N <= 0 || k <= 0)
+        return (size_t)-1;
+    const Plan pl = make_plan(B, N, k, d);
+    return pl.paced ? pl.pace_off + (size_t)pl.main.n_chunks * PACE_R * sizeof(int) : (size_t)-1;
+}
 
 TT_EXPORT size_t tt_score_topk_workspace_bytes(int B, int64_t N, int d, int k)
 {
