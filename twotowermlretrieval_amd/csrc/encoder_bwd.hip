@@ -373,7 +373,8 @@ int colsum(const float *X, int64_t ld, int N, int M, const int *m_dyn, float *sl
 // C[Mo][No] = A[:, a0:a0+Mo]^T * Bsrc (both summed over tokens), split-K + deterministic reduce.
 // a_absmax != nullptr: on the f16 pipes (fp16 hi/lo split of both operands, sgemm.h): A = gradients, scaled by the
 // power of two that *a_absmax (max |A|, from the colsum pass over the same matrix) implies; B scaled by 2^b_exp.
-int gemm_tn(const float *A, int64_t lda, int Mo, const float *Bsrc, int64_t ldb, const int32_t *b_map, int No,
+// b_rows: an upper bound of Bsrc's row count (the 256-row-tile kernel addresses B with 32-bit offsets and checks it).
+int gemm_tn(const float *A, int64_t lda, int Mo, const float *Bsrc, int64_t ldb, const int32_t *b_map, int64_t b_rows, int No,
             int Ktok, const int *k_dyn, float *slabs, float *out, hipStream_t st, const unsigned *a_absmax = nullptr,
             int b_exp = 0, const unsigned *b_absmax = nullptr)
 {
@@ -400,7 +401,7 @@ int gemm_tn(const float *A, int64_t lda, int Mo, const float *Bsrc, int64_t ldb,
     g.b_exp = b_exp;
     g.b_hi16 = g.b_lo16 = nullptr;
     g.ldb16 = 0;
-    if (a_absmax && tt_wgrad16_supported(Mo, No, lda, ldb) && !((uintptr_t)A & 15) && !((uintptr_t)Bsrc & 15)) {
+    if (a_absmax && tt_wgrad16_supported(Mo, No, lda, ldb, b_rows) && !((uintptr_t)A & 15) && !((uintptr_t)Bsrc & 15)) {
         // 256-row output tiles with the whole K slab in one workgroup per CU (wgrad16.hip)
         int dev = 0, cus = 256;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
@@ -623,17 +624,17 @@ TT_EXPORT int tt_encoder_backward_f32(const int64_t *ids, int B, int T, const fl
             // (f16-split products: embedding rows scaled by the power of two of the batch's largest |x|, which the training
             //  forward left in the status block; hidden states (|h| < 1, times 1/(1-p) when dropped) 2^6)
             if (l == 0)
-                rc = gemm_tn(dgi, H3, H3, table, E, idsp, E, MT, m_valid, slabs, g[0], st, mx_dgi, 0,
+                rc = gemm_tn(dgi, H3, H3, table, E, idsp, V, E, MT, m_valid, slabs, g[0], st, mx_dgi, 0,
                              (const unsigned *)(ws + lo.flag) + ENC_FLAG_XMAX);
             else
-                rc = gemm_tn(dgi, H3, H3, (const float *)(ws + (drop ? lo.xd[l] : lo.x[l])), I, nullptr, I, MT, m_valid,
+                rc = gemm_tn(dgi, H3, H3, (const float *)(ws + (drop ? lo.xd[l] : lo.x[l])), I, nullptr, MT, I, MT, m_valid,
                              slabs, g[0], st, mx_dgi, 6);
             if (rc != TT_OK)
                 return rc;
             // W_hh <- dGh^T H_prev, H_prev rows through the previous-token map into this layer's own output
             const int32_t *pm = (const int32_t *)(ws + lo.prevmap[d]);
             // (GRU: the hidden-side gradients dGh = [dr_pre, dz_pre, dn_pre r]; LSTM / RNN: the same matrix as dGi)
-            rc = gemm_tn(rnn_type == CELL_GRU ? dghn : dgi, H3, H3, hseq + (size_t)d * H, ndir * H, pm, H, MT, m_valid, slabs, g[1],
+            rc = gemm_tn(rnn_type == CELL_GRU ? dghn : dgi, H3, H3, hseq + (size_t)d * H, ndir * H, pm, (int64_t)MT + 1, H, MT, m_valid, slabs, g[1],
                          st, rnn_type == CELL_GRU ? mx_dghn : mx_dgi, 10);
             if (rc != TT_OK)
                 return rc;

@@ -16,16 +16,29 @@
 //   * rows are 544 bytes apart (136 dwords = 8 banks mod 64: the four rows of a block fall into four different 8-bank windows)
 //     and the 16-byte chunks of rows 8 .. 15, 24 .. 31 are XORed with 8 (128 bytes = 32 banks): the two 16-lane groups of a
 //     32-lane half read rows 8 apart and land on different halves of the bank array;
-//   * two LDS stages (2 x 4 images x 32 rows x 544 B = 136 KB) and two register sets of operand rows: tile t is multiplied
-//     from LDS while tile t + 1 is committed and the loads of tile t + 2 are in flight; one barrier per tile.
-// Measured (75 k tokens, one box): dW_ih 263 -> 180 us, dW_hh 153 -> 140 us, train step 1.52 -> 1.40 ms.  Ablation builds
-// (phases switched off at run time, tools/experiments/wgrad_ablation.sh at the commit that carried the switches; profiler
-// timings): loop + LDS reads + barriers alone 35 us; + MFMAs 63; + commit (of stale registers) 59; + loads (never waited for)
-// 63; MFMAs + commit 84; MFMAs + loads 86; commit + LOADED data 184; everything 214: what costs is WAITING for the operand rows
-// -- 2.3 us per 52 KB tile and CU whether one or two tiles are in flight -- although HBM delivers only the unique 320 MB
-// (TCC misses x 128 B; L2 hit rate 64 %: the XCD placement works) = 1.8 TB/s.  Open: where those loads queue (the gathered
-// table rows are the suspects: the dW_hh launch, whose B rows are the packed hidden sequence, halves without its MFMAs, the
-// dW_ih launch does not).
+//   * two LDS stages (2 x 4 images x 32 rows x 544 B = 136 KB) and ONE register set of operand rows: tile t is multiplied
+//     from LDS while tile t + 1 is converted piece by piece and every piece's registers are requested again at once for tile
+//     t + 2 (a request has a whole iteration to arrive); one barrier per tile.
+// What bounds it (round 3, measured in this order -- the first explanation, "waiting for the operand rows", was wrong):
+//   * s_memtime stamps inside the loop: the wait for loaded rows is 10 - 50 clocks per tile; the time went into ISSUING -- 1370
+//     clocks per tile for 14 load instructions per wave when all eight waves queue at the CU's one texture-address path
+//     together -- and into the conversion: 1900 - 2300 clocks per tile for ~120 vector instructions;
+//   * tools/experiments/valu_rate.hip: a lone wave issues a vector instruction every 8.7 clocks (v_fma_mix: 12.5), and next to
+//     a wave that keeps the matrix pipe busy the SIMD's other wave issues ONE vector instruction per MFMA (16.3 clocks; the
+//     packed fp32 forms 25).  A tile's 120 MFMAs per SIMD therefore hide 120 vector instructions and every further one costs
+//     4 - 8 clocks of an idle matrix pipe; the first build issued 420 per SIMD and tile (64-bit row-address arithmetic with
+//     quarter-rate multiplies, a bound check per float4, 17 instructions of conversion per float4);
+//   * so: scalar row addresses for A (rows are wave-uniform), 24-bit multiplies and 32-bit offsets for B, the past-the-slab zero
+//     on A only (scalar), the conversion as eight v_fma_mix per float4 (inline asm: hi = f16(s v), lo = f16(s v - hi), both one
+//     instruction) -- 80 - 90 per wave and tile -- and the fill cut into 5 + BJ pieces spread over the twelve MFMA runs of a
+//     tile (sched_group_barrier inside a run, sched_barrier between runs; one basic block: no map / tail branches);
+//   * tried and dropped: the two waves of a SIMD taking "fill" and "multiply" in opposite order (the filling wave then runs
+//     at one instruction per 16 clocks for the whole multiply of its partner: 3840 clocks per tile against 3400 interleaved),
+//     two register sets of rows (no gain once the requests are spread), XCD-unaware block order (730 MB instead of 320).
+// Measured (75 k tokens, one box, profiler): dW_ih 263 (tiled) -> 180 -> 147 us, dW_hh 153 -> 140 -> 125 us; a tile takes
+// ~3400 clocks against 1920 of MFMAs.  What is left: LDS traffic is 83 % of the MFMA time (147 KB of operand reads + 57 KB of
+// writes per tile at 128 B / clock), ~200 vector instructions per SIMD and tile against 120 free slots, ~600 clocks at the
+// barrier.  HBM delivers only the unique 320 MB (TCC misses x 128 B; L2 hit rate 64 %: the XCD placement works).
 // Products and their order per element: (A hi)(B hi) + (A lo)(B hi) + (A hi)(B lo), token tiles ascending inside a slab, slabs
 // reduced in slab order by tt_slab_reduce: deterministic, fp32-grade; NOT bit-identical to the tiled kernel (another slab
 // partition).  TT_WGRAD_TILED=1 keeps the tiled kernel (A/B).
@@ -58,8 +71,14 @@ __device__ __forceinline__ h8 tr_frag(const char *p0, const char *p1)
     return __builtin_bit_cast(h8, t);
 }
 
+#ifdef TT_WG_DBG // a measuring build (tools/experiments/wgdbg.sh), never the shipped one: s_memtime clocks per tile, printed every 16th launch
+__device__ unsigned long long wg_dbg[8];
+#define WG_T(i) do { __builtin_amdgcn_sched_barrier(0); tm[i] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define WG_T(i) do { } while (0)
+#endif
 // NT: 16-column tiles per wave along N (the workgroup's tile is 2 NT x 16 columns wide)
-template <int NT>
+template <int NT, bool BMAP>
 __global__ __launch_bounds__(512, 1) void wgrad16_kernel(SgemmParams p, int n_ntiles, int kchunk, int nslabs)
 {
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -69,6 +88,9 @@ __global__ __launch_bounds__(512, 1) void wgrad16_kernel(SgemmParams p, int n_nt
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = w & 3, wn = w >> 2;
+#ifdef TT_WG_DBG
+    const unsigned long long t_start = __builtin_amdgcn_s_memtime();
+#endif
     // The tiles of one K slab read the same rows of both operands (dGi: once per column tile, X: once per row tile): they are
     // put on ONE XCD so that its L2 serves the re-reads -- blocks are dealt round-robin over the 8 XCDs, so block L lands on XCD
     // L % 8 (a speed bonus, never relied on): slab z = 8 (L / (8 tiles)) + L % 8, tile = (L / 8) % tiles.  Spread over the XCDs
@@ -92,77 +114,81 @@ __global__ __launch_bounds__(512, 1) void wgrad16_kernel(SgemmParams p, int n_nt
         for (int b = 0; b < NT; ++b)
             acc[a][b] = (f32x4v){0, 0, 0, 0};
 
-    // ---- fill mapping.  A: thread -> rows (tid >> 6) + 8 j, float4 column tid & 63 (a wave reads 1 KB of one token row).
-    //      B: float4 index tid + 512 j of the 32 x BQ tile, row = idx / BQ (source row through b_map), column idx % BQ.
-    //      Every load is UNCONDITIONAL from a clamped, valid address (what lies past the slab's end or past column N is
-    //      zeroed by a select when it is committed) and the source-row indices of a tile are fetched one tile before its
-    //      data: a row index loaded right in front of its row would put a wait between any two data loads -- seven
-    //      serialised round trips per tile, which is what the first build of this kernel spent its time on ----
+    // ---- fill mapping and its instruction budget.  The matrix pipe takes one MFMA per 16 clocks, and next to a wave that
+    //      keeps it busy a vector instruction of the SIMD's other wave issues once per MFMA (tools/experiments/valu_rate.hip:
+    //      16.3 clocks per v_fma / v_cvt / v_mul next to MFMAs, 25 for the packed fp32 forms, 8.7 alone): a tile's 60 MFMAs
+    //      per wave hide 60 vector instructions of its partner, and every further one costs 4 - 8 clocks of an idle matrix
+    //      pipe.  The first build spent 210 per wave and tile (64-bit row-address arithmetic with quarter-rate multiplies,
+    //      per-float4 bound checks, a conversion the compiler spread over 17 instructions per float4); this one 80 - 90:
+    //        A: thread -> token rows w + 8 j (wave-uniform: row base and the past-the-slab test live in scalar registers),
+    //           float4 column tid & 63 (a wave reads 1 KB of one row);
+    //        B: float4 index (tid + 512 j) mod (32 BQ) of the 32 x BQ tile (threads past the last float4 redo the first
+    //           ones: no divergent tail), row idx / BQ through b_map, 32-bit byte offset row * ldb + column (24-bit multiply;
+    //           tt_wgrad16_supported bounds the operand sizes);
+    //        conversion: hi = f16(s v), lo = f16(s v - hi) as ONE v_fma_mix each (s a power of two: exact products), 8 per
+    //           float4; only A carries the past-the-slab zero (a zero A row makes the token's contribution zero whatever
+    //           its B row holds), B only the constant past-column-N zero.
+    //      Every load is UNCONDITIONAL from a clamped, valid address and the source-row indices of a tile are fetched one
+    //      tile before its data (an index loaded right in front of its row would put a wait between any two data loads) ----
     const int klast = K > 0 ? K - 1 : 0;
-    int ia[4], ib[BJ];
-    f32x4v ra0[4], rb0[BJ], ra1[4], rb1[BJ]; // two tiles of operand rows in flight (registers), two tiles staged (LDS)
+    f32x4v ra[4], rb[BJ];    // one tile of operand rows in flight (registers), two tiles staged (LDS)
+    int ib[BJ];              // B source rows of the next tile to request
+    int brow[BJ];            // this thread's row of the tile per piece
+    unsigned bcol[BJ];       // ... and byte offset of its float4 inside a B row (clamped to the last whole float4 of the row)
+    float bscale[BJ];        // 2^eb, or 0 for a float4 past column N
+    int b_lds[BJ];           // where its halves go in a B image
+#pragma unroll
+    for (int j = 0; j < BJ; ++j) {
+        const int idx = (tid + 512 * j) % (WG_KT * BQ), c = idx % BQ;
+        brow[j] = idx / BQ;
+        bcol[j] = 4u * (unsigned)min(n0 + 4 * c, p.N - 4);
+        bscale[j] = n0 + 4 * c < p.N ? sb : 0.0f;
+        b_lds[j] = 2 * WG_IMG + img_off(brow[j], c >> 1, (c & 1) * 8);
+    }
+    const unsigned ldb4 = 4u * (unsigned)p.ldb;
+    const unsigned a_lane = 4u * (unsigned)(m0 + 4 * lane); // byte offset inside an A row
+    int a_lds[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        a_lds[j] = img_off(w + 8 * j, lane >> 1, (lane & 1) * 8);
     auto fetch_idx = [&](int k0) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int tok = min(k0 + (tid >> 6) + 8 * j, klast);
-            ia[j] = tok;
-        }
-        if (p.a_map) { // (uniform)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                ia[j] = p.a_map[ia[j]];
-        }
-#pragma unroll
         for (int j = 0; j < BJ; ++j) {
-            const int idx = min(tid + 512 * j, WG_KT * BQ - 1);
-            ib[j] = min(k0 + idx / BQ, klast);
-        }
-        if (p.b_map) {
-#pragma unroll
-            for (int j = 0; j < BJ; ++j)
-                ib[j] = p.b_map[ib[j]];
+            const int tok = min(k0 + brow[j], klast);
+            ib[j] = BMAP ? p.b_map[tok] : tok;
         }
     };
-    const int acol = m0 + 4 * (tid & 63);
-    auto fetch = [&](f32x4v (&ra)[4], f32x4v (&rb)[BJ]) { // the tile whose indices are in ia / ib
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            ra[j] = *(const f32x4v *)(p.A + (int64_t)ia[j] * p.lda + acol);
-#pragma unroll
-        for (int j = 0; j < BJ; ++j) {
-            const int idx = min(tid + 512 * j, WG_KT * BQ - 1);
-            const int col = min(n0 + 4 * (idx % BQ), p.N - 4);
-            rb[j] = *(const f32x4v *)(p.B + (int64_t)ib[j] * p.ldb + col);
-        }
+    auto fetch_a = [&](int k0, int j) { // (scalar row address + one lane offset)
+        const char *row = (const char *)(p.A + (size_t)min(k0 + w + 8 * j, klast) * (size_t)p.lda);
+        return *(const f32x4v *)(row + a_lane);
     };
-    // one float4 -> 4 hi + 4 lo halves; rows past the slab's end / columns past N are zeroed through the scale (the clamped
-    // addresses hold finite numbers: valid tokens, valid columns)
-    auto split4 = [&](f32x4v v, float s, h4 &hi, h4 &lo) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float x = v[e] * s;
-            const _Float16 hv = (_Float16)x;
-            hi[e] = hv;
-            lo[e] = (_Float16)(x - (float)hv);
-        }
+    auto fetch_b = [&](int j) { return *(const f32x4v *)((const char *)p.B + (size_t)(__umul24((unsigned)ib[j], ldb4) + bcol[j])); };
+    // one float4 -> 4 hi + 4 lo halves (two packed registers each)
+    typedef unsigned u2v __attribute__((ext_vector_type(2)));
+    auto split4 = [&](f32x4v v, float s, u2v &hi, u2v &lo) {
+        unsigned h0, h1, l0, l1;
+        asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h0) : "v"(s), "v"(v[0]));
+        asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h0) : "v"(s), "v"(v[1]));
+        asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h1) : "v"(s), "v"(v[2]));
+        asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h1) : "v"(s), "v"(v[3]));
+        asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(l0) : "v"(s), "v"(v[0]), "v"(h0));
+        asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l0) : "v"(s), "v"(v[1]), "v"(h0));
+        asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(l1) : "v"(s), "v"(v[2]), "v"(h1));
+        asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l1) : "v"(s), "v"(v[3]), "v"(h1));
+        hi = (u2v){h0, h1};
+        lo = (u2v){l0, l1};
     };
     auto commit_a = [&](char *stage, int k0, int j, f32x4v v) { // A piece j of the tile that starts at token k0
-        h4 hi, lo;
-        const int r = (tid >> 6) + 8 * j;
-        split4(v, k0 + r < ke ? sa : 0.0f, hi, lo);
-        const int off = img_off(r, (tid & 63) >> 1, (tid & 1) * 8);
-        *(h4 *)(stage + off) = hi;
-        *(h4 *)(stage + WG_IMG + off) = lo;
+        u2v hi, lo;
+        split4(v, k0 + w + 8 * j < ke ? sa : 0.0f, hi, lo);
+        *(u2v *)(stage + a_lds[j]) = hi;
+        *(u2v *)(stage + WG_IMG + a_lds[j]) = lo;
     };
-    auto commit_b = [&](char *stage, int k0, int j, f32x4v v) {
-        const int idx = tid + 512 * j, r = idx / BQ, c = idx % BQ;
-        if (idx < WG_KT * BQ) {
-            h4 hi, lo;
-            split4(v, (k0 + r < ke && n0 + 4 * c < p.N) ? sb : 0.0f, hi, lo);
-            const int off = img_off(r, c >> 1, (c & 1) * 8);
-            *(h4 *)(stage + 2 * WG_IMG + off) = hi;
-            *(h4 *)(stage + 3 * WG_IMG + off) = lo;
-        }
+    auto commit_b = [&](char *stage, int j, f32x4v v) {
+        u2v hi, lo;
+        split4(v, bscale[j], hi, lo);
+        *(u2v *)(stage + b_lds[j]) = hi;
+        *(u2v *)(stage + WG_IMG + b_lds[j]) = lo;
     };
 
     // ---- operand read addresses: lane (g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3) of a 16-lane group supplies row
@@ -177,70 +203,99 @@ __global__ __launch_bounds__(512, 1) void wgrad16_kernel(SgemmParams p, int n_nt
     for (int nt = 0; nt < NT; ++nt)
         b_off[nt] = img_off(rrow, (NT * 16 * wn + 16 * nt) / 8 + (pp >> 1), (pp & 1) * 8);
 
-    // Tile t is multiplied from LDS stage t & 1 while the rows of tile t + 2 are in flight to one register set and tile
-    // t + 1 is committed from the other (loaded during the previous iteration).  The commit is spread over the four
-    // MFMA groups of the iteration and pinned there (sched_group_barrier: one MFMA, then a few conversion instructions):
-    // with the commit BEHIND the MFMAs both waves of a SIMD converted while the matrix pipe idled and multiplied while the
-    // VALU idled -- 3.1 us per tile for 0.9 us of MFMAs.  The body is branch-free: loads, index loads and commits past the
-    // slab's end go to clamped addresses / the unused stage.
-    int cur = 0;
-    auto iter = [&](int k0, f32x4v (&la)[4], f32x4v (&lb)[BJ], const f32x4v (&ca)[4], const f32x4v (&cb)[BJ]) {
-        fetch(la, lb);              // tile k0 + 64 (its indices arrived during the previous iteration)
-        fetch_idx(k0 + 3 * WG_KT);
-        const char *st = lds + cur * WG_STAGE;
-        char *nx = lds + (cur ^ 1) * WG_STAGE;
+    // the fill of one tile cut into 12 chunks, one behind each run of NT MFMAs: a piece is converted out of its registers and
+    // the same registers are requested again for the tile two ahead (so a request has a whole iteration to arrive)
+    auto chunk = [&](char *nx, int k0, int c) {
+        if (c < 4) {
+            commit_a(nx, k0 + WG_KT, c, ra[c]);
+            ra[c] = fetch_a(k0 + 2 * WG_KT, c);
+        } else if (c < 4 + BJ) {
+            commit_b(nx, c - 4, rb[c - 4]);
+            rb[c - 4] = fetch_b(c - 4);
+        } else if (c == 4 + BJ) {
+            fetch_idx(k0 + 3 * WG_KT);
+        }
+    };
+    auto fused = [&](const char *st, char *nx, int k0) {
         h8 bh[NT], bl[NT];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             bh[nt] = tr_frag(st + 2 * WG_IMG + b_off[nt], st + 2 * WG_IMG + b_off[nt] + 4 * WG_ROW);
             bl[nt] = tr_frag(st + 3 * WG_IMG + b_off[nt], st + 3 * WG_IMG + b_off[nt] + 4 * WG_ROW);
         }
+        h8 ah = tr_frag(st + a_off[0], st + a_off[0] + 4 * WG_ROW);
+        h8 al = tr_frag(st + WG_IMG + a_off[0], st + WG_IMG + a_off[0] + 4 * WG_ROW);
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
-            const h8 ah = tr_frag(st + a_off[mt], st + a_off[mt] + 4 * WG_ROW);
-            const h8 al = tr_frag(st + WG_IMG + a_off[mt], st + WG_IMG + a_off[mt] + 4 * WG_ROW);
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[nt], acc[mt][nt], 0, 0, 0);
-#if !(TT_MUTATE_DROP_LO & 8)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[nt], acc[mt][nt], 0, 0, 0);
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[nt], acc[mt][nt], 0, 0, 0);
-#endif
-            commit_a(nx, k0 + WG_KT, mt, ca[mt]);
-            if (mt < BJ)
-                commit_b(nx, k0 + WG_KT, mt, cb[mt]);
-#pragma unroll
-            for (int i = 0; i < 3 * NT; ++i) { // this group's 3 NT MFMAs, each followed by a slice of the conversion work
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); // MFMA
-                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0); // VALU
+            h8 ahn = ah, aln = al;
+            if (mt < 3) {
+                ahn = tr_frag(st + a_off[mt + 1], st + a_off[mt + 1] + 4 * WG_ROW);
+                aln = tr_frag(st + WG_IMG + a_off[mt + 1], st + WG_IMG + a_off[mt + 1] + 4 * WG_ROW);
             }
+#pragma unroll
+            for (int sub = 0; sub < 3; ++sub) {
+#if TT_MUTATE_DROP_LO & 8
+                if (sub == 0)
+#endif
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(sub == 1 ? al : ah, sub == 2 ? bl[nt] : bh[nt], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+                for (int c = 0; c < 5 + BJ; ++c) // the 5 + BJ pieces of the fill spread evenly over the 12 runs
+                    if (c * 12 / (5 + BJ) == 3 * mt + sub)
+                        chunk(nx, k0, c);
+#pragma unroll
+                for (int i = 0; i < NT; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); // MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x222, 3, 0); // vector ALU / memory read / LDS write
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            ah = ahn;
+            al = aln;
         }
-        __syncthreads();
-        cur ^= 1;
     };
-    if (kb < ke) {
+    if (kb < ke) { // tile kb converted into stage 0, tile kb + 32 requested, the row indices of tile kb + 64 on their way
         fetch_idx(kb);
-        fetch(ra0, rb0);
-        fetch_idx(kb + WG_KT);
-        fetch(ra1, rb1);
-        fetch_idx(kb + 2 * WG_KT);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            commit_a(lds, kb, j, ra0[j]);
+            ra[j] = fetch_a(kb, j);
 #pragma unroll
         for (int j = 0; j < BJ; ++j)
-            commit_b(lds, kb, j, rb0[j]);
+            rb[j] = fetch_b(j);
+        fetch_idx(kb + WG_KT);
+#pragma unroll
+        for (int c = 0; c < 12; ++c)
+            chunk(lds, kb - WG_KT, c);
     }
     __syncthreads();
-    for (int k0 = kb; k0 < ke; k0 += 2 * WG_KT) {
-        iter(k0, ra0, rb0, ra1, rb1);
-        if (k0 + WG_KT < ke)
-            iter(k0 + WG_KT, ra1, rb1, ra0, rb0);
+#ifdef TT_WG_DBG
+    unsigned long long tm[3], tacc[2] = {0, 0};
+#endif
+    int cur = 0;
+    for (int k0 = kb; k0 < ke; k0 += WG_KT) {
+        WG_T(0);
+        fused(lds + cur * WG_STAGE, lds + (cur ^ 1) * WG_STAGE, k0);
+        WG_T(1);
+        __syncthreads();
+        WG_T(2);
+#ifdef TT_WG_DBG
+        tacc[0] += tm[1] - tm[0];
+        tacc[1] += tm[2] - tm[1];
+#endif
+        cur ^= 1;
     }
+#ifdef TT_WG_DBG
+    if (NT == 5 && ke - kb > 1024 && lane == 0) {
+        atomicAdd(&wg_dbg[0], tacc[0]);
+        atomicAdd(&wg_dbg[1], tacc[1]);
+        if (w == 0) {
+            atomicAdd(&wg_dbg[2], (unsigned long long)((ke - kb) / WG_KT));
+            atomicAdd(&wg_dbg[3], __builtin_amdgcn_s_memtime() - t_start);
+            atomicAdd(&wg_dbg[4], 1ull);
+        }
+    }
+#endif
     // ---- this slab's tile: rows m0 + 64 wm + 16 mt + 4 g + e, columns n0 + NT 16 wn + 16 nt + (lane & 15) ----
     float *C = p.C + (size_t)slab * p.slab_stride;
     const int jn = lane & 15;
@@ -266,10 +321,12 @@ bool wgrad_tiled()
 
 } // namespace
 
-// shapes this kernel takes: output rows a multiple of 256, N a multiple of 4, operand rows 16-byte aligned
-bool tt_wgrad16_supported(int M, int N, int64_t lda, int64_t ldb)
+// shapes this kernel takes: output rows a multiple of 256, N a multiple of 4, operand rows 16-byte aligned, A rows direct (no
+// a_map), and a B operand of b_rows source rows that 32-bit byte offsets and 24-bit multiplies can address
+bool tt_wgrad16_supported(int M, int N, int64_t lda, int64_t ldb, int64_t b_rows)
 {
-    return !wgrad_tiled() && M > 0 && M % WG_MT == 0 && N >= 64 && N % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0;
+    return !wgrad_tiled() && M > 0 && M % WG_MT == 0 && N >= 64 && N % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0 && ldb > 0 &&
+           ldb < (1 << 22) && b_rows < (1 << 24) && b_rows * ldb < (int64_t(1) << 30);
 }
 
 // how many K slabs the launch will write (the caller reduces that many): one workgroup per CU, at most max_slabs
@@ -288,24 +345,34 @@ int tt_wgrad16(const SgemmParams &p, int nslabs, hipStream_t st)
 {
     if (p.M <= 0 || p.N <= 0 || p.K <= 0 || nslabs < 1)
         return TT_OK;
-    if (!tt_wgrad16_supported(p.M, p.N, p.lda, p.ldb) || ((uintptr_t)p.A & 15) || ((uintptr_t)p.B & 15))
+    if (p.a_map || ((uintptr_t)p.A & 15) || ((uintptr_t)p.B & 15)) // (the caller checked tt_wgrad16_supported with B's row count)
         return TT_ERR_UNSUPPORTED;
+#ifdef TT_WG_DBG
+    static int calls = 0;
+    if (++calls % 16 == 0) {
+        unsigned long long h[8];
+        if (hipMemcpyFromSymbol(h, HIP_SYMBOL(wg_dbg), sizeof h) == hipSuccess && h[2])
+            fprintf(stderr, "wgdbg NT=5: clocks per wave and tile: multiply + fill %.0f, barrier %.0f; %llu workgroups, %.1f tiles each, %.0f clocks from kernel entry to the end of the token loop\n",
+                    h[0] / 8.0 / h[2], h[1] / 8.0 / h[2], h[4], (double)h[2] / h[4], (double)h[3] / h[4]);
+    }
+#endif
     const bool wide = p.N > 256 && p.N <= 320;
     const int NW = wide ? 160 : 128;
     const int n_ntiles = (p.N + NW - 1) / NW;
     int kchunk = (p.K + nslabs - 1) / nslabs;
     kchunk = (kchunk + WG_KT - 1) / WG_KT * WG_KT;
     const dim3 grid((unsigned)((p.M / WG_MT) * n_ntiles * ((nslabs + 7) / 8 * 8)));
+    // four instantiations: column tiles per wave (5 / 4) x B rows direct or through b_map
+    using Kern = void (*)(SgemmParams, int, int, int);
+    static const Kern kerns[4] = {wgrad16_kernel<4, false>, wgrad16_kernel<4, true>, wgrad16_kernel<5, false>, wgrad16_kernel<5, true>};
     static bool attr_done = false;
     if (!attr_done) {
-        TT_HIP_CHECK(hipFuncSetAttribute((const void *)wgrad16_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, WG_LDS));
-        TT_HIP_CHECK(hipFuncSetAttribute((const void *)wgrad16_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, WG_LDS));
+        for (Kern k : kerns)
+            TT_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, WG_LDS));
         attr_done = true;
     }
-    if (wide)
-        hipLaunchKernelGGL(wgrad16_kernel<5>, grid, dim3(512), WG_LDS, st, p, n_ntiles, kchunk, nslabs);
-    else
-        hipLaunchKernelGGL(wgrad16_kernel<4>, grid, dim3(512), WG_LDS, st, p, n_ntiles, kchunk, nslabs);
+    const Kern k = kerns[(wide ? 2 : 0) + (p.b_map ? 1 : 0)];
+    hipLaunchKernelGGL(k, grid, dim3(512), WG_LDS, st, p, n_ntiles, kchunk, nslabs);
     TT_LAUNCH_CHECK();
     return TT_OK;
 }
