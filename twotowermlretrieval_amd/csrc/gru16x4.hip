@@ -727,6 +727,369 @@ __global__ __launch_bounds__(256, 1) void gru_bwd16x4_kernel(GruSplitBwdParams s
     }
 }
 
+// ------------------------------------------------------------------ the same recurrence with TWO waves per SIMD
+// A lone wave issues one instruction every ~8.7 clocks whatever its kind; two waves on a SIMD each do (tools/experiments/
+// valu_rate.hip) -- and gru_bwd16x4_kernel's step is nothing but its instruction count (~4 ns per instruction of the step).
+// Here a member is EIGHT waves: the pair (w, w + 4) shares unit slice [16 w, 16 w + 16) and halves the step between its waves
+// (half kh = wave >> 2):
+//   * gate derivatives, row maxima, image writes, stash loads and gradient stores of rows 4 kq + 2 kh + {0, 1} (two of the
+//     lane's four rows);
+//   * the products for destination members oo = 2 kh, 2 kh + 1 (36 MFMAs, 24 resident W fragments = 96 registers): every
+//     accumulator is still one chain over the member's six k-steps, so partials, sums and dh are BIT-IDENTICAL to
+//     gru_bwd16x4_kernel's and the granule traffic is the same (half 0 publishes one block, half 1 two);
+//   * the receive side for its two rows: ONE 16-byte load per source member (rows 2 kh | 2 kh + 1 on the even | odd lane of a
+//     pair); half 1 gets the member's own partial (oo = 0, computed by half 0) through LDS -- a third barrier per step.
+// The row scale factors are computed once per row (by the lanes that own the row) and read back as one LDS vector per lane.
+// Bias sums accumulate per half and are added at the end (half 0 + half 1): deterministic, not bit-identical to the
+// four-wave kernel's interleaved order.
+constexpr int XP_RDOWN = 2 * 16 * 4;             // [buffer][row] 2^-(e_row + e_W)
+constexpr int XP_PART = 4 * 64 * 8;              // [unit slice w][lane] rows 2, 3 of the member's own partial
+constexpr int XP_BIAS = 4 * 64 * 16;             // [w][lane] half 1's four bias sums (end of the kernel)
+constexpr int XP_LDS = XB_LDS + XP_RDOWN + XP_PART + XP_BIAS; // + 16 for the abort word
+
+__global__ __launch_bounds__(512, 1) void gru_bwd16x4p_kernel(GruSplitBwdParams sp)
+{
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    int &abort_flag = *(int *)(lds + XP_LDS);
+    const GruBwdParams &p = sp.g;
+    const int chunk = blockIdx.x >> 5, r32 = blockIdx.x & 31;
+    const int m = __builtin_amdgcn_readfirstlane(r32 >> 3), team = chunk * 8 + (r32 & 7);
+    if (team >= sp.nteams)
+        return;
+    const GruBwdDir d = p.dir[blockIdx.y];
+    constexpr int H = X4_H, H3 = 3 * X4_H;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int w = wv & 3, kh = wv >> 2;
+    const int j = lane & 15, kq = lane >> 4;
+    const int row0 = team * ENC_RB;
+    const int ul = 16 * w + j;          // this lane's unit within the member
+    const int unit = 64 * m + ul;
+
+    int len_e[2], off_e[2], rid_e[2], steps = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { // (all four rows of the lane for the step count, two of them kept)
+        const int br = row0 + kq * 4 + e;
+        const int rid = br < p.B ? p.perm[br] : -1;
+        const int len = rid >= 0 ? p.len[rid] : 0;
+        steps = max(steps, len);
+        if ((e >> 1) == kh) {
+            rid_e[e & 1] = rid;
+            len_e[e & 1] = len;
+            off_e[e & 1] = rid >= 0 ? p.tok_off[rid] : 0;
+        }
+    }
+    steps = max(steps, __shfl_xor(steps, 16));
+    steps = max(steps, __shfl_xor(steps, 32));
+    float dh[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+        dh[e] = (d.d_hfin && rid_e[e] >= 0) ? d.d_hfin[(size_t)rid_e[e] * H + unit] : 0.0f;
+    const int exw = tt_pow2_exponent(*d.wmax);
+
+    char *const img = lds;                                       // [hi, lo][16][XB_LDG] fp16
+    float *const rmax = (float *)(lds + 2 * XB_IMG);             // [2][16 rows][4 unit slices]
+    float *const rdown = (float *)(lds + XB_LDS);                // [2][16 rows]
+    float *const xpart = (float *)(lds + XB_LDS + XP_RDOWN);     // [4][64 lanes][2]
+    float *const xbias = (float *)(lds + XB_LDS + XP_RDOWN + XP_PART); // [4][64 lanes][4]
+    if (tid == 0)
+        abort_flag = 0;
+
+    // ---- this wave's 24 fragments of W_hh: destinations oo = 2 kh + o2 (gru_bwd16x4_kernel's order and addressing) ----
+    h8 wreg[2][6][2];
+#pragma unroll
+    for (int o2 = 0; o2 < 2; ++o2) {
+        const int o = (m + 2 * kh + o2) & 3;
+        const __amdgpu_buffer_rsrc_t wsrc = __builtin_amdgcn_make_buffer_rsrc(
+            (void *)((const char *)d.wtp + (size_t)(2 * o + (w >> 1)) * 96 * 1024), 0, 96 * 1024, 0x00020000);
+        const int loff = lane * 16 + (w & 1) * 1024;
+#pragma unroll
+        for (int s2 = 0; s2 < 6; ++s2) {
+            const int sg = 8 * (s2 >> 1) + 2 * m + (s2 & 1);
+#pragma unroll
+            for (int part = 0; part < 2; ++part)
+                wreg[o2][s2][part] = frag_load(wsrc, loff + (4 * sg + 2 * part) * 1024, 0);
+        }
+    }
+
+    char *const xteam = sp.xch + ((size_t)blockIdx.y * sp.nteams + team) * (XB_TEAM_BYTES + X4_HEADER);
+    const __amdgpu_buffer_rsrc_t xsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void *)xteam, 0, (int)XB_TEAM_BYTES + X4_HEADER, 0x00020000);
+    const bool odd = j & 1;
+    // send (all four rows of a block, as the four-wave kernel): the even lane moves rows 0, 1 of columns (ul, ul + 1), the odd
+    // lane rows 2, 3 of (ul - 1, ul); receive (this half's two rows): the even lane row 2 kh, the odd lane row 2 kh + 1
+    const int send_off = ((kq * 4 + (odd ? 2 : 0)) * 64 + (ul & ~1)) * 8; // + 512 for the second row
+    const int recv_off = ((kq * 4 + 2 * kh + (odd ? 1 : 0)) * 64 + (ul & ~1)) * 8;
+
+    const int same_xcd = team_shares_xcd(xsrc, (int)XB_TEAM_BYTES, m, tid, sp.spin_max, &abort_flag + 1);
+    if (same_xcd < 0) {
+        if (tid == 0) {
+            abort_flag = 1; // (poisons the bias sums below)
+            int32_t *stw = sp.status_pp ? *sp.status_pp : nullptr;
+            if (stw)
+                atomicOr(stw, 4);
+        }
+        steps = 0;
+    }
+
+    const unsigned ld = (unsigned)p.ld, cu = (unsigned)d.col0 + (unsigned)unit;
+    struct Stash {
+        float r[2], z[2], n[2], ghn[2], hp[2], dsv[2];
+    };
+    auto load_stash = [&](int s, Stash &st) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const bool a = s >= 0 && s < len_e[e];
+            const int t = d.reverse ? len_e[e] - 1 - s : s;
+            const unsigned tok = (unsigned)(off_e[e] + (a ? t : 0));
+            const unsigned ptok = (a && s > 0) ? (d.reverse ? tok + 1u : tok - 1u) : tok;
+            const unsigned go = tok * (4u * H) + (unsigned)unit;
+            st.r[e] = d.gates[go];
+            st.z[e] = d.gates[go + H];
+            st.n[e] = d.gates[go + 2 * H];
+            st.ghn[e] = d.gates[go + 3 * H];
+            const float hpv = d.hseq[ptok * ld + cu];
+            st.hp[e] = s > 0 ? hpv : 0.0f;
+            st.dsv[e] = d.d_seq ? d.d_seq[tok * ld + cu] : 0.0f;
+        }
+    };
+    Stash cur_st, next_st;
+    load_stash(steps - 1, cur_st);
+    __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): fragments and the first stash are in (no such waits inside the loop)
+    __syncthreads();
+    int rb = 0;
+    float bsum[4] = {0, 0, 0, 0}; // column sums over this lane's rows and all steps: dr, dz, dn, dn r
+    float mx_i = 0.0f, mx_h = 0.0f;
+    unsigned it = 0;              // steps done: tag = it + 1, parity = it & 1
+
+    for (int s = steps - 1; s >= 0; --s, ++it) {
+        float direct[2], gv[3][2], dnp[2], mrow[2];
+        bool act[2];
+        unsigned tokv[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            act[e] = s < len_e[e];
+            const int t = d.reverse ? len_e[e] - 1 - s : s;
+            tokv[e] = (unsigned)(off_e[e] + (act[e] ? t : 0));
+            const float r = cur_st.r[e], z = cur_st.z[e], n = cur_st.n[e], ghn = cur_st.ghn[e], hp = cur_st.hp[e];
+            float dsv = cur_st.dsv[e];
+            if (d.d_seq && p.drop_p > 0.0f) // (uniform)
+                dsv *= tt_dropout_scale(p.drop_seed, p.drop_layer, ((uint64_t)(rid_e[e] < 0 ? 0 : rid_e[e]) * p.T + t) * p.ld + cu,
+                                        p.drop_p);
+            const float dhv = dh[e] + dsv;
+            const float dn_pre = dhv * (1.0f - z) * (1.0f - n * n);
+            const float dz_pre = dhv * (hp - n) * z * (1.0f - z);
+            const float dr_pre = dn_pre * ghn * r * (1.0f - r);
+            const float dghn_v = dn_pre * r;
+            gv[0][e] = act[e] ? dr_pre : 0.0f;
+            gv[1][e] = act[e] ? dz_pre : 0.0f;
+            gv[2][e] = act[e] ? dghn_v : 0.0f;
+            dnp[e] = act[e] ? dn_pre : 0.0f;
+            direct[e] = dhv * z;
+            bsum[0] += gv[0][e];
+            bsum[1] += gv[1][e];
+            bsum[2] += dnp[e];
+            bsum[3] += gv[2][e];
+            const float m2 = fmaxf(fabsf(gv[0][e]), fabsf(gv[1][e]));
+            mx_i = fmaxf(mx_i, fmaxf(m2, fabsf(dnp[e])));
+            mrow[e] = fmaxf(m2, fabsf(gv[2][e]));
+            mx_h = fmaxf(mx_h, mrow[e]);
+        }
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            mrow[e] = fmaxf(mrow[e], row_ror<1>(mrow[e]));
+            mrow[e] = fmaxf(mrow[e], row_ror<2>(mrow[e]));
+            mrow[e] = fmaxf(mrow[e], row_ror<4>(mrow[e]));
+            mrow[e] = fmaxf(mrow[e], row_ror<8>(mrow[e]));
+            if (j == 0)
+                rmax[(rb * 16 + kq * 4 + 2 * kh + e) * 4 + w] = mrow[e];
+        }
+        load_stash(s - 1, next_st); // in flight during the MFMAs and the hand-off below
+        __syncthreads();            // B1: row maxima visible; every wave is done reading the previous step's images
+        if (abort_flag) // (set, if at all, before its wave reached B1: every wave reads the same value here)
+            break;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int row = kq * 4 + 2 * kh + e;
+            const f32x4v rm = *(const f32x4v *)(rmax + (rb * 16 + row) * 4); // the four unit slices' maxima of this row
+            const float mm = fmaxf(fmaxf(rm[0], rm[1]), fmaxf(rm[2], rm[3]));
+            const int er = tt_pow2_exponent(__float_as_uint(mm));
+            const float upr = ldexpf(1.0f, er);
+            if (w == 0 && j == 0)
+                rdown[rb * 16 + row] = ldexpf(1.0f, -(er + exw));
+            _Float16 *dst = (_Float16 *)img + row * XB_LDG + ul;
+#pragma unroll
+            for (int g = 0; g < 3; ++g) {
+                const float x = gv[g][e] * upr;
+                const _Float16 hi = (_Float16)x;
+                dst[g * 64] = hi;
+                dst[XB_IMG / 2 + g * 64] = (_Float16)(x - (float)hi);
+            }
+        }
+        __syncthreads(); // B2: the dGh images and the row factors are complete
+        const f32x4v down = *(const f32x4v *)(rdown + rb * 16 + kq * 4); // rows 4 kq + 0 .. 3: the rows of this lane's accumulators
+        rb ^= 1;
+
+        f32x4v acc[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}}; // destination members (m + 2 kh + o2) & 3
+        const char *arow = img + j * (XB_LDG * 2) + kq * 16;
+        h8 a_hi[2], a_lo[2];
+        a_hi[0] = *(const h8 *)(arow);
+        a_lo[0] = *(const h8 *)(arow + XB_IMG);
+#pragma unroll
+        for (int s2 = 0; s2 < 6; ++s2) {
+            if (s2 + 1 < 6) {
+                a_hi[(s2 + 1) & 1] = *(const h8 *)(arow + (s2 + 1) * 64);
+                a_lo[(s2 + 1) & 1] = *(const h8 *)(arow + XB_IMG + (s2 + 1) * 64);
+            }
+#pragma unroll
+            for (int o2 = 0; o2 < 2; ++o2)
+                acc[o2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[s2 & 1], wreg[o2][s2][0], acc[o2], 0, 0, 0);
+#if !(TT_MUTATE_DROP_LO & 2)
+#pragma unroll
+            for (int o2 = 0; o2 < 2; ++o2)
+                acc[o2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo[s2 & 1], wreg[o2][s2][0], acc[o2], 0, 0, 0);
+#pragma unroll
+            for (int o2 = 0; o2 < 2; ++o2)
+                acc[o2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[s2 & 1], wreg[o2][s2][1], acc[o2], 0, 0, 0);
+#endif
+        }
+        float part[2][4]; // [o2][row 4 kq + e of the accumulator]
+#pragma unroll
+        for (int o2 = 0; o2 < 2; ++o2)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                part[o2][e] = acc[o2][e] * down[e];
+        float sum[2] = {0, 0};
+        if (s > 0) { // (the partials of the last step would only feed a dh nobody reads)
+            const unsigned tag = it + 1u;
+            const int par = (int)(it & 1u);
+            // ---- publish the foreign blocks of this half: oo = 1 (half 0), oo = 2, 3 (half 1); [parity][dest][src = m] ----
+#pragma unroll
+            for (int o2 = 0; o2 < 2; ++o2) {
+                if (kh == 0 && o2 == 0) // (uniform) the member's own block stays here
+                    continue;
+                const int o = (m + 2 * kh + o2) & 3;
+                const unsigned p0 = __float_as_uint(part[o2][0]), p1 = __float_as_uint(part[o2][1]);
+                const unsigned p2 = __float_as_uint(part[o2][2]), p3 = __float_as_uint(part[o2][3]);
+                const unsigned g0 = swap1(odd ? p0 : p2), g1 = swap1(odd ? p1 : p3);
+                const u32x4 v0 = odd ? (u32x4){g0, tag, p2, tag} : (u32x4){p0, tag, g0, tag};
+                const u32x4 v1 = odd ? (u32x4){g1, tag, p3, tag} : (u32x4){p1, tag, g1, tag};
+                const int base = ((par * 4 + o) * 4 + m) * XB_REGION + send_off;
+                if (same_xcd) { // the partners read this XCD's L2
+                    __builtin_amdgcn_raw_buffer_store_b128(v0, xsrc, base, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(v1, xsrc, base + 512, 0, 0);
+                } else {
+                    __builtin_amdgcn_raw_buffer_store_b128(v0, xsrc, base, 0, 16); // aux 16 = sc1 (write-through)
+                    __builtin_amdgcn_raw_buffer_store_b128(v1, xsrc, base + 512, 0, 16);
+                }
+            }
+            if (kh == 0) // rows 2, 3 of the member's own partial for the other half
+                *(__attribute__((ext_vector_type(2))) float *)(xpart + (w * 64 + lane) * 2) = (__attribute__((ext_vector_type(2))) float){part[0][2], part[0][3]};
+            // ---- sweep this half's rows of the three blocks addressed to this member until every tag is this step's ----
+            u32x4 got[3];
+            unsigned spins = 0;
+            while (true) {
+                bool ok = true;
+#pragma unroll
+                for (int oo = 1; oo < 4; ++oo) {
+                    const int src = (m + oo) & 3;
+                    got[oo - 1] = __builtin_amdgcn_raw_buffer_load_b128(xsrc, ((par * 4 + m) * 4 + src) * XB_REGION + recv_off, 0, 16);
+                    ok = ok && got[oo - 1].y == tag && got[oo - 1].w == tag;
+                }
+                if (__all(ok))
+                    break;
+                if (++spins > sp.spin_max) {
+                    if (lane == 0) {
+                        abort_flag = 1;
+                        int32_t *stw = sp.status_pp ? *sp.status_pp : nullptr; // the forward call's status word, if it had one
+                        if (stw)
+                            atomicOr(stw, 4);
+                    }
+                    break;
+                }
+                sweep_backoff(spins);
+            }
+            __syncthreads(); // B3: half 0's rows 2, 3 of the own partial are in LDS
+            float th[4][2]; // [oo][e]: the partial of member (m + oo) & 3 for this lane's unit, rows 2 kh + e
+            if (kh == 0) {
+                th[0][0] = part[0][0];
+                th[0][1] = part[0][1];
+            } else {
+                const __attribute__((ext_vector_type(2))) float own = *(const __attribute__((ext_vector_type(2))) float *)(xpart + (w * 64 + lane) * 2);
+                th[0][0] = own.x;
+                th[0][1] = own.y;
+            }
+#pragma unroll
+            for (int oo = 1; oo < 4; ++oo) {
+                const u32x4 a = got[oo - 1];
+                // even lane: row 2 kh of columns (ul, ul + 1); odd lane: row 2 kh + 1 of (ul - 1, ul)
+                const unsigned other = swap1(odd ? a.x : a.z); // my column, the neighbour's row
+                th[oo][0] = __uint_as_float(odd ? other : a.x);
+                th[oo][1] = __uint_as_float(odd ? a.z : other);
+            }
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                float t;
+                switch (m) { // (uniform) members 0, 1, 2, 3 -- always in that order
+                case 0: t = ((th[0][e] + th[1][e]) + th[2][e]) + th[3][e]; break;
+                case 1: t = ((th[3][e] + th[0][e]) + th[1][e]) + th[2][e]; break;
+                case 2: t = ((th[2][e] + th[3][e]) + th[0][e]) + th[1][e]; break;
+                default: t = ((th[1][e] + th[2][e]) + th[3][e]) + th[0][e]; break;
+                }
+                sum[e] = t;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+            if (act[e]) {
+                const unsigned go = tokv[e] * (unsigned)H3 + (unsigned)unit;
+                d.dgi[go] = gv[0][e];
+                d.dgi[go + H] = gv[1][e];
+                d.dgi[go + 2 * H] = dnp[e];
+                d.dghn[go] = gv[0][e];
+                d.dghn[go + H] = gv[1][e];
+                d.dghn[go + 2 * H] = gv[2][e];
+                dh[e] = direct[e] + sum[e];
+            }
+        cur_st = next_st;
+    }
+    __syncthreads();
+    if (d.bias_slab) {
+        float *slab = d.bias_slab + (size_t)team * 2 * H3;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float v = bsum[g];
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            bsum[g] = v;
+        }
+        if (kh == 1)
+            *(f32x4v *)(xbias + (w * 64 + lane) * 4) = (f32x4v){bsum[0], bsum[1], bsum[2], bsum[3]};
+        __syncthreads();
+        if (kh == 0 && kq == 0) {
+            const f32x4v o = *(const f32x4v *)(xbias + (w * 64 + lane) * 4);
+            const float nanv = __uint_as_float(0x7fc00000u); // a team that gave up poisons its sums: NaN gradients, not wrong ones
+            const float b0 = abort_flag ? nanv : bsum[0] + o[0], b1 = abort_flag ? nanv : bsum[1] + o[1];
+            const float b2 = abort_flag ? nanv : bsum[2] + o[2], b3 = abort_flag ? nanv : bsum[3] + o[3];
+            slab[unit] = b0;
+            slab[H + unit] = b1;
+            slab[2 * H + unit] = b2;
+            slab[H3 + unit] = b0;
+            slab[H3 + H + unit] = b1;
+            slab[H3 + 2 * H + unit] = b3;
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            mx_i = fmaxf(mx_i, __shfl_xor(mx_i, off));
+            mx_h = fmaxf(mx_h, __shfl_xor(mx_h, off));
+        }
+        if (lane == 0) {
+            atomicMax(d.mx_dgi, __float_as_uint(mx_i));
+            atomicMax(d.mx_dghn, __float_as_uint(mx_h));
+        }
+    }
+}
+
 int device_cus()
 {
     int dev = 0, cus = 0;
@@ -792,9 +1155,14 @@ int gru16x4_bwd_launch(const GruBwdParams &bp, int ndir, void *xch, int32_t *con
     static bool attr_done = false;
     if (!attr_done) {
         TT_HIP_CHECK(hipFuncSetAttribute((const void *)gru_bwd16x4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, XB_LDS + 16));
+        TT_HIP_CHECK(hipFuncSetAttribute((const void *)gru_bwd16x4p_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, XP_LDS + 16));
         attr_done = true;
     }
-    hipLaunchKernelGGL(gru_bwd16x4_kernel, dim3((sp.nteams + 7) / 8 * 32, ndir), dim3(256), XB_LDS + 16, st, sp);
+    const char *e = getenv("TT_GRU_SPLIT_BWD"); // "4": the four-wave member (A/B)
+    if (e && e[0] == '4')
+        hipLaunchKernelGGL(gru_bwd16x4_kernel, dim3((sp.nteams + 7) / 8 * 32, ndir), dim3(256), XB_LDS + 16, st, sp);
+    else
+        hipLaunchKernelGGL(gru_bwd16x4p_kernel, dim3((sp.nteams + 7) / 8 * 32, ndir), dim3(512), XP_LDS + 16, st, sp);
     TT_LAUNCH_CHECK();
     return TT_OK;
 }
