@@ -27,6 +27,7 @@ the 512-passage doc-tower forward and the 512-triplet train step).
 from __future__ import annotations
 
 import argparse
+import gc
 import ctypes as C
 import json
 import os
@@ -302,9 +303,18 @@ def encoder_corpus_leg(dev, model, n_docs=2_097_152, seed=11):
     return out
 
 
+def _settle_gc():
+    """A full collection now, and everything alive moved to the permanent generation: CPython's generation-2 pass walks every
+    tracked object of the process (~40 ms with torch and numpy imported, once per ~100 train steps: tools/experiments/
+    step_times.py) and would land inside some timed loops and not others.  The collector stays on."""
+    gc.collect()
+    gc.freeze()
+
+
 def _time_gpu(fn, iters, warm):
     for _ in range(warm):
         fn()
+    _settle_gc()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(iters):
@@ -471,6 +481,7 @@ def main():
     for _ in range(a.warmup):
         out = step()
     out = drain() or out
+    _settle_gc()
     fence()
     t0 = time.perf_counter()
     for _ in range(a.steps):

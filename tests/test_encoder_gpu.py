@@ -444,7 +444,8 @@ def _with_split(flag, fn, bwd=None):
     """Run fn with the column-split recurrences (gru16x4.hip) on or off: libtt reads TT_GRU_SPLIT (both directions of time) and
     TT_GRU_SPLIT_BWD (the reverse-time one alone) at every call."""
     import os
-    keys = {"TT_GRU_SPLIT": "1" if flag else "0", "TT_GRU_SPLIT_BWD": "1" if (flag if bwd is None else bwd) else "0"}
+    val = lambda f: f if isinstance(f, str) else ("1" if f else "0")   # "4": the four-wave members (gru_seq16x4 / gru_bwd16x4_kernel)
+    keys = {"TT_GRU_SPLIT": val(flag), "TT_GRU_SPLIT_BWD": val(flag if bwd is None else bwd)}
     old = {k: os.environ.get(k) for k in keys}
     os.environ.update(keys)
     try:
@@ -493,6 +494,38 @@ def test_column_split_recurrence_vs_the_one_cu_kernels(B, T, layers, bi):
     assert torch.equal(y1, y4) and all(torch.equal(a, b) for a, b in zip(g4, g4b))
     for a, b in zip(g4, g1):
         assert_grad_close(a.cpu().numpy(), b.cpu().numpy())
+
+
+@pytest.mark.parametrize("B,T,layers,bi", [(70, 40, 1, False), (1024, 33, 1, False), (300, 21, 2, True), (1, 7, 1, False)])
+def test_eight_wave_members_vs_four_wave_members(B, T, layers, bi):
+    """The split recurrences run a member as EIGHT waves (two per SIMD; gru_seq16x4p / gru_bwd16x4p_kernel) -- the four-wave
+    members they replaced stay in the library as the reference (TT_GRU_SPLIT=4 / TT_GRU_SPLIT_BWD=4).  Forward: every column's
+    accumulator chain is handed from one wave of a pair to the other, same products in the same order: outputs and stash are
+    the same bits.  Backward: the pair splits the destination members, every partial is still one chain: dW_ih / dW_hh are the
+    same bits; the bias sums accumulate per half (another order): gradient tolerance."""
+    V, E, H, seed = 400, 300, 256, 1300 + B
+    enc, table, sd = make_encoder(V, E, H, seed, layers, bi)
+    ids = torch.from_numpy(synth.make_ids(seed + 5, B, T, V, zero_inside=0.05)).cuda()
+    enc.cache_prepared = False
+    enc.train()
+    d_out = torch.from_numpy(np.random.RandomState(seed).standard_normal((B, H)).astype(np.float32)).cuda()
+
+    def grads(fwd, bwd):
+        enc.zero_grad()
+        y = _with_split(fwd, lambda: enc(ids), bwd)
+        _with_split(fwd, lambda: y.backward(d_out), bwd)
+        torch.cuda.synchronize()
+        return {n: p.grad.clone() for n, p in enc.named_parameters() if p.grad is not None}, y.detach().clone()
+    g44, y44 = grads("4", "4")
+    g84, y84 = grads("1", "4")     # eight-wave forward, four-wave backward: the stash is the same bits
+    assert torch.equal(y44, y84) and all(torch.equal(g44[n], g84[n]) for n in g44)
+    g88, y88 = grads("1", "1")
+    assert torch.equal(y44, y88)
+    for n in g44:
+        if "weight" in n:
+            assert torch.equal(g44[n], g88[n]), n
+        else:
+            assert_grad_close(g88[n].cpu().numpy(), g44[n].cpu().numpy(), what=n)
 
 
 def test_column_split_recurrence_with_both_towers_in_flight():

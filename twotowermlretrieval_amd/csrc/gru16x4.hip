@@ -15,6 +15,10 @@
 //     of the slowest (it needs everybody's step-s state to produce step s + 1), so the slot it overwrites has been read.
 //   * arithmetic, operand order and rounding are gru_seq16_kernel's: a column's accumulator sees the same products in the
 //     same order, so outputs, stash and final states are BIT-IDENTICAL to that kernel (tests/test_encoder_gpu.py).
+// Since round 3 a member is EIGHT waves, two per SIMD (gru_seq16x4p_kernel / gru_bwd16x4p_kernel below): a lone wave issues one
+// instruction per ~8.7 clocks whatever its kind, two waves on a SIMD each do (tools/experiments/valu_rate.hip), and a step of
+// these kernels is little more than its instruction count.  The four-wave members stay as the reference the tests compare
+// the eight-wave ones with (TT_GRU_SPLIT=4 / TT_GRU_SPLIT_BWD=4); everything said here about the protocol holds for both.
 // Co-residency: the grid is at most one workgroup per CU (the host only takes this path when 4 x row groups x directions
 // <= CUs); members of a team that is not resident yet are waited for with a BOUNDED sweep: a wave that exhausts its budget
 // raises bit 2 (value 4) of the call's status word and the team leaves the step loop -- it never spins forever.
@@ -361,6 +365,307 @@ __global__ __launch_bounds__(256, 1) void gru_seq16x4_kernel(GruSplitParams sp)
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e)
+        if (rid_e[e] >= 0)
+            d.h_final[(size_t)rid_e[e] * H + unit] = hreg[e];
+}
+
+// ------------------------------------------------------------------ the forward recurrence with TWO waves per SIMD
+// (see gru_bwd16x4p_kernel below for why: a lone wave issues one instruction per ~8.7 clocks, and the step is its instruction
+// count.)  A member is eight waves; the pair (w, w + 4) shares unit slice u16 = 4 m + w:
+//   * the accumulator CHAIN of a column stays what it is in gru_seq16_kernel -- bias, then k-steps 0 .. 7, three products each
+//     -- but runs through both waves: half 0 starts from the bias and takes k-steps 0 .. 3 (24 resident W fragments), hands its
+//     three accumulators to half 1 through LDS (barrier X1), half 1 continues with k-steps 4 .. 7.  The matrix pipe is busy for
+//     72 MFMAs per SIMD and step either way; outputs, stash and final states stay BIT-IDENTICAL to gru_seq16_kernel and to
+//     the four-wave gru_seq16x4_kernel;
+//   * half 1 hands the finished sums of rows 0, 1 back (barrier X2) and each half does gate math, fp16 split, image write,
+//     publish (ONE 16-byte store per lane: the even lane of a pair row 2 kh, the odd lane row 2 kh + 1), stash / output stores
+//     and the next step's projections for ITS two rows of the lane's four;
+//   * the sweep of the other members' granules is one 16-byte load per member and thread (barrier X3 closes the step).
+constexpr int XF_ACC = 4 * 64 * 12 * 4;  // [w][lane][3 gates x 4 rows] half 0 -> half 1
+constexpr int XF_SUM = 4 * 64 * 8 * 4;   // [w][lane][3 gates x 2 rows (+ 2 pad)] half 1 -> half 0
+constexpr int XF_LDS = X4_LDS + XF_ACC + XF_SUM; // + 16 for the abort word
+
+#ifdef TT_X4_DBG // a measuring build: s_memtime clocks per phase of the step, printed every 8th launch
+__device__ unsigned long long x4_dbg[16];
+#define X4_T(i) do { __builtin_amdgcn_sched_barrier(0); tm[i] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define X4_T(i) do { } while (0)
+#endif
+__global__ __launch_bounds__(512, 1) void gru_seq16x4p_kernel(GruSplitParams sp)
+{
+#ifdef TT_X4_DBG
+    unsigned long long tm[7], tacc[6] = {0, 0, 0, 0, 0, 0};
+#endif
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    int &abort_flag = *(int *)(lds + XF_LDS);
+    const GruParams &p = sp.g;
+    const int chunk = blockIdx.x >> 5, r32 = blockIdx.x & 31;
+    const int m = r32 >> 3, team = chunk * 8 + (r32 & 7);
+    if (team >= sp.nteams)
+        return;
+    const GruDir d = p.dir[blockIdx.y];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int w = wv & 3, kh = wv >> 2;
+    const int j = lane & 15, kq = lane >> 4;
+    const int row0 = team * ENC_RB;
+    constexpr int H = X4_H, H3 = 3 * X4_H;
+
+    int len_e[2], off_e[2], rid_e[2], steps = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { // (all four rows of the lane for the step count, two of them kept)
+        const int br = row0 + kq * 4 + e;
+        const int rid = br < p.B ? p.perm[br] : -1;
+        const int len = rid >= 0 ? p.len[rid] : 0;
+        steps = max(steps, len);
+        if ((e >> 1) == kh) {
+            rid_e[e & 1] = rid;
+            len_e[e & 1] = len;
+            off_e[e & 1] = rid >= 0 ? p.tok_off[rid] : 0;
+        }
+    }
+    steps = max(steps, __shfl_xor(steps, 16));
+    steps = max(steps, __shfl_xor(steps, 32));
+
+    const int u16 = 4 * m + w;      // the pair's 16 hidden units: [16 u16, 16 u16 + 16) of every gate
+    const int unit = 16 * u16 + j;  // this lane's unit
+    const int ex = tt_pow2_exponent(*d.wmax);
+    const float up = ldexpf(1.0f, X4_H_SHIFT + ex), down = ldexpf(1.0f, -(X4_H_SHIFT + ex));
+    float bias[3];
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+        bias[g] = d.b_hh[g * H + unit] * up;
+    for (int i = tid; i < X4_LDS / 4; i += 512)
+        ((int *)lds)[i] = 0; // h_0 = 0 in both buffers, both parts
+    if (tid == 0)
+        abort_flag = 0;
+    float hreg[2] = {0, 0};
+    f32x4v *const xacc = (f32x4v *)(lds + X4_LDS) + (w * 64 + lane) * 3;
+    float *const xsum = (float *)(lds + X4_LDS + XF_ACC) + (w * 64 + lane) * 8;
+
+    // ---- this wave's 24 fragments of W_hh (k-steps 4 kh .. 4 kh + 3), gru16_pack's order as in gru_seq16x4_kernel ----
+    const __amdgpu_buffer_rsrc_t wsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)((const char *)d.wp + (size_t)(u16 >> 1) * 96 * 1024), 0, 96 * 1024, 0x00020000);
+    const int loff = lane * 16 + (u16 & 1) * 1024;
+    h8 wreg[4][3][2]; // [k-step - 4 kh][gate][hi, lo]
+#pragma unroll
+    for (int s2 = 0; s2 < 4; ++s2)
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+#pragma unroll
+            for (int part = 0; part < 2; ++part)
+                wreg[s2][g][part] = frag_load(wsrc, loff + (12 * (4 * kh + s2) + 4 * g + 2 * part) * 1024, 0);
+
+    char *const xteam = sp.xch + ((size_t)blockIdx.y * sp.nteams + team) * (X4_TEAM_BYTES + X4_HEADER);
+    const __amdgpu_buffer_rsrc_t xsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void *)xteam, 0, (int)X4_TEAM_BYTES + X4_HEADER, 0x00020000);
+    const bool odd = j & 1;
+    const int send_off = ((kq * 4 + 2 * kh + (odd ? 1 : 0)) * 64 + 16 * w + (j & ~1)) * 8;
+    const int same_xcd = team_shares_xcd(xsrc, (int)X4_TEAM_BYTES, m, tid, sp.spin_max, &abort_flag + 1);
+    if (same_xcd < 0) {
+        if (tid == 0 && sp.status)
+            atomicOr(sp.status, 4);
+        steps = 0; // (h_final = 0 is written below; the status bit tells the caller the outputs are invalid)
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): the resident fragments have landed (no such waits inside the loop)
+    __syncthreads();
+
+    auto gi_load = [&](int s, float (&gv)[3][2]) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const bool a = s < len_e[e];
+            const int t = d.reverse ? len_e[e] - 1 - s : s;
+            const size_t tk = (size_t)(off_e[e] + (a ? t : 0)); // (a valid token even when the row is done)
+#pragma unroll
+            for (int g = 0; g < 3; ++g)
+                gv[g][e] = d.gi[tk * H3 + g * H + unit];
+        }
+    };
+    float giv[3][2], gnx[3][2];
+    if (steps > 0)
+        gi_load(0, giv);
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+
+    int cur = 0;
+    for (int s = 0; s < steps; ++s) {
+        bool act[2];
+        size_t tok[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            act[e] = s < len_e[e];
+            const int t = d.reverse ? len_e[e] - 1 - s : s;
+            tok[e] = (size_t)(off_e[e] + (act[e] ? t : 0));
+        }
+        X4_T(0);
+        if (s + 1 < steps)
+            gi_load(s + 1, gnx); // in flight under this step's MFMAs and hand-off
+        const char *img = lds + cur * 2 * X4_IMG + j * (X4_LDH * 2) + kq * 16 + kh * 4 * 64;
+        h8 a_hi[2], a_lo[2]; // by k-step parity
+        a_hi[0] = *(const h8 *)(img);
+        a_lo[0] = *(const h8 *)(img + X4_IMG);
+        f32x4v acc[3];
+        if (kh == 0) {
+#pragma unroll
+            for (int g = 0; g < 3; ++g)
+                acc[g] = (f32x4v){bias[g], bias[g], bias[g], bias[g]};
+        } else {
+            __syncthreads(); // X1: half 0's accumulators after k-steps 0 .. 3
+#pragma unroll
+            for (int g = 0; g < 3; ++g)
+                acc[g] = xacc[g];
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) {
+            if (s2 + 1 < 4) {
+                a_hi[(s2 + 1) & 1] = *(const h8 *)(img + (s2 + 1) * 64);
+                a_lo[(s2 + 1) & 1] = *(const h8 *)(img + X4_IMG + (s2 + 1) * 64);
+            }
+#pragma unroll
+            for (int g = 0; g < 3; ++g)
+                acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[s2 & 1], wreg[s2][g][0], acc[g], 0, 0, 0);
+#if !(TT_MUTATE_DROP_LO & 1)
+#pragma unroll
+            for (int g = 0; g < 3; ++g)
+                acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo[s2 & 1], wreg[s2][g][0], acc[g], 0, 0, 0);
+#pragma unroll
+            for (int g = 0; g < 3; ++g)
+                acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[s2 & 1], wreg[s2][g][1], acc[g], 0, 0, 0);
+#endif
+        }
+        float sm[3][2]; // the finished sums of this half's rows
+        if (kh == 0) {
+#pragma unroll
+            for (int g = 0; g < 3; ++g)
+                xacc[g] = acc[g];
+            __syncthreads(); // X1
+            __syncthreads(); // X2: half 1's sums of rows 0, 1
+            const f32x4v a = *(const f32x4v *)xsum, b = *(const f32x4v *)(xsum + 4);
+            sm[0][0] = a[0], sm[0][1] = a[1], sm[1][0] = a[2], sm[1][1] = a[3], sm[2][0] = b[0], sm[2][1] = b[1];
+        } else {
+            *(f32x4v *)xsum = (f32x4v){acc[0][0], acc[0][1], acc[1][0], acc[1][1]};
+            *(f32x4v *)(xsum + 4) = (f32x4v){acc[2][0], acc[2][1], 0.0f, 0.0f};
+            __syncthreads(); // X2
+#pragma unroll
+            for (int g = 0; g < 3; ++g)
+                sm[g][0] = acc[g][2], sm[g][1] = acc[g][3];
+        }
+
+        X4_T(1);
+        char *nimg = lds + (cur ^ 1) * 2 * X4_IMG;
+        unsigned pk[2]; // fp16 hi | lo << 16 of this lane's two new states
+        float sv_r[2], sv_z[2], sv_n[2], sv_g[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const float r = tt_fast_sigmoid(giv[0][e] + sm[0][e] * down);
+            const float z = tt_fast_sigmoid(giv[1][e] + sm[1][e] * down);
+            const float ghn = sm[2][e] * down;
+            const float n = tt_fast_tanh(giv[2][e] + r * ghn);
+            const float hn = (hreg[e] - n) * z + n;
+            if (act[e])
+                hreg[e] = hn;
+            sv_r[e] = r;
+            sv_z[e] = z;
+            sv_n[e] = n;
+            sv_g[e] = ghn;
+            const float hs = hreg[e] * (float)(1 << X4_H_SHIFT);
+            const _Float16 hi = (_Float16)hs;
+            const _Float16 lo = (_Float16)(hs - (float)hi);
+            _Float16 *dst = (_Float16 *)nimg + (kq * 4 + 2 * kh + e) * X4_LDH + unit;
+            dst[0] = hi;
+            dst[X4_IMG / 2] = lo;
+            pk[e] = (unsigned)__builtin_bit_cast(unsigned short, hi) | ((unsigned)__builtin_bit_cast(unsigned short, lo) << 16);
+        }
+        X4_T(2);
+#ifdef TT_X4_DBG
+        tm[3] = tm[4] = tm[2];
+#endif
+        if (s + 1 < steps) {
+            const unsigned tag = (unsigned)s + 1u;
+            const int par = s & 1;
+            // ---- publish: the even lane row 2 kh of units (2 q, 2 q + 1), the odd lane row 2 kh + 1 ----
+            const unsigned g0 = swap1(odd ? pk[0] : pk[1]);
+            const u32x4 v0 = odd ? (u32x4){g0, tag, pk[1], tag} : (u32x4){pk[0], tag, g0, tag};
+            const int sbase = (par * 4 + m) * X4_REGION + send_off;
+            if (same_xcd) // the partners read this XCD's L2
+                __builtin_amdgcn_raw_buffer_store_b128(v0, xsrc, sbase, 0, 0);
+            else
+                __builtin_amdgcn_raw_buffer_store_b128(v0, xsrc, sbase, 0, 16); // aux 16 = sc1 (write-through)
+            X4_T(3);
+            // ---- sweep the other three members' granules (chunk tid of each) until every tag is this step's ----
+            u32x4 got[3];
+            unsigned spins = 0;
+            while (true) {
+                bool ok = true;
+#pragma unroll
+                for (int o = 0; o < 3; ++o) {
+                    const int om = (m + 1 + o) & 3;
+                    got[o] = __builtin_amdgcn_raw_buffer_load_b128(xsrc, (par * 4 + om) * X4_REGION + tid * 16, 0, 16);
+                    ok = ok && got[o].y == tag && got[o].w == tag;
+                }
+                if (__all(ok))
+                    break;
+                if (++spins > sp.spin_max) { // (wave-uniform: spins is)
+                    if (lane == 0) {
+                        abort_flag = 1;
+                        if (sp.status)
+                            atomicOr(sp.status, 4);
+                    }
+                    break;
+                }
+                sweep_backoff(spins);
+            }
+            X4_T(4);
+            // chunk tid of a member's region: row = tid >> 5, units 2 (tid & 31), + 1
+#pragma unroll
+            for (int o = 0; o < 3; ++o) {
+                const int om = (m + 1 + o) & 3;
+                unsigned *dst = (unsigned *)(nimg + ((tid >> 5) * X4_LDH + 64 * om + 2 * (tid & 31)) * 2);
+                const unsigned a = got[o].x, b = got[o].z;
+                dst[0] = (a & 0xffffu) | (b << 16);
+                dst[X4_IMG / 4] = (a >> 16) | (b & 0xffff0000u);
+            }
+        }
+        // (the step's bulk stores go out behind the hand-off: vector memory operations complete in issue order)
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+            if (act[e]) {
+                if (d.out_seq)
+                    d.out_seq[tok[e] * p.out_ld + d.out_col0 + unit] = hreg[e];
+                if (d.gates) {
+                    float *gs = d.gates + tok[e] * 4 * H + unit;
+                    gs[0] = sv_r[e];
+                    gs[H] = sv_z[e];
+                    gs[2 * H] = sv_n[e];
+                    gs[3 * H] = sv_g[e];
+                }
+            }
+        X4_T(5);
+        __syncthreads(); // X3: the next image is complete
+        X4_T(6);
+#ifdef TT_X4_DBG
+        for (int i = 0; i < 6; ++i)
+            tacc[i] += tm[i + 1] - tm[i];
+#endif
+        if (abort_flag)
+            break;
+        cur ^= 1;
+        if (s + 1 < steps) {
+#pragma unroll
+            for (int g = 0; g < 3; ++g)
+#pragma unroll
+                for (int e = 0; e < 2; ++e)
+                    giv[g][e] = gnx[g][e];
+        }
+    }
+#ifdef TT_X4_DBG
+    if (team == 0 && m == 1 && w == 0 && lane == 0 && steps > 40) {
+        for (int i = 0; i < 6; ++i)
+            atomicAdd(&x4_dbg[8 * kh + i], tacc[i]);
+        atomicAdd(&x4_dbg[8 * kh + 6], (unsigned long long)steps);
+    }
+#endif
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
         if (rid_e[e] >= 0)
             d.h_final[(size_t)rid_e[e] * H + unit] = hreg[e];
 }
@@ -747,8 +1052,14 @@ constexpr int XP_PART = 4 * 64 * 8;              // [unit slice w][lane] rows 2,
 constexpr int XP_BIAS = 4 * 64 * 16;             // [w][lane] half 1's four bias sums (end of the kernel)
 constexpr int XP_LDS = XB_LDS + XP_RDOWN + XP_PART + XP_BIAS; // + 16 for the abort word
 
+#ifdef TT_X4_DBG
+__device__ unsigned long long xb_dbg[32];
+#endif
 __global__ __launch_bounds__(512, 1) void gru_bwd16x4p_kernel(GruSplitBwdParams sp)
 {
+#ifdef TT_X4_DBG
+    unsigned long long tm[10], tacc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
     extern __shared__ __attribute__((aligned(16))) char lds[];
     int &abort_flag = *(int *)(lds + XP_LDS);
     const GruBwdParams &p = sp.g;
@@ -863,6 +1174,7 @@ __global__ __launch_bounds__(512, 1) void gru_bwd16x4p_kernel(GruSplitBwdParams 
     unsigned it = 0;              // steps done: tag = it + 1, parity = it & 1
 
     for (int s = steps - 1; s >= 0; --s, ++it) {
+        X4_T(0);
         float direct[2], gv[3][2], dnp[2], mrow[2];
         bool act[2];
         unsigned tokv[2];
@@ -904,8 +1216,11 @@ __global__ __launch_bounds__(512, 1) void gru_bwd16x4p_kernel(GruSplitBwdParams 
             if (j == 0)
                 rmax[(rb * 16 + kq * 4 + 2 * kh + e) * 4 + w] = mrow[e];
         }
+        X4_T(1);
         load_stash(s - 1, next_st); // in flight during the MFMAs and the hand-off below
+        X4_T(2);
         __syncthreads();            // B1: row maxima visible; every wave is done reading the previous step's images
+        X4_T(3);
         if (abort_flag) // (set, if at all, before its wave reached B1: every wave reads the same value here)
             break;
 #pragma unroll
@@ -926,7 +1241,9 @@ __global__ __launch_bounds__(512, 1) void gru_bwd16x4p_kernel(GruSplitBwdParams 
                 dst[XB_IMG / 2 + g * 64] = (_Float16)(x - (float)hi);
             }
         }
+        X4_T(4);
         __syncthreads(); // B2: the dGh images and the row factors are complete
+        X4_T(5);
         const f32x4v down = *(const f32x4v *)(rdown + rb * 16 + kq * 4); // rows 4 kq + 0 .. 3: the rows of this lane's accumulators
         rb ^= 1;
 
@@ -960,6 +1277,10 @@ __global__ __launch_bounds__(512, 1) void gru_bwd16x4p_kernel(GruSplitBwdParams 
             for (int e = 0; e < 4; ++e)
                 part[o2][e] = acc[o2][e] * down[e];
         float sum[2] = {0, 0};
+        X4_T(6);
+#ifdef TT_X4_DBG
+        tm[7] = tm[8] = tm[6];
+#endif
         if (s > 0) { // (the partials of the last step would only feed a dh nobody reads)
             const unsigned tag = it + 1u;
             const int par = (int)(it & 1u);
@@ -985,6 +1306,7 @@ __global__ __launch_bounds__(512, 1) void gru_bwd16x4p_kernel(GruSplitBwdParams 
             }
             if (kh == 0) // rows 2, 3 of the member's own partial for the other half
                 *(__attribute__((ext_vector_type(2))) float *)(xpart + (w * 64 + lane) * 2) = (__attribute__((ext_vector_type(2))) float){part[0][2], part[0][3]};
+            X4_T(7);
             // ---- sweep this half's rows of the three blocks addressed to this member until every tag is this step's ----
             u32x4 got[3];
             unsigned spins = 0;
@@ -1009,6 +1331,7 @@ __global__ __launch_bounds__(512, 1) void gru_bwd16x4p_kernel(GruSplitBwdParams 
                 }
                 sweep_backoff(spins);
             }
+            X4_T(8);
             __syncthreads(); // B3: half 0's rows 2, 3 of the own partial are in LDS
             float th[4][2]; // [oo][e]: the partial of member (m + oo) & 3 for this lane's unit, rows 2 kh + e
             if (kh == 0) {
@@ -1052,7 +1375,19 @@ __global__ __launch_bounds__(512, 1) void gru_bwd16x4p_kernel(GruSplitBwdParams 
                 dh[e] = direct[e] + sum[e];
             }
         cur_st = next_st;
+        X4_T(9);
+#ifdef TT_X4_DBG
+        for (int i = 0; i < 9; ++i)
+            tacc[i] += tm[i + 1] - tm[i];
+#endif
     }
+#ifdef TT_X4_DBG
+    if (team == 0 && m == 1 && w == 0 && lane == 0 && steps > 40) {
+        for (int i = 0; i < 9; ++i)
+            atomicAdd(&xb_dbg[16 * kh + i], tacc[i]);
+        atomicAdd(&xb_dbg[16 * kh + 9], (unsigned long long)steps);
+    }
+#endif
     __syncthreads();
     if (d.bias_slab) {
         float *slab = d.bias_slab + (size_t)team * 2 * H3;
@@ -1158,6 +1493,19 @@ int gru16x4_bwd_launch(const GruBwdParams &bp, int ndir, void *xch, int32_t *con
         TT_HIP_CHECK(hipFuncSetAttribute((const void *)gru_bwd16x4p_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, XP_LDS + 16));
         attr_done = true;
     }
+#ifdef TT_X4_DBG
+    static int calls = 0;
+    if (++calls % 8 == 0) {
+        unsigned long long h[32];
+        if (hipMemcpyFromSymbol(h, HIP_SYMBOL(xb_dbg), sizeof h) == hipSuccess && h[9] && h[25])
+            for (int k = 0; k < 2; ++k) {
+                const unsigned long long *q = h + 16 * k;
+                fprintf(stderr, "xbdbg half %d: clocks per step: gate derivatives %.0f, stash requests %.0f, B1 %.0f, scale + image %.0f, B2 %.0f, matrix %.0f, publish %.0f, sweep %.0f, B3 + sum + stores %.0f\n", k,
+                        (double)q[0] / q[9], (double)q[1] / q[9], (double)q[2] / q[9], (double)q[3] / q[9], (double)q[4] / q[9], (double)q[5] / q[9],
+                        (double)q[6] / q[9], (double)q[7] / q[9], (double)q[8] / q[9]);
+            }
+    }
+#endif
     const char *e = getenv("TT_GRU_SPLIT_BWD"); // "4": the four-wave member (A/B)
     if (e && e[0] == '4')
         hipLaunchKernelGGL(gru_bwd16x4_kernel, dim3((sp.nteams + 7) / 8 * 32, ndir), dim3(256), XB_LDS + 16, st, sp);
@@ -1179,9 +1527,25 @@ int gru16x4_launch(const GruParams &gp, int ndir, void *xch, int32_t *status, hi
     static bool attr_done = false;
     if (!attr_done) {
         TT_HIP_CHECK(hipFuncSetAttribute((const void *)gru_seq16x4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, X4_LDS + 16));
+        TT_HIP_CHECK(hipFuncSetAttribute((const void *)gru_seq16x4p_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, XF_LDS + 16));
         attr_done = true;
     }
-    hipLaunchKernelGGL(gru_seq16x4_kernel, dim3((sp.nteams + 7) / 8 * 32, ndir), dim3(256), X4_LDS + 16, st, sp);
+#ifdef TT_X4_DBG
+    static int calls = 0;
+    if (++calls % 8 == 0) {
+        unsigned long long h[16];
+        if (hipMemcpyFromSymbol(h, HIP_SYMBOL(x4_dbg), sizeof h) == hipSuccess && h[6] && h[14])
+            for (int k = 0; k < 2; ++k)
+                fprintf(stderr, "x4dbg half %d: clocks per step: matrix + hand-over %.0f, gates %.0f, publish %.0f, sweep %.0f, unpack + stores %.0f, barrier %.0f\n", k,
+                        (double)h[8 * k] / h[8 * k + 6], (double)h[8 * k + 1] / h[8 * k + 6], (double)h[8 * k + 2] / h[8 * k + 6],
+                        (double)h[8 * k + 3] / h[8 * k + 6], (double)h[8 * k + 4] / h[8 * k + 6], (double)h[8 * k + 5] / h[8 * k + 6]);
+    }
+#endif
+    const char *e = getenv("TT_GRU_SPLIT"); // "4": the four-wave member (A/B)
+    if (e && e[0] == '4')
+        hipLaunchKernelGGL(gru_seq16x4_kernel, dim3((sp.nteams + 7) / 8 * 32, ndir), dim3(256), X4_LDS + 16, st, sp);
+    else
+        hipLaunchKernelGGL(gru_seq16x4p_kernel, dim3((sp.nteams + 7) / 8 * 32, ndir), dim3(512), XF_LDS + 16, st, sp);
     TT_LAUNCH_CHECK();
     return TT_OK;
 }
