@@ -68,23 +68,42 @@ __device__ __forceinline__ void static_for(F &&f)
 // round the waves: wave w takes chunks w, w + W, ..., one per PASS (runtime loop).
 __host__ __device__ static inline int rs_chunks_of(int nchunks, int w, int W) { return (nchunks - w + W - 1) / W; }
 
+// The TAIL SPLIT.  A workgroup owns 64 tokens and ALL columns, and `slots` of them are resident at a time (two per CU): the
+// last round of a launch is as long as any other however few token blocks it holds -- 1 098 blocks on 512 slots (the train
+// step's document call) are 2.14 rounds of work in the time of 3, a serving-size query batch is one round at 10 % occupancy.
+// When every wave makes the same number of passes and that number is a multiple of RS_SPLIT, the token blocks beyond the last
+// full round -- if there are at most slots / RS_SPLIT of them -- are each given to RS_SPLIT workgroups that fill the same
+// block and take a third of every wave's passes.  M may only be known on the device (m_dyn), so every workgroup derives its
+// role from the block index itself; the host launches enough blocks for either outcome.
+constexpr int RS_SPLIT = 3;
+
 template <int NKS, bool WIDE>
-__global__ __launch_bounds__(WIDE ? 512 : 256, WIDE ? 1 : 2) void gemm_rows16_kernel(SgemmParams p)
+__global__ __launch_bounds__(WIDE ? 512 : 256, WIDE ? 1 : 2) void gemm_rows16_kernel(SgemmParams p, int slots)
 {
     using C = RSCfg<NKS, WIDE>;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6); // wave-uniform: the buffer resource below must live in SGPRs
     const int M = p.m_dyn ? min(p.M, *p.m_dyn) : p.M;
-    const int row0 = blockIdx.x * RS_ROWS;
+    const int nchunks = p.N / C::CHUNK;
+    const int nblocks = (M + RS_ROWS - 1) / RS_ROWS, nfull = slots > 0 ? nblocks / slots * slots : nblocks, ntail = nblocks - nfull;
+    const bool split = slots > 0 && nchunks % (C::WAVES * RS_SPLIT) == 0 && ntail > 0 && ntail * RS_SPLIT <= slots;
+    int tb = blockIdx.x, part = 0, nparts = 1; // token block, and which share of every wave's passes
+    if (split && tb >= nfull) {
+        tb = nfull + (blockIdx.x - nfull) / RS_SPLIT;
+        part = (blockIdx.x - nfull) % RS_SPLIT;
+        nparts = RS_SPLIT;
+    }
+    const int row0 = tb * RS_ROWS;
     if (row0 >= M)
         return;
     const int ea = p.a_absmax ? tt_pow2_exponent(*p.a_absmax) : p.a_exp;
     const int eb = p.b_absmax ? tt_pow2_exponent(*p.b_absmax) : p.b_exp;
     const int i = lane & 31, h = lane >> 5;
     float *const tdown = (float *)(lds + 2 * C::IMG); // [RS_ROWS]: 2^-(e_row + e_B), what a token's accumulators are multiplied by
-    const int nchunks = p.N / C::CHUNK, npass = rs_chunks_of(nchunks, w, C::WAVES);
-    int first = 0; // this wave's first pass in the (wave-major) fragment stream
+    const int npass_all = rs_chunks_of(nchunks, w, C::WAVES);
+    const int npass = npass_all / nparts, pass0 = part * npass; // this workgroup's passes of the wave: pass0 .. pass0 + npass - 1
+    int first = pass0; // this wave's first pass in the (wave-major) fragment stream
     for (int j = 0; j < w; ++j)
         first += rs_chunks_of(nchunks, j, C::WAVES);
     // The bias (added when a pass's accumulators are scaled back) is fetched one pass ahead: a load issued in the epilogue
@@ -93,7 +112,7 @@ __global__ __launch_bounds__(WIDE ? 512 : 256, WIDE ? 1 : 2) void gemm_rows16_ke
     auto load_bias = [&](int pass) {
 #pragma unroll
         for (int ct = 0; ct < C::CT; ++ct)
-            bnext[ct] = (p.bias && pass < npass) ? p.bias[(pass * C::WAVES + w) * C::CHUNK + 32 * ct + i] : 0.0f;
+            bnext[ct] = (p.bias && pass < npass) ? p.bias[((pass0 + pass) * C::WAVES + w) * C::CHUNK + 32 * ct + i] : 0.0f;
     };
     load_bias(0);
 
@@ -138,7 +157,7 @@ __global__ __launch_bounds__(WIDE ? 512 : 256, WIDE ? 1 : 2) void gemm_rows16_ke
         const float sa = ldexpf(1.0f, ea_row);
         if (q == 0)
             tdown[r] = ldexpf(1.0f, -(ea_row + eb));
-        if (p.a_absmax_out) { // one atomic per wave (non-negative floats order like their bit patterns)
+        if (p.a_absmax_out && part == 0) { // one atomic per wave (non-negative floats order like their bit patterns)
             float mw = mx;
 #pragma unroll
             for (int off = C::TPR; off < 64; off <<= 1)
@@ -255,7 +274,7 @@ __global__ __launch_bounds__(WIDE ? 512 : 256, WIDE ? 1 : 2) void gemm_rows16_ke
             __builtin_amdgcn_sched_barrier(0);
         });
         // end of a pass: 64 tokens x CHUNK columns out
-        float *cp = cbase + pass * (C::WAVES * C::CHUNK);
+        float *cp = cbase + (pass0 + pass) * (C::WAVES * C::CHUNK);
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
@@ -319,8 +338,21 @@ int launch_rows16(const SgemmParams &p, hipStream_t st)
                                          C::LDS));
         attr_done = true;
     }
-    hipLaunchKernelGGL((gemm_rows16_kernel<NKS, WIDE>), dim3((unsigned)((p.M + RS_ROWS - 1) / RS_ROWS)), dim3(C::WAVES * 64), C::LDS,
-                       st, p);
+    // resident workgroups (the kernel's rounds): two per CU for the narrow form, one for the wide one; TT_ROWS_SPLIT=0: no tail split
+    static const int slots = [] {
+        const char *e = getenv("TT_ROWS_SPLIT");
+        if (e && e[0] == '0')
+            return 0;
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) {
+            (void)hipGetLastError();
+            cus = 256;
+        }
+        return (WIDE ? 1 : 2) * cus;
+    }();
+    // (a split tail has at most slots / RS_SPLIT token blocks, each RS_SPLIT workgroups: (RS_SPLIT - 1) slots / RS_SPLIT extra)
+    const unsigned blocks = (unsigned)((p.M + RS_ROWS - 1) / RS_ROWS) + (unsigned)(slots - slots / RS_SPLIT);
+    hipLaunchKernelGGL((gemm_rows16_kernel<NKS, WIDE>), dim3(blocks), dim3(C::WAVES * 64), C::LDS, st, p, slots);
     TT_LAUNCH_CHECK();
     return TT_OK;
 }
