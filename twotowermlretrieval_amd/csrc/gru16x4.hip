@@ -372,18 +372,19 @@ __global__ __launch_bounds__(256, 1) void gru_seq16x4_kernel(GruSplitParams sp)
 // ------------------------------------------------------------------ the forward recurrence with TWO waves per SIMD
 // (see gru_bwd16x4p_kernel below for why: a lone wave issues one instruction per ~8.7 clocks, and the step is its instruction
 // count.)  A member is eight waves; the pair (w, w + 4) shares unit slice u16 = 4 m + w:
-//   * the accumulator CHAIN of a column stays what it is in gru_seq16_kernel -- bias, then k-steps 0 .. 7, three products each
-//     -- but runs through both waves: half 0 starts from the bias and takes k-steps 0 .. 3 (24 resident W fragments), hands its
-//     three accumulators to half 1 through LDS (barrier X1), half 1 continues with k-steps 4 .. 7.  The matrix pipe is busy for
-//     72 MFMAs per SIMD and step either way; outputs, stash and final states stay BIT-IDENTICAL to gru_seq16_kernel and to
-//     the four-wave gru_seq16x4_kernel;
-//   * half 1 hands the finished sums of rows 0, 1 back (barrier X2) and each half does gate math, fp16 split, image write,
-//     publish (ONE 16-byte store per lane: the even lane of a pair row 2 kh, the odd lane row 2 kh + 1), stash / output stores
-//     and the next step's projections for ITS two rows of the lane's four;
+//   * the pair splits the GATES: half 0 multiplies for r and z (48 MFMAs, 32 resident W fragments), half 1 for n (24 MFMAs, 16
+//     fragments).  A column's accumulator chain -- bias, then k-steps 0 .. 7, three products each -- stays inside one wave, so
+//     outputs, stash and final states are BIT-IDENTICAL to gru_seq16_kernel and to the four-wave gru_seq16x4_kernel, and the
+//     matrix pipe is busy for 72 MFMAs per SIMD and step as before.  (A first build handed the chain itself from half 0 (k-steps
+//     0 .. 3) to half 1 (4 .. 7) through LDS: two hops and two barriers per step around the MFMAs, 2 360 clocks for 1 152 of
+//     matrix work.)
+//   * then ONE exchange through LDS (barrier X2): half 0 gives the r and z sums of rows 2, 3, half 1 the n sums of rows 0, 1, and
+//     each half does gate math, fp16 split, image write, publish (ONE 16-byte store per lane: the even lane of a pair row 2 kh,
+//     the odd lane row 2 kh + 1), stash / output stores and the next step's projections for ITS two rows of the lane's four;
 //   * the sweep of the other members' granules is one 16-byte load per member and thread (barrier X3 closes the step).
-constexpr int XF_ACC = 4 * 64 * 12 * 4;  // [w][lane][3 gates x 4 rows] half 0 -> half 1
-constexpr int XF_SUM = 4 * 64 * 8 * 4;   // [w][lane][3 gates x 2 rows (+ 2 pad)] half 1 -> half 0
-constexpr int XF_LDS = X4_LDS + XF_ACC + XF_SUM; // + 16 for the abort word
+constexpr int XF_RZ = 4 * 64 * 4 * 4;    // [w][lane][r, z sums of rows 2, 3] half 0 -> half 1
+constexpr int XF_N = 4 * 64 * 2 * 4;     // [w][lane][n sums of rows 0, 1] half 1 -> half 0
+constexpr int XF_LDS = X4_LDS + XF_RZ + XF_N; // + 16 for the abort word
 
 #ifdef TT_X4_DBG // a measuring build: s_memtime clocks per phase of the step, printed every 8th launch
 __device__ unsigned long long x4_dbg[16];
@@ -440,21 +441,24 @@ __global__ __launch_bounds__(512, 1) void gru_seq16x4p_kernel(GruSplitParams sp)
     if (tid == 0)
         abort_flag = 0;
     float hreg[2] = {0, 0};
-    f32x4v *const xacc = (f32x4v *)(lds + X4_LDS) + (w * 64 + lane) * 3;
-    float *const xsum = (float *)(lds + X4_LDS + XF_ACC) + (w * 64 + lane) * 8;
+    typedef float f32x2v __attribute__((ext_vector_type(2)));
+    f32x4v *const xrz = (f32x4v *)(lds + X4_LDS) + (w * 64 + lane);
+    f32x2v *const xn = (f32x2v *)(lds + X4_LDS + XF_RZ) + (w * 64 + lane);
 
-    // ---- this wave's 24 fragments of W_hh (k-steps 4 kh .. 4 kh + 3), gru16_pack's order as in gru_seq16x4_kernel ----
+    // ---- this wave's fragments of W_hh: gates r, z (half 0) or n (half 1), all eight k-steps; gru16_pack's order as in
+    //      gru_seq16x4_kernel (fragment 12 s + 4 g + 2 part + ct of wave u16 >> 1) ----
     const __amdgpu_buffer_rsrc_t wsrc = __builtin_amdgcn_make_buffer_rsrc(
         (void *)((const char *)d.wp + (size_t)(u16 >> 1) * 96 * 1024), 0, 96 * 1024, 0x00020000);
     const int loff = lane * 16 + (u16 & 1) * 1024;
-    h8 wreg[4][3][2]; // [k-step - 4 kh][gate][hi, lo]
+    h8 wreg[X4_NK][2][2]; // [k-step][gate - 2 kh (half 1 uses index 0 only)][hi, lo]
 #pragma unroll
-    for (int s2 = 0; s2 < 4; ++s2)
+    for (int s2 = 0; s2 < X4_NK; ++s2)
 #pragma unroll
-        for (int g = 0; g < 3; ++g)
+        for (int gg = 0; gg < 2; ++gg)
 #pragma unroll
             for (int part = 0; part < 2; ++part)
-                wreg[s2][g][part] = frag_load(wsrc, loff + (12 * (4 * kh + s2) + 4 * g + 2 * part) * 1024, 0);
+                if (kh == 0 || gg == 0)
+                    wreg[s2][gg][part] = frag_load(wsrc, loff + (12 * s2 + 4 * (2 * kh + gg) + 2 * part) * 1024, 0);
 
     char *const xteam = sp.xch + ((size_t)blockIdx.y * sp.nteams + team) * (X4_TEAM_BYTES + X4_HEADER);
     const __amdgpu_buffer_rsrc_t xsrc =
@@ -499,55 +503,47 @@ __global__ __launch_bounds__(512, 1) void gru_seq16x4p_kernel(GruSplitParams sp)
         X4_T(0);
         if (s + 1 < steps)
             gi_load(s + 1, gnx); // in flight under this step's MFMAs and hand-off
-        const char *img = lds + cur * 2 * X4_IMG + j * (X4_LDH * 2) + kq * 16 + kh * 4 * 64;
+        const char *img = lds + cur * 2 * X4_IMG + j * (X4_LDH * 2) + kq * 16;
         h8 a_hi[2], a_lo[2]; // by k-step parity
         a_hi[0] = *(const h8 *)(img);
         a_lo[0] = *(const h8 *)(img + X4_IMG);
-        f32x4v acc[3];
-        if (kh == 0) {
+        f32x4v acc[2]; // half 0: r, z; half 1: n (index 0)
+        acc[0] = (f32x4v){bias[2 * kh], bias[2 * kh], bias[2 * kh], bias[2 * kh]};
+        acc[1] = (f32x4v){bias[1], bias[1], bias[1], bias[1]};
+        auto run = [&](auto ngc) {
+            constexpr int NG = decltype(ngc)::value;
 #pragma unroll
-            for (int g = 0; g < 3; ++g)
-                acc[g] = (f32x4v){bias[g], bias[g], bias[g], bias[g]};
-        } else {
-            __syncthreads(); // X1: half 0's accumulators after k-steps 0 .. 3
+            for (int s2 = 0; s2 < X4_NK; ++s2) {
+                if (s2 + 1 < X4_NK) {
+                    a_hi[(s2 + 1) & 1] = *(const h8 *)(img + (s2 + 1) * 64);
+                    a_lo[(s2 + 1) & 1] = *(const h8 *)(img + X4_IMG + (s2 + 1) * 64);
+                }
 #pragma unroll
-            for (int g = 0; g < 3; ++g)
-                acc[g] = xacc[g];
-        }
-#pragma unroll
-        for (int s2 = 0; s2 < 4; ++s2) {
-            if (s2 + 1 < 4) {
-                a_hi[(s2 + 1) & 1] = *(const h8 *)(img + (s2 + 1) * 64);
-                a_lo[(s2 + 1) & 1] = *(const h8 *)(img + X4_IMG + (s2 + 1) * 64);
-            }
-#pragma unroll
-            for (int g = 0; g < 3; ++g)
-                acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[s2 & 1], wreg[s2][g][0], acc[g], 0, 0, 0);
+                for (int g = 0; g < NG; ++g)
+                    acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[s2 & 1], wreg[s2][g][0], acc[g], 0, 0, 0);
 #if !(TT_MUTATE_DROP_LO & 1)
 #pragma unroll
-            for (int g = 0; g < 3; ++g)
-                acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo[s2 & 1], wreg[s2][g][0], acc[g], 0, 0, 0);
+                for (int g = 0; g < NG; ++g)
+                    acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo[s2 & 1], wreg[s2][g][0], acc[g], 0, 0, 0);
 #pragma unroll
-            for (int g = 0; g < 3; ++g)
-                acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[s2 & 1], wreg[s2][g][1], acc[g], 0, 0, 0);
+                for (int g = 0; g < NG; ++g)
+                    acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[s2 & 1], wreg[s2][g][1], acc[g], 0, 0, 0);
 #endif
-        }
+            }
+        };
         float sm[3][2]; // the finished sums of this half's rows
         if (kh == 0) {
-#pragma unroll
-            for (int g = 0; g < 3; ++g)
-                xacc[g] = acc[g];
-            __syncthreads(); // X1
-            __syncthreads(); // X2: half 1's sums of rows 0, 1
-            const f32x4v a = *(const f32x4v *)xsum, b = *(const f32x4v *)(xsum + 4);
-            sm[0][0] = a[0], sm[0][1] = a[1], sm[1][0] = a[2], sm[1][1] = a[3], sm[2][0] = b[0], sm[2][1] = b[1];
-        } else {
-            *(f32x4v *)xsum = (f32x4v){acc[0][0], acc[0][1], acc[1][0], acc[1][1]};
-            *(f32x4v *)(xsum + 4) = (f32x4v){acc[2][0], acc[2][1], 0.0f, 0.0f};
+            run(std::integral_constant<int, 2>{});
+            *xrz = (f32x4v){acc[0][2], acc[0][3], acc[1][2], acc[1][3]};
             __syncthreads(); // X2
-#pragma unroll
-            for (int g = 0; g < 3; ++g)
-                sm[g][0] = acc[g][2], sm[g][1] = acc[g][3];
+            const f32x2v nn = *xn;
+            sm[0][0] = acc[0][0], sm[0][1] = acc[0][1], sm[1][0] = acc[1][0], sm[1][1] = acc[1][1], sm[2][0] = nn[0], sm[2][1] = nn[1];
+        } else {
+            run(std::integral_constant<int, 1>{});
+            *xn = (f32x2v){acc[0][0], acc[0][1]};
+            __syncthreads(); // X2
+            const f32x4v rz = *xrz;
+            sm[0][0] = rz[0], sm[0][1] = rz[1], sm[1][0] = rz[2], sm[1][1] = rz[3], sm[2][0] = acc[0][2], sm[2][1] = acc[0][3];
         }
 
         X4_T(1);
@@ -574,6 +570,15 @@ __global__ __launch_bounds__(512, 1) void gru_seq16x4p_kernel(GruSplitParams sp)
             dst[0] = hi;
             dst[X4_IMG / 2] = lo;
             pk[e] = (unsigned)__builtin_bit_cast(unsigned short, hi) | ((unsigned)__builtin_bit_cast(unsigned short, lo) << 16);
+        }
+        // the next step's projections take their place HERE, in front of the sweep: behind a loop of loads the compiler no longer
+        // knows what is in flight and waits with vmcnt(0) -- at the end of the step that meant waiting for the ten stores below
+        if (s + 1 < steps) {
+#pragma unroll
+            for (int g = 0; g < 3; ++g)
+#pragma unroll
+                for (int e = 0; e < 2; ++e)
+                    giv[g][e] = gnx[g][e];
         }
         X4_T(2);
 #ifdef TT_X4_DBG
@@ -649,13 +654,6 @@ __global__ __launch_bounds__(512, 1) void gru_seq16x4p_kernel(GruSplitParams sp)
         if (abort_flag)
             break;
         cur ^= 1;
-        if (s + 1 < steps) {
-#pragma unroll
-            for (int g = 0; g < 3; ++g)
-#pragma unroll
-                for (int e = 0; e < 2; ++e)
-                    giv[g][e] = gnx[g][e];
-        }
     }
 #ifdef TT_X4_DBG
     if (team == 0 && m == 1 && w == 0 && lane == 0 && steps > 40) {
@@ -1277,6 +1275,9 @@ __global__ __launch_bounds__(512, 1) void gru_bwd16x4p_kernel(GruSplitBwdParams 
             for (int e = 0; e < 4; ++e)
                 part[o2][e] = acc[o2][e] * down[e];
         float sum[2] = {0, 0};
+        // (the next step's stash takes its place here, in front of the sweep: behind a loop of loads the compiler waits with
+        //  vmcnt(0), which at the end of the step would include the twelve gradient stores)
+        cur_st = next_st;
         X4_T(6);
 #ifdef TT_X4_DBG
         tm[7] = tm[8] = tm[6];
@@ -1374,7 +1375,6 @@ __global__ __launch_bounds__(512, 1) void gru_bwd16x4p_kernel(GruSplitBwdParams 
                 d.dghn[go + 2 * H] = gv[2][e];
                 dh[e] = direct[e] + sum[e];
             }
-        cur_st = next_st;
         X4_T(9);
 #ifdef TT_X4_DBG
         for (int i = 0; i < 9; ++i)
