@@ -253,6 +253,15 @@ int tt_encoder_forward_prepared_f32(const int64_t *ids, int B, int T, const floa
                                     size_t workspace_bytes, int32_t *status, tt_stream_t stream);
 
 /*
+ * Two padded id batches as one: out [Ba + Bb][T] (T >= max(Ta, Tb)), rows of a then rows of b, padded with id 0
+ * (padding_idx).  The train step of backend/main.py:244-259 runs positives and negatives through the SAME tower
+ * (model.py:96-106): as one 2B-row call the recurrence fills twice the CUs and the weight-gradient products run once; this is
+ * the host's torch.zeros + two slice copies in one launch.
+ */
+int tt_concat_ids_i64(const int64_t *a, int Ba, int Ta, const int64_t *b, int Bb, int Tb, int64_t *out, int T,
+                      tt_stream_t stream);
+
+/*
  * Replaces loss.backward() through RNNEncoder.forward     backend/main.py:254 over model.py:48-75
  * d_out [B,H] = gradient w.r.t. the forward's `out`.  `workspace` is the buffer a forward call with
  * train=1 and the SAME ids/weights filled.  grads: HOST array of DEVICE pointers laid out like

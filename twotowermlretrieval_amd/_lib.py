@@ -50,6 +50,7 @@ SIGNATURES = {
     "tt_encoder_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i, _i, _i]),
     "tt_encoder_forward_f32": (_i, [_vp, _i, _i, _vp, _i64, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _f, _u64, _vp, _vp,
                                     _sz, _vp, _vp]),
+    "tt_concat_ids_i64": (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _i, _vp]),
     "tt_encoder_prepared_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "tt_encoder_prepare_f32": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "tt_encoder_forward_prepared_f32": (_i, [_vp, _i, _i, _vp, _i64, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _sz,

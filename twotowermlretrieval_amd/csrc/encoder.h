@@ -257,6 +257,6 @@ int gru16_pack(const float *W_hh, int H, unsigned *absmax, void *wp16, hipStream
 int gru16_launch(const GruParams &gp, int ndir, hipStream_t st);
 int gru16_pack_t(const float *W_hh, int H, const unsigned *absmax, void *wtp16, hipStream_t st);
 int gru16_bwd_launch(const GruBwdParams &bp, int ndir, hipStream_t st);
-int gru16x4_launch(const GruParams &gp, int ndir, void *xch, int32_t *status, hipStream_t st);
+int gru16x4_launch(const GruParams &gp, int ndir, void *xch, int32_t *status, hipStream_t st, bool xch_zeroed = false);
 // the reverse-time recurrence on four CUs per row group (reduction split; deterministic, not bit-identical to gru16_bwd_launch)
 int gru16x4_bwd_launch(const GruBwdParams &bp, int ndir, void *xch, int32_t *const *status_pp, hipStream_t st);

@@ -588,6 +588,40 @@ static int enc_pack_weights(int I, int H, int rnn_type, const float *const *w, u
     return TT_OK;
 }
 
+namespace {
+__global__ __launch_bounds__(256) void concat_ids_kernel(const int64_t *__restrict__ a, int Ba, int Ta, const int64_t *__restrict__ b,
+                                                         int Bb, int Tb, int64_t *__restrict__ out, int T)
+{
+    const int64_t n = (int64_t)(Ba + Bb) * T;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int r = (int)(i / T), t = (int)(i % T);
+        int64_t v = 0;
+        if (r < Ba) {
+            if (t < Ta)
+                v = a[(int64_t)r * Ta + t];
+        } else if (t < Tb) {
+            v = b[(int64_t)(r - Ba) * Tb + t];
+        }
+        out[i] = v;
+    }
+}
+} // namespace
+
+TT_EXPORT int tt_concat_ids_i64(const int64_t *a, int Ba, int Ta, const int64_t *b, int Bb, int Tb, int64_t *out, int T,
+                                tt_stream_t stream)
+{
+    if (Ba < 0 || Bb < 0 || Ta < 0 || Tb < 0 || T < Ta || T < Tb || (Ba > 0 && Ta > 0 && !a) || (Bb > 0 && Tb > 0 && !b) || !out)
+        return tt_fail(TT_ERR_BAD_SHAPE, "tt_concat_ids_i64: Ba=%d Ta=%d Bb=%d Tb=%d T=%d (or null pointer)", Ba, Ta, Bb, Tb, T);
+    const int64_t n = (int64_t)(Ba + Bb) * T;
+    if (n == 0)
+        return TT_OK;
+    const int64_t want = (n + 255) / 256;
+    hipLaunchKernelGGL(concat_ids_kernel, dim3((unsigned)(want > 2048 ? 2048 : want)), dim3(256), 0, (hipStream_t)stream, a, Ba, Ta, b, Bb,
+                       Tb, out, T);
+    TT_LAUNCH_CHECK();
+    return TT_OK;
+}
+
 TT_EXPORT size_t tt_encoder_prepared_bytes(int E, int H, int num_layers, int bidirectional, int rnn_type)
 {
     if (num_layers < 1 || num_layers > ENC_MAX_LAYERS || rnn_type < 0 || rnn_type > 2 || E <= 0 || H <= 0)
@@ -650,12 +684,23 @@ static int encoder_forward(const char *who, const int64_t *ids, int B, int T, co
     // (training: the backward's "previous token" maps are made here -- they depend on the lengths only)
     int32_t *pm_fwd = train ? (int32_t *)(ws + lo.prevmap[0]) : nullptr;
     int32_t *pm_rev = (train && ndir == 2) ? (int32_t *)(ws + lo.prevmap[1]) : nullptr;
-    if (B <= 1024 && (int64_t)B * T <= PREP_FUSED_MAX_IDS) {
+    // Layer 0's zero fills ride on ONE launch in front of the prep kernels (each was its own ~5 us launch on the call's chain):
+    // the status flags (when the prep kernels do not clear them themselves), the all-zero row behind layer 0's output
+    // (training) and the split recurrence's hand-off slots.
+    const bool use16_early = rnn_type == CELL_GRU && gru16_supported(H) && !enc_force_f32();
+    const bool split0 = use16_early && lo.xch && gru16x4_usable(B, H, ndir);
+    const bool fused_prep = B <= 1024 && (int64_t)B * T <= PREP_FUSED_MAX_IDS;
+    {
+        float *x1 = (num_layers == 1 && !train) ? nullptr : (float *)(ws + lo.x[1]);
+        TT_RC_CHECK(tt_zero3_async(fused_prep ? nullptr : (void *)flag, fused_prep ? 0 : 256,
+                                   train ? (void *)(x1 + (size_t)lo.MT * ndir * H) : nullptr, train ? sizeof(float) * ndir * H : 0,
+                                   split0 ? (void *)(ws + lo.xch) : nullptr, split0 ? gru16x4_xch_bytes(B, H, ndir) : 0, st));
+    }
+    if (fused_prep) {
         hipLaunchKernelGGL(prep_fused_kernel, dim3(1), dim3(1024), 0, st, ids, B, T, V, len, flag, tok_off, perm, idsp, status,
                            pm_fwd, pm_rev, (int)lo.MT);
         TT_LAUNCH_CHECK();
     } else {
-        TT_RC_CHECK(tt_zero_async(flag, 256, st));
         hipLaunchKernelGGL(prep_len_kernel, dim3((B + 3) / 4), dim3(256), 0, st, ids, B, T, V, len, flag);
         hipLaunchKernelGGL(prep_scan_sort_kernel, dim3(1), dim3(1024), 0, st, len, B, T, tok_off, perm);
         hipLaunchKernelGGL(prep_pack_ids_kernel, dim3(B), dim3(256), 0, st, ids, B, T, len, tok_off, V, idsp, flag, status,
@@ -680,7 +725,7 @@ static int encoder_forward(const char *who, const int64_t *ids, int B, int T, co
         gp.slots = 2 * enc_cus();
         const bool last = l == num_layers - 1;
         float *xout = (last && !train) ? nullptr : (float *)(ws + lo.x[l + 1]);
-        if (train) // the all-zero row that stands for "h before the first step" in the backward GEMMs
+        if (train && l > 0) // the all-zero row that stands for "h before the first step" in the backward GEMMs (layer 0: above)
             TT_RC_CHECK(tt_zero_async(xout + (size_t)lo.MT * ndir * H, sizeof(float) * ndir * H, st));
         for (int d = 0; d < ndir; ++d) {
             const float *const *w = weights + ((size_t)l * ndir + d) * 4;
@@ -769,7 +814,7 @@ static int encoder_forward(const char *who, const int64_t *ids, int B, int T, co
             gp.dir[1] = gp.dir[0];
         if (use16 && lo.xch && gru16x4_usable(B, H, ndir)) {
             // a row group's gate columns on four CUs (gru16x4.hip): same bits out, ~half the time per step
-            rc = gru16x4_launch(gp, ndir, ws + lo.xch, status, st);
+            rc = gru16x4_launch(gp, ndir, ws + lo.xch, status, st, /*xch_zeroed=*/l == 0 && split0);
             if (rc != TT_OK)
                 return rc;
         } else if (use16) {

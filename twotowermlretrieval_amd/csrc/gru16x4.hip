@@ -1515,7 +1515,7 @@ int gru16x4_bwd_launch(const GruBwdParams &bp, int ndir, void *xch, int32_t *con
     return TT_OK;
 }
 
-int gru16x4_launch(const GruParams &gp, int ndir, void *xch, int32_t *status, hipStream_t st)
+int gru16x4_launch(const GruParams &gp, int ndir, void *xch, int32_t *status, hipStream_t st, bool xch_zeroed)
 {
     GruSplitParams sp;
     sp.g = gp;
@@ -1523,7 +1523,8 @@ int gru16x4_launch(const GruParams &gp, int ndir, void *xch, int32_t *status, hi
     sp.status = status;
     sp.nteams = (gp.B + ENC_RB - 1) / ENC_RB;
     sp.spin_max = 1u << 17; // ~0.3 s of backed-off sweeps: a partner that is merely waiting for a CU arrives long before that
-    TT_RC_CHECK(tt_zero_async(xch, gru16x4_xch_bytes(gp.B, gp.H, ndir), st));
+    if (!xch_zeroed) // (the first layer's slots are cleared by the call's one zero launch)
+        TT_RC_CHECK(tt_zero_async(xch, gru16x4_xch_bytes(gp.B, gp.H, ndir), st));
     static bool attr_done = false;
     if (!attr_done) {
         TT_HIP_CHECK(hipFuncSetAttribute((const void *)gru_seq16x4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, X4_LDS + 16));

@@ -39,6 +39,7 @@ static inline size_t tt_align_up(size_t x, size_t a) { return (x + a - 1) / a * 
 // recycled) -- observed in torch.cuda.graph captures of the encoder forward and of a screened search
 // (tools/experiments/encoder_graph_flags.py; small stand-alone graphs do not show it: memset_graph.hip).
 int tt_zero_async(void *p, size_t bytes, hipStream_t st);
+int tt_zero3_async(void *p0, size_t b0, void *p1, size_t b1, void *p2, size_t b2, hipStream_t st);
 
 // MUTATION SWITCH, never set in the product build (tools/mutation_guard.py builds the variants): a bit mask of f16-split
 // kernels whose `lo` products (hi*lo and lo*hi) are compiled out, which turns "fp32-grade" into plain fp16 (2^-11 per

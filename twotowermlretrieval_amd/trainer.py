@@ -131,6 +131,19 @@ def _tower_streams(device):
     return _TOWER_STREAMS[key]
 
 
+def _concat_ids(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """[a; b] padded to the longer T with id 0, on the CURRENT stream: one launch (tt_concat_ids_i64) instead of torch's zero
+    fill + two slice copies -- the document tower's whole chain waits for it."""
+    from . import _lib
+    T = max(a.shape[1], b.shape[1])
+    a, b = a.contiguous(), b.contiguous()
+    out = torch.empty((a.shape[0] + b.shape[0], T), dtype=torch.int64, device=a.device)
+    with torch.cuda.device(a.device):
+        _lib.check(_lib.lib().tt_concat_ids_i64(a.data_ptr(), a.shape[0], a.shape[1], b.data_ptr(), b.shape[0], b.shape[1],
+                                                out.data_ptr(), T, torch.cuda.current_stream(a.device).cuda_stream))
+    return out
+
+
 def _train_step_direct(model: TwoTowerModel, optimizer, queries, pos_docs, neg_docs, margin: float):
     """The same step without the autograd engine: tower forwards (train mode), the fused loss + gradient kernel, tower backwards
     written STRAIGHT into the optimizer's flat gradient buffer, optimizer step.  Every parameter receives its gradient exactly
@@ -158,11 +171,14 @@ def _train_step_direct(model: TwoTowerModel, optimizer, queries, pos_docs, neg_d
     dev = queries.device
     cur = torch.cuda.current_stream(dev)
     B = queries.shape[0]
-    T = max(pos_docs.shape[1], neg_docs.shape[1])
-    both = pos_docs.new_zeros((2 * B, T))
-    both[:B, :pos_docs.shape[1]] = pos_docs
-    both[B:, :neg_docs.shape[1]] = neg_docs
     streams = _tower_streams(dev)[:2]
+    if pos_docs.dtype != torch.int64 or neg_docs.dtype != torch.int64:
+        return None
+    streams[0].wait_stream(cur)
+    with torch.cuda.stream(streams[0]):  # (on the document tower's own stream: no hop from the caller's)
+        pos_docs.record_stream(streams[0])
+        neg_docs.record_stream(streams[0])
+        both = _concat_ids(pos_docs, neg_docs)
     ids_of = (both, queries)
     # dropout seeds from torch's CPU generator in the order the autograd path draws them (query tower, then document tower)
     seeds = {id(enc): (int(torch.randint(0, 2 ** 62, (1,)).item()) if enc.dropout > 0.0 else 0)
@@ -244,10 +260,7 @@ def train_step(model: TwoTowerModel, optimizer: FusedClipAdam, queries: torch.Te
         if neg_docs.shape[0] == B:
             # positives and negatives go through the SAME tower: one call over 2B rows (rows are independent),
             # so the recurrence kernels fill twice the CUs and the weight-gradient GEMMs run once
-            T = max(pos_docs.shape[1], neg_docs.shape[1])
-            both = pos_docs.new_zeros((2 * B, T))
-            both[:B, :pos_docs.shape[1]] = pos_docs
-            both[B:, :neg_docs.shape[1]] = neg_docs
+            both = _concat_ids(pos_docs.long(), neg_docs.long())
             calls = ((model.encode_query, queries), (model.encode_document, both))
         else:
             calls = ((model.encode_query, queries), (model.encode_document, pos_docs), (model.encode_document, neg_docs))
