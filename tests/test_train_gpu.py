@@ -277,3 +277,27 @@ def test_direct_train_step_reports_bad_input_like_the_reference():
     with pytest.raises(RuntimeError):
         tt.train_step(m, opt, *ids, margin=0.5)
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("Ba,Ta,Bb,Tb", [(5, 7, 3, 11), (512, 70, 512, 93), (1, 1, 1, 1), (4, 9, 4, 9), (0, 5, 3, 2)])
+def test_concat_ids_kernel_is_torch_zeros_plus_two_slice_copies(Ba, Ta, Bb, Tb):
+    """tt_concat_ids_i64 (the 2B-row document call of the train step: positives then negatives, padded with id 0 to the longer T)
+    against the torch ops it replaced (backend/main.py:244-259 runs the two batches through the same tower)."""
+    from twotowermlretrieval_amd.trainer import _concat_ids
+    rs = np.random.RandomState(Ba * 131 + Tb)
+    a = torch.from_numpy(rs.randint(0, 2 ** 40, size=(Ba, Ta)).astype(np.int64)).cuda()
+    b = torch.from_numpy(rs.randint(0, 2 ** 40, size=(Bb, Tb)).astype(np.int64)).cuda()
+    got = _concat_ids(a, b)
+    torch.cuda.synchronize()
+    T = max(Ta, Tb)
+    want = torch.zeros((Ba + Bb, T), dtype=torch.int64, device="cuda")
+    want[:Ba, :Ta] = a
+    want[Ba:, :Tb] = b
+    assert got.shape == want.shape and torch.equal(got, want)
+    # a non-contiguous view (a collate_fn's slice) goes through .contiguous()
+    if Ta > 2 and Ba > 0:
+        got2 = _concat_ids(a[:, : Ta - 1], b)
+        want2 = torch.zeros((Ba + Bb, max(Ta - 1, Tb)), dtype=torch.int64, device="cuda")
+        want2[:Ba, : Ta - 1] = a[:, : Ta - 1]
+        want2[Ba:, :Tb] = b
+        assert torch.equal(got2, want2)
