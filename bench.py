@@ -306,15 +306,19 @@ def encoder_corpus_leg(dev, model, n_docs=2_097_152, seed=11):
 def _settle_gc():
     """A full collection now, and everything alive moved to the permanent generation: CPython's generation-2 pass walks every
     tracked object of the process (~40 ms with torch and numpy imported, once per ~100 train steps: tools/experiments/
-    step_times.py) and would land inside some timed loops and not others.  The collector stays on."""
+    step_times.py) and would land inside some of the encoder / train legs' timed loops and not others.  The collector stays on.
+    NOT used around the headline loop (10 - 20 search calls allocate too little to trigger a collection, and a full collection
+    in front of them made the following calls 1 - 4 % slower, A/B on one box)."""
+    if os.environ.get("TT_BENCH_NO_GC_FREEZE") == "1":  # (A/B switch)
+        return
     gc.collect()
     gc.freeze()
 
 
 def _time_gpu(fn, iters, warm):
+    _settle_gc()   # BEFORE the warm-up: the first calls after a full collection pay ~3 ms once (A/B: TT_BENCH_NO_GC_FREEZE)
     for _ in range(warm):
         fn()
-    _settle_gc()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(iters):
@@ -481,7 +485,6 @@ def main():
     for _ in range(a.warmup):
         out = step()
     out = drain() or out
-    _settle_gc()
     fence()
     t0 = time.perf_counter()
     for _ in range(a.steps):
