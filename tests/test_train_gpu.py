@@ -301,3 +301,40 @@ def test_concat_ids_kernel_is_torch_zeros_plus_two_slice_copies(Ba, Ta, Bb, Tb):
         want2[:Ba, : Ta - 1] = a[:, : Ta - 1]
         want2[Ba:, :Tb] = b
         assert torch.equal(got2, want2)
+
+
+def test_a_bad_batch_raises_and_leaves_the_weights_untouched():
+    """The direct train step reads the towers' status words behind the backward kernels and in front of the optimizer: an id out
+    of range raises the reference's IndexError (nn.Embedding, backend/model.py:49), a zero-length row its RuntimeError
+    (pack_padded_sequence, model.py:56), the optimizer step is not enqueued -- parameters, Adam moments and the step number stay
+    what they were -- and the next good batch trains as if nothing had happened.  (Tried: the optimizer enqueued first and made
+    conditional on the status words on the device, the read moved to the end of the step -- no gain: what the read costs, ~0.1
+    ms per step, is the host enqueueing the NEXT step's first kernels with the GPU idle, wherever in the step the read sits.)"""
+    import copy
+    import twotowermlretrieval_amd as tt
+    V, E, H, B = 300, 300, 256, 32
+    torch.manual_seed(3)
+    m = tt.TwoTowerModel({"VOCAB_SIZE": V, "EMBED_DIM": E, "HIDDEN_DIM": H}, synth.make_table(4, V, E)).cuda().train()
+    opt = tt.FusedClipAdam(m.parameters(), lr=1e-3, max_norm=1.0)
+    ids = [torch.from_numpy(synth.make_ids(70 + s, B, T, V)).cuda() for s, T in enumerate((7, 20, 25))]
+    tt.train_step(m, opt, *ids, margin=0.5)          # one good step: moments are non-zero from here on
+    torch.cuda.synchronize()
+    ref = copy.deepcopy(m)
+    ref_opt = tt.FusedClipAdam(ref.parameters(), lr=1e-3, max_norm=1.0)
+    ref_opt.exp_avg.copy_(opt.exp_avg); ref_opt.exp_avg_sq.copy_(opt.exp_avg_sq); ref_opt.step_count = opt.step_count
+    before = (opt.flat_params.clone(), opt.exp_avg.clone(), opt.exp_avg_sq.clone(), opt.step_count)
+    bad_id = [t.clone() for t in ids]
+    bad_id[1][3, 0] = V + 5                            # a positive passage with an id out of range
+    with pytest.raises(IndexError):
+        tt.train_step(m, opt, *bad_id, margin=0.5)
+    empty = [t.clone() for t in ids]
+    empty[0][5, :] = 0                                 # a query of padding only
+    with pytest.raises(RuntimeError):
+        tt.train_step(m, opt, *empty, margin=0.5)
+    torch.cuda.synchronize()
+    assert torch.equal(opt.flat_params, before[0]) and torch.equal(opt.exp_avg, before[1]) and torch.equal(opt.exp_avg_sq, before[2])
+    assert opt.step_count == before[3]
+    l1 = tt.train_step(m, opt, *ids, margin=0.5)
+    l2 = tt.train_step(ref, ref_opt, *ids, margin=0.5)
+    torch.cuda.synchronize()
+    assert float(l1) == float(l2) and torch.equal(opt.flat_params, ref_opt.flat_params)
