@@ -16,6 +16,7 @@
 //   K3        head: (bidirectional) cat + Linear(2H,H) (model.py:65-69), F.normalize eps 1e-12
 //             (model.py:73-74).
 #include "encoder.h"
+#include "pack16.h"
 #include "sgemm.h"
 
 #include <limits.h>
@@ -565,10 +566,33 @@ static bool enc_rows16(int NGH, int I) { return !enc_tiled_k1() && tt_gemm_rows1
 // One layer and direction's weights into the forms the forward kernels read.  wih_max / wmax: zeroed words that receive
 // the bit patterns of max |W_ih| / max |W_hh|; w16: W_ih split into fp16 hi/lo parts (scaled by the power of two its
 // maximum implies) as gemm_rows16's fragment stream or the tiled GEMM's [rows][Kp] images; wp: W_hh in packed order.
+namespace {
+// both conversions of a GRU layer in one launch (pack16.h): blockIdx.y = 0: W_ih -> fragment stream, 1: W_hh -> packed order
+__global__ __launch_bounds__(256) void pack2_kernel(const float *__restrict__ Wih, int N, int K, int nks, int waves, int ctn,
+                                                    const unsigned *__restrict__ wih_max, _Float16 *__restrict__ w16,
+                                                    const float *__restrict__ Whh, int H, const unsigned *__restrict__ wmax,
+                                                    _Float16 *__restrict__ wp16)
+{
+    if (blockIdx.y == 0)
+        pack_frag16_body(Wih, N, K, nks, waves, ctn, wih_max, w16, (int)blockIdx.x, (int)gridDim.x);
+    else
+        pack_whh16_body(Whh, H, wmax, wp16, (int)blockIdx.x, (int)gridDim.x);
+}
+} // namespace
+
 static int enc_pack_weights(int I, int H, int rnn_type, const float *const *w, unsigned *wih_max, unsigned *wmax, char *w16,
                             char *wp, hipStream_t st)
 {
     const int NGH = enc_gates(rnn_type) * H;
+    if (!enc_force_f32() && rnn_type == CELL_GRU && gru16_supported(H) && enc_rows16(NGH, I) && (I + 15) / 16 <= 19) {
+        // the north-star shape: two launches instead of four (both maxima, then both conversions)
+        TT_RC_CHECK(tt_absmax2(w[0], (int64_t)NGH * I, wih_max, w[1], (int64_t)3 * H * H, wmax, st));
+        const int nks = (I + 15) / 16;
+        hipLaunchKernelGGL(pack2_kernel, dim3(96, 2), dim3(256), 0, st, w[0], NGH, I, nks, 4, 2, (const unsigned *)wih_max,
+                           (_Float16 *)w16, w[1], H, (const unsigned *)wmax, (_Float16 *)wp);
+        TT_LAUNCH_CHECK();
+        return TT_OK;
+    }
     if (!enc_force_f32()) {
         TT_RC_CHECK(tt_absmax(w[0], (int64_t)NGH * I, wih_max, st));
         if (enc_rows16(NGH, I)) {

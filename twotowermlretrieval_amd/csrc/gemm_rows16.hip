@@ -17,6 +17,7 @@
 // Bounds per 573 k-token launch: MFMA 0.34 ms, L2 -> CU fragment stream 8.4 GB (0.4 ms at the ~87 GB/s per CU measured
 // for gru16), output 1.76 GB (0.3 ms of HBM writes), all overlapped.
 #include "sgemm.h"
+#include "pack16.h"
 
 #include <type_traits>
 
@@ -66,7 +67,6 @@ __device__ __forceinline__ void static_for(F &&f)
 
 // NKS = ceil(K / 16) k-steps (compile time: the k loop is fully unrolled and software-pipelined).  The column chunks go
 // round the waves: wave w takes chunks w, w + W, ..., one per PASS (runtime loop).
-__host__ __device__ static inline int rs_chunks_of(int nchunks, int w, int W) { return (nchunks - w + W - 1) / W; }
 
 // The TAIL SPLIT.  A workgroup owns 64 tokens and ALL columns, and `slots` of them are resident at a time (two per CU): the
 // last round of a launch is as long as any other however few token blocks it holds -- 1 098 blocks on 512 slots (the train
@@ -295,37 +295,11 @@ __global__ __launch_bounds__(WIDE ? 512 : 256, WIDE ? 1 : 2) void gemm_rows16_ke
     }
 }
 
-// W [N][K] fp32 -> the fragment stream gemm_rows16_kernel reads: 1-KiB blocks ordered (wave, pass, k-step, column tile,
-// hi | lo), lane l of a block = 8 halves of column (W pass + wave) CHUNK + 32 ct + (l & 31) at k = 16 s + 8 (l >> 5) ..
+// W [N][K] fp32 -> the fragment stream (pack16.h)
 __global__ __launch_bounds__(256) void pack_frag16_kernel(const float *__restrict__ W, int N, int K, int nks, int waves, int ctn,
                                                           const unsigned *__restrict__ absmax, _Float16 *__restrict__ out)
 {
-    const float sc = ldexpf(1.0f, tt_pow2_exponent(*absmax));
-    const int chunk_cols = 32 * ctn, nchunks = N / chunk_cols;
-    const int total = nchunks * nks * ctn * 64; // (chunk, s, ct, lane)
-    for (int t = blockIdx.x * 256 + threadIdx.x; t < total; t += gridDim.x * 256) {
-        const int l = t & 63;
-        int rest = t >> 6;
-        const int ct = rest % ctn;
-        rest /= ctn;
-        const int s = rest % nks, chunk = rest / nks;
-        const int w = chunk % waves, pass = chunk / waves;
-        int first = 0;
-        for (int j = 0; j < w; ++j)
-            first += rs_chunks_of(nchunks, j, waves);
-        const int col = chunk * chunk_cols + 32 * ct + (l & 31), k0 = 16 * s + 8 * (l >> 5);
-        h8 vh, vl;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float x = (k0 + e < K) ? W[(size_t)col * K + k0 + e] * sc : 0.0f;
-            const _Float16 hv = (_Float16)x;
-            vh[e] = hv;
-            vl[e] = (_Float16)(x - (float)hv);
-        }
-        _Float16 *blk = out + ((size_t)(((first + pass) * nks + s) * ctn + ct) * 2) * 512 + l * 8;
-        *(h8 *)blk = vh;
-        *(h8 *)(blk + 512) = vl;
-    }
+    pack_frag16_body(W, N, K, nks, waves, ctn, absmax, out, (int)blockIdx.x, (int)gridDim.x);
 }
 
 template <int NKS, bool WIDE>

@@ -23,6 +23,7 @@
 // and outputs are those of gru_seq_kernel.
 #include "encoder.h"
 #include "sgemm.h"
+#include "pack16.h"
 
 #include <type_traits>
 
@@ -114,33 +115,11 @@ __device__ __forceinline__ void static_for(F &&f)
     }
 }
 
-// Packed order: wave w, fragment f = (s, pair, within): s = f / 12 the k-step, pair = (f % 12) / 4 the pair of column
-// tiles {2 pair, 2 pair + 1}, within = f % 4 -> part = within >> 1 (0 hi, 1 lo), tile t = 2 pair + (within & 1),
-// gate g = t >> 1, ct = t & 1.  Lane (n = lane & 15, kq = lane >> 4) holds the 8 fp16 of
-//   W_hh[g H + 32 w + 16 ct + n][32 s + 8 kq .. + 7]  (scaled by 2^e; hi or lo part):  16 bytes at
-//   wp16[((w NF + f) 64 + lane) 8 ...].
+// W_hh -> packed fragment order (pack16.h)
 __global__ __launch_bounds__(256) void pack_whh16_kernel(const float *__restrict__ W, int H, const unsigned *__restrict__ absmax,
                                                          _Float16 *__restrict__ wp16)
 {
-    const int NK = H / 32, NF = 12 * NK;
-    const float sc = ldexpf(1.0f, tt_pow2_exponent(*absmax));
-    const int n = (H / 32) * NF * 64; // (wave, fragment, lane) triples
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-        const int lane = i & 63;
-        const int f = (i >> 6) % NF, w = (i >> 6) / NF;
-        const int s = f / 12, pair = (f % 12) / 4, within = f % 4;
-        const int part = within >> 1, t = 2 * pair + (within & 1), g = t >> 1, ct = t & 1;
-        const float *src = W + (size_t)(g * H + 32 * w + 16 * ct + (lane & 15)) * H + 32 * s + 8 * (lane >> 4);
-        const f32x4v a = *(const f32x4v *)src, b = *(const f32x4v *)(src + 4);
-        h8 o;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float x = (e < 4 ? a[e] : b[e - 4]) * sc;
-            const _Float16 hi = (_Float16)x;
-            o[e] = part ? (_Float16)(x - (float)hi) : hi;
-        }
-        *(h8 *)(wp16 + (size_t)i * 8) = o;
-    }
+    pack_whh16_body(W, H, absmax, wp16, (int)blockIdx.x, (int)gridDim.x);
 }
 
 __device__ __forceinline__ float fast_sigmoid16(float x) { return tt_fast_sigmoid(x); }

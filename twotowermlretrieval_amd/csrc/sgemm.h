@@ -85,6 +85,7 @@ int tt_wgrad16(const SgemmParams &p, int nslabs, hipStream_t st);
 
 // bit pattern of max |x| over n floats -> *out (atomicMax; the caller zeroes *out on the stream first)
 int tt_absmax(const float *x, int64_t n, unsigned *out, hipStream_t st);
+int tt_absmax2(const float *x0, int64_t n0, unsigned *out0, const float *x1, int64_t n1, unsigned *out1, hipStream_t st);
 
 // the same over the gathered rows x[map[r]][0..K), r < min(M, *m_dyn) (K, ld multiples of 4)
 int tt_absmax_rows(const float *x, int64_t ld, int K, const int32_t *map, int M, const int *m_dyn, unsigned *out, hipStream_t st);

@@ -428,7 +428,7 @@ __global__ __launch_bounds__(256) void pack_rows16_kernel(const float *__restric
 // max|x| into *out (atomicMax on the bit pattern: non-negative floats order like their bits).  ONE atomic per workgroup and
 // at most 64 workgroups: a thousand same-address atomics serialise in L2 (the 230 k-element weight matrices took 13-14 us
 // with one atomic per wave of 256 workgroups, 4 us of it the reads).
-__global__ __launch_bounds__(256) void absmax_kernel(const float *__restrict__ x, int64_t n, unsigned *__restrict__ out)
+static __device__ __forceinline__ void absmax_body(const float *__restrict__ x, int64_t n, unsigned *__restrict__ out)
 {
     __shared__ float part[4];
     float m = 0.0f;
@@ -454,6 +454,19 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float *__restrict__ x
     __syncthreads();
     if (threadIdx.x == 0)
         atomicMax(out, __float_as_uint(fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3]))));
+}
+
+__global__ __launch_bounds__(256) void absmax_kernel(const float *__restrict__ x, int64_t n, unsigned *__restrict__ out)
+{
+    absmax_body(x, n, out);
+}
+__global__ __launch_bounds__(256) void absmax2_kernel(const float *__restrict__ x0, int64_t n0, unsigned *__restrict__ out0,
+                                                      const float *__restrict__ x1, int64_t n1, unsigned *__restrict__ out1)
+{
+    if (blockIdx.y == 0)
+        absmax_body(x0, n0, out0);
+    else
+        absmax_body(x1, n1, out1);
 }
 
 // the same over the rows map[0 .. min(M, *m_dyn)) of a [.][ld] table, K (a multiple of 4) elements each: the embedding vectors
@@ -606,6 +619,17 @@ int tt_pack_rows16(const float *W, int N, int K, const unsigned *absmax, void *h
     const int64_t want = ((int64_t)N * (Kp / 8) + 255) / 256;
     hipLaunchKernelGGL(pack_rows16_kernel, dim3((unsigned)(want > 1024 ? 1024 : want)), dim3(256), 0, st, W, N, K, Kp, absmax,
                        (_Float16 *)hi16, (_Float16 *)lo16);
+    TT_LAUNCH_CHECK();
+    return TT_OK;
+}
+
+// two tensors in one launch (blockIdx.y picks): the two weight matrices of a GRU layer
+int tt_absmax2(const float *x0, int64_t n0, unsigned *out0, const float *x1, int64_t n1, unsigned *out1, hipStream_t st)
+{
+    if (n0 <= 0 || n1 <= 0)
+        return tt_fail(TT_ERR_BAD_SHAPE, "tt_absmax2: n0=%lld n1=%lld", (long long)n0, (long long)n1);
+    const int64_t big = n0 > n1 ? n0 : n1, want = (big + 1023) / 1024;
+    hipLaunchKernelGGL(absmax2_kernel, dim3((unsigned)(want > 64 ? 64 : want), 2), dim3(256), 0, st, x0, n0, out0, x1, n1, out1);
     TT_LAUNCH_CHECK();
     return TT_OK;
 }
