@@ -51,6 +51,9 @@ typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 typedef short s4v __attribute__((__vector_size__(4 * sizeof(short))));
 
+#ifndef WG_OTHER_PER_MFMA
+#define WG_OTHER_PER_MFMA 3 // vector ALU / memory / LDS-write instructions scheduled behind every MFMA of a run (A/B: 2, 4, 6 no faster)
+#endif
 constexpr int WG_KT = 32;            // tokens per tile = one MFMA K
 constexpr int WG_MT = 256;           // output rows per workgroup
 constexpr int WG_ROW = 544;          // bytes per image row
@@ -247,7 +250,7 @@ __global__ __launch_bounds__(512, 1) void wgrad16_kernel(SgemmParams p, int n_nt
 #pragma unroll
                 for (int i = 0; i < NT; ++i) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); // MFMA
-                    __builtin_amdgcn_sched_group_barrier(0x222, 3, 0); // vector ALU / memory read / LDS write
+                    __builtin_amdgcn_sched_group_barrier(0x222, WG_OTHER_PER_MFMA, 0); // vector ALU / memory read / LDS write
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
