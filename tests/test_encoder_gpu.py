@@ -528,6 +528,40 @@ def test_eight_wave_members_vs_four_wave_members(B, T, layers, bi):
             assert_grad_close(g88[n].cpu().numpy(), g44[n].cpu().numpy(), what=n)
 
 
+@pytest.mark.parametrize("B,T", [(1, 5), (33, 12), (512, 70), (700, 64)])
+def test_k1_tail_split_writes_the_same_bits(B, T):
+    """gemm_rows16's tail split (the token blocks beyond the last full round of resident workgroups are each given to three
+    workgroups that take a third of every wave's passes) against the unsplit launch (TT_ROWS_SPLIT=0): same arithmetic per column,
+    so the tower's output and the training stash must be the same bits -- for a serving-size batch (one round, every block split),
+    a batch just over one round (512 x 70: ~560 token blocks on 512 slots) and one whose tail is too large to split."""
+    import os
+    V, E, H, seed = 400, 300, 256, 1700 + B
+    enc, table, sd = make_encoder(V, E, H, seed, 1, False)
+    ids = torch.from_numpy(synth.make_ids(seed + 5, B, T, V, zero_inside=0.05)).cuda()
+    enc.cache_prepared = False
+    outs = {}
+    for flag in ("1", "0"):
+        old = os.environ.get("TT_ROWS_SPLIT")
+        os.environ["TT_ROWS_SPLIT"] = flag
+        try:
+            with torch.no_grad():
+                y = enc(ids).clone()
+            enc.train()
+            enc.zero_grad()
+            yt = enc(ids)
+            yt.backward(torch.ones_like(yt))
+            torch.cuda.synchronize()
+            outs[flag] = (y, yt.detach().clone(), [p.grad.clone() for p in enc._flat_params()])
+            enc.eval()
+        finally:
+            if old is None:
+                os.environ.pop("TT_ROWS_SPLIT", None)
+            else:
+                os.environ["TT_ROWS_SPLIT"] = old
+    a, b = outs["1"], outs["0"]
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and all(torch.equal(x, y) for x, y in zip(a[2], b[2]))
+
+
 def test_column_split_recurrence_with_both_towers_in_flight():
     """The train step launches the query tower and the 2B-row document tower on two streams: 32 + 64 teams = 384 workgroups
     for 256 CUs, so members of some teams wait for a CU while their partners already sweep for them.  Three steps: with the

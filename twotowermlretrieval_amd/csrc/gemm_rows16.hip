@@ -313,10 +313,7 @@ int launch_rows16(const SgemmParams &p, hipStream_t st)
         attr_done = true;
     }
     // resident workgroups (the kernel's rounds): two per CU for the narrow form, one for the wide one; TT_ROWS_SPLIT=0: no tail split
-    static const int slots = [] {
-        const char *e = getenv("TT_ROWS_SPLIT");
-        if (e && e[0] == '0')
-            return 0;
+    static const int resident = [] {
         int dev = 0, cus = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) {
             (void)hipGetLastError();
@@ -324,6 +321,8 @@ int launch_rows16(const SgemmParams &p, hipStream_t st)
         }
         return (WIDE ? 1 : 2) * cus;
     }();
+    const char *e = getenv("TT_ROWS_SPLIT"); // (read at every call, so that one process can compare the two forms)
+    const int slots = (e && e[0] == '0') ? 0 : resident;
     // (a split tail has at most slots / RS_SPLIT token blocks, each RS_SPLIT workgroups: (RS_SPLIT - 1) slots / RS_SPLIT extra)
     const unsigned blocks = (unsigned)((p.M + RS_ROWS - 1) / RS_ROWS) + (unsigned)(slots - slots / RS_SPLIT);
     hipLaunchKernelGGL((gemm_rows16_kernel<NKS, WIDE>), dim3(blocks), dim3(C::WAVES * 64), C::LDS, st, p, slots);
