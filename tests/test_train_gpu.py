@@ -338,3 +338,40 @@ def test_a_bad_batch_raises_and_leaves_the_weights_untouched():
     l2 = tt.train_step(ref, ref_opt, *ids, margin=0.5)
     torch.cuda.synchronize()
     assert float(l1) == float(l2) and torch.equal(opt.flat_params, ref_opt.flat_params)
+
+
+def test_weight_gradient_kernel_against_the_tiled_one():
+    """wgrad16 (256-row output tiles, K-major LDS images, one K slab per workgroup) and the tiled f16-split GEMM it replaced
+    (TT_WGRAD_TILED=1) compute dW_ih / dW_hh from the same dGi / dGh with different slab partitions: they agree to the gradient
+    tolerance (both are fp32-grade; the oracle comparisons elsewhere pin each of them), everything else is the same bits."""
+    import os
+    V, E, H, B, T = 500, 300, 256, 512, 40
+    torch.manual_seed(11)
+    import twotowermlretrieval_amd as tt
+    enc = tt.RNNEncoder(V, E, H, pretrained_embeddings=synth.make_table(4, V, E)).cuda().train()
+    ids = torch.from_numpy(synth.make_ids(91, B, T, V)).cuda()
+    d_out = torch.from_numpy(np.random.RandomState(5).standard_normal((B, H)).astype(np.float32)).cuda()
+    res = {}
+    for flag in ("0", "1"):
+        old = os.environ.get("TT_WGRAD_TILED")
+        os.environ["TT_WGRAD_TILED"] = flag
+        try:
+            enc.zero_grad()
+            y = enc(ids)
+            y.backward(d_out)
+            torch.cuda.synchronize()
+            res[flag] = {n: p.grad.clone() for n, p in enc.named_parameters() if p.grad is not None}
+        finally:
+            if old is None:
+                os.environ.pop("TT_WGRAD_TILED", None)
+            else:
+                os.environ["TT_WGRAD_TILED"] = old
+    differ = 0
+    for n in res["0"]:
+        a, b = res["0"][n], res["1"][n]
+        if "weight" in n:
+            assert_grad_close(a.cpu().numpy(), b.cpu().numpy(), what=n)
+            differ += int((a != b).sum())
+        else:
+            assert torch.equal(a, b), n
+    assert differ > 0   # (the switch really selects another kernel)

@@ -316,10 +316,10 @@ __global__ __launch_bounds__(512, 1) void wgrad16_kernel(SgemmParams p, int n_nt
         }
 }
 
-bool wgrad_tiled()
+bool wgrad_tiled() // (read at every call, so that one process can compare the two kernels)
 {
-    static const bool v = [] { const char *e = getenv("TT_WGRAD_TILED"); return e && atoi(e) != 0; }();
-    return v;
+    const char *e = getenv("TT_WGRAD_TILED");
+    return e && atoi(e) != 0;
 }
 
 } // namespace
