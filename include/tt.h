@@ -32,6 +32,8 @@ extern "C" {
 
 typedef void *tt_stream_t; /* hipStream_t */
 
+#define TT_TOPK_INVALID_INDEX (1ll << 62) /* see tt_score_topk_f32 */
+
 enum tt_status {
     TT_OK = 0,
     TT_ERR_BAD_SHAPE = 1,   /* -> ValueError / RuntimeError in the Python shim */
@@ -66,6 +68,10 @@ int tt_event_elapsed_ms(void *start, void *stop, float *ms); /* blocks until `st
  * {320,384,448,512} (16-query tiles, 16x16x4 MFMA: the same chain, bit for bit), 1 <= k <= 64,
  * N < 2^31 - 64 per call (shard larger corpora; idx_offset makes indices global).
  * Inputs must be finite (a NaN score is never selected).
+ * Every wait between waves inside the kernels is bounded.  One of them cannot be skipped without losing documents (a wave
+ * waiting ~2 us for a neighbour's draw from the shared tile pool, B >= 96 only): should its budget (~4 ms) ever run out, the
+ * affected queries come back with out_val = +inf and out_idx >= TT_TOPK_INVALID_INDEX in their first places instead of a
+ * silently incomplete result.  Never observed; a host that wants to be sure checks out_idx[.,0] < N.
  */
 /* Diagnostic: byte offset, in the workspace of a finished exact search of this shape, of an int32 counting the waves whose
  * chunk-pacing wait timed out (the pacing counters are coherent only among waves on one XCD: a launch whose chunks straddle
@@ -128,10 +134,12 @@ int tt_score_topk_screened_f32(const float *Q, int B, int d, const float *D32, c
  *                                         maxima (unordered; -3e38 / -inf entries where the shard has no such sample)
  *   [caller]                              ONE all-gather of the ranks' seed lists (k_seed floats per query and rank: 40 KB per
  *                                         rank at B = 1024, k_seed = 10 -- tt_allgather_topk moves any byte block), then
- *   tt_seed_union_f32                     seed[q] = the k_seed-th largest of the world * k_seed gathered values.  They are
+ *   tt_seed_union_f32                     seed[q] = the kth-th largest of the world * list_len gathered values (kth = the FINAL
+ *                                         k; list_len = k_seed of the lists, normally kth too -- a job so wide that
+ *                                         world * kth > 512 lists fewer per rank, list_len = 512 / world >= kth / world).  They are
  *                                         approximate scores of DISTINCT documents (one per 32-document sample tile, the shards'
- *                                         rows are disjoint), so k_seed documents of the whole corpus reach seed[q]: it bounds the
- *                                         GLOBAL k_seed-th best approximate score from below -- the seed the unsharded search
+ *                                         rows are disjoint), so kth documents of the whole corpus reach seed[q]: it bounds the
+ *                                         GLOBAL kth-th best approximate score from below -- the seed the unsharded search
  *                                         would take from a sample of the same total size
  *   tt_score_topk_screened_seeded_f32     the screen with thresholds seed[q] - 2 eps_q, pooling + exact rescoring, predicated exact
  *                                         kernels; writes this shard's documents above the global threshold (up to k, best first,
@@ -145,8 +153,8 @@ int tt_score_topk_screened_seed_f32(const float *Q, int B, int d, const void *D1
 int tt_score_topk_screened_seed_list_f32(const float *Q, int B, int d, const void *D16, int64_t N, int k, int k_seed,
                                          float dmax_norm, int32_t *fallback_flag, float *seed_list /*[B][k_seed] out*/,
                                          void *workspace, size_t workspace_bytes, tt_stream_t stream);
-int tt_seed_union_f32(const float *lists /*[world][B][k_seed]*/, int world, int B, int k_seed, float *seed /*[B] out*/,
-                      tt_stream_t stream);
+int tt_seed_union_f32(const float *lists /*[world][B][list_len]*/, int world, int B, int list_len, int kth,
+                      float *seed /*[B] out*/, tt_stream_t stream);
 int tt_score_topk_screened_seeded_f32(const float *Q, int B, int d, const float *D32, const void *D16, int64_t N, int k,
                                       float dmax_norm, int64_t idx_offset, float *out_val, int64_t *out_idx,
                                       int32_t *fallback_flag, const float *seed /*[B]*/, void *workspace, size_t workspace_bytes,
@@ -218,14 +226,25 @@ int tt_score_all_f32(const float *Q, int B, int d, const float *D, int64_t N, fl
  * id outside [0,V) (IndexError).  Such rows produce finite garbage, never a fault.  bit 2 = the column-split GRU
  * recurrence (H = 256, B <= 1024: a row group's gate columns on four workgroups that hand the hidden state to each other
  * every step, csrc/gru16x4.hip) gave up waiting for a partner workgroup: its waits are bounded, so a workgroup that is
- * never scheduled ends the call with this bit instead of a hang; the outputs are then invalid (TT_GRU_SPLIT=0 in the
- * environment selects the one-workgroup kernel, whose results are bit-identical).
- * train != 0 keeps the activations the backward pass needs inside the workspace: the SAME workspace
- * (sized with train = 1) must then be passed, untouched, to tt_encoder_backward_f32.
+ * never scheduled ends the call with this bit instead of a hang; the outputs are then invalid: call again with
+ * TT_ENC_ONE_WORKGROUP, which keeps every recurrence on the one-workgroup kernels (no hand-off between workgroups, nothing to
+ * wait for; results bit-identical to the column-split forward's).  The column-split kernels need every member of a row
+ * group's team on a CU at the same time: ONE such launch always fits (checked against the device's CU count), a host that
+ * keeps SEVERAL encoder calls in flight on different streams passes TT_ENC_ONE_WORKGROUP to all but the largest (what
+ * trainer.train_step does for the query tower) -- or relies on the bounded wait and the retry above.
+ * train: 0 inference, 1 training, 2 training with a trainable table, optionally | TT_ENC_ONE_WORKGROUP.  train != 0 keeps the
+ * activations the backward pass needs inside the workspace: the SAME workspace (sized with the same train value) must then be
+ * passed, untouched, to tt_encoder_backward_f32.  The library reads no environment variable on any call.
  * Supported: H multiple of 32 in [32,512], E multiple of 4, 1 <= num_layers <= 4.
  */
+#define TT_ENC_TRAIN_MASK 0xff
+#define TT_ENC_ONE_WORKGROUP 0x100 /* option bit of `train` / `opts`: recurrences on one workgroup per 16-row group */
+/* CUs the column-split recurrence of one call of this shape occupies (one workgroup each, all resident at once); 0 = the call
+ * runs the one-workgroup kernels whatever `train` says.  A host with several calls in flight keeps the sum within the device's
+ * CU count by passing TT_ENC_ONE_WORKGROUP to the smaller ones. */
+int tt_encoder_split_workgroups(int B, int H, int bidirectional, int rnn_type);
 size_t tt_encoder_workspace_bytes(int B, int T, int E, int H, int num_layers, int bidirectional, int rnn_type,
-                                  int train /* 0 inference, 1 training, 2 training with a trainable table */,
+                                  int train /* as tt_encoder_forward_f32's (the option bits do not change the size) */,
                                   int dropout /* train && dropout_p > 0 && num_layers > 1 */);
 int tt_encoder_forward_f32(const int64_t *ids, int B, int T, const float *table, int64_t V, int E, int H,
                            int num_layers, int bidirectional, int rnn_type, const float *const *weights /*host array*/,
@@ -240,7 +259,8 @@ int tt_encoder_forward_f32(const int64_t *ids, int B, int T, const float *table,
  * (backend/query_inferencer.py:51-75, frontend/main.py:150-156: weights loaded once, never changed) prepares them once:
  *   tt_encoder_prepared_bytes(...)  size of the caller-owned device buffer `prepared` (256-B aligned)
  *   tt_encoder_prepare_f32(...)     fills it from `weights` on `stream`; call again after the weights change
- *   tt_encoder_forward_prepared_f32 = tt_encoder_forward_f32 with train = 0 reading `prepared` (same results, bit for bit)
+ *   tt_encoder_forward_prepared_f32 = tt_encoder_forward_f32 with train = 0 | opts reading `prepared` (same results, bit for
+ *                                     bit); opts: 0 or TT_ENC_ONE_WORKGROUP
  */
 size_t tt_encoder_prepared_bytes(int E, int H, int num_layers, int bidirectional, int rnn_type);
 int tt_encoder_prepare_f32(int E, int H, int num_layers, int bidirectional, int rnn_type,
@@ -249,8 +269,8 @@ int tt_encoder_prepare_f32(int E, int H, int num_layers, int bidirectional, int 
 int tt_encoder_forward_prepared_f32(const int64_t *ids, int B, int T, const float *table, int64_t V, int E, int H,
                                     int num_layers, int bidirectional, int rnn_type,
                                     const float *const *weights /*host array*/, const void *prepared,
-                                    const float *proj_w, const float *proj_b, int normalize, float *out, void *workspace,
-                                    size_t workspace_bytes, int32_t *status, tt_stream_t stream);
+                                    const float *proj_w, const float *proj_b, int normalize, int opts, float *out,
+                                    void *workspace, size_t workspace_bytes, int32_t *status, tt_stream_t stream);
 
 /*
  * Two padded id batches as one: out [Ba + Bb][T] (T >= max(Ta, Tb)), rows of a then rows of b, padded with id 0
@@ -269,13 +289,19 @@ int tt_concat_ids_i64(const int64_t *a, int Ba, int Ta, const int64_t *b, int Bb
  * does).  With GloVe vectors the embedding table is frozen (model.py:25-27) and gets no gradient: g_table = NULL.
  * Without them the reference trains it (nn.Embedding(V, E, padding_idx=0), model.py:23): pass g_table [V,E]
  * (overwritten: dense gradient, row 0 = padding_idx stays zero) and size / run the forward with train = 2.
+ * opts: 0 or TT_ENC_ONE_WORKGROUP (the reverse-time recurrence on the one-workgroup kernel; any combination with the forward's
+ * choice is valid -- the stash is the same bits either way).
+ * status (nullable): device int32 word into which the call ORs bit 2 (value 4) when its column-split recurrence gave up
+ * waiting for a partner workgroup (the gradients are then invalid; the bias gradients are NaN).  The word is ONLY OR-ed into,
+ * never cleared: pass the forward call's status word (one read then covers both calls) or a word zeroed beforehand.  The
+ * call writes to no other caller memory than grads / g_* / workspace / status.
  */
 int tt_encoder_backward_f32(const int64_t *ids, int B, int T, const float *table, int64_t V, int E, int H,
                             int num_layers, int bidirectional, int rnn_type, const float *const *weights /*host array*/,
                             const float *proj_w, const float *proj_b, int normalize, float dropout_p,
                             uint64_t dropout_seed, const float *d_out, float *const *grads /*host array*/,
                             float *g_proj_w, float *g_proj_b, float *g_table /*nullable*/, void *workspace,
-                            size_t workspace_bytes, tt_stream_t stream);
+                            size_t workspace_bytes, int opts, int32_t *status /*nullable*/, tt_stream_t stream);
 
 /* ------------------------------------------------------------------ */
 /* Training step pieces                                                */
@@ -302,6 +328,32 @@ size_t tt_clip_adam_scratch_bytes(void);
 int tt_clip_adam_step_f32(float *params, float *grads, float *exp_avg, float *exp_avg_sq, int64_t n, int64_t step,
                           float lr, float beta1, float beta2, float eps, float max_norm, float grad_scale,
                           float *total_norm_out, void *scratch, tt_stream_t stream);
+
+/*
+ * The same step as a COLLECTIVE DECISION of a data-parallel job, with nothing baked into the launch that changes from step to
+ * step (so the whole train step can sit in one hipGraph):
+ *   gate (nullable): device float [TT_STEP_GATE_WORDS], the tail of the flat gradient bucket -- the host all-reduces
+ *     n + TT_STEP_GATE_WORDS floats (tt_allreduce_grads), so after the reduction every rank holds the SAME words:
+ *     gate[b] = how many encoder calls, over all ranks, raised status bit b this step (tt_step_gate_f32 below).  If any word
+ *     is non-zero NO rank applies the step: params, grads, moments and the step counter stay untouched (total_norm_out is
+ *     still written).  The reference's step is single-process: a bad batch raises and the run stops
+ *     (backend/main.py:244-259); here every rank reads the same reduced words and raises the same exception, instead of one
+ *     rank leaving the step while its peers wait in the all-reduce.
+ *   step_counter: device int64, the number of steps applied so far; incremented (by one thread, after the norm pass) iff
+ *     the step is applied; the bias corrections 1 - beta^t are computed on the device from it, in double precision as
+ *     torch.optim.Adam does on the host.
+ */
+#define TT_STEP_GATE_WORDS 4
+int tt_clip_adam_step_gated_f32(float *params, float *grads, float *exp_avg, float *exp_avg_sq, int64_t n,
+                                int64_t *step_counter, float lr, float beta1, float beta2, float eps, float max_norm,
+                                float grad_scale, float *total_norm_out, const float *gate /*nullable*/, void *scratch,
+                                tt_stream_t stream);
+/*
+ * gate[b] = number of the n_status status words (HOST array of DEVICE int32 pointers, n_status <= 8, null entries skipped)
+ * that have bit b set, b = 0 .. 2 (tt_encoder_forward_f32's bits; the backward ORs bit 2 into the same words); gate[3] = 0.
+ * One launch, on `stream`, behind the encoder calls it looks at.
+ */
+int tt_step_gate_f32(const int32_t *const *status_words /*host array*/, int n_status, float *gate, tt_stream_t stream);
 
 /* ------------------------------------------------------------------ */
 /* Collectives of the sharded path (RCCL over xGMI), SURVEY 8e          */

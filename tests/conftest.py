@@ -1,3 +1,4 @@
+import contextlib
 import json
 import os
 import sys
@@ -79,3 +80,40 @@ def oracle():
     from oracle import oracle as o
     o.build()
     return o
+
+
+_AB = {}
+
+
+@contextlib.contextmanager
+def ab_library(**switches):
+    """Run the block on the COMPARISON build of the library (ab/libtt_ab.so = -DTT_AB, built by __graft_entry__.build():
+    the superseded kernels + the A/B switches of csrc/tt_common.h read from the environment at every call) with the given
+    TT_* switches set; the product library -- which reads no environment and does not contain those kernels -- is put back
+    on exit.  For tests that pin a product kernel against the kernel it replaced:  with ab_library(TT_WGRAD_TILED=1): ...
+    Both libraries use the same workspace layouts, so tensors made under one can be consumed under the other."""
+    import ctypes as C
+    from twotowermlretrieval_amd import _lib
+    path = ROOT / "ab" / "libtt_ab.so"
+    if "lib" not in _AB:
+        if not path.exists():
+            from twotowermlretrieval_amd import build as b
+            b.build_ab()
+        lib = C.CDLL(str(path))
+        for name, (res, args) in _lib.SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+        _AB["lib"] = lib
+    _lib.lib()  # (the product library is loaded first: it is what the rest of the test runs on)
+    keep, old = _lib._lib, {k: os.environ.get(k) for k in switches}
+    os.environ.update({k: str(v) for k, v in switches.items()})
+    _lib._lib = _AB["lib"]
+    try:
+        yield
+    finally:
+        _lib._lib = keep
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v

@@ -440,31 +440,35 @@ def test_status_word_is_written_not_accumulated(B, T):
     assert torch.isfinite(enc(torch.from_numpy(base).cuda())).all()
 
 
-def _with_split(flag, fn, bwd=None):
-    """Run fn with the column-split recurrences (gru16x4.hip) on or off: libtt reads TT_GRU_SPLIT (both directions of time) and
-    TT_GRU_SPLIT_BWD (the reverse-time one alone) at every call."""
-    import os
-    val = lambda f: f if isinstance(f, str) else ("1" if f else "0")   # "4": the four-wave members (gru_seq16x4 / gru_bwd16x4_kernel)
-    keys = {"TT_GRU_SPLIT": val(flag), "TT_GRU_SPLIT_BWD": val(flag if bwd is None else bwd)}
-    old = {k: os.environ.get(k) for k in keys}
-    os.environ.update(keys)
+def _with_split(mod, flag, fn, bwd=None):
+    """Run fn with the recurrences of the encoders inside `mod` column-split (gru16x4.hip; True), on the one-workgroup kernels
+    (False: TT_ENC_ONE_WORKGROUP, a per-call option of the product library), or -- "4" -- on the four-wave members the
+    eight-wave ones replaced, which only the comparison build contains (conftest.ab_library).  bwd: the reverse-time recurrence
+    alone (default: as flag)."""
+    import contextlib
+    from conftest import ab_library
+    import twotowermlretrieval_amd as tt
+    bwd = flag if bwd is None else bwd
+    encs = [e for e in mod.modules() if isinstance(e, tt.RNNEncoder)]
+    old = [(e.one_workgroup, e.one_workgroup_bwd) for e in encs]
+    for e in encs:
+        e.one_workgroup, e.one_workgroup_bwd = (flag is False), (bwd is False)
+    four = {k: 4 for k, f in (("TT_GRU_SPLIT", flag), ("TT_GRU_SPLIT_BWD", bwd)) if f == "4"}
     try:
-        return fn()
+        with (ab_library(**four) if four else contextlib.nullcontext()):
+            return fn()
     finally:
-        for k, v in old.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
+        for e, (o, ob) in zip(encs, old):
+            e.one_workgroup, e.one_workgroup_bwd = o, ob
 
 
 @pytest.mark.parametrize("B,T,layers,bi", [(70, 40, 1, False), (5, 250, 1, False), (1024, 33, 1, False), (1, 7, 1, False),
                                           (300, 21, 2, True), (512, 12, 1, True), (17, 9, 3, False)])
 def test_column_split_recurrence_vs_the_one_cu_kernels(B, T, layers, bi):
-    """gru_seq16x4_kernel (a row group's gate columns on four CUs, hidden state handed over through tagged granules every
-    step) against gru_seq16_kernel: same products in the same order -> the SAME BITS, in eval mode and in train mode, stash
-    included: with the split forward and the one-CU backward every gradient is bit-identical to the all-one-CU run.
-    gru_bwd16x4_kernel splits the REDUCTION (four partial chains per column, summed in member order): its gradients agree
+    """gru_seq16x4p_kernel (a row group's gate columns on four CUs, hidden state handed over through tagged granules every
+    step) against gru_seq16_kernel (TT_ENC_ONE_WORKGROUP): same products in the same order -> the SAME BITS, in eval mode and in
+    train mode, stash included: with the split forward and the one-CU backward every gradient is bit-identical to the all-one-CU
+    run.  gru_bwd16x4p_kernel splits the REDUCTION (four partial chains per column, summed in member order): its gradients agree
     with the one-CU backward to the tests' gradient tolerance and are the same bits on every run.  Ragged lengths, one-row
     batches, 64 teams (every CU taken), both directions in one launch, stacked layers."""
     V, E, H, seed = 400, 300, 256, 900 + B
@@ -472,18 +476,21 @@ def test_column_split_recurrence_vs_the_one_cu_kernels(B, T, layers, bi):
     ids = torch.from_numpy(synth.make_ids(seed + 5, B, T, V, zero_inside=0.05)).cuda()
     enc.cache_prepared = False
     with torch.no_grad():
-        one = _with_split(False, lambda: enc(ids).clone())
-        four = _with_split(True, lambda: enc(ids).clone())
+        one = _with_split(enc, False, lambda: enc(ids).clone())
+        four = _with_split(enc, True, lambda: enc(ids).clone())
+        enc.cache_prepared = True      # (the prepared-weights entry point takes the option too)
+        one_p = _with_split(enc, False, lambda: enc(ids).clone())
+        enc.cache_prepared = False
     torch.cuda.synchronize()
-    assert torch.equal(one, four)
+    assert torch.equal(one, four) and torch.equal(one, one_p)
     assert torch.isfinite(four).all() and float(four.norm(dim=1).min()) > 0.99
     enc.train()
     d_out = torch.from_numpy(np.random.RandomState(seed).standard_normal((B, H)).astype(np.float32)).cuda()
 
     def grads(flag, bwd):
         enc.zero_grad()
-        y = _with_split(flag, lambda: enc(ids), bwd)
-        _with_split(flag, lambda: y.backward(d_out), bwd)
+        y = _with_split(enc, flag, lambda: enc(ids), bwd)
+        _with_split(enc, flag, lambda: y.backward(d_out), bwd)
         torch.cuda.synchronize()
         return [p.grad.clone() for p in enc._flat_params()], y.detach().clone()
     g1, y1 = grads(False, False)
@@ -499,10 +506,10 @@ def test_column_split_recurrence_vs_the_one_cu_kernels(B, T, layers, bi):
 @pytest.mark.parametrize("B,T,layers,bi", [(70, 40, 1, False), (1024, 33, 1, False), (300, 21, 2, True), (1, 7, 1, False)])
 def test_eight_wave_members_vs_four_wave_members(B, T, layers, bi):
     """The split recurrences run a member as EIGHT waves (two per SIMD; gru_seq16x4p / gru_bwd16x4p_kernel) -- the four-wave
-    members they replaced stay in the library as the reference (TT_GRU_SPLIT=4 / TT_GRU_SPLIT_BWD=4).  Forward: every column's
-    accumulator chain is handed from one wave of a pair to the other, same products in the same order: outputs and stash are
-    the same bits.  Backward: the pair splits the destination members, every partial is still one chain: dW_ih / dW_hh are the
-    same bits; the bias sums accumulate per half (another order): gradient tolerance."""
+    members they replaced are compiled into the comparison build only (-DTT_AB, TT_GRU_SPLIT=4 / TT_GRU_SPLIT_BWD=4) and stay the
+    reference here.  Forward: every column's accumulator chain is handed from one wave of a pair to the other, same products in
+    the same order: outputs and stash are the same bits.  Backward: the pair splits the destination members, every partial is
+    still one chain: dW_ih / dW_hh are the same bits; the bias sums accumulate per half (another order): gradient tolerance."""
     V, E, H, seed = 400, 300, 256, 1300 + B
     enc, table, sd = make_encoder(V, E, H, seed, layers, bi)
     ids = torch.from_numpy(synth.make_ids(seed + 5, B, T, V, zero_inside=0.05)).cuda()
@@ -512,14 +519,14 @@ def test_eight_wave_members_vs_four_wave_members(B, T, layers, bi):
 
     def grads(fwd, bwd):
         enc.zero_grad()
-        y = _with_split(fwd, lambda: enc(ids), bwd)
-        _with_split(fwd, lambda: y.backward(d_out), bwd)
+        y = _with_split(enc, fwd, lambda: enc(ids), bwd)
+        _with_split(enc, fwd, lambda: y.backward(d_out), bwd)
         torch.cuda.synchronize()
         return {n: p.grad.clone() for n, p in enc.named_parameters() if p.grad is not None}, y.detach().clone()
     g44, y44 = grads("4", "4")
-    g84, y84 = grads("1", "4")     # eight-wave forward, four-wave backward: the stash is the same bits
+    g84, y84 = grads(True, "4")    # eight-wave forward (product library), four-wave backward: the stash is the same bits
     assert torch.equal(y44, y84) and all(torch.equal(g44[n], g84[n]) for n in g44)
-    g88, y88 = grads("1", "1")
+    g88, y88 = grads(True, True)
     assert torch.equal(y44, y88)
     for n in g44:
         if "weight" in n:
@@ -531,19 +538,19 @@ def test_eight_wave_members_vs_four_wave_members(B, T, layers, bi):
 @pytest.mark.parametrize("B,T", [(1, 5), (33, 12), (512, 70), (700, 64)])
 def test_k1_tail_split_writes_the_same_bits(B, T):
     """gemm_rows16's tail split (the token blocks beyond the last full round of resident workgroups are each given to three
-    workgroups that take a third of every wave's passes) against the unsplit launch (TT_ROWS_SPLIT=0): same arithmetic per column,
-    so the tower's output and the training stash must be the same bits -- for a serving-size batch (one round, every block split),
-    a batch just over one round (512 x 70: ~560 token blocks on 512 slots) and one whose tail is too large to split."""
-    import os
+    workgroups that take a third of every wave's passes) against the unsplit launch (the comparison build with TT_ROWS_SPLIT=0):
+    same arithmetic per column, so the tower's output and the training stash must be the same bits -- for a serving-size batch
+    (one round, every block split), a batch just over one round (512 x 70: ~560 token blocks on 512 slots) and one whose tail is
+    too large to split."""
+    import contextlib
+    from conftest import ab_library
     V, E, H, seed = 400, 300, 256, 1700 + B
     enc, table, sd = make_encoder(V, E, H, seed, 1, False)
     ids = torch.from_numpy(synth.make_ids(seed + 5, B, T, V, zero_inside=0.05)).cuda()
     enc.cache_prepared = False
     outs = {}
     for flag in ("1", "0"):
-        old = os.environ.get("TT_ROWS_SPLIT")
-        os.environ["TT_ROWS_SPLIT"] = flag
-        try:
+        with (contextlib.nullcontext() if flag == "1" else ab_library(TT_ROWS_SPLIT=0)):   # "1": the product library
             with torch.no_grad():
                 y = enc(ids).clone()
             enc.train()
@@ -553,35 +560,52 @@ def test_k1_tail_split_writes_the_same_bits(B, T):
             torch.cuda.synchronize()
             outs[flag] = (y, yt.detach().clone(), [p.grad.clone() for p in enc._flat_params()])
             enc.eval()
-        finally:
-            if old is None:
-                os.environ.pop("TT_ROWS_SPLIT", None)
-            else:
-                os.environ["TT_ROWS_SPLIT"] = old
     a, b = outs["1"], outs["0"]
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and all(torch.equal(x, y) for x, y in zip(a[2], b[2]))
 
 
-def test_column_split_recurrence_with_both_towers_in_flight():
-    """The train step launches the query tower and the 2B-row document tower on two streams: 32 + 64 teams = 384 workgroups
-    for 256 CUs, so members of some teams wait for a CU while their partners already sweep for them.  Three steps: with the
-    split forward alone the parameters are the one-CU run's bit for bit; with both recurrences split the run repeats itself
-    bit for bit and its last gradient agrees with the one-CU run's to the gradient tolerance."""
+def test_train_step_keeps_the_split_recurrences_within_the_cus():
+    """The train step launches the query tower and the 2B-row document tower on two streams.  Both column-split would be 32 + 64
+    teams = 384 one-per-CU workgroups for 256 CUs: members of some teams would wait for a CU while their partners already sweep
+    for them, and progress would rest on dispatch order.  trainer._towers_in_flight keeps the sum within the CU count instead
+    (the smaller tower runs the one-workgroup recurrences, same bits forward): checked here on the options the tower calls
+    really got.  Three steps: with the split forward alone the parameters are the all-one-workgroup run's bit for bit; with the
+    document tower's backward split too the run repeats itself bit for bit and its last gradient agrees with the one-workgroup
+    run's to the gradient tolerance."""
     import copy
     import twotowermlretrieval_amd as tt
+    from twotowermlretrieval_amd import _lib
     V, E, H, B = 500, 300, 256, 512
     torch.manual_seed(5)
     m0 = tt.TwoTowerModel({"VOCAB_SIZE": V, "EMBED_DIM": E, "HIDDEN_DIM": H}, synth.make_table(4, V, E)).cuda().train()
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
     runs = {}
     for name, (flag, bwd) in {"one": (False, False), "fwd": (True, False), "both": (True, True), "both2": (True, True)}.items():
         m = copy.deepcopy(m0)
         o = tt.FusedClipAdam(m.parameters(), lr=1e-5, max_norm=1.0)
+        seen = []
+        for enc in (m.query_encoder, m.doc_encoder):
+            fwd0 = enc._run_forward
+
+            def spy(x, train, *a, _f=fwd0, _e=enc, **k):
+                seen.append((_e, x.shape[0], _e._opts(), _e._opts_bwd()))
+                return _f(x, train, *a, **k)
+            enc._run_forward = spy
         losses = []
         for step in range(3):
             ids = [torch.from_numpy(synth.make_ids(60 + 3 * step + s, B, T, V)).cuda() for s, T in enumerate((9, 60, 70))]
-            losses.append(float(_with_split(flag, lambda: tt.train_step(m, o, *ids, margin=0.5), bwd).item()))
+            losses.append(float(_with_split(m, flag, lambda: tt.train_step(m, o, *ids, margin=0.5), bwd).item()))
             torch.cuda.synchronize()
         runs[name] = (losses, o.flat_params.clone(), o.flat_grads.clone())
+        # what was in flight together never asked for more CUs than the device has
+        for i in range(0, len(seen), 2):
+            want = sum(_lib.lib().tt_encoder_split_workgroups(b, H, 0, 0) for e, b, of, ob in seen[i:i + 2]
+                       if not (of and ob))
+            assert want <= cus, (name, seen[i:i + 2])
+        if name == "both" and cus < 384:
+            q_calls = [t for t in seen if t[0] is m.query_encoder]
+            d_calls = [t for t in seen if t[0] is m.doc_encoder]
+            assert all(of and ob for _, _, of, ob in q_calls) and all(not of and not ob for _, _, of, ob in d_calls)
     assert runs["one"][0] == runs["fwd"][0] and torch.equal(runs["one"][1], runs["fwd"][1])
     assert runs["both"][0] == runs["both2"][0] and torch.equal(runs["both"][1], runs["both2"][1])
     np.testing.assert_allclose(runs["both"][0], runs["one"][0], atol=2e-6)

@@ -152,6 +152,59 @@ def test_dp_allreduce_then_clip_then_adam_two_ranks(oracle):
     assert np.array_equal(out[0][0], out[1][0])  # replicas stay bit-identical
 
 
+def _dp_bad_rank_worker(rank, world, port, out):
+    sys.path[:0] = [str(ROOT), str(GOLDEN)]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import oracle as o
+    from twotowermlretrieval_amd.model import SplitRecurrenceTimeout
+    from twotowermlretrieval_amd.trainer import _FlatClipAdam
+
+    def step_fn(p, g, m, v, step, lr, betas, eps, max_norm, grad_scale, total_norm, scratch):
+        gn = g.numpy()
+        gn *= np.float32(grad_scale)
+        total_norm[0] = o.clip_adam_step(p.numpy(), gn, m.numpy(), v.numpy(), step, lr, betas, eps, max_norm)
+
+    rs = np.random.RandomState(3)
+    params = [torch.nn.Parameter(torch.from_numpy(rs.standard_normal(s).astype(np.float32))) for s in [(12, 5), (7,)]]
+    opt = _FlatClipAdam(params, step_fn, lambda g: dist.all_reduce(g, op=dist.ReduceOp.SUM), world, lr=1e-2,
+                        betas=(0.9, 0.999), eps=1e-8, max_norm=1.0, scratch_bytes=64)
+    log = []
+    # per step: the status words this rank's two tower calls produced (bit 0 zero-length row, 1 id out of range, 2 time-out)
+    plan = [((0, 0), (0, 0)), ((0, 0), (2, 0)), ((1, 0), (0, 0)), ((0, 4), (0, 0)), ((4, 0), (0, 3)), ((0, 0), (0, 0))]
+    for step, per_rank in enumerate(plan):
+        opt.zero_grad()
+        gr = np.random.RandomState(100 + 10 * step + rank)
+        for prm in params:
+            prm.grad.add_(torch.from_numpy(gr.standard_normal(tuple(prm.shape)).astype(np.float32)))
+        opt._pending_status.extend(torch.tensor([w], dtype=torch.int32) for w in per_rank[rank])
+        before = opt.flat_params.clone()
+        try:
+            opt.step()
+            log.append(("ok", opt.step_count))
+            assert not torch.equal(before, opt.flat_params)
+        except (IndexError, SplitRecurrenceTimeout, RuntimeError) as e:
+            log.append((type(e).__name__, opt.step_count))
+            assert torch.equal(before, opt.flat_params) and not opt._pending_status
+    out[rank] = (opt.flat_params.detach().numpy().copy(), log)
+    dist.destroy_process_group()
+
+
+def test_a_failed_step_is_a_collective_decision_two_ranks(oracle):
+    """The status words of a rank's encoder calls ride behind the gradients in the ONE all-reduced bucket
+    (trainer._FlatClipAdam): whichever rank had the bad batch, BOTH ranks raise the same exception in the same step (the
+    reference's: IndexError for an id out of range, RuntimeError for a zero-length row -- backend/main.py:244-259 is
+    single-process and simply stops), neither applies the step, and the replicas stay bit-identical.  Data errors win over
+    the transient time-out bit; a time-out alone raises SplitRecurrenceTimeout (train_step redoes the step on it)."""
+    world, port = 2, _free_port()
+    mgr = mp.get_context("spawn").Manager()
+    out = mgr.dict()
+    mp.spawn(_dp_bad_rank_worker, args=(world, port, out), nprocs=world, join=True)
+    want = [("ok", 1), ("IndexError", 1), ("RuntimeError", 1), ("SplitRecurrenceTimeout", 1), ("IndexError", 1), ("ok", 2)]
+    assert out[0][1] == want and out[1][1] == want
+    assert np.array_equal(out[0][0], out[1][0])
+
+
 def test_load_config_reads_json(tmp_path):
     from twotowermlretrieval_amd.query_inferencer import load_config
     (tmp_path / "config.json").write_text('{"HIDDEN_DIM": 256, "RNN_TYPE": "GRU"}')

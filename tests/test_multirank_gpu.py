@@ -26,7 +26,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, tmp):
+def _worker(rank, world, port, tmp, search_only=False):
     sys.path[:0] = [str(ROOT), str(GOLDEN)]
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -61,6 +61,52 @@ def _worker(rank, world, port, tmp):
         v2, i2 = ix.search(Q.to(dev), k=10)     # and the synchronous form still works after pipelined steps
         torch.cuda.synchronize()
         assert torch.equal(v2, v) and torch.equal(i2, i)
+        # any interleaving that is the same on every rank: a result() straight after its submit() (the exchange is issued by
+        # result() itself), a search() with a submitted step still pending (issued first), a step nobody collects before its
+        # slot comes round again
+        Qs = [torch.from_numpy(synth.unit_rows(900 + 10 * B + j, B, 256)).to(dev) for j in range(4)]
+        a = ix.submit(Qs[0], k=10).result()
+        res[f"xv{B}_0"], res[f"xi{B}_0"] = a[0].cpu().numpy(), a[1].cpu().numpy()
+        pend = ix.submit(Qs[1], k=10)
+        sv, si = ix.search(Qs[2], k=10)
+        pv, pi = pend.result()
+        res[f"xv{B}_1"], res[f"xi{B}_1"] = pv.cpu().numpy(), pi.cpu().numpy()
+        res[f"xv{B}_2"], res[f"xi{B}_2"] = sv.cpu().numpy(), si.cpu().numpy()
+        ix.submit(Qs[0], k=10); ix.submit(Qs[1], k=10)          # two steps dropped on the floor
+        pv, pi = ix.submit(Qs[3], k=10).result()
+        res[f"xv{B}_3"], res[f"xi{B}_3"] = pv.cpu().numpy(), pi.cpu().numpy()
+    # ---- shards on both sides of the screen's minimum size, a k too wide for k seeds per rank: no rank may enter an
+    #      all-gather the others skip (the seed exchange is agreed once, in the constructor)
+    _index.SCREEN_MIN_DOCS = 65536
+    if world == 2:
+        lo, hi = (0, 66000) if rank == 0 else (66000, 70001)   # rank 0 could screen on its own, rank 1 (4001 rows) could not
+    else:
+        lo, hi = tt.shard_bounds(70001, rank, world)           # ~17.5k rows each: below the minimum everywhere
+    ux = tt.ShardedIndex(D[lo:hi].to(dev), lo, shard_k=50, screen=True)
+    assert ux._seed_exchange is False and (ux._index.docs16 is not None)
+    Qu = torch.from_numpy(synth.unit_rows(77, 40, 256)).to(dev)
+    uv, ui = ux.search(Qu, k=10)
+    pv, pi = ux.submit(Qu, k=10).result()
+    torch.cuda.synchronize()
+    assert torch.equal(uv, pv) and torch.equal(ui, pi)
+    res["uv"], res["ui"] = uv.cpu().numpy(), ui.cpu().numpy()
+    _index.SCREEN_MIN_DOCS = 0
+    wx = tt.ShardedIndex.from_global(D.to(dev), shard_k=64, screen=True)
+    old_max, _index.SEED_UNION_MAX = _index.SEED_UNION_MAX, 96     # as if the job were ~5x wider: fewer than k = 64 seeds per rank
+    assert wx._seed_plan(64) == (96 // world, 64) and wx._seed_plan(10) == (10, 10)
+    wv, wi = wx.search(Qu, k=64)
+    _index.SEED_UNION_MAX = 8
+    assert wx._seed_plan(64) is None                             # too wide even for that: every shard seeds itself
+    wv2, wi2 = wx.search(Qu, k=64)
+    _index.SEED_UNION_MAX = old_max
+    torch.cuda.synchronize()
+    assert torch.equal(wv, wv2) and torch.equal(wi, wi2)
+    res["wv"], res["wi"] = wv.cpu().numpy(), wi.cpu().numpy()
+    if search_only:
+        np.savez(os.path.join(tmp, f"rank{rank}.npz"), **res)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     # ---- index build across ranks: every rank embeds only its shard of the document list, then the usual sharded search
     words = ["the", ",", ".", "of", "and"] + [f"w{i}" for i in range(5, 80)]
     tok = tt.PretrainedTokenizer(word2idx={w: i for i, w in enumerate(words)})
@@ -100,23 +146,45 @@ def _worker(rank, world, port, tmp):
     dist.destroy_process_group()
 
 
-def test_two_ranks_on_one_gpu_sharded_search_and_dp_step(oracle, tmp_path):
-    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
-    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+def _check_search(oracle, ranks):
     D = synth.unit_rows(31, 70001, 256).copy()
     D[60000] = D[17]
     for B in (5, 200):
         Q = synth.unit_rows(32 + B, B, 256).copy()
         Q[0] = D[17]
         ov, oi = oracle.score_topk(Q, D, 10)
-        for r in (r0, r1):                       # identical on every rank, identical to the unsharded oracle
+        for r in ranks:                          # identical on every rank, identical to the unsharded oracle
             assert np.array_equal(r[f"i{B}"], oi) and np.array_equal(r[f"v{B}"], ov)
         assert list(oi[0][:2]) == [17, 60000]
         for step in range(4):                    # pipelined steps: every one bit-identical to the oracle on every rank
             Qs = synth.unit_rows(500 + 10 * B + step, B, 256)
             sv, si = oracle.score_topk(Qs, D, 10)
-            for r in (r0, r1):
+            for r in ranks:
                 assert np.array_equal(r[f"pi{B}_{step}"], si) and np.array_equal(r[f"pv{B}_{step}"], sv), (B, step)
+        for j in range(4):                       # the other interleavings of submit / result / search
+            sv, si = oracle.score_topk(synth.unit_rows(900 + 10 * B + j, B, 256), D, 10)
+            for r in ranks:
+                assert np.array_equal(r[f"xi{B}_{j}"], si) and np.array_equal(r[f"xv{B}_{j}"], sv), (B, j)
+    Qu = synth.unit_rows(77, 40, 256)
+    ov, oi = oracle.score_topk(Qu, D, 10)
+    wv, wi = oracle.score_topk(Qu, D, 64)
+    for r in ranks:
+        assert np.array_equal(r["ui"], oi) and np.array_equal(r["uv"], ov)      # uneven shards, no seed exchange
+        assert np.array_equal(r["wi"], wi) and np.array_equal(r["wv"], wv)      # k = 64 with fewer seeds per rank than k
+
+
+def test_four_ranks_on_one_gpu_sharded_search(oracle, tmp_path):
+    """The search half of the two-rank test with four ranks (gloo, four processes on the one GPU): every interleaving of
+    submit / result / search, the deferred list exchange, the agreed seed decision and the wide-k seed plan, bit-identical to
+    the oracle on every rank."""
+    mp.spawn(_worker, args=(4, _free_port(), str(tmp_path), True), nprocs=4, join=True)
+    _check_search(oracle, [np.load(tmp_path / f"rank{r}.npz") for r in range(4)])
+
+
+def test_two_ranks_on_one_gpu_sharded_search_and_dp_step(oracle, tmp_path):
+    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    _check_search(oracle, (r0, r1))
     # the document-sharded build: both ranks return the same global rows, and they are what one process computes
     assert np.array_equal(r0["doc_i"], r1["doc_i"]) and np.array_equal(r0["doc_v"], r1["doc_v"])
     import twotowermlretrieval_amd as tt
@@ -147,3 +215,92 @@ def test_two_ranks_on_one_gpu_sharded_search_and_dp_step(oracle, tmp_path):
     torch.cuda.synchronize()
     assert abs(float(loss.item()) - 0.5 * (float(r0["loss"]) + float(r1["loss"]))) < 1e-6
     np.testing.assert_allclose(opt.flat_params.detach().cpu().numpy(), r0["params"], rtol=0, atol=2e-6)
+
+
+def _bad_rank_worker(rank, world, port, tmp):
+    sys.path[:0] = [str(ROOT), str(GOLDEN)]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=__import__("datetime").timedelta(seconds=120))
+    torch.cuda.set_device(0)
+    import twotowermlretrieval_amd as tt
+    dev = torch.device("cuda", 0)
+    V, E, H, B = 300, 300, 256, 32          # (H = 256: the column-split recurrences are the ones that run)
+    torch.manual_seed(7)
+    m = tt.TwoTowerModel({"VOCAB_SIZE": V, "EMBED_DIM": E, "HIDDEN_DIM": H}, synth.make_table(4, V, E)).to(dev)
+    tr = tt.trainer.DataParallelTrainer(m, lr=1e-3, margin=0.5)
+    tr.broadcast_parameters()
+    opt = tr.optimizer
+    ids = [torch.from_numpy(synth.make_ids(70 + s, 2 * B, T, V)) for s, T in enumerate((7, 20, 25))]
+    mine = lambda batch: [t[rank * B:(rank + 1) * B].clone().to(dev) for t in batch]
+    res, log = {}, []
+    tr.step(*mine(ids))                      # one good step: the moments are non-zero from here on
+    torch.cuda.synchronize()
+    snap = lambda: [t.detach().cpu().numpy().copy() for t in (opt.flat_params, opt.exp_avg, opt.exp_avg_sq)] + [opt.step_count]
+    before = snap()
+    # 1. rank 1's positives hold an id out of range; rank 0's batch is fine.  2. rank 0 has a query of padding only.
+    # 3. BOTH kinds at once on different ranks: the data error with the higher bit wins on both.
+    cases = []
+    bad = [t.clone() for t in ids]; bad[1][B + 3, 0] = V + 5; cases.append(bad)
+    bad = [t.clone() for t in ids]; bad[0][5, :] = 0; cases.append(bad)
+    bad = [t.clone() for t in ids]; bad[0][5, :] = 0; bad[2][B + 1, 2] = -4; cases.append(bad)
+    for batch in cases:
+        try:
+            tr.step(*mine(batch))
+            log.append("ok")
+        except IndexError:
+            log.append("IndexError")
+        except RuntimeError as e:
+            log.append("RuntimeError" if "Length of all samples" in str(e) else repr(e))
+        torch.cuda.synchronize()
+        after = snap()
+        assert all(np.array_equal(a, b) for a, b in zip(before[:3], after[:3])) and before[3] == after[3], "a failed step changed the state"
+    # the hand-written loop of backend/main.py:244-259 around the same optimizer fails collectively too (the trainer watches the model)
+    batch = mine(cases[0])
+    try:
+        opt.zero_grad()
+        q, p_, n_ = m.encode_query(batch[0]), m.encode_document(batch[1]), m.encode_document(batch[2])
+        loss = tt.triplet_loss_cosine((q, p_, n_), margin=0.5)
+        loss.backward()
+        opt.step()
+        log.append("ok")
+    except IndexError:
+        log.append("IndexError")
+    torch.cuda.synchronize()
+    after = snap()
+    assert all(np.array_equal(a, b) for a, b in zip(before[:3], after[:3])) and before[3] == after[3]
+    l2 = tr.step(*mine(ids))                 # and a good batch trains as if nothing had happened
+    torch.cuda.synchronize()
+    res["log"] = np.array(log)
+    res["params"], res["m"], res["v"] = snap()[:3]
+    res["steps"] = np.array(opt.step_count)
+    res["loss"] = np.array(float(l2.item()))
+    np.savez(os.path.join(tmp, f"bad{rank}.npz"), **res)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_a_bad_batch_on_one_rank_fails_the_step_on_both(tmp_path):
+    """backend/main.py:244-259 is single-process: a bad batch raises and the run stops.  Data-parallel, the rank with the bad
+    batch must not leave the step alone -- its peers would wait in the gradient all-reduce forever.  The towers' status words
+    ride behind the gradients in the one all-reduced bucket and the optimizer kernel is predicated on the reduced words on the
+    device (tt_step_gate_f32, tt_clip_adam_step_gated_f32): BOTH ranks raise the reference's exception inside the step (no
+    hang: the process group's time-out is 120 s and mp.spawn joins), parameters, moments and step number are equal on both
+    and untouched, and the next good step trains -- identically to a two-rank run that never saw the bad batches."""
+    mp.spawn(_bad_rank_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "bad0.npz"), np.load(tmp_path / "bad1.npz")
+    want = ["IndexError", "RuntimeError", "IndexError", "IndexError"]
+    assert list(r0["log"]) == want and list(r1["log"]) == want
+    for k in ("params", "m", "v"):
+        assert np.array_equal(r0[k], r1[k]), k
+    assert int(r0["steps"]) == int(r1["steps"]) == 2
+    # one process on the concatenated batches, two good steps: the same trajectory up to the reduction order
+    import twotowermlretrieval_amd as tt
+    V, E, H, B = 300, 300, 256, 32
+    torch.manual_seed(7)
+    m = tt.TwoTowerModel({"VOCAB_SIZE": V, "EMBED_DIM": E, "HIDDEN_DIM": H}, synth.make_table(4, V, E)).cuda().train()
+    opt = tt.FusedClipAdam(m.parameters(), lr=1e-3, max_norm=1.0)
+    ids = [torch.from_numpy(synth.make_ids(70 + s, 2 * B, T, V)).cuda() for s, T in enumerate((7, 20, 25))]
+    for _ in range(2):
+        loss = tt.train_step(m, opt, *ids, margin=0.5)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(opt.flat_params.detach().cpu().numpy(), r0["params"], rtol=0, atol=5e-6)

@@ -304,12 +304,11 @@ def test_concat_ids_kernel_is_torch_zeros_plus_two_slice_copies(Ba, Ta, Bb, Tb):
 
 
 def test_a_bad_batch_raises_and_leaves_the_weights_untouched():
-    """The direct train step reads the towers' status words behind the backward kernels and in front of the optimizer: an id out
-    of range raises the reference's IndexError (nn.Embedding, backend/model.py:49), a zero-length row its RuntimeError
-    (pack_padded_sequence, model.py:56), the optimizer step is not enqueued -- parameters, Adam moments and the step number stay
-    what they were -- and the next good batch trains as if nothing had happened.  (Tried: the optimizer enqueued first and made
-    conditional on the status words on the device, the read moved to the end of the step -- no gain: what the read costs, ~0.1
-    ms per step, is the host enqueueing the NEXT step's first kernels with the GPU idle, wherever in the step the read sits.)"""
+    """The towers' status words are folded into the gate words behind the gradients and the optimizer kernel is predicated on them
+    on the device (tt_clip_adam_step_gated_f32; with a process group the gate is all-reduced with the gradients, so the ranks
+    decide together: tests/test_multirank_gpu.py): an id out of range raises the reference's IndexError (nn.Embedding,
+    backend/model.py:49), a zero-length row its RuntimeError (pack_padded_sequence, model.py:56), parameters, Adam moments and the
+    step number stay what they were, and the next good batch trains as if nothing had happened."""
     import copy
     import twotowermlretrieval_amd as tt
     V, E, H, B = 300, 300, 256, 32
@@ -340,32 +339,81 @@ def test_a_bad_batch_raises_and_leaves_the_weights_untouched():
     assert float(l1) == float(l2) and torch.equal(opt.flat_params, ref_opt.flat_params)
 
 
+def test_a_recurrence_time_out_redoes_the_step_on_the_one_workgroup_kernels():
+    """Status bit 2 (a column-split recurrence gave up waiting for a partner workgroup: CUs held by other work) is transient and
+    rank-local.  It reaches the optimizer like the data errors -- through the gate behind the gradients, so every rank sees it --
+    but train_step does not raise: the step is redone with TT_ENC_ONE_WORKGROUP (ordinary relaunch, nothing to wait for).  The
+    time-out cannot be provoked on an idle device, so it is injected: the first document-tower backward of the step ORs bit 2
+    into its status word, exactly where gru_bwd16x4p_kernel would.  The redone step equals, bit for bit, a step of a model whose
+    encoders run the one-workgroup recurrences from the start; the failed attempt left no trace (step number 1, not 2)."""
+    import copy
+    import twotowermlretrieval_amd as tt
+    from twotowermlretrieval_amd import _lib
+    V, E, H, B = 300, 300, 256, 48
+    torch.manual_seed(3)
+    m = tt.TwoTowerModel({"VOCAB_SIZE": V, "EMBED_DIM": E, "HIDDEN_DIM": H}, synth.make_table(4, V, E)).cuda().train()
+    ref = copy.deepcopy(m)
+    opt = tt.FusedClipAdam(m.parameters(), lr=1e-3, max_norm=1.0)
+    ref_opt = tt.FusedClipAdam(ref.parameters(), lr=1e-3, max_norm=1.0)
+    ids = [torch.from_numpy(synth.make_ids(70 + s, B, T, V)).cuda() for s, T in enumerate((7, 20, 25))]
+    calls = []
+    bwd0 = m.doc_encoder._run_backward
+
+    def flaky_backward(ids_, ws, d_out, *a, status=None, opts=None, **k):
+        calls.append(opts)
+        out = bwd0(ids_, ws, d_out, *a, status=status, opts=opts, **k)
+        if len(calls) == 1:
+            status.bitwise_or_(4)          # on the backward's stream, behind its kernels
+        return out
+    m.doc_encoder._run_backward = flaky_backward
+    for direct in (True, False):
+        calls.clear()
+        loss = tt.train_step(m, opt, *ids, margin=0.5, direct=direct)
+        torch.cuda.synchronize()
+        assert len(calls) == 2 and not (calls[0] & _lib.TT_ENC_ONE_WORKGROUP) and (calls[1] & _lib.TT_ENC_ONE_WORKGROUP)
+        for enc in (ref.query_encoder, ref.doc_encoder):
+            enc.one_workgroup = True
+        ref_loss = tt.train_step(ref, ref_opt, *ids, margin=0.5, direct=direct)
+        torch.cuda.synchronize()
+        assert float(loss) == float(ref_loss) and torch.equal(opt.flat_params, ref_opt.flat_params)
+        assert opt.step_count == ref_opt.step_count == (1 if direct else 2)
+        assert not m.doc_encoder.one_workgroup and not m.query_encoder.one_workgroup   # (the option was the step's, not the model's)
+    # a hand-written autograd loop gets the exception itself (nothing can redo somebody else's loop)
+    calls.clear()
+    opt.watch(m)
+    opt.zero_grad()
+    loss = tt.triplet_loss_cosine((m.encode_query(ids[0]), m.encode_document(ids[1]), m.encode_document(ids[2])), margin=0.5)
+    loss.backward()
+    with pytest.raises(tt.model.SplitRecurrenceTimeout):
+        opt.step()
+    assert opt.step_count == 2
+
+
 def test_weight_gradient_kernel_against_the_tiled_one():
     """wgrad16 (256-row output tiles, K-major LDS images, one K slab per workgroup) and the tiled f16-split GEMM it replaced
-    (TT_WGRAD_TILED=1) compute dW_ih / dW_hh from the same dGi / dGh with different slab partitions: they agree to the gradient
-    tolerance (both are fp32-grade; the oracle comparisons elsewhere pin each of them), everything else is the same bits."""
-    import os
+    (the comparison build with TT_WGRAD_TILED=1) compute dW_ih / dW_hh from the same dGi / dGh with different slab partitions: they
+    agree to the gradient tolerance (both are fp32-grade; the oracle comparisons elsewhere pin each of them), everything else is
+    the same bits."""
+    from conftest import ab_library
     V, E, H, B, T = 500, 300, 256, 512, 40
     torch.manual_seed(11)
     import twotowermlretrieval_amd as tt
     enc = tt.RNNEncoder(V, E, H, pretrained_embeddings=synth.make_table(4, V, E)).cuda().train()
     ids = torch.from_numpy(synth.make_ids(91, B, T, V)).cuda()
     d_out = torch.from_numpy(np.random.RandomState(5).standard_normal((B, H)).astype(np.float32)).cuda()
-    res = {}
-    for flag in ("0", "1"):
-        old = os.environ.get("TT_WGRAD_TILED")
-        os.environ["TT_WGRAD_TILED"] = flag
-        try:
-            enc.zero_grad()
-            y = enc(ids)
-            y.backward(d_out)
-            torch.cuda.synchronize()
-            res[flag] = {n: p.grad.clone() for n, p in enc.named_parameters() if p.grad is not None}
-        finally:
-            if old is None:
-                os.environ.pop("TT_WGRAD_TILED", None)
-            else:
-                os.environ["TT_WGRAD_TILED"] = old
+
+    def grads():
+        enc.zero_grad()
+        y = enc(ids)
+        y.backward(d_out)
+        torch.cuda.synchronize()
+        return {n: p.grad.clone() for n, p in enc.named_parameters() if p.grad is not None}
+    res = {"0": grads()}                      # the product library
+    with ab_library(TT_WGRAD_TILED=1):
+        res["1"] = grads()
+    with ab_library():                        # the comparison build with every switch at its default = the product's bits
+        same = grads()
+    assert all(torch.equal(res["0"][n], same[n]) for n in same)
     differ = 0
     for n in res["0"]:
         a, b = res["0"][n], res["1"][n]

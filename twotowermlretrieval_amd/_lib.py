@@ -9,6 +9,9 @@ _PKG = Path(__file__).resolve().parent
 LIB_PATH = _PKG / "libtt.so"
 
 TT_OK, TT_ERR_BAD_SHAPE, TT_ERR_BAD_INDEX, TT_ERR_ZERO_LENGTH, TT_ERR_UNSUPPORTED, TT_ERR_WORKSPACE, TT_ERR_HIP = range(7)
+TT_ENC_ONE_WORKGROUP = 0x100  # option bit of the encoder calls (include/tt.h)
+TT_STEP_GATE_WORDS = 4
+TT_TOPK_INVALID_INDEX = 1 << 62
 
 
 class TTError(RuntimeError):
@@ -33,7 +36,7 @@ SIGNATURES = {
     "tt_score_topk_screened_stats_offset": (_sz, [_i, _i64, _i, _i]),
     "tt_score_topk_screened_seed_f32": (_i, [_vp, _i, _i, _vp, _i64, _i, _i, _f, _vp, _vp, _vp, _sz, _vp]),
     "tt_score_topk_screened_seed_list_f32": (_i, [_vp, _i, _i, _vp, _i64, _i, _i, _f, _vp, _vp, _vp, _sz, _vp]),
-    "tt_seed_union_f32": (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    "tt_seed_union_f32": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "tt_score_topk_screened_seeded_f32": (_i, [_vp, _i, _i, _vp, _vp, _i64, _i, _f, _i64, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
     "tt_score_topk_screened_f32": (_i, [_vp, _i, _i, _vp, _vp, _i64, _i, _f, _i64, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
     "tt_event_create": (_i, [_vp]),
@@ -47,16 +50,17 @@ SIGNATURES = {
     "tt_tok_destroy": (None, [_vp]),
     "tt_tok_encode": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _i]),
     "tt_tok_pad": (_i, [_vp, _vp, _vp, _i64, _i64, _vp, _i]),
+    "tt_encoder_split_workgroups": (_i, [_i, _i, _i, _i]),
     "tt_encoder_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i, _i, _i]),
     "tt_encoder_forward_f32": (_i, [_vp, _i, _i, _vp, _i64, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _f, _u64, _vp, _vp,
                                     _sz, _vp, _vp]),
     "tt_concat_ids_i64": (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _i, _vp]),
     "tt_encoder_prepared_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "tt_encoder_prepare_f32": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
-    "tt_encoder_forward_prepared_f32": (_i, [_vp, _i, _i, _vp, _i64, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _sz,
-                                             _vp, _vp]),
+    "tt_encoder_forward_prepared_f32": (_i, [_vp, _i, _i, _vp, _i64, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp,
+                                             _sz, _vp, _vp]),
     "tt_encoder_backward_f32": (_i, [_vp, _i, _i, _vp, _i64, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _f, _u64, _vp, _vp,
-                                     _vp, _vp, _vp, _vp, _sz, _vp]),
+                                     _vp, _vp, _vp, _vp, _sz, _i, _vp, _vp]),
     "tt_triplet_loss_f32": (_i, [_vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
     "tt_allgather_topk": (_i, [_vp, _vp, _vp, _sz, _vp]),
     "tt_allreduce_grads": (_i, [_vp, _vp, _i64, _vp]),
@@ -67,6 +71,8 @@ SIGNATURES = {
     "tt_comm_destroy": (_i, [_vp]),
     "tt_clip_adam_scratch_bytes": (_sz, []),
     "tt_clip_adam_step_f32": (_i, [_vp, _vp, _vp, _vp, _i64, _i64, _f, _f, _f, _f, _f, _f, _vp, _vp, _vp]),
+    "tt_clip_adam_step_gated_f32": (_i, [_vp, _vp, _vp, _vp, _i64, _vp, _f, _f, _f, _f, _f, _f, _vp, _vp, _vp, _vp]),
+    "tt_step_gate_f32": (_i, [_vp, _i, _vp, _vp]),
 }
 
 _lib = None

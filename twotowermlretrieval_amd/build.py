@@ -78,5 +78,49 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     return LIB
 
 
+def build_variant(name: str, defs, force: bool = False) -> Path:
+    """A macro variant of the library, NEVER loaded by the package itself: <repo>/ab/libtt_<name>.so, objects under
+    ab/obj_<name>/.  Sources that mention one of the macros (all of them when a header does, or with no -D at all) are compiled
+    with `defs`; the rest come from the product build.  `ab` = -DTT_AB, the comparison build (csrc/tt_common.h: A/B switches
+    read from the environment at every call + the superseded kernels) that tests/ pin product kernels against; the mutation
+    guard and tools/experiments build theirs the same way (tools/build_variant.py)."""
+    import re
+    build()
+    root = PKG.parent
+    out = root / "ab" / f"libtt_{name}.so"
+    newest = max(p.stat().st_mtime for p in [*sources(), *_headers()])
+    if not force and out.exists() and out.stat().st_mtime > newest:
+        return out
+    macros = [re.sub(r"^-D", "", d).split("=")[0] for d in defs]
+    hdr_hit = any(any(m in h.read_text() for m in macros) for h in _headers())
+    objdir = root / "ab" / f"obj_{name}"
+    objdir.mkdir(parents=True, exist_ok=True)
+    flags = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
+    objs, procs = [], []
+    for src in sources():
+        if hdr_hit or not macros or any(m in src.read_text() for m in macros):
+            obj = objdir / (src.stem + ".o")
+            procs.append((src, subprocess.Popen([_hipcc(), *flags, *defs, "-c", str(src), "-o", str(obj)],
+                                                stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+        else:
+            obj = PKG / "build" / (src.stem + ".o")
+        objs.append(obj)
+    for src, p in procs:
+        o, _ = p.communicate()
+        if p.returncode:
+            raise RuntimeError(f"hipcc failed on {src.name} ({' '.join(defs)}):\n{o}")
+    r = subprocess.run([_hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", str(out), *map(str, objs), "-ldl"],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode:
+        raise RuntimeError(f"link failed:\n{r.stdout}")
+    return out
+
+
+def build_ab(force: bool = False) -> Path:
+    return build_variant("ab", ["-DTT_AB"], force)
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    if "--ab" in sys.argv:
+        print(build_ab(force="--force" in sys.argv))

@@ -48,9 +48,6 @@ struct EncLayout {
 // scale of dW_ih = dGi^T X.  (Other words: 0 error flags, 16.. max|W_hh| forward, 32.. backward, 40.. max|W_ih|, 48..63
 // max|dGi| / max|dGh|.)
 constexpr int ENC_FLAG_XMAX = 8;
-// Words 2..3 (8-byte aligned): the forward call's `status` pointer, left there by the training forward so that the backward
-// call -- which has no status argument of its own -- can raise bit 2 if its column-split recurrence gives up (gru16x4.hip).
-constexpr int ENC_FLAG_STATUS_PTR = 2;
 
 #ifndef TT_ENC_SPLITK
 #define TT_ENC_SPLITK 64
@@ -76,8 +73,8 @@ __host__ __device__ static inline float tt_dropout_scale(uint64_t seed, int laye
 // gru16_launch.  gru16x4_xch_bytes: hand-off scratch for B rows (0 when H != 256; host-only arithmetic, no GPU call).
 size_t gru16x4_xch_bytes(int B, int H, int ndir);
 size_t gru16x4_bwd_xch_bytes(int B, int H, int ndir);
-bool gru16x4_usable(int B, int H, int ndir); // this device has a CU for every member of every team (and TT_GRU_SPLIT != 0)
-bool gru16x4_bwd_usable(int B, int H, int ndir); // ... and TT_GRU_SPLIT_BWD != 0
+bool gru16x4_usable(int B, int H, int ndir); // this device has a CU for every member of every team of ONE launch
+bool gru16x4_bwd_usable(int B, int H, int ndir);
 
 static inline EncLayout enc_layout(int B, int T, int E, int H, int L, int bidir, int train, int dropout = 0,
                                    int cell = CELL_GRU)
@@ -259,4 +256,4 @@ int gru16_pack_t(const float *W_hh, int H, const unsigned *absmax, void *wtp16, 
 int gru16_bwd_launch(const GruBwdParams &bp, int ndir, hipStream_t st);
 int gru16x4_launch(const GruParams &gp, int ndir, void *xch, int32_t *status, hipStream_t st, bool xch_zeroed = false);
 // the reverse-time recurrence on four CUs per row group (reduction split; deterministic, not bit-identical to gru16_bwd_launch)
-int gru16x4_bwd_launch(const GruBwdParams &bp, int ndir, void *xch, int32_t *const *status_pp, hipStream_t st);
+int gru16x4_bwd_launch(const GruBwdParams &bp, int ndir, void *xch, int32_t *status, hipStream_t st);

@@ -234,8 +234,6 @@ __global__ __launch_bounds__(1024) void prep_fused_kernel(const int64_t *__restr
     if (tid == 0 && status)
         status[0] = st_bits;
     __syncthreads();
-    if (tid == 0) // the backward call finds this call's status word through the workspace (encoder.h: ENC_FLAG_STATUS_PTR)
-        *(int32_t **)(flag + ENC_FLAG_STATUS_PTR) = status;
     scan_sort_block(len, B, T, tok_off, perm);
     __syncthreads();
 #pragma unroll
@@ -255,8 +253,7 @@ __global__ __launch_bounds__(1024) void prep_fused_kernel(const int64_t *__restr
     }
 }
 
-// (last kernel of the four-kernel prep: block 0 also hands the status word to the caller and leaves the caller's status
-//  pointer in the flag block -- a device-to-device copy and a one-thread kernel before)
+// (last kernel of the four-kernel prep: block 0 also hands the status word to the caller -- a device-to-device copy before)
 __global__ __launch_bounds__(256) void prep_pack_ids_kernel(const int64_t *__restrict__ ids, int B, int T,
                                                             const int32_t *__restrict__ len,
                                                             const int32_t *__restrict__ tok_off, int64_t V,
@@ -265,11 +262,8 @@ __global__ __launch_bounds__(256) void prep_pack_ids_kernel(const int64_t *__res
 {
     const int b = blockIdx.x;
     const int L = len[b], o = tok_off[b];
-    if (b == 0 && threadIdx.x == 0) {
-        if (status)
-            status[0] = flag[0];
-        *(int32_t **)(flag + ENC_FLAG_STATUS_PTR) = status;
-    }
+    if (b == 0 && threadIdx.x == 0 && status)
+        status[0] = flag[0];
     for (int t = threadIdx.x; t < L; t += 256) {
         int64_t id = ids[(size_t)b * T + t];
         packed[o + t] = (int32_t)(id < 0 || id >= V ? 0 : id); // out-of-range ids are flagged, never dereferenced
@@ -546,20 +540,19 @@ TT_EXPORT size_t tt_encoder_workspace_bytes(int B, int T, int E, int H, int num_
 {
     if (B <= 0 || T <= 0 || num_layers < 1 || num_layers > ENC_MAX_LAYERS || rnn_type < 0 || rnn_type > 2)
         return 0;
-    return enc_layout(B, T, E, H, num_layers, bidirectional, train < 0 ? 0 : (train > 2 ? 2 : train), dropout, rnn_type).total;
+    train = train < 0 ? 0 : (train & TT_ENC_TRAIN_MASK); // (the option bits above the mask do not change the layout)
+    return enc_layout(B, T, E, H, num_layers, bidirectional, train > 2 ? 2 : train, dropout, rnn_type).total;
 }
 
 // H = 128 / 256: the recurrence runs on the f16 matrix pipes with both operands split into fp16 hi + lo parts
 // (gru16.hip; fp32-grade accuracy at 3/16 of the fp32 MFMA time).  TT_GRU_F32=1 keeps the fp32-MFMA kernels.
 static bool enc_force_f32()
 {
-    static const bool v = [] { const char *e = getenv("TT_GRU_F32"); return e && e[0] == '1'; }();
-    return v;
+    return TT_AB_SWITCH(TT_GRU_F32, 0) != 0;
 }
 static bool enc_tiled_k1() // A/B switch: the tiled f16 GEMM instead of the token-stationary one
 {
-    static const bool v = [] { const char *e = getenv("TT_K1_TILED"); return e && atoi(e) != 0; }();
-    return v;
+    return TT_AB_SWITCH(TT_K1_TILED, 0) != 0;
 }
 static bool enc_rows16(int NGH, int I) { return !enc_tiled_k1() && tt_gemm_rows16_supported(NGH, I, I, NGH); }
 
@@ -687,6 +680,10 @@ static int encoder_forward(const char *who, const int64_t *ids, int B, int T, co
     int rc = enc_check_shape(who, B, T, E, H, num_layers, V);
     if (rc != TT_OK)
         return rc;
+    if (train < 0 || (train & ~(TT_ENC_TRAIN_MASK | TT_ENC_ONE_WORKGROUP)) || (train & TT_ENC_TRAIN_MASK) > 2)
+        return tt_fail(TT_ERR_BAD_SHAPE, "%s: train=0x%x (0, 1 or 2, optionally | TT_ENC_ONE_WORKGROUP)", who, train);
+    const bool one_wg = (train & TT_ENC_ONE_WORKGROUP) != 0; // the caller keeps the recurrences off the column-split kernels
+    train &= TT_ENC_TRAIN_MASK;
     if (!ids || !table || !weights || !out || (bidirectional && (!proj_w || !proj_b)))
         return tt_fail(TT_ERR_BAD_SHAPE, "%s: null pointer", who);
     if (!(dropout_p >= 0.0f && dropout_p < 1.0f))
@@ -695,8 +692,7 @@ static int encoder_forward(const char *who, const int64_t *ids, int B, int T, co
         return tt_fail(TT_ERR_UNSUPPORTED, "%s: rnn_type=%d (0 GRU, 1 LSTM, 2 RNN)", who, rnn_type);
     const int NGH = enc_gates(rnn_type) * H;
     const bool drop = train && dropout_p > 0.0f && num_layers > 1;
-    const EncLayout lo = enc_layout(B, T, E, H, num_layers, bidirectional, train < 0 ? 0 : (train > 2 ? 2 : train), drop,
-                                    rnn_type);
+    const EncLayout lo = enc_layout(B, T, E, H, num_layers, bidirectional, train, drop, rnn_type);
     if (!workspace || workspace_bytes < lo.total || ((uintptr_t)workspace & 255))
         return tt_fail(TT_ERR_WORKSPACE, "%s: workspace %zu < %zu bytes (or not 256-B aligned)", who, workspace_bytes,
                        lo.total);
@@ -712,7 +708,7 @@ static int encoder_forward(const char *who, const int64_t *ids, int B, int T, co
     // the status flags (when the prep kernels do not clear them themselves), the all-zero row behind layer 0's output
     // (training) and the split recurrence's hand-off slots.
     const bool use16_early = rnn_type == CELL_GRU && gru16_supported(H) && !enc_force_f32();
-    const bool split0 = use16_early && lo.xch && gru16x4_usable(B, H, ndir);
+    const bool split0 = use16_early && lo.xch && !one_wg && gru16x4_usable(B, H, ndir);
     const bool fused_prep = B <= 1024 && (int64_t)B * T <= PREP_FUSED_MAX_IDS;
     {
         float *x1 = (num_layers == 1 && !train) ? nullptr : (float *)(ws + lo.x[1]);
@@ -836,7 +832,7 @@ static int encoder_forward(const char *who, const int64_t *ids, int B, int T, co
         }
         if (ndir == 1)
             gp.dir[1] = gp.dir[0];
-        if (use16 && lo.xch && gru16x4_usable(B, H, ndir)) {
+        if (use16 && lo.xch && !one_wg && gru16x4_usable(B, H, ndir)) {
             // a row group's gate columns on four CUs (gru16x4.hip): same bits out, ~half the time per step
             rc = gru16x4_launch(gp, ndir, ws + lo.xch, status, st, /*xch_zeroed=*/l == 0 && split0);
             if (rc != TT_OK)
@@ -895,6 +891,17 @@ static int encoder_forward(const char *who, const int64_t *ids, int B, int T, co
     return TT_OK;
 }
 
+// Workgroups (= CUs: one each) the column-split recurrence of a call of this shape occupies, 0 when the call runs the
+// one-workgroup kernels anyway.  For hosts that keep several encoder calls in flight (include/tt.h).
+TT_EXPORT int tt_encoder_split_workgroups(int B, int H, int bidirectional, int rnn_type)
+{
+    const int ndir = bidirectional ? 2 : 1;
+    if (rnn_type != CELL_GRU || !gru16_supported(H) || enc_force_f32() || gru16x4_xch_bytes(B, H, ndir) == 0 ||
+        !gru16x4_usable(B, H, ndir))
+        return 0;
+    return ((B + ENC_RB - 1) / ENC_RB + 7) / 8 * 32 * ndir;
+}
+
 TT_EXPORT int tt_encoder_forward_f32(const int64_t *ids, int B, int T, const float *table, int64_t V, int E, int H,
                                      int num_layers, int bidirectional, int rnn_type, const float *const *weights,
                                      const float *proj_w, const float *proj_b, int normalize, int train,
@@ -909,12 +916,14 @@ TT_EXPORT int tt_encoder_forward_f32(const int64_t *ids, int B, int T, const flo
 TT_EXPORT int tt_encoder_forward_prepared_f32(const int64_t *ids, int B, int T, const float *table, int64_t V, int E, int H,
                                               int num_layers, int bidirectional, int rnn_type,
                                               const float *const *weights, const void *prepared, const float *proj_w,
-                                              const float *proj_b, int normalize, float *out, void *workspace,
+                                              const float *proj_b, int normalize, int opts, float *out, void *workspace,
                                               size_t workspace_bytes, int32_t *status, tt_stream_t stream)
 {
     if (!prepared || ((uintptr_t)prepared & 255))
         return tt_fail(TT_ERR_WORKSPACE, "tt_encoder_forward_prepared_f32: prepared buffer null or not 256-B aligned");
+    if (opts & ~TT_ENC_ONE_WORKGROUP)
+        return tt_fail(TT_ERR_BAD_SHAPE, "tt_encoder_forward_prepared_f32: opts=0x%x (0 or TT_ENC_ONE_WORKGROUP)", opts);
     return encoder_forward("tt_encoder_forward_prepared_f32", ids, B, T, table, V, E, H, num_layers, bidirectional, rnn_type,
-                           weights, prepared, proj_w, proj_b, normalize, 0, 0.0f, 0, out, workspace, workspace_bytes, status,
-                           (hipStream_t)stream);
+                           weights, prepared, proj_w, proj_b, normalize, /*train=*/0 | opts, 0.0f, 0, out, workspace,
+                           workspace_bytes, status, (hipStream_t)stream);
 }

@@ -426,7 +426,7 @@ TT_EXPORT int tt_encoder_backward_f32(const int64_t *ids, int B, int T, const fl
                                       const float *proj_w, const float *proj_b, int normalize, float dropout_p,
                                       uint64_t dropout_seed, const float *d_out, float *const *grads,
                                       float *g_proj_w, float *g_proj_b, float *g_table, void *workspace,
-                                      size_t workspace_bytes, tt_stream_t stream)
+                                      size_t workspace_bytes, int opts, int32_t *status, tt_stream_t stream)
 {
     (void)ids;
     (void)proj_b;
@@ -434,6 +434,9 @@ TT_EXPORT int tt_encoder_backward_f32(const int64_t *ids, int B, int T, const fl
     int rc = enc_check_shape("tt_encoder_backward_f32", B, T, E, H, num_layers, V);
     if (rc != TT_OK)
         return rc;
+    if (opts & ~TT_ENC_ONE_WORKGROUP)
+        return tt_fail(TT_ERR_BAD_SHAPE, "tt_encoder_backward_f32: opts=0x%x (0 or TT_ENC_ONE_WORKGROUP)", opts);
+    const bool one_wg = (opts & TT_ENC_ONE_WORKGROUP) != 0;
     if (!table || !weights || !d_out || !grads || (bidirectional && (!proj_w || !g_proj_w || !g_proj_b)))
         return tt_fail(TT_ERR_BAD_SHAPE, "tt_encoder_backward_f32: null pointer");
     if (rnn_type < CELL_GRU || rnn_type > CELL_RNN)
@@ -523,7 +526,7 @@ TT_EXPORT int tt_encoder_backward_f32(const int64_t *ids, int B, int T, const fl
     // (the "previous token" maps were made by the training forward's prep: csrc/encoder.hip)
 
     const size_t lds = sizeof(float) * ENC_RB * (H3 + 4);
-    static const bool force_f32 = [] { const char *e = getenv("TT_GRU_F32"); return e && e[0] == '1'; }();
+    const bool force_f32 = TT_AB_SWITCH(TT_GRU_F32, 0) != 0;
     const bool use16 = rnn_type == CELL_GRU && gru16_supported(H) && !force_f32; // (gru16.hip)
     const int n_rowgroups = (B + ENC_RB - 1) / ENC_RB;
     // the recurrence kernel's bias partial sums live in the split-K scratch (free while it runs): they must fit
@@ -574,10 +577,9 @@ TT_EXPORT int tt_encoder_backward_f32(const int64_t *ids, int B, int T, const fl
         }
         if (ndir == 1)
             bp.dir[1] = bp.dir[0];
-        if (use16 && fused_bias && lo.xchb && gru16x4_bwd_usable(B, H, ndir)) {
-            // a row group's reduction over the gate columns on four CUs (gru16x4.hip); the forward call left its status
-            // pointer in the flag block
-            rc = gru16x4_bwd_launch(bp, ndir, ws + lo.xchb, (int32_t *const *)((int32_t *)(ws + lo.flag) + ENC_FLAG_STATUS_PTR), st);
+        if (use16 && fused_bias && lo.xchb && !one_wg && gru16x4_bwd_usable(B, H, ndir)) {
+            // a row group's reduction over the gate columns on four CUs (gru16x4.hip); a time-out ORs bit 2 into `status`
+            rc = gru16x4_bwd_launch(bp, ndir, ws + lo.xchb, status, st);
         } else if (use16) {
             rc = gru16_bwd_launch(bp, ndir, st);
         } else {

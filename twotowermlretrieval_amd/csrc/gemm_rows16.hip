@@ -321,8 +321,7 @@ int launch_rows16(const SgemmParams &p, hipStream_t st)
         }
         return (WIDE ? 1 : 2) * cus;
     }();
-    const char *e = getenv("TT_ROWS_SPLIT"); // (read at every call, so that one process can compare the two forms)
-    const int slots = (e && e[0] == '0') ? 0 : resident;
+    const int slots = TT_AB_SWITCH(TT_ROWS_SPLIT, 1) ? resident : 0; // (tt_common.h: a constant in the product build)
     // (a split tail has at most slots / RS_SPLIT token blocks, each RS_SPLIT workgroups: (RS_SPLIT - 1) slots / RS_SPLIT extra)
     const unsigned blocks = (unsigned)((p.M + RS_ROWS - 1) / RS_ROWS) + (unsigned)(slots - slots / RS_SPLIT);
     hipLaunchKernelGGL((gemm_rows16_kernel<NKS, WIDE>), dim3(blocks), dim3(C::WAVES * 64), C::LDS, st, p, slots);

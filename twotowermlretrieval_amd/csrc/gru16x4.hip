@@ -120,6 +120,7 @@ struct GruSplitParams {
     unsigned spin_max; // sweeps a wave makes for one step's granules before it gives up
 };
 
+#ifdef TT_AB // the four-wave member: superseded by gru_seq16x4p_kernel, kept in the comparison build as its bit-identity reference
 __global__ __launch_bounds__(256, 1) void gru_seq16x4_kernel(GruSplitParams sp)
 {
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -368,6 +369,7 @@ __global__ __launch_bounds__(256, 1) void gru_seq16x4_kernel(GruSplitParams sp)
         if (rid_e[e] >= 0)
             d.h_final[(size_t)rid_e[e] * H + unit] = hreg[e];
 }
+#endif // TT_AB
 
 // ------------------------------------------------------------------ the forward recurrence with TWO waves per SIMD
 // (see gru_bwd16x4p_kernel below for why: a lone wave issues one instruction per ~8.7 clocks, and the step is its instruction
@@ -690,11 +692,12 @@ constexpr size_t XB_TEAM_BYTES = 2 * 4 * 4 * (size_t)XB_REGION; // [parity][dest
 struct GruSplitBwdParams {
     GruBwdParams g;
     char *xch;                  // [dir][team] x XB_TEAM_BYTES, zeroed before the launch
-    int32_t *const *status_pp;  // device word holding the forward call's status pointer (may hold null): bit 2 on a time-out
+    int32_t *status;            // nullable: the backward call's own status word, bit 2 (value 4) on a time-out
     int nteams;
     unsigned spin_max;
 };
 
+#ifdef TT_AB // the four-wave member: superseded by gru_bwd16x4p_kernel, kept in the comparison build as its bit-identity reference
 __global__ __launch_bounds__(256, 1) void gru_bwd16x4_kernel(GruSplitBwdParams sp)
 {
     // One wave per SIMD: every instruction of the step is on the critical path (nothing else issues while it does), so the
@@ -770,7 +773,7 @@ __global__ __launch_bounds__(256, 1) void gru_bwd16x4_kernel(GruSplitBwdParams s
     if (same_xcd < 0) {
         if (tid == 0) {
             abort_flag = 1; // (poisons the bias sums below)
-            int32_t *stw = sp.status_pp ? *sp.status_pp : nullptr;
+            int32_t *stw = sp.status;
             if (stw)
                 atomicOr(stw, 4);
         }
@@ -947,7 +950,7 @@ __global__ __launch_bounds__(256, 1) void gru_bwd16x4_kernel(GruSplitBwdParams s
                 if (++spins > sp.spin_max) {
                     if (lane == 0) {
                         abort_flag = 1;
-                        int32_t *stw = sp.status_pp ? *sp.status_pp : nullptr; // the forward call's status word, if it had one
+                        int32_t *stw = sp.status;
                         if (stw)
                             atomicOr(stw, 4);
                     }
@@ -1029,6 +1032,7 @@ __global__ __launch_bounds__(256, 1) void gru_bwd16x4_kernel(GruSplitBwdParams s
         }
     }
 }
+#endif // TT_AB
 
 // ------------------------------------------------------------------ the same recurrence with TWO waves per SIMD
 // A lone wave issues one instruction every ~8.7 clocks whatever its kind; two waves on a SIMD each do (tools/experiments/
@@ -1134,7 +1138,7 @@ __global__ __launch_bounds__(512, 1) void gru_bwd16x4p_kernel(GruSplitBwdParams 
     if (same_xcd < 0) {
         if (tid == 0) {
             abort_flag = 1; // (poisons the bias sums below)
-            int32_t *stw = sp.status_pp ? *sp.status_pp : nullptr;
+            int32_t *stw = sp.status;
             if (stw)
                 atomicOr(stw, 4);
         }
@@ -1324,7 +1328,7 @@ __global__ __launch_bounds__(512, 1) void gru_bwd16x4p_kernel(GruSplitBwdParams 
                 if (++spins > sp.spin_max) {
                     if (lane == 0) {
                         abort_flag = 1;
-                        int32_t *stw = sp.status_pp ? *sp.status_pp : nullptr; // the forward call's status word, if it had one
+                        int32_t *stw = sp.status;
                         if (stw)
                             atomicOr(stw, 4);
                     }
@@ -1438,13 +1442,10 @@ int device_cus()
 
 } // namespace
 
-// TT_GRU_SPLIT=0 keeps every recurrence on gru_seq16_kernel (A/B, and the reference point of the bit-identity tests)
-// (read at every call, so that one process can compare the two kernels)
-static bool split_enabled()
-{
-    const char *e = getenv("TT_GRU_SPLIT");
-    return !(e && e[0] == '0');
-}
+// The caller chooses between these kernels and the one-workgroup recurrences per call (TT_ENC_ONE_WORKGROUP, include/tt.h); the
+// comparison build (-DTT_AB) can also switch them off from the environment (TT_GRU_SPLIT=0 / TT_GRU_SPLIT_BWD=0) and select
+// the four-wave members (=4).
+static bool split_enabled() { return TT_AB_SWITCH(TT_GRU_SPLIT, 1) != 0; }
 
 size_t gru16x4_xch_bytes(int B, int H, int ndir)
 {
@@ -1470,26 +1471,25 @@ size_t gru16x4_bwd_xch_bytes(int B, int H, int ndir)
     return (size_t)ndir * ((B + ENC_RB - 1) / ENC_RB) * (XB_TEAM_BYTES + X4_HEADER);
 }
 
-// TT_GRU_SPLIT_BWD=0 keeps the backward recurrence on gru_bwd16_kernel while the forward one is split (A/B; the tests that
-// pin the split forward's stash bit for bit against the one-CU kernel's)
 bool gru16x4_bwd_usable(int B, int H, int ndir)
 {
-    const char *e = getenv("TT_GRU_SPLIT_BWD");
-    return !(e && e[0] == '0') && gru16x4_usable(B, H, ndir);
+    return TT_AB_SWITCH(TT_GRU_SPLIT_BWD, 1) != 0 && gru16x4_usable(B, H, ndir);
 }
 
-int gru16x4_bwd_launch(const GruBwdParams &bp, int ndir, void *xch, int32_t *const *status_pp, hipStream_t st)
+int gru16x4_bwd_launch(const GruBwdParams &bp, int ndir, void *xch, int32_t *status, hipStream_t st)
 {
     GruSplitBwdParams sp;
     sp.g = bp;
     sp.xch = (char *)xch;
-    sp.status_pp = status_pp;
+    sp.status = status;
     sp.nteams = (bp.B + ENC_RB - 1) / ENC_RB;
     sp.spin_max = 1u << 17;
     TT_RC_CHECK(tt_zero_async(xch, gru16x4_bwd_xch_bytes(bp.B, bp.H, ndir), st));
     static bool attr_done = false;
     if (!attr_done) {
+#ifdef TT_AB
         TT_HIP_CHECK(hipFuncSetAttribute((const void *)gru_bwd16x4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, XB_LDS + 16));
+#endif
         TT_HIP_CHECK(hipFuncSetAttribute((const void *)gru_bwd16x4p_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, XP_LDS + 16));
         attr_done = true;
     }
@@ -1506,10 +1506,11 @@ int gru16x4_bwd_launch(const GruBwdParams &bp, int ndir, void *xch, int32_t *con
             }
     }
 #endif
-    const char *e = getenv("TT_GRU_SPLIT_BWD"); // "4": the four-wave member (A/B)
-    if (e && e[0] == '4')
+#ifdef TT_AB
+    if (TT_AB_SWITCH(TT_GRU_SPLIT_BWD, 1) == 4) // the four-wave member
         hipLaunchKernelGGL(gru_bwd16x4_kernel, dim3((sp.nteams + 7) / 8 * 32, ndir), dim3(256), XB_LDS + 16, st, sp);
     else
+#endif
         hipLaunchKernelGGL(gru_bwd16x4p_kernel, dim3((sp.nteams + 7) / 8 * 32, ndir), dim3(512), XP_LDS + 16, st, sp);
     TT_LAUNCH_CHECK();
     return TT_OK;
@@ -1527,7 +1528,9 @@ int gru16x4_launch(const GruParams &gp, int ndir, void *xch, int32_t *status, hi
         TT_RC_CHECK(tt_zero_async(xch, gru16x4_xch_bytes(gp.B, gp.H, ndir), st));
     static bool attr_done = false;
     if (!attr_done) {
+#ifdef TT_AB
         TT_HIP_CHECK(hipFuncSetAttribute((const void *)gru_seq16x4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, X4_LDS + 16));
+#endif
         TT_HIP_CHECK(hipFuncSetAttribute((const void *)gru_seq16x4p_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, XF_LDS + 16));
         attr_done = true;
     }
@@ -1542,10 +1545,11 @@ int gru16x4_launch(const GruParams &gp, int ndir, void *xch, int32_t *status, hi
                         (double)h[8 * k + 3] / h[8 * k + 6], (double)h[8 * k + 4] / h[8 * k + 6], (double)h[8 * k + 5] / h[8 * k + 6]);
     }
 #endif
-    const char *e = getenv("TT_GRU_SPLIT"); // "4": the four-wave member (A/B)
-    if (e && e[0] == '4')
+#ifdef TT_AB
+    if (TT_AB_SWITCH(TT_GRU_SPLIT, 1) == 4) // the four-wave member
         hipLaunchKernelGGL(gru_seq16x4_kernel, dim3((sp.nteams + 7) / 8 * 32, ndir), dim3(256), X4_LDS + 16, st, sp);
     else
+#endif
         hipLaunchKernelGGL(gru_seq16x4p_kernel, dim3((sp.nteams + 7) / 8 * 32, ndir), dim3(512), XF_LDS + 16, st, sp);
     TT_LAUNCH_CHECK();
     return TT_OK;

@@ -42,6 +42,8 @@ constexpr int WPB = 4;               // waves per block
 constexpr int DMA_PER_SLAB = 4;      // global_load_lds_dwordx4 per slab per wave
 constexpr int PACE_R = 16;            // pacing counter slots per chunk (> pace_lag + 1)
 constexpr int PACE_POLLS = 400;       // bound of one wait (~0.3 us per poll)
+constexpr int DRAW_POLLS = 1 << 16;   // bound of the wait for a chunk-mate's pool draw (s_sleep 2 = 128 clocks per poll: ~4 ms)
+constexpr int DRAW_GAVE_UP = 0x7fffffff;
 
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void gbl_void;
@@ -266,6 +268,7 @@ __global__ __launch_bounds__(WPB * 64, 2) void score_topk_kernel(ScoreParams p)
     int gb = 0;                   // blocks of pace_g tiles this wave has finished
     int in_blk = 0;               // tiles of the current block done
     int seg = 0;                  // pool blocks this wave has taken
+    bool gave_up = false;         // a shared pool draw timed out (wave-uniform)
     auto pace_gate = [&](int b) { // all n_qtiles waves of the chunk have finished their block b?
         const int need = p.n_qtiles * (b / PACE_R + 1);
         const int *slot = pace + (b % PACE_R);
@@ -420,17 +423,21 @@ __global__ __launch_bounds__(WPB * 64, 2) void score_topk_kernel(ScoreParams p)
                     v = expected;
                 }
             }
-            while (v < 0) { // the drawing wave is between its two atomics: it waits for nobody
+            // the drawing wave is between its two atomics (it waits for nobody: ~2 us).  Bounded like every other cross-wave
+            // wait of the library: DRAW_POLLS sleeps (~4 ms) and the wave gives up -- its partial lists then say so (below)
+            for (int polls = 0; v < 0 && polls < DRAW_POLLS; ++polls) {
                 __builtin_amdgcn_s_sleep(2);
                 v = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            blk = v - 1;
+            blk = v < 0 ? DRAW_GAVE_UP : v - 1;
         }
         ++seg;
     } else if (lane == 0) {
         blk = atomicAdd(p.tail_ctr + qtile, 1);
     }
     blk = __builtin_amdgcn_readfirstlane(blk);
+    if (blk == DRAW_GAVE_UP)
+        gave_up = true;
     if (blk >= p.tail_blocks)
         break;
     t0 = p.static_tiles + blk * p.tail_g;
@@ -469,8 +476,10 @@ __global__ __launch_bounds__(WPB * 64, 2) void score_topk_kernel(ScoreParams p)
         c.x = -1;
         if (t < n)
             c = cand_load_l2(p.cand + ((size_t)task * 32 + q) * CAP + t);
-        p.pval[o] = c.v;
-        p.pidx[o] = t < n ? p.idx_offset + c.x : -1;
+        // a wave that gave up a pool draw has not seen every document: its lists carry (+inf, TT_TOPK_INVALID_INDEX + t),
+        // which the merge ranks first -- the results for these queries are visibly invalid instead of silently short
+        p.pval[o] = gave_up ? INFINITY : c.v;
+        p.pidx[o] = gave_up ? (int64_t)TT_TOPK_INVALID_INDEX + t : (t < n ? p.idx_offset + c.x : -1);
     }
 }
 
@@ -1101,8 +1110,7 @@ int device_cus()
 
 bool tt_score_pacing() // TT_SCORE_PACE=0: every wave for itself (measurement)
 {
-    static const bool on = [] { const char *e = getenv("TT_SCORE_PACE"); return !e || atoi(e) != 0; }();
-    return on;
+    return TT_AB_SWITCH(TT_SCORE_PACE, 1) != 0;
 }
 
 Pass make_pass(int B, int64_t N, int slots, int qt, bool tail = false)
@@ -1125,7 +1133,7 @@ Pass make_pass(int B, int64_t N, int slots, int qt, bool tail = false)
     if (tail) {
         // pool = the last 1/TT_SCORE_TAIL_DIV of every chunk's share (0: everything static) in blocks of a quarter of it,
         // 4..64 tiles (a block costs one refill of the wave's ring, ~2 us)
-        static const int tail_div = [] { const char *e = getenv("TT_SCORE_TAIL_DIV"); return e ? atoi(e) : 8; }();
+        const int tail_div = TT_AB_SWITCH(TT_SCORE_TAIL_DIV, 8);
         const int share = tail_div > 0 ? ps.tiles_per_chunk / tail_div : 0;
         if (share >= 8) {
             const int own = ps.tiles_per_chunk - share;
@@ -1189,8 +1197,8 @@ Plan make_plan(int B, int64_t N, int k, int d)
     {
         // the chunks of one XCD (an eighth of them) share its 4 MiB L2: a chunk's waves must stay within its part of
         // ~3 MiB of each other, i.e. (pace_lag + 1) * pace_g tiles
-        static const int env_g = [] { const char *e = getenv("TT_SCORE_PACE_G"); return e ? atoi(e) : 0; }();
-        static const int env_lag = [] { const char *e = getenv("TT_SCORE_PACE_LAG"); return e ? atoi(e) : 0; }();
+        const int env_g = TT_AB_SWITCH(TT_SCORE_PACE_G, 0);
+        const int env_lag = TT_AB_SWITCH(TT_SCORE_PACE_LAG, 0);
         const int64_t per_xcd = (pl.main.n_chunks + 7) / 8;
         const int64_t window = (3 << 20) / (per_xcd * TILE_DOCS * d * 4); // tiles
         pl.pace_lag = env_lag > 0 ? env_lag : 2;
@@ -1498,11 +1506,13 @@ int tt_k_largest_list(const float *vals, int B, int M, int k, float *list, hipSt
 
 namespace {
 // Union seed of a row-sharded search: lists [world][B][ks] (every shard's ks largest sample maxima per query, as the
-// all-gather left them) -> seed[q] = the ks-th largest of the world * ks values of query q.  Those are approximate scores
-// of world * ks DISTINCT documents (one per 32-document sample tile, the shards' rows are disjoint), so ks documents of the
-// whole corpus score at least seed[q]: a valid lower bound of the global ks-th best approximate score A_ks, and a much
-// tighter one than any single shard's ks-th sample maximum.  One wave per query, rank by counting (world * ks <= 512).
-__global__ __launch_bounds__(64) void seed_union_kernel(const float *__restrict__ lists, int world, int B, int ks,
+// all-gather left them) -> seed[q] = the kth-th largest of the world * ks values of query q.  Those are approximate scores
+// of world * ks DISTINCT documents (one per 32-document sample tile, the shards' rows are disjoint), so kth documents of the
+// whole corpus score at least seed[q]: a valid lower bound of the global kth-th best approximate score, and a much
+// tighter one than any single shard's kth-th sample maximum.  (ks < kth on wide jobs: 16 ranks x k = 64 would be 1024 values;
+// every rank then lists its 32 largest and the 64th of the 512 is taken -- still 64 distinct documents above the seed.)
+// One wave per query, rank by counting (world * ks <= 512).
+__global__ __launch_bounds__(64) void seed_union_kernel(const float *__restrict__ lists, int world, int B, int ks, int kth,
                                                         float *__restrict__ seed)
 {
     const int q = blockIdx.x, lane = threadIdx.x;
@@ -1516,17 +1526,19 @@ __global__ __launch_bounds__(64) void seed_union_kernel(const float *__restrict_
         int before = 0; // entries ranking before entry i in (value desc, position asc) order
         for (int j = 0; j < M; ++j)
             before += (v[j] > x) || (v[j] == x && j < i);
-        if (before == ks - 1)
+        if (before == kth - 1)
             seed[q] = x; // exactly one entry has this rank (NaNs do not occur: the lists hold MFMA sums of finite inputs)
     }
 }
 } // namespace
 
-TT_EXPORT int tt_seed_union_f32(const float *lists, int world, int B, int k_seed, float *seed, tt_stream_t stream)
+TT_EXPORT int tt_seed_union_f32(const float *lists, int world, int B, int list_len, int kth, float *seed, tt_stream_t stream)
 {
-    if (!lists || !seed || world < 1 || B <= 0 || k_seed < 1 || (int64_t)world * k_seed > 512)
-        return tt_fail(TT_ERR_BAD_SHAPE, "tt_seed_union_f32: world=%d B=%d k_seed=%d (world * k_seed <= 512)", world, B, k_seed);
-    hipLaunchKernelGGL(seed_union_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, lists, world, B, k_seed, seed);
+    if (!lists || !seed || world < 1 || B <= 0 || list_len < 1 || (int64_t)world * list_len > 512 || kth < 1 ||
+        kth > world * list_len)
+        return tt_fail(TT_ERR_BAD_SHAPE, "tt_seed_union_f32: world=%d B=%d list_len=%d kth=%d (kth <= world * list_len <= 512)",
+                       world, B, list_len, kth);
+    hipLaunchKernelGGL(seed_union_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, lists, world, B, list_len, kth, seed);
     TT_LAUNCH_CHECK();
     return TT_OK;
 }

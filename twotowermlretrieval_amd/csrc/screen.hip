@@ -1198,7 +1198,7 @@ SPlan make_splan(int B, int64_t N, int k)
     {
         // pool = the last 1/TT_SCREEN_TAIL_DIV of every chunk's share (0: everything static), in blocks of a quarter of
         // that share, 8..32 tiles; only worth it when a share is long enough for several blocks
-        static const int tail_div = [] { const char *e = getenv("TT_SCREEN_TAIL_DIV"); return e ? atoi(e) : 8; }();
+        const int tail_div = TT_AB_SWITCH(TT_SCREEN_TAIL_DIV, 8);
         const int share = tail_div > 0 ? pl.tiles_per_chunk / tail_div : 0;
         if (!pl.stream && share >= 16) {
             const int own = pl.tiles_per_chunk - share;

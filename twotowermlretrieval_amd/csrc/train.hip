@@ -82,11 +82,21 @@ __global__ __launch_bounds__(1024) void sum_fixed_kernel(const float *__restrict
 // ------------------------------------------------------------------ K8
 constexpr int ADAM_BLOCKS = 512;
 
-// pass 1: per-block partial sum of (g*grad_scale)^2 in fp64 -> partial[ADAM_BLOCKS]
+// The step is applied iff every word of the (all-reduced) gate is zero; a NaN closes it too.
+__device__ __forceinline__ bool gate_open(const float *gate)
+{
+    return !gate || (gate[0] == 0.0f && gate[1] == 0.0f && gate[2] == 0.0f && gate[3] == 0.0f);
+}
+
+// pass 1: per-block partial sum of (g*grad_scale)^2 in fp64 -> partial[ADAM_BLOCKS]; the gated form also counts the step
+// (one thread; pass 2 of this step starts after every block of this launch, pass 2 of the previous step ended before it)
 __global__ __launch_bounds__(256) void sqnorm_partial_kernel(const float *__restrict__ g, int64_t n, float grad_scale,
-                                                             double *__restrict__ partial)
+                                                             double *__restrict__ partial, int64_t *step_counter,
+                                                             const float *gate)
 {
     __shared__ double red[4];
+    if (step_counter && blockIdx.x == 0 && threadIdx.x == 0 && gate_open(gate))
+        *step_counter += 1;
     double s = 0.0;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         const double v = (double)(g[i] * grad_scale);
@@ -111,9 +121,12 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(float *__restrict__ p, f
                                                         float grad_scale, float max_norm, float lr, float b1,
                                                         float b2, float eps, float bc1, float bc2_sqrt,
                                                         const double *__restrict__ partial, int npartial,
-                                                        float *__restrict__ total_norm_out)
+                                                        float *__restrict__ total_norm_out,
+                                                        const int64_t *__restrict__ step_counter,
+                                                        const float *__restrict__ gate)
 {
-    __shared__ float s_coef;
+    __shared__ float s_coef, s_bc1, s_bc2_sqrt;
+    __shared__ int s_open;
     __shared__ double s_red[4];
     {
         // every block sums the partials in the SAME fixed order (thread t: t, t + 256, ...; xor tree; the four waves in
@@ -139,8 +152,20 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(float *__restrict__ p, f
         s_coef = coef * grad_scale;
         if (blockIdx.x == 0 && total_norm_out)
             *total_norm_out = total;
+        s_open = gate_open(gate) ? 1 : 0;
+        if (step_counter) { // the gated form: step number from the device counter (already counted by pass 1)
+            const double t = (double)*step_counter;
+            bc1 = (float)(1.0 - pow((double)b1, t));
+            bc2_sqrt = (float)sqrt(1.0 - pow((double)b2, t));
+        }
+        s_bc1 = bc1;
+        s_bc2_sqrt = bc2_sqrt;
     }
     __syncthreads();
+    if (!s_open) // some rank's batch was bad (or its recurrence gave up): no rank applies this step
+        return;
+    bc1 = s_bc1;
+    bc2_sqrt = s_bc2_sqrt;
     const float coef = s_coef;
     const float step_size = lr / bc1;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
@@ -190,12 +215,64 @@ TT_EXPORT int tt_clip_adam_step_f32(float *params, float *grads, float *exp_avg,
     blocks = blocks > ADAM_BLOCKS ? ADAM_BLOCKS : blocks;
     double *partial = (double *)scratch;
     hipLaunchKernelGGL(sqnorm_partial_kernel, dim3(blocks), dim3(256), 0, st, (const float *)grads, n, grad_scale,
-                       partial);
-    const float bc1 = 1.0f - powf(beta1, (float)step);
-    const float bc2_sqrt = sqrtf(1.0f - powf(beta2, (float)step));
+                       partial, (int64_t *)nullptr, (const float *)nullptr);
+    // (in double, as torch.optim.Adam computes them on the host; the gated form does the same on the device)
+    const float bc1 = (float)(1.0 - pow((double)beta1, (double)step));
+    const float bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)step));
     hipLaunchKernelGGL(clip_adam_kernel, dim3(blocks), dim3(256), 0, st, params, grads, exp_avg, exp_avg_sq, n,
                        grad_scale, max_norm, lr, beta1, beta2, eps, bc1, bc2_sqrt, (const double *)partial, blocks,
-                       total_norm_out);
+                       total_norm_out, (const int64_t *)nullptr, (const float *)nullptr);
+    TT_LAUNCH_CHECK();
+    return TT_OK;
+}
+
+TT_EXPORT int tt_clip_adam_step_gated_f32(float *params, float *grads, float *exp_avg, float *exp_avg_sq, int64_t n,
+                                          int64_t *step_counter, float lr, float beta1, float beta2, float eps,
+                                          float max_norm, float grad_scale, float *total_norm_out, const float *gate,
+                                          void *scratch, tt_stream_t stream)
+{
+    if (n < 0)
+        return tt_fail(TT_ERR_BAD_SHAPE, "tt_clip_adam_step_gated_f32: n=%lld", (long long)n);
+    if (n == 0)
+        return TT_OK;
+    if (!params || !grads || !exp_avg || !exp_avg_sq || !scratch || !step_counter)
+        return tt_fail(TT_ERR_BAD_SHAPE, "tt_clip_adam_step_gated_f32: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    int blocks = (int)((n + 255) / 256);
+    blocks = blocks > ADAM_BLOCKS ? ADAM_BLOCKS : blocks;
+    double *partial = (double *)scratch;
+    hipLaunchKernelGGL(sqnorm_partial_kernel, dim3(blocks), dim3(256), 0, st, (const float *)grads, n, grad_scale,
+                       partial, step_counter, gate);
+    hipLaunchKernelGGL(clip_adam_kernel, dim3(blocks), dim3(256), 0, st, params, grads, exp_avg, exp_avg_sq, n,
+                       grad_scale, max_norm, lr, beta1, beta2, eps, 1.0f, 1.0f, (const double *)partial, blocks,
+                       total_norm_out, (const int64_t *)step_counter, gate);
+    TT_LAUNCH_CHECK();
+    return TT_OK;
+}
+
+namespace {
+struct GateWords {
+    const int32_t *w[8];
+};
+__global__ void step_gate_kernel(GateWords g, int n, float *gate)
+{
+    const int b = threadIdx.x; // 0 .. TT_STEP_GATE_WORDS - 1
+    int count = 0;
+    for (int i = 0; i < n; ++i)
+        if (g.w[i] && b < 3 && ((*g.w[i] >> b) & 1))
+            ++count;
+    gate[b] = (float)count;
+}
+} // namespace
+
+TT_EXPORT int tt_step_gate_f32(const int32_t *const *status_words, int n_status, float *gate, tt_stream_t stream)
+{
+    if (n_status < 0 || n_status > 8 || !gate || (n_status && !status_words))
+        return tt_fail(TT_ERR_BAD_SHAPE, "tt_step_gate_f32: n_status=%d (0..8), gate=%p", n_status, (void *)gate);
+    GateWords g = {};
+    for (int i = 0; i < n_status; ++i)
+        g.w[i] = status_words[i];
+    hipLaunchKernelGGL(step_gate_kernel, dim3(1), dim3(TT_STEP_GATE_WORDS), 0, (hipStream_t)stream, g, n_status, gate);
     TT_LAUNCH_CHECK();
     return TT_OK;
 }

@@ -45,9 +45,26 @@ int tt_zero3_async(void *p0, size_t b0, void *p1, size_t b1, void *p2, size_t b2
 // kernels whose `lo` products (hi*lo and lo*hi) are compiled out, which turns "fp32-grade" into plain fp16 (2^-11 per
 // product).  The parity tests' tolerances must be tight enough to FAIL on every one of them.
 //   1 = K2 gru_seq16 (forward recurrence)   2 = K7 gru_bwd16 (backward recurrence)
-//   4 = K1 gemm_rows16 (input projection)   8 = sgemm16 (weight gradients, input gradients, tiled K1)
+//   4 = K1 gemm_rows16 (input projection)   8 = sgemm16 (input gradients, tiled K1, tiled weight gradients)
+//  16 = wgrad16 (the weight gradients dW_ih / dW_hh of the training step)
 #ifndef TT_MUTATE_DROP_LO
 #define TT_MUTATE_DROP_LO 0
+#endif
+
+// A/B SWITCHES.  The product library reads NO environment variable on any call path: every switch below is the compile-time
+// constant `dflt` there.  A comparison build (-DTT_AB: tools/build_variant.py ab -> ab/libtt_ab.so, loaded by the tests that
+// pin a product kernel against the kernel it replaced, and by tools/experiments) reads the variable of the same name at EVERY
+// call, so that one process can run both forms; the superseded kernels themselves are compiled only into that build.
+#ifdef TT_AB
+#include <stdlib.h>
+static inline int tt_ab_env(const char *name, int dflt)
+{
+    const char *e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+#define TT_AB_SWITCH(name, dflt) tt_ab_env(#name, (dflt))
+#else
+#define TT_AB_SWITCH(name, dflt) (dflt)
 #endif
 
 #define TT_WAVE 64

@@ -11,7 +11,7 @@ int tt_fail(int code, const char *fmt, ...)
     return code;
 }
 
-TT_EXPORT const char *tt_version(void) { return "tt 0.1.0 (gfx950)"; }
+TT_EXPORT const char *tt_version(void) { return "tt 0.2.0 (gfx950)"; }
 TT_EXPORT const char *tt_last_error(void) { return g_err; }
 
 // Thin hipEvent wrappers so a host without HIP headers (the Python shim, bench.py) can time a single

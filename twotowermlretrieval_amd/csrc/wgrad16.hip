@@ -237,7 +237,7 @@ __global__ __launch_bounds__(512, 1) void wgrad16_kernel(SgemmParams p, int n_nt
             }
 #pragma unroll
             for (int sub = 0; sub < 3; ++sub) {
-#if TT_MUTATE_DROP_LO & 8
+#if TT_MUTATE_DROP_LO & 16
                 if (sub == 0)
 #endif
 #pragma unroll
@@ -316,10 +316,9 @@ __global__ __launch_bounds__(512, 1) void wgrad16_kernel(SgemmParams p, int n_nt
         }
 }
 
-bool wgrad_tiled() // (read at every call, so that one process can compare the two kernels)
+bool wgrad_tiled() // (tt_common.h: false in the product build; the comparison build reads it at every call)
 {
-    const char *e = getenv("TT_WGRAD_TILED");
-    return e && atoi(e) != 0;
+    return TT_AB_SWITCH(TT_WGRAD_TILED, 0) != 0;
 }
 
 } // namespace

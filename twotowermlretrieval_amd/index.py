@@ -184,7 +184,7 @@ class BruteForceIndex:
         return ws[off:off + 8 * B].view(torch.int32).view(B, 2).clone()
 
     def search(self, q: torch.Tensor, k: int = 10, _prof_events=None, out=None, _seed_union=None,
-               _k_seed: int = 0) -> Tuple[torch.Tensor, torch.Tensor]:
+               _k_seed: int = 0, _k_list: int = 0) -> Tuple[torch.Tensor, torch.Tensor]:
         """out: optional (vals f32 [B,k], idx int64 [B,k]) contiguous device tensors to write into (2-D q only).
         _seed_union (ShardedIndex): a callable that turns this shard's seed list [B, _k_seed] f32 (its _k_seed largest
         sample maxima per query, tt_score_topk_screened_seed_list_f32) into the seed thresholds [B] f32 -- the _k_seed-th
@@ -222,7 +222,7 @@ class BruteForceIndex:
                 if self.keep_stats:
                     self._last_ws = (ws_s, B, k)
                 if _seed_union is not None:
-                    ks = min(_k_seed or k, k)
+                    ks = min(_k_list or _k_seed or k, k)  # entries per seed list (the caller ranks the union)
                     lst = torch.empty((B, ks), dtype=torch.float32, device=self.docs.device)
                     _lib.check(L.tt_score_topk_screened_seed_list_f32(q.data_ptr(), B, d, self.docs16.data_ptr(), N, k, ks,
                                                                       self.dmax_norm, flags.data_ptr(), lst.data_ptr(),
@@ -315,14 +315,18 @@ def _exchange_and_merge(vals: torch.Tensor, idx: torch.Tensor, k: int, merge: Ca
     return merge(gv, gi, k)
 
 
-def seed_union(lists: torch.Tensor, world: int) -> torch.Tensor:
-    """lists [world, B, ks] f32 (every rank's ks largest sample maxima per query) -> seed [B]: the ks-th largest of each
-    query's world * ks values (tt_seed_union_f32), on the current stream."""
+SEED_UNION_MAX = 512  # values per query tt_seed_union_f32 ranks (one LDS tile)
+
+
+def seed_union(lists: torch.Tensor, world: int, kth: Optional[int] = None) -> torch.Tensor:
+    """lists [world, B, ks] f32 (every rank's ks largest sample maxima per query) -> seed [B]: the kth-th (default ks-th)
+    largest of each query's world * ks values (tt_seed_union_f32), on the current stream."""
     world_, B, ks = lists.shape
     assert world_ == world and lists.is_contiguous() and lists.dtype == torch.float32
     seed = torch.empty(B, dtype=torch.float32, device=lists.device)
     with torch.cuda.device(lists.device):
-        _lib.check(_lib.lib().tt_seed_union_f32(lists.data_ptr(), world, B, ks, seed.data_ptr(), _stream(lists)))
+        _lib.check(_lib.lib().tt_seed_union_f32(lists.data_ptr(), world, B, ks, ks if kth is None else int(kth), seed.data_ptr(),
+                                                _stream(lists)))
     return seed
 
 
@@ -345,8 +349,10 @@ class _Slot:
         self.send_i = self.send[self.nv:].view(torch.int64).view(B, kp)
         self.out_v = torch.empty((B, k), dtype=torch.float32, device=dev)
         self.out_i = torch.empty((B, k), dtype=torch.int64, device=dev)
-        self.searched = torch.cuda.Event()
-        self.merged = torch.cuda.Event()
+        self.sampled = torch.cuda.Event()   # caller's stream: the seed list is written
+        self.seeded = torch.cuda.Event()    # exchange stream: the ranks' seed lists have been gathered
+        self.searched = torch.cuda.Event()  # caller's stream: the send block is written
+        self.merged = torch.cuda.Event()    # exchange stream: outputs are valid, send / receive buffers free
 
     def tensors(self):
         return (self.send, self.recv, self.out_v, self.out_i)
@@ -357,10 +363,13 @@ class PendingSearch:
     synchronisation) and returns (values, indices) views valid until two more submits of the same shape on the same
     index (search() has a slot of its own and never overwrites them)."""
 
-    def __init__(self, slot: _Slot):
-        self._slot = slot
+    def __init__(self, slot: _Slot, index: "ShardedIndex"):
+        self._slot, self._index = slot, index
 
     def result(self) -> Tuple[torch.Tensor, torch.Tensor]:
+        """(A COLLECTIVE when this step's exchange has not been issued yet -- it normally goes out inside the NEXT submit():
+        every rank must then call result() at the same point of its sequence of submit / search / result calls.)"""
+        self._index._flush(self._slot)
         torch.cuda.current_stream(self._slot.out_v.device).wait_event(self._slot.merged)
         return self._slot.out_v, self._slot.out_i
 
@@ -375,8 +384,22 @@ class ShardedIndex:
     (tt_allgather_topk on torch.distributed's RCCL communicator; torch.distributed's own call for other backends),
     and the merge kernel reads the receive buffer in place (tt_topk_merge_shards).
 
-    submit() pipelines consecutive searches: step i's all-gather + merge run on a second HIP stream with their own
-    buffers while step i+1's search runs on the caller's stream."""
+    submit() pipelines consecutive searches on two streams, and keeps the collectives off the search's critical path.  One
+    steady-state step (caller's stream C, exchange stream X; AG = all-gather on the one communicator):
+
+        C: sample(i+1) ──sampled──┐                      ┌──seeded── union + screen(i+1) + rescoring ──searched(i+1)──> ...
+        X:                        └─ seedAG(i+1) ────────┴─ listAG(i) ─ merge(i) ──merged(i)──> result(i)
+
+    screen(i+1) waits for seedAG(i+1) only (k floats per query and rank: 40 KB per rank at B = 1024, k = 10); step i's list
+    exchange (410-614 KB per rank) and merge are ISSUED BEHIND it and run under screen(i+1).  (Round 3 issued listAG(i) + merge(i)
+    at the end of submit(i), in front of seedAG(i+1) on the same stream: the screen then waited for the whole previous exchange.)
+    Every rank issues the same collectives in the same order -- seedAG(1), seedAG(2), listAG(1), seedAG(3), listAG(2), ... -- as
+    long as all ranks make the same sequence of submit / result / search calls, which a sharded search requires anyway; a
+    result() or search() that finds the last step's exchange still unissued issues it first, at the same point on every rank.
+
+    Whether the seed exchange happens at all is agreed ONCE, in the constructor (a collective): every rank has an fp16 shadow
+    copy and at least SCREEN_MIN_DOCS rows, or no rank exchanges seeds -- a rank-local decision (shard sizes straddling the
+    minimum, one shard outside the fp16 range) would leave some ranks in an all-gather the others never enter."""
 
     def __init__(self, local_docs: torch.Tensor, row_offset: int, group=None, shard_k: int = 50, screen: bool = False,
                  comm=None):
@@ -389,6 +412,28 @@ class ShardedIndex:
         self._slots = {}
         self._n_submitted = 0
         self._xs: Optional[torch.cuda.Stream] = None
+        self._deferred = None  # (slot, B, kp, k) of the last submit(): its list exchange goes out behind the next seed gather
+        N, d = self._index.docs.shape
+        mine = int(self._index.docs16 is not None and d == 256 and N >= SCREEN_MIN_DOCS)
+        if self._coll.world > 1:
+            dev = self._index.docs.device
+            send = torch.tensor([mine], dtype=torch.int64, device=dev)
+            recv = torch.empty(self._coll.world, dtype=torch.int64, device=dev)
+            self._coll.all_gather_blocks(send.view(torch.uint8), recv.view(torch.uint8))
+            mine = int(recv.min().item())
+        self._seed_exchange = bool(mine)  # the same on every rank
+
+    def _seed_plan(self, k: int):
+        """(list length per rank, rank taken from the union) of the seed exchange, or None when the union does not apply:
+        world * list length is bounded by tt_seed_union_f32's tile; a job too wide for k values per rank lists fewer (the
+        k-th of the union is still reached by k distinct documents)."""
+        world = self._coll.world
+        if not self._seed_exchange or k > 64:
+            return None
+        ks = min(k, SEED_UNION_MAX // world)
+        if ks < 1 or world * ks < k:
+            return None
+        return ks, k
 
     def _local_search(self, q: torch.Tensor, kp: int, k: int, sl: "_Slot", comm_stream=None) -> None:
         """This shard's list for the exchange: up to kp = max(k, shard_k) entries, best first.  The screen is seeded for
@@ -400,31 +445,42 @@ class ShardedIndex:
         The shard then owes the exchange only its documents above that global threshold: entries beyond them are padding
         (-inf / -1), which the merge ignores; the merged top-k is exact (two real-kernel ranks vs the oracle,
         tests/test_multirank_gpu.py).
-        comm_stream: the stream the seed all-gather is issued on (submit(): the index's exchange stream, so that ALL
-        collectives of this index go out on one stream in one order); None = the caller's."""
+        comm_stream: the stream the seed all-gather is issued on (submit(): the index's exchange stream; the previous step's
+        deferred list exchange is issued right behind it); None = the caller's."""
         coll, world = self._coll, self._coll.world
+        plan = self._seed_plan(k)
+        B = q.shape[0]
+        padded = self._index.docs.shape[1] != 256
+        screens = plan is not None and B >= (SCREEN_MIN_BATCH if not padded else SCREEN_PADDED_MIN_BATCH)  # (BruteForceIndex.search's rule)
+        if not screens or (world == 1 and kp == k):
+            # no seed exchange on any rank (agreed in the constructor; B and k are the same everywhere): the shard's own search
+            if comm_stream is not None:
+                self._flush()
+            self._index.search(q, kp, out=(sl.send_v, sl.send_i))
+            return
+        ks, kth = plan
 
         def union(lst: torch.Tensor) -> torch.Tensor:
             if world == 1:
-                return _local_seed(lst)
+                return seed_union(lst.unsqueeze(0), 1, kth)
             recv = torch.empty((world,) + tuple(lst.shape), dtype=torch.float32, device=lst.device)
             send_b, recv_b = lst.view(-1).view(torch.uint8), recv.view(-1).view(torch.uint8)
             if comm_stream is None:
                 coll.all_gather_blocks(send_b, recv_b)
             else:
                 cur = torch.cuda.current_stream(lst.device)
-                comm_stream.wait_stream(cur)
+                sl.sampled.record(cur)
                 with torch.cuda.stream(comm_stream):
+                    comm_stream.wait_event(sl.sampled)
                     lst.record_stream(comm_stream)
                     recv.record_stream(comm_stream)
                     coll.all_gather_blocks(send_b, recv_b)
-                cur.wait_stream(comm_stream)
-            return seed_union(recv, world)
+                    sl.seeded.record(comm_stream)
+                self._flush()                # the PREVIOUS step's list exchange + merge: behind this step's seed gather
+                cur.wait_event(sl.seeded)    # (the event, not the stream: the screen does not wait for that exchange)
+            return seed_union(recv, world, kth)
 
-        if self._index.docs16 is not None:
-            self._index.search(q, kp, out=(sl.send_v, sl.send_i), _seed_union=union, _k_seed=k)
-        else:
-            self._index.search(q, kp, out=(sl.send_v, sl.send_i))
+        self._index.search(q, kp, out=(sl.send_v, sl.send_i), _seed_union=union, _k_seed=k, _k_list=ks)
 
     @property
     def collective(self) -> str:
@@ -470,6 +526,21 @@ class ShardedIndex:
             self._slots[key] = [_Slot(B, kp, k, self._coll.world, self._index.docs.device) for _ in range(3)]
         return self._slots[key][which]
 
+    def _flush(self, only: Optional[_Slot] = None) -> None:
+        """Issue the deferred list exchange + merge of the last submit() on the exchange stream (only: just if it is that
+        slot's)."""
+        d = self._deferred
+        if d is None or (only is not None and d[0] is not only):
+            return
+        self._deferred = None
+        sl, B, kp, k = d
+        with torch.cuda.stream(self._xs):
+            self._xs.wait_event(sl.searched)
+            for t in sl.tensors():           # allocated on the caller's stream, used on the exchange stream
+                t.record_stream(self._xs)
+            self._exchange_merge(sl, B, kp, k)
+            sl.merged.record(self._xs)
+
     def _exchange_merge(self, sl: _Slot, B: int, kp: int, k: int) -> None:
         """all-gather + in-place merge of one slot on the CURRENT stream."""
         self._coll.all_gather_blocks(sl.send, sl.recv)
@@ -486,14 +557,16 @@ class ShardedIndex:
         sl = self._slot(q.shape[0], kp, k, 2)
         cur = torch.cuda.current_stream(sl.send.device)
         cur.wait_event(sl.merged)  # (a search() on another stream may still own the slot)
+        self._flush()              # (a submitted step's exchange goes out first: one issue order on every rank)
         self._local_search(q, kp, k, sl)
         self._exchange_merge(sl, q.shape[0], kp, k)
         sl.merged.record(cur)
         return sl.out_v.clone(), sl.out_i.clone()
 
     def submit(self, q: torch.Tensor, k: int = 10) -> PendingSearch:
-        """Pipelined search of a [B,d] batch: the local search is enqueued on the caller's stream now, the exchange
-        and the merge on this index's second stream; call .result() when the answer is needed."""
+        """Pipelined search of a [B,d] batch: the local search is enqueued on the caller's stream now; its list exchange and
+        merge go out on this index's second stream inside the NEXT submit() (behind that step's seed gather), or when
+        .result() / search() asks for them.  Call .result() when the answer is needed."""
         if q.dim() != 2:
             raise ValueError("submit wants a [B,d] batch")
         kp = max(k, self.shard_k)
@@ -504,16 +577,13 @@ class ShardedIndex:
         if self._xs is None:
             self._xs = torch.cuda.Stream(device=dev)
         cur = torch.cuda.current_stream(dev)
+        self._flush(sl)                      # (the slot's own previous step, if nobody collected it: issue before reuse)
         cur.wait_event(sl.merged)            # the slot's previous exchange has read its send block
-        self._local_search(q, kp, k, sl, comm_stream=self._xs if self._coll.world > 1 else None)
+        self._local_search(q, kp, k, sl, comm_stream=self._xs)
+        self._flush()                        # (a local search without a seed exchange has not issued the previous step's yet)
         sl.searched.record(cur)
-        with torch.cuda.stream(self._xs):
-            self._xs.wait_event(sl.searched)
-            for t in sl.tensors():           # allocated on the caller's stream, used on the exchange stream
-                t.record_stream(self._xs)
-            self._exchange_merge(sl, B, kp, k)
-            sl.merged.record(self._xs)
-        return PendingSearch(sl)
+        self._deferred = (sl, B, kp, k)
+        return PendingSearch(sl, self)
 
 
 class StreamedIndex:

@@ -26,7 +26,15 @@ import torch.nn as nn
 
 from . import _lib
 
-__all__ = ["RNNEncoder", "TwoTowerModel", "triplet_loss_cosine"]
+__all__ = ["RNNEncoder", "TwoTowerModel", "triplet_loss_cosine", "SplitRecurrenceTimeout"]
+
+
+class SplitRecurrenceTimeout(RuntimeError):
+    """Status bit 2: a column-split GRU recurrence (csrc/gru16x4.hip) gave up waiting for a partner workgroup -- a transient
+    condition of the device (CUs held by other work), not of the data.  The call's outputs are invalid; the same call with
+    `one_workgroup` recurrences (TT_ENC_ONE_WORKGROUP) cannot time out and returns the same bits.  RNNEncoder's inference
+    forward and trainer.train_step redo the call that way themselves; this exception reaches the caller of a hand-written
+    autograd loop only."""
 
 
 def _stream(dev) -> int:
@@ -114,14 +122,16 @@ def _or_all(status_tensors) -> int:
 
 
 def _raise_status(status: int) -> None:
-    if status & 4:
-        raise RuntimeError("libtt: the column-split GRU recurrence gave up waiting for a partner workgroup (bounded hand-off "
-                           "sweep, csrc/gru16x4.hip); the call's outputs are invalid.  TT_GRU_SPLIT=0 selects the one-CU kernel")
+    """Data errors first (they are properties of the batch: the reference's exceptions), the transient time-out last."""
     if status & 2:
         raise IndexError("index out of range in self")  # nn.Embedding's message (tests/golden/g10_errors.json)
     if status & 1:
         raise RuntimeError("Length of all samples has to be greater than 0, but found an element in 'lengths' "
                            "that is <= 0")  # pack_padded_sequence's message (model.py:55-57)
+    if status & 4:
+        raise SplitRecurrenceTimeout("libtt: a column-split GRU recurrence gave up waiting for a partner workgroup (bounded "
+                                     "hand-off sweep, csrc/gru16x4.hip); the call's outputs are invalid.  Set "
+                                     "encoder.one_workgroup = True (TT_ENC_ONE_WORKGROUP) and call again: same bits, no hand-off")
 
 
 class _EncoderFn(torch.autograd.Function):
@@ -132,16 +142,24 @@ class _EncoderFn(torch.autograd.Function):
         p = enc.dropout if enc.training else 0.0
         # the mask stream is seeded from torch's default CPU generator (torch.manual_seed reproduces it)
         seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if p > 0.0 else 0
+        # a status word handed to a watching optimizer is read in its step(), behind the backward; one that was checked here (or
+        # at the end of a deferred_input_checks block) is re-read behind the backward for the backward's time-out bit
+        ctx.handed_over = enc.check_inputs and enc._deferred_status is None and enc._status_sink is not None
         out, ws, status = enc._run_forward(ids, train=True, dropout_p=p, dropout_seed=seed)
         ctx.enc, ctx.ids, ctx.ws, ctx.status = enc, ids, ws, status
         ctx.dropout = (p, seed)
+        ctx.opts = enc._opts_bwd()
         ctx.n_params = len(params)
         return out
 
     @staticmethod
     def backward(ctx, d_out: torch.Tensor):
-        grads = ctx.enc._run_backward(ctx.ids, ctx.ws, d_out.contiguous(), *ctx.dropout)
+        enc = ctx.enc
+        grads = enc._run_backward(ctx.ids, ctx.ws, d_out.contiguous(), *ctx.dropout, status=ctx.status, opts=ctx.opts)
         ctx.ws = None
+        if enc.check_inputs and not ctx.handed_over and enc._backward_may_time_out(ctx.ids.shape[0], ctx.opts):
+            # the backward ORs bit 2 into the forward's word (include/tt.h); nobody else reads it on this path
+            _raise_status(int(ctx.status.item()) & 4)
         return (None, None, *grads)
 
 
@@ -174,6 +192,12 @@ class RNNEncoder(nn.Module):
         self.cache_prepared = True
         self._prep: dict = {}
         self._deferred_status = None  # a list while a caller (trainer.train_step) batches the status reads
+        # a list owned by an optimizer that watches this encoder (FusedClipAdam.watch): TRAINING calls hand their status words
+        # over instead of raising here, and optimizer.step() decides -- together with the other ranks -- whether the step happens
+        self._status_sink = None
+        # keep every recurrence of this encoder's calls on the one-workgroup kernels (TT_ENC_ONE_WORKGROUP, include/tt.h)
+        self.one_workgroup = False
+        self.one_workgroup_bwd = None  # None: as one_workgroup; True / False: the reverse-time recurrence alone (any mix is valid)
 
     # ---- plumbing ---------------------------------------------------------------
     def _flat_params(self):
@@ -181,6 +205,18 @@ class RNNEncoder(nn.Module):
         if self.projection is not None:
             ps += [self.projection.weight, self.projection.bias]
         return ps
+
+    def _opts(self) -> int:
+        return _lib.TT_ENC_ONE_WORKGROUP if self.one_workgroup else 0
+
+    def _opts_bwd(self) -> int:
+        one = self.one_workgroup if self.one_workgroup_bwd is None else self.one_workgroup_bwd
+        return _lib.TT_ENC_ONE_WORKGROUP if one else 0
+
+    def _backward_may_time_out(self, B: int, opts: int) -> bool:
+        if opts & _lib.TT_ENC_ONE_WORKGROUP:
+            return False
+        return _lib.lib().tt_encoder_split_workgroups(B, self.hidden_dim, int(self.bidirectional), self._cell) > 0
 
     def _check_device(self, x: torch.Tensor):
         if not x.is_cuda:
@@ -227,8 +263,9 @@ class RNNEncoder(nn.Module):
             self._prep[device] = (key, blob, ent[1] if ent is not None else None)
         return blob
 
-    def _run_forward(self, x: torch.Tensor, train: bool, dropout_p: float = 0.0, dropout_seed: int = 0):
+    def _run_forward(self, x: torch.Tensor, train: bool, dropout_p: float = 0.0, dropout_seed: int = 0, opts: Optional[int] = None):
         L = _lib.lib()
+        opts = self._opts() if opts is None else opts
         ids = x.contiguous()
         if ids.dtype != torch.int64:
             ids = ids.to(torch.int64)
@@ -262,27 +299,37 @@ class RNNEncoder(nn.Module):
                 _lib.check(L.tt_encoder_forward_prepared_f32(
                     ids.data_ptr(), B, T, table.data_ptr(), V, E, H, self.num_layers, int(self.bidirectional),
                     self._cell, wptr, prepared.data_ptr(), pw.data_ptr() if pw is not None else None,
-                    pb.data_ptr() if pb is not None else None, int(self.normalize_output), out.data_ptr(),
+                    pb.data_ptr() if pb is not None else None, int(self.normalize_output), opts, out.data_ptr(),
                     ws.data_ptr(), ws.numel(), status.data_ptr(), _stream(ids.device)))
             else:
                 _lib.check(L.tt_encoder_forward_f32(
                     ids.data_ptr(), B, T, table.data_ptr(), V, E, H, self.num_layers, int(self.bidirectional),
                     self._cell, wptr, pw.data_ptr() if pw is not None else None,
-                    pb.data_ptr() if pb is not None else None, int(self.normalize_output), train_mode, float(dropout_p),
-                    int(dropout_seed), out.data_ptr(), ws.data_ptr(), ws.numel(), status.data_ptr(),
+                    pb.data_ptr() if pb is not None else None, int(self.normalize_output), train_mode | opts,
+                    float(dropout_p), int(dropout_seed), out.data_ptr(), ws.data_ptr(), ws.numel(), status.data_ptr(),
                     _stream(ids.device)))
         if self.check_inputs:
             if self._deferred_status is not None:
                 self._deferred_status.append(status)  # the caller reads them once, after enqueuing its other calls
+            elif train and self._status_sink is not None:
+                self._status_sink.append(status)  # the watching optimizer reads them, reduced over the ranks, in step()
             else:
-                _raise_status(int(status.item()))
+                st = int(status.item())
+                if (st & 7) == 4 and not train and not (opts & _lib.TT_ENC_ONE_WORKGROUP):
+                    # inference: a transient time-out of the column-split recurrence and nothing wrong with the data -- the
+                    # same call on the one-workgroup kernels (same bits, nothing to wait for)
+                    return self._run_forward(x, train, dropout_p, dropout_seed, opts | _lib.TT_ENC_ONE_WORKGROUP)
+                _raise_status(st)
         return out, ws, status
 
     def _run_backward(self, ids: torch.Tensor, ws: torch.Tensor, d_out: torch.Tensor, dropout_p: float = 0.0,
-                      dropout_seed: int = 0, into: Optional[list] = None):
+                      dropout_seed: int = 0, into: Optional[list] = None, status: Optional[torch.Tensor] = None,
+                      opts: Optional[int] = None):
         """into: contiguous float32 tensors, one per _flat_params() entry, that receive the gradients (the C entry point
-        OVERWRITES its gradient buffers): trainer.train_step hands over the optimizer's gradient views."""
+        OVERWRITES its gradient buffers): trainer.train_step hands over the optimizer's gradient views.
+        status: the forward call's status word; a time-out of the column-split backward recurrence ORs bit 2 into it."""
         L = _lib.lib()
+        opts = self._opts_bwd() if opts is None else opts
         B, T = ids.shape
         V, E = self.embedding.weight.shape
         H = self.hidden_dim
@@ -303,8 +350,8 @@ class RNNEncoder(nn.Module):
                 int(dropout_seed), d_out.data_ptr(), gptr,
                 grads[nq].data_ptr() if pw is not None else None,
                 grads[nq + 1].data_ptr() if pb is not None else None,
-                g_table.data_ptr() if g_table is not None else None, ws.data_ptr(), ws.numel(),
-                _stream(ids.device)))
+                g_table.data_ptr() if g_table is not None else None, ws.data_ptr(), ws.numel(), opts,
+                status.data_ptr() if status is not None else None, _stream(ids.device)))
         return grads + ([g_table] if g_table is not None else [])
 
     # ---- public -----------------------------------------------------------------

@@ -15,12 +15,27 @@ from __future__ import annotations
 
 import pickle
 import re
+import threading
 from typing import Dict, Iterable, List, Sequence
 
 import numpy as np
 
 _TOKEN_RE = re.compile(r"\w+|[.,!?;]")
 UNK = "<UNK>"
+
+_SCRATCH = threading.local()
+
+
+def _scratch(name: str, n: int, dtype) -> np.ndarray:
+    """A per-thread array of at least n elements that is REUSED from call to call (grown geometrically).  The ragged id
+    buffer of one 16k-document batch is ~50 MB; as a fresh np.empty every call it is ~12k first-touch page faults, which cost
+    more than the tokenising and do not scale over threads (they serialise in the kernel): 145 ms cold against 10 ms warm for
+    the same native call with 8 threads."""
+    a = getattr(_SCRATCH, name, None)
+    if a is None or a.shape[0] < n:
+        a = np.empty(max(int(n * 1.25), 1024), dtype=dtype)
+        setattr(_SCRATCH, name, a)
+    return a
 
 
 class PretrainedTokenizer:
@@ -111,9 +126,11 @@ class PretrainedTokenizer:
                 np.cumsum([len(b) for b in enc], out=off[1:])
             blob = b"".join(enc)
         total = int(off[-1])
-        ragged = np.empty(max(total, 1), dtype=np.int64)
-        lens = np.zeros(max(n, 1), dtype=np.int32)
-        status = np.zeros(max(n, 1), dtype=np.int32)
+        ragged = _scratch("ragged", max(total, 1), np.int64)   # (a text never has more tokens than bytes)
+        lens = _scratch("lens", max(n, 1), np.int32)
+        status = _scratch("status", max(n, 1), np.int32)
+        lens[:max(n, 1)] = 0
+        status[:max(n, 1)] = 0
         nt = n_threads or min(16, len(os.sched_getaffinity(0)))
         _lib.check(L.tt_tok_encode(self._native(), blob, off.ctypes.data, n, ragged.ctypes.data, lens.ctypes.data,
                                    status.ctypes.data, nt))

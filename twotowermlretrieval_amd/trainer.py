@@ -18,7 +18,7 @@ are ordinary tensors); the fused optimizer is the MI355X-native path.
 """
 from __future__ import annotations
 
-from typing import Callable, Iterable, Tuple
+from typing import Callable, Iterable, Optional, Tuple
 
 import torch
 
@@ -37,27 +37,76 @@ def _hip_clip_adam(flat_p, flat_g, m, v, step, lr, betas, eps, max_norm, grad_sc
                                            torch.cuda.current_stream(flat_p.device).cuda_stream))
 
 
+def _hip_clip_adam_gated(flat_p, flat_g, m, v, step_dev, lr, betas, eps, max_norm, grad_scale, total_norm, gate, scratch):
+    L = _lib.lib()
+    with torch.cuda.device(flat_p.device):
+        _lib.check(L.tt_clip_adam_step_gated_f32(flat_p.data_ptr(), flat_g.data_ptr(), m.data_ptr(), v.data_ptr(),
+                                                 flat_p.numel(), step_dev.data_ptr(), lr, betas[0], betas[1], eps, max_norm,
+                                                 grad_scale, total_norm.data_ptr(),
+                                                 gate.data_ptr() if gate is not None else None, scratch.data_ptr(),
+                                                 torch.cuda.current_stream(flat_p.device).cuda_stream))
+
+
+def _hip_step_gate(status_words, gate):
+    """gate[b] = how many of the status words have bit b set (one launch, no host read)."""
+    import ctypes as C
+    cur = torch.cuda.current_stream(gate.device)
+    arr = (C.c_void_p * len(status_words))()
+    for i, st in enumerate(status_words):
+        st.record_stream(cur)  # (written on a tower's stream, read here)
+        arr[i] = st.data_ptr()
+    with torch.cuda.device(gate.device):
+        _lib.check(_lib.lib().tt_step_gate_f32(arr, len(status_words), gate.data_ptr(), cur.cuda_stream))
+
+
+def _torch_step_gate(status_words, gate):
+    """The same on ordinary tensors (the CPU rehearsals of the host logic)."""
+    bits = torch.stack([st.reshape(()).to(torch.int64) for st in status_words])
+    for b in range(3):
+        gate[b] = float(((bits >> b) & 1).sum())
+    gate[3] = 0.0
+
+
 class _FlatClipAdam:
     """Host logic of the fused optimizer on ordinary tensors: all trainable parameters are re-pointed at views of one
     contiguous fp32 buffer (`flat_params`) and their .grad at views of `flat_grads`, so the optimizer and the
     data-parallel all-reduce touch two pointers; step() = summing all-reduce -> step_fn(..., grad_scale = 1/world).
+
+    A FAILED STEP IS A COLLECTIVE DECISION.  The gradient bucket has TT_STEP_GATE_WORDS extra floats behind the gradients (the
+    `gate`): before the all-reduce they hold, per status bit, how many of this rank's encoder calls raised it (zero-length row,
+    id out of range, column-split recurrence timed out: the status words the watched encoders handed over -- `watch`); the ONE
+    all-reduce sums them with the gradients, so afterwards every rank holds the same counts, the device applies the step on
+    all ranks or on none, and every rank raises the same exception.  The reference's step is single-process (a bad batch
+    raises and the run stops, backend/main.py:244-259); a rank-local raise in front of the all-reduce would leave the peers
+    waiting in it forever.
+
     Private: the CPU tests drive it over gloo with the oracle's step; the product class is FusedClipAdam."""
 
+    GATE = _lib.TT_STEP_GATE_WORDS
+
     def __init__(self, params: Iterable[torch.nn.Parameter], step_fn: Callable, all_reduce: Callable, world: int,
-                 lr: float, betas: Tuple[float, float], eps: float, max_norm: float, scratch_bytes: int):
+                 lr: float, betas: Tuple[float, float], eps: float, max_norm: float, scratch_bytes: int,
+                 gate_fn: Callable = _torch_step_gate, gated_step_fn: Optional[Callable] = None):
         self.params = [p for p in params if p.requires_grad]
         if not self.params:
             raise ValueError("no trainable parameters")
         dev = self.params[0].device
         self.lr, self.betas, self.eps, self.max_norm = float(lr), (float(betas[0]), float(betas[1])), float(eps), float(max_norm)
         self._step_fn, self._all_reduce, self.world = step_fn, all_reduce, int(world)
+        self._gate_fn, self._gated_step_fn = gate_fn, gated_step_fn
         n = sum(p.numel() for p in self.params)
         self.flat_params = torch.empty(n, dtype=torch.float32, device=dev)
-        self.flat_grads = torch.zeros(n, dtype=torch.float32, device=dev)
+        self._bucket = torch.zeros(n + self.GATE, dtype=torch.float32, device=dev)  # what the all-reduce sees
+        self.flat_grads = self._bucket[:n]
+        self.gate = self._bucket[n:]
         self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
         self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
         self.total_norm = torch.zeros(1, dtype=torch.float32, device=dev)
         self._scratch = torch.empty(scratch_bytes, dtype=torch.uint8, device=dev)
+        self._step_dev = torch.zeros(1, dtype=torch.int64, device=dev)  # steps applied (the gated kernel counts on the device)
+        self._step_host = 0
+        self._pending_status: list = []  # status words of the watched encoders' training calls since the last step()
+        self.check = True                # step() reads the reduced gate (one host synchronisation) and raises
         self._views = []
         off = 0
         with torch.no_grad():
@@ -69,7 +118,36 @@ class _FlatClipAdam:
                 p.grad = gv
                 self._views.append(gv)
                 off += k
-        self.step_count = 0
+
+    # ---- step number -----------------------------------------------------------
+    @property
+    def step_count(self) -> int:
+        """Steps applied so far (reads the device counter of the gated kernel: a host synchronisation)."""
+        return int(self._step_dev.item()) if self._gated_step_fn is not None else self._step_host
+
+    @step_count.setter
+    def step_count(self, value: int) -> None:
+        self._step_host = int(value)
+        self._step_dev.fill_(int(value))
+
+    # ---- status words of the encoders -------------------------------------------
+    def watch(self, *modules) -> None:
+        """The RNNEncoders inside `modules` hand the status words of their TRAINING calls to this optimizer instead of raising
+        at the call: step() reduces them over the ranks with the gradients and raises -- on every rank -- what the reference
+        would have raised.  DataParallelTrainer and train_step do this for their model; a hand-written loop around
+        FusedClipAdam(group=...) must, or a bad batch on one rank leaves the others waiting in the all-reduce."""
+        from .model import RNNEncoder
+        for mod in modules:
+            for enc in mod.modules():
+                if isinstance(enc, RNNEncoder):
+                    enc._status_sink = self._pending_status
+
+    def unwatch(self, *modules) -> None:
+        from .model import RNNEncoder
+        for mod in modules:
+            for enc in mod.modules():
+                if isinstance(enc, RNNEncoder) and enc._status_sink is self._pending_status:
+                    enc._status_sink = None
 
     def zero_grad(self) -> None:
         self.flat_grads.zero_()
@@ -85,16 +163,41 @@ class _FlatClipAdam:
                 gv.copy_(p.grad)
             p.grad = gv
 
-    def step(self) -> torch.Tensor:
-        """Returns the pre-clip global gradient norm (device tensor, no sync)."""
+    def step(self, check: Optional[bool] = None) -> torch.Tensor:
+        """Returns the pre-clip global gradient norm (device tensor).  With status words pending or a process group, the step
+        is gated (class docstring) and -- unless check is False -- the reduced gate is read back (the step's one host
+        synchronisation): IndexError / RuntimeError as the reference raises them, model.SplitRecurrenceTimeout for a time-out,
+        on every rank alike; parameters, moments and step number are then untouched."""
         self._collect()
+        status = list(self._pending_status)
+        self._pending_status.clear()  # (in place: the watched encoders hold this list)
+        gated = bool(status) or self.world > 1
+        if status:
+            self._gate_fn(status, self.gate)
+        elif gated:
+            self.gate.zero_()
         if self.world > 1:
-            self._all_reduce(self.flat_grads)  # one 3.4 MB bucket
-        self.step_count += 1
-        self._step_fn(self.flat_params, self.flat_grads, self.exp_avg, self.exp_avg_sq, self.step_count, self.lr,
-                      self.betas, self.eps, self.max_norm, 1.0 / self.world, self.total_norm, self._scratch)
+            self._all_reduce(self._bucket)  # ONE bucket: 3.4 MB of gradients + the gate words
+        args = (self.lr, self.betas, self.eps, self.max_norm, 1.0 / self.world, self.total_norm)
+        words = None
+        if self._gated_step_fn is not None:
+            self._gated_step_fn(self.flat_params, self.flat_grads, self.exp_avg, self.exp_avg_sq, self._step_dev, *args,
+                                self.gate if gated else None, self._scratch)
+        else:  # ordinary tensors: the gate is looked at on the host
+            words = self.gate.tolist() if gated else None
+            if not words or not any(words):
+                self._step_host += 1
+                self._step_fn(self.flat_params, self.flat_grads, self.exp_avg, self.exp_avg_sq, self._step_host, *args,
+                              self._scratch)
         self.mark_params_changed()
+        if gated and (self.check if check is None else check):
+            self.raise_for_gate(self.gate.tolist() if words is None else words)
         return self.total_norm
+
+    @staticmethod
+    def raise_for_gate(words) -> None:
+        from .model import _raise_status
+        _raise_status(sum(1 << b for b in range(3) if words[b] != 0))
 
     def mark_params_changed(self) -> None:
         """Call after ANY write to `flat_params` that did not go through the parameters themselves (this class's own step,
@@ -106,8 +209,9 @@ class _FlatClipAdam:
 
 class FusedClipAdam(_FlatClipAdam):
     """clip_grad_norm_(max_norm) + Adam(lr, betas, eps, weight_decay=0) over one flat buffer in ONE kernel pair
-    (tt_clip_adam_step_f32); with a process group, ONE summing all-reduce of that buffer first (tt_allreduce_grads on
-    torch.distributed's RCCL communicator; torch.distributed's own call for other backends)."""
+    (tt_clip_adam_step_gated_f32: step number and bias corrections on the device, the step predicated on the reduced gate);
+    with a process group, ONE summing all-reduce of the bucket first (tt_allreduce_grads on torch.distributed's RCCL
+    communicator; torch.distributed's own call for other backends)."""
 
     def __init__(self, params: Iterable[torch.nn.Parameter], lr: float = 1e-4, betas: Tuple[float, float] = (0.9, 0.999),
                  eps: float = 1e-8, max_norm: float = 1.0, group=None, comm=None):
@@ -118,7 +222,7 @@ class FusedClipAdam(_FlatClipAdam):
         self.group = group
         self._coll = Collective(group, params[0].device if params else None, comm=comm)
         super().__init__(params, _hip_clip_adam, self._coll.all_reduce_sum, self._coll.world, lr, betas, eps, max_norm,
-                         _lib.lib().tt_clip_adam_scratch_bytes())
+                         _lib.lib().tt_clip_adam_scratch_bytes(), gate_fn=_hip_step_gate, gated_step_fn=_hip_clip_adam_gated)
 
 
 _TOWER_STREAMS = {}
@@ -144,6 +248,46 @@ def _concat_ids(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     return out
 
 
+class _towers_in_flight:
+    """For the duration of one train step: (1) the model's encoders hand their status words to `optimizer` (watch), so that
+    the step's failure is decided in optimizer.step(), by all ranks together; (2) the towers that are in flight at the same time
+    keep their column-split recurrences within the device's CUs -- a split launch needs every member of every team resident at
+    once (one workgroup per CU), which ONE launch guarantees against the CU count and two launches on two streams do not: the
+    smaller towers run the one-workgroup recurrences (TT_ENC_ONE_WORKGROUP: same bits, no hand-off) until the sum fits.  Then
+    every resident workgroup either waits for nobody or waits for partners that get a CU as soon as independent workgroups
+    drain: co-residency is guaranteed by construction, not observed (csrc/gru16x4.hip, include/tt.h)."""
+
+    def __init__(self, model: TwoTowerModel, optimizer, rows: dict, force_one_workgroup: bool = False):
+        self.model, self.optimizer, self.rows, self.force = model, optimizer, rows, force_one_workgroup
+
+    def __enter__(self):
+        encs = [self.model.query_encoder, self.model.doc_encoder]
+        self._saved = [(e, e.one_workgroup, e.one_workgroup_bwd, e._status_sink) for e in encs]
+        if isinstance(self.optimizer, _FlatClipAdam):
+            self.optimizer.watch(*encs)
+        if self.force:
+            for e in encs:
+                e.one_workgroup, e.one_workgroup_bwd = True, None
+        elif self.rows and encs[0].embedding.weight.is_cuda:
+            L = _lib.lib()
+            cus = torch.cuda.get_device_properties(encs[0].embedding.weight.device).multi_processor_count
+            need = {e: (0 if (e.one_workgroup and e.one_workgroup_bwd is not False) else L.tt_encoder_split_workgroups(int(B), e.hidden_dim, int(e.bidirectional), e._cell))
+                    for e, B in self.rows.items()}
+            for e in sorted(need, key=lambda e: need[e]):  # smallest first
+                if sum(need.values()) <= cus:
+                    break
+                if need[e]:
+                    e.one_workgroup, e.one_workgroup_bwd, need[e] = True, None, 0
+        return self
+
+    def __exit__(self, exc_type, exc, tb):
+        for e, one, one_bwd, sink in self._saved:
+            e.one_workgroup, e.one_workgroup_bwd, e._status_sink = one, one_bwd, sink
+        if exc_type is not None and isinstance(self.optimizer, _FlatClipAdam):
+            self.optimizer._pending_status.clear()  # (a step that died before optimizer.step(): its words are nobody's)
+        return False
+
+
 def _train_step_direct(model: TwoTowerModel, optimizer, queries, pos_docs, neg_docs, margin: float):
     """The same step without the autograd engine: tower forwards (train mode), the fused loss + gradient kernel, tower backwards
     written STRAIGHT into the optimizer's flat gradient buffer, optimizer step.  Every parameter receives its gradient exactly
@@ -152,8 +296,6 @@ def _train_step_direct(model: TwoTowerModel, optimizer, queries, pos_docs, neg_d
     tower, the 3.4 MB zero fill -- is ~0.1 ms of small launches on the document tower's critical path.  Returns None when the
     shortcut does not apply (another optimizer, a trainable embedding table, parameters without the optimizer's gradient
     views): the caller then takes the autograd path, which computes the same numbers."""
-    from . import _lib
-    from .model import _raise_status
     if not isinstance(optimizer, _FlatClipAdam) or not torch.is_grad_enabled():
         return None
     # the document tower (2B rows of ~70 tokens) is the step's critical path: its launches go out FIRST, the query tower's
@@ -174,86 +316,80 @@ def _train_step_direct(model: TwoTowerModel, optimizer, queries, pos_docs, neg_d
     streams = _tower_streams(dev)[:2]
     if pos_docs.dtype != torch.int64 or neg_docs.dtype != torch.int64:
         return None
-    streams[0].wait_stream(cur)
-    with torch.cuda.stream(streams[0]):  # (on the document tower's own stream: no hop from the caller's)
-        pos_docs.record_stream(streams[0])
-        neg_docs.record_stream(streams[0])
-        both = _concat_ids(pos_docs, neg_docs)
-    ids_of = (both, queries)
-    # dropout seeds from torch's CPU generator in the order the autograd path draws them (query tower, then document tower)
-    seeds = {id(enc): (int(torch.randint(0, 2 ** 62, (1,)).item()) if enc.dropout > 0.0 else 0)
-             for enc in (model.query_encoder, model.doc_encoder)}
-    fw = []
-    for enc, ids, s in zip(encs, ids_of, streams):
-        s.wait_stream(cur)
-        with torch.cuda.stream(s):
-            ids.record_stream(s)
-            p_drop = enc.dropout
-            seed = seeds[id(enc)]
-            check, enc.check_inputs = enc.check_inputs, False
-            try:
-                out, ws, status = enc._run_forward(ids, train=True, dropout_p=p_drop, dropout_seed=seed)
-            finally:
-                enc.check_inputs = check
-            fw.append((out, ws, status, p_drop, seed))
-    # The document tower's stream carries the step's critical path from here on: the loss, the document backward and the
-    # optimizer are enqueued on IT (a hop to the caller's stream and back cost ~20 us each way on that path: event wait +
-    # launch); the query tower's stream joins for the loss and again before the optimizer.
     s_doc, s_qry = streams
-    pn, q = fw[0][0], fw[1][0]
-    p, n = pn[:B], pn[B:]
-    H = q.shape[1]
-    s_doc.wait_stream(s_qry)
-    with torch.cuda.stream(s_doc):
-        loss = torch.empty((), dtype=torch.float32, device=dev)
-        dq = torch.empty_like(q)
-        dpn = torch.empty_like(pn)
-        rows = torch.empty(B, dtype=torch.float32, device=dev)
-        for t in (q, loss, dq, dpn, rows):
-            t.record_stream(s_doc)
-        with torch.cuda.device(dev):
-            _lib.check(_lib.lib().tt_triplet_loss_f32(q.data_ptr(), p.data_ptr(), n.data_ptr(), B, H, float(margin), loss.data_ptr(),
-                                                      dq.data_ptr(), dpn[:B].data_ptr(), dpn[B:].data_ptr(), rows.data_ptr(),
-                                                      s_doc.cuda_stream))
-    s_qry.wait_stream(s_doc)
-    for enc, ids, s, f, d_out, grads in zip(encs, ids_of, streams, fw, (dpn, dq), into):
-        with torch.cuda.stream(s):
-            d_out.record_stream(s)
-            enc._run_backward(ids.contiguous(), f[1], d_out, f[3], f[4], into=grads)
-    s_doc.wait_stream(s_qry)
-    for p_, gv in zip(optimizer.params, optimizer._views):
-        p_.grad = gv
-    with torch.cuda.stream(s_doc):
-        # The towers' status words (zero-length rows / ids out of range raise as in the reference; a column-split recurrence
-        # that gave up) are read HERE, behind the backward kernels: the read is the one host synchronisation of the step, and
-        # the optimizer step is not enqueued for a bad batch -- the weights stay untouched (the gradient buffer holds garbage,
-        # which the next step overwrites).
-        for enc, f in zip(encs, fw):
-            if enc.check_inputs:
-                _raise_status(int(f[2].item()))
-        for t in (optimizer.flat_params, optimizer.flat_grads, optimizer.exp_avg, optimizer.exp_avg_sq, optimizer.total_norm,
-                  optimizer._scratch):
-            t.record_stream(s_doc)
-        optimizer.step()
-    cur.wait_stream(s_doc)
+    try:
+        s_doc.wait_stream(cur)
+        with torch.cuda.stream(s_doc):  # (on the document tower's own stream: no hop from the caller's)
+            pos_docs.record_stream(s_doc)
+            neg_docs.record_stream(s_doc)
+            both = _concat_ids(pos_docs, neg_docs)
+        ids_of = (both, queries)
+        # dropout seeds from torch's CPU generator in the order the autograd path draws them (query tower, then document tower)
+        seeds = {id(enc): (int(torch.randint(0, 2 ** 62, (1,)).item()) if enc.dropout > 0.0 else 0)
+                 for enc in (model.query_encoder, model.doc_encoder)}
+        fw = []
+        for enc, ids, s in zip(encs, ids_of, streams):
+            s.wait_stream(cur)
+            with torch.cuda.stream(s):
+                ids.record_stream(s)
+                p_drop = enc.dropout
+                seed = seeds[id(enc)]
+                # (the encoders are watched -- _towers_in_flight -- so the status word goes to the optimizer instead of a read here)
+                out, ws, status = enc._run_forward(ids, train=True, dropout_p=p_drop, dropout_seed=seed)
+                fw.append((out, ws, status, p_drop, seed, enc._opts_bwd()))
+        # The document tower's stream carries the step's critical path from here on: the loss, the document backward and the
+        # optimizer are enqueued on IT (a hop to the caller's stream and back cost ~20 us each way on that path: event wait +
+        # launch); the query tower's stream joins for the loss and again before the optimizer.
+        pn, q = fw[0][0], fw[1][0]
+        p, n = pn[:B], pn[B:]
+        H = q.shape[1]
+        s_doc.wait_stream(s_qry)
+        with torch.cuda.stream(s_doc):
+            loss = torch.empty((), dtype=torch.float32, device=dev)
+            dq = torch.empty_like(q)
+            dpn = torch.empty_like(pn)
+            rows = torch.empty(B, dtype=torch.float32, device=dev)
+            for t in (q, loss, dq, dpn, rows):
+                t.record_stream(s_doc)
+            with torch.cuda.device(dev):
+                _lib.check(_lib.lib().tt_triplet_loss_f32(q.data_ptr(), p.data_ptr(), n.data_ptr(), B, H, float(margin), loss.data_ptr(),
+                                                          dq.data_ptr(), dpn[:B].data_ptr(), dpn[B:].data_ptr(), rows.data_ptr(),
+                                                          s_doc.cuda_stream))
+        s_qry.wait_stream(s_doc)
+        for enc, ids, s, f, d_out, grads in zip(encs, ids_of, streams, fw, (dpn, dq), into):
+            with torch.cuda.stream(s):
+                d_out.record_stream(s)
+                # (a time-out of the split backward recurrence ORs bit 2 into the forward's word, which the optimizer reads)
+                enc._run_backward(ids.contiguous(), f[1], d_out, f[3], f[4], into=grads, status=f[2], opts=f[5])
+        s_doc.wait_stream(s_qry)
+        for p_, gv in zip(optimizer.params, optimizer._views):
+            p_.grad = gv
+        with torch.cuda.stream(s_doc):
+            # The optimizer is enqueued unconditionally: the towers' status words (zero-length rows / ids out of range raise as
+            # in the reference; a column-split recurrence that gave up) are folded into the gate behind the gradients, reduced
+            # over the ranks with them, and the device applies the step on every rank or on none.  The read of the reduced gate
+            # inside step() is the one host synchronisation of the step; for a bad batch the weights stay untouched (the
+            # gradient buffer holds garbage, which the next step overwrites).
+            for t in (optimizer.flat_params, optimizer._bucket, optimizer.exp_avg, optimizer.exp_avg_sq, optimizer.total_norm,
+                      optimizer._scratch, optimizer._step_dev):
+                t.record_stream(s_doc)
+            optimizer.step()
+    finally:
+        # (also when step() raised: the caller's stream joins the towers' streams, nothing of this step is left running
+        #  behind the caller's back)
+        cur.wait_stream(s_qry)
+        cur.wait_stream(s_doc)
     loss.record_stream(cur)
     return loss
 
 
-def train_step(model: TwoTowerModel, optimizer: FusedClipAdam, queries: torch.Tensor, pos_docs: torch.Tensor,
-               neg_docs: torch.Tensor, margin: float = 0.2, concurrent_towers: bool = True, direct: bool = True) -> torch.Tensor:
-    """One step of backend/main.py:244-259 on this rank's (equal-sized) share of the global batch.
-    Returns the local loss as a 0-d device tensor (no .item(): the reference's per-step sync is dropped).
-
-    concurrent_towers: the encoder calls are independent and each recurrence kernel only occupies ceil(B/16)
-    CUs, so the query tower and the document tower (positives and negatives in one 2B-row call) are issued
-    on separate HIP streams (autograd replays each call's backward on the stream its forward ran on).
-    direct: skip the autograd engine when the step has the standard shape (_train_step_direct: same kernels, same numbers)."""
+def _train_step_once(model, optimizer, queries, pos_docs, neg_docs, margin, concurrent_towers, direct):
     if direct and concurrent_towers and queries.is_cuda and neg_docs.shape[0] == pos_docs.shape[0] == queries.shape[0]:
         loss = _train_step_direct(model, optimizer, queries, pos_docs, neg_docs, margin)
         if loss is not None:
             return loss
     optimizer.zero_grad()
+    watched = isinstance(optimizer, _FlatClipAdam)
     if concurrent_towers and queries.is_cuda:
         cur = torch.cuda.current_stream(queries.device)
         B = pos_docs.shape[0]
@@ -265,10 +401,8 @@ def train_step(model: TwoTowerModel, optimizer: FusedClipAdam, queries: torch.Te
         else:
             calls = ((model.encode_query, queries), (model.encode_document, pos_docs), (model.encode_document, neg_docs))
         outs = []
-        # input checking stays on (zero-length rows / out-of-range ids raise as in the reference), but the status
-        # words of the towers are read ONCE, after all of them have been enqueued: a per-call read would make the
-        # host wait for the query tower before it could launch the document tower
-        with deferred_input_checks(model.query_encoder, model.doc_encoder):
+
+        def launch():
             for s, (fn, ids) in zip(_tower_streams(queries.device), calls):
                 s.wait_stream(cur)
                 with torch.cuda.stream(s):
@@ -277,6 +411,14 @@ def train_step(model: TwoTowerModel, optimizer: FusedClipAdam, queries: torch.Te
             for s, o in zip(_tower_streams(queries.device), outs):
                 cur.wait_stream(s)
                 o.record_stream(cur)
+        if watched:
+            launch()  # (the status words go to the optimizer, which reads them -- reduced over the ranks -- in step())
+        else:
+            # another optimizer: input checking stays on (zero-length rows / out-of-range ids raise as in the reference), but the
+            # status words of the towers are read ONCE, after all of them have been enqueued: a per-call read would make the
+            # host wait for the query tower before it could launch the document tower
+            with deferred_input_checks(model.query_encoder, model.doc_encoder):
+                launch()
         if len(outs) == 2:
             q, p, n = outs[0], outs[1][:B], outs[1][B:]
         else:
@@ -291,13 +433,43 @@ def train_step(model: TwoTowerModel, optimizer: FusedClipAdam, queries: torch.Te
     return loss.detach()
 
 
+def train_step(model: TwoTowerModel, optimizer: FusedClipAdam, queries: torch.Tensor, pos_docs: torch.Tensor,
+               neg_docs: torch.Tensor, margin: float = 0.2, concurrent_towers: bool = True, direct: bool = True) -> torch.Tensor:
+    """One step of backend/main.py:244-259 on this rank's (equal-sized) share of the global batch.
+    Returns the local loss as a 0-d device tensor (no .item(): the reference's per-step sync is dropped).
+
+    concurrent_towers: the encoder calls are independent, so the query tower and the document tower (positives and negatives in
+    one 2B-row call) are issued on separate HIP streams (autograd replays each call's backward on the stream its forward ran on).
+    direct: skip the autograd engine when the step has the standard shape (_train_step_direct: same kernels, same numbers).
+
+    Failure is collective (FusedClipAdam): a zero-length row or an id out of range on ANY rank raises the reference's
+    exception on EVERY rank, inside this call, with parameters, moments and step number untouched everywhere.  A time-out of a
+    column-split recurrence (transient: CUs held by other work) does not raise: all ranks see it in the same reduced gate and
+    redo the step on the one-workgroup kernels (ordinary relaunch, same bits as the split forward)."""
+    from .model import SplitRecurrenceTimeout
+    encs = (model.query_encoder, model.doc_encoder)
+    n_doc = pos_docs.shape[0] + neg_docs.shape[0] if (concurrent_towers and neg_docs.shape[0] == pos_docs.shape[0]) else max(
+        pos_docs.shape[0], neg_docs.shape[0])
+    rows = {model.query_encoder: queries.shape[0], model.doc_encoder: n_doc} if concurrent_towers else {}
+    rng = torch.get_rng_state() if any(e.dropout > 0.0 and e.training for e in encs) else None
+    try:
+        with _towers_in_flight(model, optimizer, rows if queries.is_cuda else {}):
+            return _train_step_once(model, optimizer, queries, pos_docs, neg_docs, margin, concurrent_towers, direct)
+    except SplitRecurrenceTimeout:
+        if rng is not None:
+            torch.set_rng_state(rng)  # (the redone step draws the dropout seeds the failed attempt drew)
+        with _towers_in_flight(model, optimizer, {}, force_one_workgroup=True):
+            return _train_step_once(model, optimizer, queries, pos_docs, neg_docs, margin, concurrent_towers, direct)
+
+
 class DataParallelTrainer:
-    """Replicated model, per-rank batch shard, gradient all-reduce inside FusedClipAdam.step()."""
+    """Replicated model, per-rank batch shard, gradient all-reduce (with the step's failure gate) inside FusedClipAdam.step()."""
 
     def __init__(self, model: TwoTowerModel, lr: float = 1e-4, margin: float = 0.2, max_norm: float = 1.0, group=None):
         self.model = model
         self.margin = margin
         self.optimizer = FusedClipAdam(model.parameters(), lr=lr, max_norm=max_norm, group=group)
+        self.optimizer.watch(model)  # (a hand-written loop over self.model / self.optimizer fails collectively too)
 
     def broadcast_parameters(self, src: int = 0) -> None:
         import torch.distributed as dist
