@@ -303,6 +303,114 @@ def encoder_corpus_leg(dev, model, n_docs=2_097_152, seed=11):
     return out
 
 
+def make_clustered_corpus(n_docs, n_queries, dev, seed=21, n_centres=20_000, dup_groups=1000, dup=64, noise=0.08, common=0.6):
+    """A corpus the screen can lose on (MS MARCO has near-duplicate passages and a trained tower clusters them,
+    backend/model.py:71-74): unit rows = one of n_centres centres + small noise, the centres themselves sharing a common
+    direction (pairwise cosine of two random rows ~ `common`, of two rows of one cluster ~ 1 - noise^2); on top, dup_groups
+    groups of `dup` EXACT duplicates (more tied documents than any k) scattered over the corpus.  Queries = noisy copies of
+    centres, the first dup_groups of them copies of the duplicated rows (so the tie groups ARE the top of their lists).
+    Returns (D [n_docs,256], Q [n_queries,256], first row index of every duplicate group's members [dup_groups, dup])."""
+    g = torch.Generator(device=dev).manual_seed(seed)
+    u = torch.randn(DIM, device=dev, generator=g)
+    u /= u.norm()
+    cen = torch.randn((n_centres, DIM), device=dev, generator=g)
+    cen /= cen.norm(dim=1, keepdim=True)
+    cen = (common ** 0.5) * u + ((1.0 - common) ** 0.5) * cen
+    cen /= cen.norm(dim=1, keepdim=True)
+    D = torch.empty((n_docs, DIM), dtype=torch.float32, device=dev)
+    for lo in range(0, n_docs, GEN_BLOCK):
+        n = min(GEN_BLOCK, n_docs - lo)
+        z = torch.randint(0, n_centres, (n,), device=dev, generator=g)
+        x = cen[z] + noise * torch.randn((n, DIM), device=dev, generator=g) / (DIM ** 0.5)
+        D[lo:lo + n] = x / x.norm(dim=1, keepdim=True)
+    dup_groups = min(dup_groups, n_docs // (2 * dup))
+    members = torch.randperm(n_docs, device=dev, generator=g)[:dup_groups * dup].view(dup_groups, dup)
+    D[members.reshape(-1)] = D[members[:, 0]].repeat_interleave(dup, dim=0)
+    zq = torch.randint(0, n_centres, (n_queries,), device=dev, generator=g)
+    Q = cen[zq] + noise * torch.randn((n_queries, DIM), device=dev, generator=g) / (DIM ** 0.5)
+    nq_dup = min(dup_groups, n_queries // 4)      # a quarter of the queries at most: copies of duplicated rows
+    if nq_dup:
+        Q[:nq_dup] = D[members[:nq_dup, 0]] + 0.01 * torch.randn((nq_dup, DIM), device=dev, generator=g) / (DIM ** 0.5)
+    Q /= Q.norm(dim=1, keepdim=True)
+    return D, Q.contiguous(), members
+
+
+def clustered_corpus_leg(dev, n_docs=4_194_304):
+    """Queries/s, what the fp16 filter let through and how many 32-query tiles fell back to the exact kernel on the
+    clustered corpus (make_clustered_corpus), next to the rate when EVERY tile falls back (the plain fp32 kernel on the same
+    batch): the worst case of the screened search is that number, not a wrong result -- checked bit for bit against it here."""
+    import twotowermlretrieval_amd as tt
+    D, Q, members = make_clustered_corpus(n_docs, BATCH, dev)
+    samp = D[torch.randint(0, n_docs, (2048,), device=dev)]
+    mean_cos = float(((samp @ samp.t()).sum() - 2048) / (2048 * 2047))
+    ix = tt.BruteForceIndex(D, screen=True)
+    assert ix.docs16 is not None
+    ix.keep_stats = True
+    out = {"docs": n_docs, "corpus": "20 000 clustered centres + noise, 1 000 groups of 64 exact duplicates; queries = noisy "
+                                     "copies of centres, a quarter of them of duplicated rows",
+           "mean_pairwise_cos": round(mean_cos, 4), "duplicate_groups": int(members.shape[0]), "duplicates_per_group": int(members.shape[1])}
+    for B in (BATCH, 32):
+        qb = Q[:B].contiguous()
+        t = time_search(ix, qb, TOPK)
+        v, i = ix.search(qb, TOPK)
+        st = ix.search_stats().to(torch.float32)
+        flags = int(ix.fallback_flags.ne(0).sum().item())
+        ev, ei = tt.score_topk(qb, D, TOPK)
+        ws = torch.empty(max(_lib_ws_bytes(B, n_docs), 16), dtype=torch.uint8, device=dev)
+        t_exact = _time_gpu(lambda: tt.score_topk(qb, D, TOPK, 0, ws), 3, 1) * 1e3
+        out[f"b{B}"] = {"queries_per_s": round(B / t * 1e3, 1), "search_ms": round(t, 4),
+                        "pooled_per_query_mean": round(float(st[:, 0].mean()), 1), "pooled_per_query_max": int(st[:, 0].max()),
+                        "survivors_per_query_mean": round(float(st[:, 1].mean()), 1), "survivors_per_query_max": int(st[:, 1].max()),
+                        "exact_fallback_tiles": flags, "tiles": (B + 31) // 32,
+                        "queries_per_s_if_every_tile_falls_back": round(B / t_exact * 1e3, 1),
+                        "identical_to_exact_f32": bool(torch.equal(v, ev) and torch.equal(i, ei))}
+    del ix, D
+    torch.cuda.empty_cache()
+    return out
+
+
+def _lib_ws_bytes(B, N):
+    from twotowermlretrieval_amd import _lib
+    return _lib.lib().tt_score_topk_workspace_bytes(B, N, DIM, TOPK)
+
+
+def index_build_from_strings_leg(dev, model, gpu_docs_per_s, n_docs=262_144, seed=3):
+    """Index build from STRINGS (backend/main.py:125-138 over tokenizer.py:41-43): synthetic Zipf passages as text ->
+    native tokeniser on several producer threads -> pinned batches -> document tower (evaluators.embed_corpus), against the
+    GPU-only rate of the `index_build_b8192` leg (ids already on the device)."""
+    import numpy as np
+    import twotowermlretrieval_amd as tt
+    from twotowermlretrieval_amd.evaluators import embed_corpus
+    words = ["the", ",", ".", "of", "and"] + [f"w{i}" for i in range(5, ENC_V - 1)]
+    tok = tt.PretrainedTokenizer(word2idx={w: i for i, w in enumerate(words)})
+    assert tok.vocab_size() == ENC_V
+    rs = np.random.RandomState(seed)
+    lens = np.clip(rs.poisson(70, n_docs), 10, 250)
+    z = rs.zipf(1.07, int(lens.sum())) % (ENC_V - 1)
+    docs, p0 = [], 0
+    for L_ in lens:
+        docs.append(" ".join(map(words.__getitem__, z[p0:p0 + L_])))
+        p0 += L_
+    n_tok = int(lens.sum())
+    model.eval()
+    embed_corpus(model, tok, docs[:32768], dev)          # warm-up: vocabulary table, scratch arrays, pinned blocks
+    torch.cuda.synchronize()
+    stats = {}
+    t0 = time.perf_counter()
+    emb = embed_corpus(model, tok, docs, dev, stats=stats)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    t1 = time.perf_counter()
+    for i in range(0, 65536, 16384):
+        tok.encode_batch(docs[i:i + 16384], pin=True)
+    t_host = (time.perf_counter() - t1) / 65536 * n_docs
+    return {"docs": n_docs, "tokens": n_tok, "s": round(dt, 3), "docs_per_s": round(n_docs / dt), "tokens_per_s": round(n_tok / dt),
+            "host_front_end_alone_tokens_per_s_one_producer": round(n_tok / t_host),
+            "producers": stats.get("producers"), "threads_per_producer": stats.get("threads_per_producer"),
+            "host_cores": stats.get("host_cores"), "gpu_only_docs_per_s": gpu_docs_per_s,
+            "frac_of_gpu_only_rate": round(n_docs / dt / gpu_docs_per_s, 3), "rows": list(emb.shape)}
+
+
 def _settle_gc():
     """A full collection now, and everything alive moved to the permanent generation: CPython's generation-2 pass walks every
     tracked object of the process (~40 ms with torch and numpy imported, once per ~100 train steps: tools/experiments/
@@ -560,6 +668,8 @@ def main():
         #   hbm_exact_f32   the plain fp32 kernel at B = 32 (N x 1024 bytes)
         #   mfma_exact_f32  the plain fp32 kernel on the bench batch (the strict-precision reading of the step)
         #   encoder_corpus  the same index over embeddings the encoder produces (anisotropic), with the filter's statistics
+        #   clustered_corpus  ... over clustered rows with groups of exact duplicates: fallback count and the all-fallback rate
+        #   index_build_from_strings  text -> tokeniser threads -> document tower, as a fraction of the GPU-only rate
         #   encoder, train  SURVEY 8d's secondary metrics (tower / index-build tokens/s, training triplets/s)
         roof["legs"] = {"hbm_screen": roof_hbm, "hbm_exact_f32": roof_hbm_f32, "mfma_exact_f32": roof_f32}
         enc_inputs = None
@@ -569,8 +679,12 @@ def main():
             roof["legs"]["encoder"], roof["legs"]["train"], enc_inputs, model = encoder_legs(dev)
             if not a.no_encoder_corpus:
                 roof["legs"]["encoder_corpus"] = encoder_corpus_leg(dev, model)
+                roof["legs"]["index_build_from_strings"] = index_build_from_strings_leg(
+                    dev, model, roof["legs"]["encoder"]["index_build_b8192"]["docs_per_s"])
             del model
             torch.cuda.empty_cache()
+            if not a.no_encoder_corpus:
+                roof["legs"]["clustered_corpus"] = clustered_corpus_leg(dev)
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(q, docs, enc_inputs)
         print(json.dumps(line), flush=True)

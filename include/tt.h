@@ -406,6 +406,11 @@ int tt_tok_create(const char *words_blob, const int64_t *word_off, const int64_t
 void tt_tok_destroy(void *handle);
 int tt_tok_encode(const void *handle, const char *text_blob, const int64_t *text_off, int64_t n_texts,
                   int64_t *ragged_ids, int32_t *lens, int32_t *status, int n_threads);
+/* tt_tok_encode for texts joined into one blob with the byte `sep` between them (n_texts - 1 separators; fails with
+ * TT_ERR_BAD_SHAPE when the count differs, i.e. a text contains `sep`): the offsets are found here (text_off_out [n_texts + 1],
+ * text i = blob[text_off_out[i], text_off_out[i + 1] - 1)), which saves a Python host its per-text length pass. */
+int tt_tok_encode_sep(const void *handle, const char *text_blob, int64_t blob_len, char sep, int64_t n_texts,
+                      int64_t *text_off_out, int64_t *ragged_ids, int32_t *lens, int32_t *status, int n_threads);
 int tt_tok_pad(const int64_t *ragged_ids, const int64_t *text_off, const int32_t *lens, int64_t n_texts,
                int64_t width, int64_t *out, int n_threads);
 

@@ -35,7 +35,7 @@ constexpr int X4_H = 256;
 constexpr int X4_NK = X4_H / 32;          // k-steps of 32
 constexpr int X4_LDH = X4_H + 8;          // fp16 elements per row of an h image (as gru_seq16_kernel)
 constexpr int X4_IMG = 16 * X4_LDH * 2;   // bytes of one (hi or lo) image
-constexpr int X4_LDS = 4 * X4_IMG;        // [buffer 2][hi, lo]
+[[maybe_unused]] constexpr int X4_LDS = 4 * X4_IMG; // [buffer 2][hi, lo] (these three: the four-wave member of the comparison build)
 constexpr int X4_H_SHIFT = 10;            // h is scaled by 2^10 before the split (gru16.hip: H_SHIFT)
 constexpr int X4_REGION = 16 * 64 * 8;    // one member's granules of one parity: [row 16][unit 64] x 8 B
 constexpr size_t X4_TEAM_BYTES = 2 * 4 * (size_t)X4_REGION; // [parity][member]
@@ -384,9 +384,32 @@ __global__ __launch_bounds__(256, 1) void gru_seq16x4_kernel(GruSplitParams sp)
 //     each half does gate math, fp16 split, image write, publish (ONE 16-byte store per lane: the even lane of a pair row 2 kh,
 //     the odd lane row 2 kh + 1), stash / output stores and the next step's projections for ITS two rows of the lane's four;
 //   * the sweep of the other members' granules is one 16-byte load per member and thread (barrier X3 closes the step).
+//
+// LDS image of h (fp16 hi / lo, two buffers), laid out for the MFMA A-fragment reads.  Lane (j = row, kq) of a 16x16x32 fragment
+// reads 16 bytes = units 32 s2 + 8 kq .. + 8 of row j with ds_read_b128, which the LDS serves in four groups of 16 lanes that
+// each hold ALL 16 rows at two neighbouring kq ({0-3, 12-15} at one, {4-11} at the other: MI355X_MICROARCH.md, LDS).  A
+// row-major image ([row][unit], 528-byte rows: round 3) puts kq 16 bytes = one bank slot further, so in every group one row of
+// the second set lands on a slot of the first: 2-way, 8 LDS cycles per read instead of 4 -- 128 LDS cycles per k-step for the
+// CU's eight waves against 72 of MFMA, SQ_LDS_BANK_CONFLICT 40 % of SQ_LDS_IDX_ACTIVE (profiles/r04_a_pmc_sq_train_kernels.txt).
+// Here the image is [kq plane][row][k-step] x 16 bytes: the kq term is a multiple of the 256-byte bank row (no slot shift) and a
+// row is 9 slots (odd: the 16 rows of a group fall on 16 different slots) -- conflict-free reads; the own-unit stores (2 bytes)
+// are 2-way, which a store does not pay for, and the granule unpack stores are conflict-free with xf_chunk's chunk order.
+constexpr int XF_ROWB = 8 * 16 + 16;      // bytes of one row in one plane: 8 k-steps x 16 B + one slot of padding
+constexpr int XF_PLANE = 16 * XF_ROWB;    // 2304 = 9 x 256
+constexpr int XF_IMG = 4 * XF_PLANE;      // bytes of one (hi or lo) image
+constexpr int XF_IMGS = 4 * XF_IMG;       // [buffer 2][hi, lo]
 constexpr int XF_RZ = 4 * 64 * 4 * 4;    // [w][lane][r, z sums of rows 2, 3] half 0 -> half 1
 constexpr int XF_N = 4 * 64 * 2 * 4;     // [w][lane][n sums of rows 0, 1] half 1 -> half 0
-constexpr int XF_LDS = X4_LDS + XF_RZ + XF_N; // + 16 for the abort word
+constexpr int XF_LDS = XF_IMGS + XF_RZ + XF_N; // + 16 for the abort word
+
+// Order of the 512 16-byte chunks (= two granules: units 2 p, 2 p + 1 of one row) in a member's exchange region.  The consumer's
+// thread t loads chunk t (the sweep stays one contiguous 8 KB read per member) and stores it into the image: with this order
+// the 64 stores of a wave are 16 rows x 4 dwords of ONE plane (32 banks per half-wave: conflict-free); a publishing wave still
+// writes 128-byte runs (the four pairs of a fragment lane group, rows 2 kh and 2 kh + 1).
+__device__ __forceinline__ int xf_chunk(int row, int p)
+{
+    return (p & 3) | ((row & 7) << 2) | ((row >> 3) << 5) | (((p >> 2) & 3) << 6) | ((p >> 4) << 8);
+}
 
 #ifdef TT_X4_DBG // a measuring build: s_memtime clocks per phase of the step, printed every 8th launch
 __device__ unsigned long long x4_dbg[16];
@@ -401,6 +424,7 @@ __global__ __launch_bounds__(512, 1) void gru_seq16x4p_kernel(GruSplitParams sp)
 #endif
     extern __shared__ __attribute__((aligned(16))) char lds[];
     int &abort_flag = *(int *)(lds + XF_LDS);
+    static_assert(XF_PLANE % 256 == 0 && (XF_ROWB / 16) % 2 == 1, "plane stride a multiple of the bank row, row stride an odd number of 16-B slots");
     const GruParams &p = sp.g;
     const int chunk = blockIdx.x >> 5, r32 = blockIdx.x & 31;
     const int m = r32 >> 3, team = chunk * 8 + (r32 & 7);
@@ -438,14 +462,14 @@ __global__ __launch_bounds__(512, 1) void gru_seq16x4p_kernel(GruSplitParams sp)
 #pragma unroll
     for (int g = 0; g < 3; ++g)
         bias[g] = d.b_hh[g * H + unit] * up;
-    for (int i = tid; i < X4_LDS / 4; i += 512)
+    for (int i = tid; i < XF_IMGS / 4; i += 512)
         ((int *)lds)[i] = 0; // h_0 = 0 in both buffers, both parts
     if (tid == 0)
         abort_flag = 0;
     float hreg[2] = {0, 0};
     typedef float f32x2v __attribute__((ext_vector_type(2)));
-    f32x4v *const xrz = (f32x4v *)(lds + X4_LDS) + (w * 64 + lane);
-    f32x2v *const xn = (f32x2v *)(lds + X4_LDS + XF_RZ) + (w * 64 + lane);
+    f32x4v *const xrz = (f32x4v *)(lds + XF_IMGS) + (w * 64 + lane);
+    f32x2v *const xn = (f32x2v *)(lds + XF_IMGS + XF_RZ) + (w * 64 + lane);
 
     // ---- this wave's fragments of W_hh: gates r, z (half 0) or n (half 1), all eight k-steps; gru16_pack's order as in
     //      gru_seq16x4_kernel (fragment 12 s + 4 g + 2 part + ct of wave u16 >> 1) ----
@@ -466,7 +490,13 @@ __global__ __launch_bounds__(512, 1) void gru_seq16x4p_kernel(GruSplitParams sp)
     const __amdgpu_buffer_rsrc_t xsrc =
         __builtin_amdgcn_make_buffer_rsrc((void *)xteam, 0, (int)X4_TEAM_BYTES + X4_HEADER, 0x00020000);
     const bool odd = j & 1;
-    const int send_off = ((kq * 4 + 2 * kh + (odd ? 1 : 0)) * 64 + 16 * w + (j & ~1)) * 8;
+    // the 16-byte chunk (two granules: units 2 p, 2 p + 1 of one row) this lane publishes, in xf_chunk's order
+    const int send_off = xf_chunk(kq * 4 + 2 * kh + (odd ? 1 : 0), 8 * w + (j >> 1)) * 16;
+    // where this lane's own unit sits in an image row (bytes): k-step u16 >> 1, fragment lane group 2 (u16 & 1) + (j >> 3)
+    const int own_off = (2 * (u16 & 1) + (j >> 3)) * XF_PLANE + (u16 >> 1) * 16 + (j & 7) * 2;
+    // the chunk this thread unpacks from every other member's region: chunk tid = (row urow, pair upr)
+    const int urow = ((tid >> 2) & 7) | (((tid >> 5) & 1) << 3), upr = (tid & 3) | (((tid >> 6) & 3) << 2) | ((tid >> 8) << 4);
+    const int unpack_off = ((upr >> 2) & 3) * XF_PLANE + urow * XF_ROWB + (upr >> 4) * 16 + 4 * (upr & 3); // + 32 om (two k-steps per member)
     const int same_xcd = team_shares_xcd(xsrc, (int)X4_TEAM_BYTES, m, tid, sp.spin_max, &abort_flag + 1);
     if (same_xcd < 0) {
         if (tid == 0 && sp.status)
@@ -505,10 +535,10 @@ __global__ __launch_bounds__(512, 1) void gru_seq16x4p_kernel(GruSplitParams sp)
         X4_T(0);
         if (s + 1 < steps)
             gi_load(s + 1, gnx); // in flight under this step's MFMAs and hand-off
-        const char *img = lds + cur * 2 * X4_IMG + j * (X4_LDH * 2) + kq * 16;
+        const char *img = lds + cur * 2 * XF_IMG + kq * XF_PLANE + j * XF_ROWB; // (row j, fragment lane group kq: conflict-free b128 reads)
         h8 a_hi[2], a_lo[2]; // by k-step parity
         a_hi[0] = *(const h8 *)(img);
-        a_lo[0] = *(const h8 *)(img + X4_IMG);
+        a_lo[0] = *(const h8 *)(img + XF_IMG);
         f32x4v acc[2]; // half 0: r, z; half 1: n (index 0)
         acc[0] = (f32x4v){bias[2 * kh], bias[2 * kh], bias[2 * kh], bias[2 * kh]};
         acc[1] = (f32x4v){bias[1], bias[1], bias[1], bias[1]};
@@ -517,8 +547,8 @@ __global__ __launch_bounds__(512, 1) void gru_seq16x4p_kernel(GruSplitParams sp)
 #pragma unroll
             for (int s2 = 0; s2 < X4_NK; ++s2) {
                 if (s2 + 1 < X4_NK) {
-                    a_hi[(s2 + 1) & 1] = *(const h8 *)(img + (s2 + 1) * 64);
-                    a_lo[(s2 + 1) & 1] = *(const h8 *)(img + X4_IMG + (s2 + 1) * 64);
+                    a_hi[(s2 + 1) & 1] = *(const h8 *)(img + (s2 + 1) * 16);
+                    a_lo[(s2 + 1) & 1] = *(const h8 *)(img + XF_IMG + (s2 + 1) * 16);
                 }
 #pragma unroll
                 for (int g = 0; g < NG; ++g)
@@ -549,7 +579,7 @@ __global__ __launch_bounds__(512, 1) void gru_seq16x4p_kernel(GruSplitParams sp)
         }
 
         X4_T(1);
-        char *nimg = lds + (cur ^ 1) * 2 * X4_IMG;
+        char *nimg = lds + (cur ^ 1) * 2 * XF_IMG;
         unsigned pk[2]; // fp16 hi | lo << 16 of this lane's two new states
         float sv_r[2], sv_z[2], sv_n[2], sv_g[2];
 #pragma unroll
@@ -568,9 +598,9 @@ __global__ __launch_bounds__(512, 1) void gru_seq16x4p_kernel(GruSplitParams sp)
             const float hs = hreg[e] * (float)(1 << X4_H_SHIFT);
             const _Float16 hi = (_Float16)hs;
             const _Float16 lo = (_Float16)(hs - (float)hi);
-            _Float16 *dst = (_Float16 *)nimg + (kq * 4 + 2 * kh + e) * X4_LDH + unit;
+            _Float16 *dst = (_Float16 *)(nimg + (kq * 4 + 2 * kh + e) * XF_ROWB + own_off);
             dst[0] = hi;
-            dst[X4_IMG / 2] = lo;
+            dst[XF_IMG / 2] = lo;
             pk[e] = (unsigned)__builtin_bit_cast(unsigned short, hi) | ((unsigned)__builtin_bit_cast(unsigned short, lo) << 16);
         }
         // the next step's projections take their place HERE, in front of the sweep: behind a loop of loads the compiler no longer
@@ -622,14 +652,15 @@ __global__ __launch_bounds__(512, 1) void gru_seq16x4p_kernel(GruSplitParams sp)
                 sweep_backoff(spins);
             }
             X4_T(4);
-            // chunk tid of a member's region: row = tid >> 5, units 2 (tid & 31), + 1
+            // chunk tid of a member's region: row urow, units 2 upr, 2 upr + 1 of that member (xf_chunk); a wave's 64 stores fall
+            // on 16 rows x 4 dwords of one plane: conflict-free
 #pragma unroll
             for (int o = 0; o < 3; ++o) {
                 const int om = (m + 1 + o) & 3;
-                unsigned *dst = (unsigned *)(nimg + ((tid >> 5) * X4_LDH + 64 * om + 2 * (tid & 31)) * 2);
+                unsigned *dst = (unsigned *)(nimg + unpack_off + 32 * om);
                 const unsigned a = got[o].x, b = got[o].z;
                 dst[0] = (a & 0xffffu) | (b << 16);
-                dst[X4_IMG / 4] = (a >> 16) | (b & 0xffff0000u);
+                dst[XF_IMG / 4] = (a >> 16) | (b & 0xffff0000u);
             }
         }
         // (the step's bulk stores go out behind the hand-off: vector memory operations complete in issue order)
@@ -685,7 +716,7 @@ __global__ __launch_bounds__(512, 1) void gru_seq16x4p_kernel(GruSplitParams sp)
 constexpr int XB_LDG = 192 + 8;            // fp16 elements per row of a dGh image (own 3 x 64 columns)
 constexpr int XB_IMG = 16 * XB_LDG * 2;    // bytes of one (hi or lo) image
 constexpr int XB_RM = 2 * 16 * 4 * 4;      // row maxima [buffer][row][wave], double-buffered
-constexpr int XB_LDS = 2 * XB_IMG + XB_RM; // + 16 for the abort word
+[[maybe_unused]] constexpr int XB_LDS = 2 * XB_IMG + XB_RM; // + 16 for the abort word (the four-wave member of the comparison build)
 constexpr int XB_REGION = 16 * 64 * 8;     // one (dest, src) block of one parity
 constexpr size_t XB_TEAM_BYTES = 2 * 4 * 4 * (size_t)XB_REGION; // [parity][dest][src]
 
@@ -1049,10 +1080,17 @@ __global__ __launch_bounds__(256, 1) void gru_bwd16x4_kernel(GruSplitBwdParams s
 // The row scale factors are computed once per row (by the lanes that own the row) and read back as one LDS vector per lane.
 // Bias sums accumulate per half and are added at the end (half 0 + half 1): deterministic, not bit-identical to the
 // four-wave kernel's interleaved order.
+// The dGh image (fp16 hi / lo) is laid out as gru_seq16x4p_kernel's h image, for the same reason: [kq plane][row][k-step] x 16
+// bytes, plane stride a multiple of 256 bytes, 7 slots per row -- the A-fragment reads are conflict-free (row-major with
+// 400-byte rows: one 2-way conflict in each of a read's four lane groups, SQ_LDS_BANK_CONFLICT 33 % of SQ_LDS_IDX_ACTIVE).
+constexpr int XP_ROWB = 6 * 16 + 16;             // bytes of one row in one plane: 6 k-steps x 16 B + one slot of padding
+constexpr int XP_PLANE = 16 * XP_ROWB;           // 1792 = 7 x 256
+constexpr int XP_IMG = 4 * XP_PLANE;             // bytes of one (hi or lo) image
+constexpr int XP_BASE = 2 * XP_IMG + XB_RM;      // images + row maxima
 constexpr int XP_RDOWN = 2 * 16 * 4;             // [buffer][row] 2^-(e_row + e_W)
 constexpr int XP_PART = 4 * 64 * 8;              // [unit slice w][lane] rows 2, 3 of the member's own partial
 constexpr int XP_BIAS = 4 * 64 * 16;             // [w][lane] half 1's four bias sums (end of the kernel)
-constexpr int XP_LDS = XB_LDS + XP_RDOWN + XP_PART + XP_BIAS; // + 16 for the abort word
+constexpr int XP_LDS = XP_BASE + XP_RDOWN + XP_PART + XP_BIAS; // + 16 for the abort word
 
 #ifdef TT_X4_DBG
 __device__ unsigned long long xb_dbg[32];
@@ -1100,11 +1138,15 @@ __global__ __launch_bounds__(512, 1) void gru_bwd16x4p_kernel(GruSplitBwdParams 
         dh[e] = (d.d_hfin && rid_e[e] >= 0) ? d.d_hfin[(size_t)rid_e[e] * H + unit] : 0.0f;
     const int exw = tt_pow2_exponent(*d.wmax);
 
-    char *const img = lds;                                       // [hi, lo][16][XB_LDG] fp16
-    float *const rmax = (float *)(lds + 2 * XB_IMG);             // [2][16 rows][4 unit slices]
-    float *const rdown = (float *)(lds + XB_LDS);                // [2][16 rows]
-    float *const xpart = (float *)(lds + XB_LDS + XP_RDOWN);     // [4][64 lanes][2]
-    float *const xbias = (float *)(lds + XB_LDS + XP_RDOWN + XP_PART); // [4][64 lanes][4]
+    static_assert(XP_PLANE % 256 == 0 && (XP_ROWB / 16) % 2 == 1, "plane stride a multiple of the bank row, row stride an odd number of 16-B slots");
+    char *const img = lds;                                       // [hi, lo][kq plane 4][row 16][k-step 6] x 16 B (fp16)
+    float *const rmax = (float *)(lds + 2 * XP_IMG);             // [2][16 rows][4 unit slices]
+    float *const rdown = (float *)(lds + XP_BASE);               // [2][16 rows]
+    float *const xpart = (float *)(lds + XP_BASE + XP_RDOWN);    // [4][64 lanes][2]
+    float *const xbias = (float *)(lds + XP_BASE + XP_RDOWN + XP_PART); // [4][64 lanes][4]
+    // where this lane's column of gate 0 sits in an image row (bytes): column c = 64 g + 16 w + j -> k-step c >> 5 = 2 g + (w >> 1),
+    // fragment lane group (c & 31) >> 3 = 2 (w & 1) + (j >> 3), element j & 7; gate g adds two k-steps
+    const int own_off = (2 * (w & 1) + (j >> 3)) * XP_PLANE + (w >> 1) * 16 + (j & 7) * 2;
     if (tid == 0)
         abort_flag = 0;
 
@@ -1234,13 +1276,13 @@ __global__ __launch_bounds__(512, 1) void gru_bwd16x4p_kernel(GruSplitBwdParams 
             const float upr = ldexpf(1.0f, er);
             if (w == 0 && j == 0)
                 rdown[rb * 16 + row] = ldexpf(1.0f, -(er + exw));
-            _Float16 *dst = (_Float16 *)img + row * XB_LDG + ul;
+            _Float16 *dst = (_Float16 *)(img + row * XP_ROWB + own_off);
 #pragma unroll
             for (int g = 0; g < 3; ++g) {
                 const float x = gv[g][e] * upr;
                 const _Float16 hi = (_Float16)x;
-                dst[g * 64] = hi;
-                dst[XB_IMG / 2 + g * 64] = (_Float16)(x - (float)hi);
+                dst[g * 16] = hi;                                      // (+ 32 bytes: two k-steps)
+                dst[XP_IMG / 2 + g * 16] = (_Float16)(x - (float)hi);
             }
         }
         X4_T(4);
@@ -1250,15 +1292,15 @@ __global__ __launch_bounds__(512, 1) void gru_bwd16x4p_kernel(GruSplitBwdParams 
         rb ^= 1;
 
         f32x4v acc[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}}; // destination members (m + 2 kh + o2) & 3
-        const char *arow = img + j * (XB_LDG * 2) + kq * 16;
+        const char *arow = img + kq * XP_PLANE + j * XP_ROWB; // (row j, fragment lane group kq: conflict-free b128 reads, as gru_seq16x4p)
         h8 a_hi[2], a_lo[2];
         a_hi[0] = *(const h8 *)(arow);
-        a_lo[0] = *(const h8 *)(arow + XB_IMG);
+        a_lo[0] = *(const h8 *)(arow + XP_IMG);
 #pragma unroll
         for (int s2 = 0; s2 < 6; ++s2) {
             if (s2 + 1 < 6) {
-                a_hi[(s2 + 1) & 1] = *(const h8 *)(arow + (s2 + 1) * 64);
-                a_lo[(s2 + 1) & 1] = *(const h8 *)(arow + XB_IMG + (s2 + 1) * 64);
+                a_hi[(s2 + 1) & 1] = *(const h8 *)(arow + (s2 + 1) * 16);
+                a_lo[(s2 + 1) & 1] = *(const h8 *)(arow + XP_IMG + (s2 + 1) * 16);
             }
 #pragma unroll
             for (int o2 = 0; o2 < 2; ++o2)

@@ -163,6 +163,47 @@ TT_EXPORT int tt_tok_encode(const void *handle, const char *text_blob, const int
     return TT_OK;
 }
 
+// The same for texts handed over as ONE blob with a separator byte between them (n_texts - 1 separators; the caller checks
+// nothing: a text that contains the separator makes the count differ and the call fails with TT_ERR_BAD_SHAPE, and the caller
+// takes the offsets form).  Saves the host the per-text length pass: "\0".join(texts).encode() is all the Python it needs.
+// text_off_out [n_texts + 1]: start of text i in the blob; text i ends one byte (the separator) before text_off_out[i + 1],
+// and ragged_ids / tt_tok_pad use these offsets as tt_tok_encode's.
+TT_EXPORT int tt_tok_encode_sep(const void *handle, const char *text_blob, int64_t blob_len, char sep, int64_t n_texts,
+                                int64_t *text_off_out, int64_t *ragged_ids, int32_t *lens, int32_t *status, int n_threads)
+{
+    if (!handle || n_texts < 0 || blob_len < 0 || (n_texts > 0 && (!text_blob || !text_off_out || !ragged_ids || !lens || !status)))
+        return tt_fail(TT_ERR_BAD_SHAPE, "tt_tok_encode_sep: n_texts=%lld", (long long)n_texts);
+    if (n_texts == 0)
+        return blob_len == 0 ? TT_OK : tt_fail(TT_ERR_BAD_SHAPE, "tt_tok_encode_sep: %lld bytes for no text", (long long)blob_len);
+    int64_t k = 0;
+    text_off_out[k++] = 0;
+    for (const char *q = text_blob, *end = text_blob + blob_len; q < end;) {
+        const char *hit = (const char *)memchr(q, sep, (size_t)(end - q));
+        if (!hit)
+            break;
+        if (k >= n_texts)
+            return tt_fail(TT_ERR_BAD_SHAPE, "tt_tok_encode_sep: more than %lld separators (a text contains the separator byte)",
+                           (long long)(n_texts - 1));
+        text_off_out[k++] = (int64_t)(hit - text_blob) + 1;
+        q = hit + 1;
+    }
+    if (k != n_texts)
+        return tt_fail(TT_ERR_BAD_SHAPE, "tt_tok_encode_sep: %lld separators for %lld texts", (long long)(k - 1), (long long)n_texts);
+    text_off_out[n_texts] = blob_len + 1; // (as if a separator followed the last text)
+    const TokTable &t = *(const TokTable *)handle;
+    parallel_for(n_texts, n_threads, [&](int64_t lo, int64_t hi) {
+        std::vector<char> lower;
+        lower.reserve(64);
+        for (int64_t i = lo; i < hi; ++i) {
+            const int64_t c = encode_one(t, text_blob + text_off_out[i], (size_t)(text_off_out[i + 1] - 1 - text_off_out[i]),
+                                         ragged_ids + text_off_out[i], lower);
+            status[i] = c < 0 ? 1 : 0;
+            lens[i] = c < 0 ? 0 : (int32_t)c;
+        }
+    });
+    return TT_OK;
+}
+
 TT_EXPORT int tt_tok_pad(const int64_t *ragged_ids, const int64_t *text_off, const int32_t *lens, int64_t n_texts,
                          int64_t width, int64_t *out, int n_threads)
 {

@@ -113,10 +113,37 @@ class PretrainedTokenizer:
         from . import _lib
         L = _lib.lib()
         n = len(texts)
+        nt = n_threads or min(16, len(os.sched_getaffinity(0)))
+        # Fast form (every text a str, all ASCII, none holding a NUL -- the common case): ONE join + encode under the GIL, the
+        # text boundaries are found natively (tt_tok_encode_sep).  What Python does per batch is then ~3 ms for 16k passages, which
+        # is what bounds several producer threads (evaluators.embed_corpus) once the native part is spread over enough cores.
+        fast = None
+        if n:
+            try:
+                blob = "\x00".join(texts).encode("ascii")
+                off = _scratch("off", n + 1, np.int64)
+                ragged = _scratch("ragged", len(blob) + 1, np.int64)   # (a text never has more tokens than bytes)
+                lens = _scratch("lens", n, np.int32)
+                status = _scratch("status", n, np.int32)
+                rc = L.tt_tok_encode_sep(self._native(), blob, len(blob), b"\x00", n, off.ctypes.data, ragged.ctypes.data,
+                                         lens.ctypes.data, status.ctypes.data, nt)
+                if rc == _lib.TT_OK:
+                    fast = (off, ragged, lens)
+                elif rc != _lib.TT_ERR_BAD_SHAPE:   # (BAD_SHAPE: a text contains the separator -- the general form below)
+                    _lib.check(rc)
+            except (TypeError, UnicodeEncodeError):
+                pass
+        if fast is not None:
+            off, ragged, lens = fast
+            width = int(lens[:n].max())
+            t = torch.empty((n, width), dtype=torch.int64, pin_memory=bool(pin) and n * width > 0)
+            if width:
+                _lib.check(L.tt_tok_pad(ragged.ctypes.data, off.ctypes.data, lens.ctypes.data, n, width, t.data_ptr(), nt))
+            return t
         strs = [t if type(t) is str else str(t) for t in texts]
         off = np.zeros(n + 1, dtype=np.int64)
         try:
-            # all-ASCII batch (the common case): ONE encode of the joined text, byte lengths = character lengths
+            # all-ASCII batch: ONE encode of the joined text, byte lengths = character lengths
             blob = "".join(strs).encode("ascii")
             if n:
                 np.cumsum(np.fromiter(map(len, strs), dtype=np.int64, count=n), out=off[1:])
@@ -131,7 +158,6 @@ class PretrainedTokenizer:
         status = _scratch("status", max(n, 1), np.int32)
         lens[:max(n, 1)] = 0
         status[:max(n, 1)] = 0
-        nt = n_threads or min(16, len(os.sched_getaffinity(0)))
         _lib.check(L.tt_tok_encode(self._native(), blob, off.ctypes.data, n, ragged.ctypes.data, lens.ctypes.data,
                                    status.ctypes.data, nt))
         slow = np.flatnonzero(status[:n])
