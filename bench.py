@@ -492,6 +492,25 @@ def encoder_legs(dev):
                      "input checking",
              "TFLOPs": round(tf, 2), "frac_f32_mfma": round(tf / MFMA_F32_PEAK_TFLOPS, 4),
              "frac_f16_mfma_3x": round(3.0 * tf / MFMA_F16_PEAK_TFLOPS, 4)}
+    # the same step as ONE HIP graph launch (trainer.GraphedTrainStep: ids copied into static buffers padded to the next multiple
+    # of 32 columns; same kernels, same failure semantics -- the gate words are read after every replay)
+    r32 = lambda x: (int(x) + 31) // 32 * 32  # noqa: E731
+    try:
+        gstep = tt.GraphedTrainStep(m, opt, batch=B, q_width=r32(q.shape[1]), doc_width=r32(max(p.shape[1], n.shape[1])), margin=0.5)
+        t_g = _time_gpu(lambda: gstep(qd, pd, nd), 5, 2)
+        train["graphed"] = {"ms_per_step": round(t_g * 1e3, 3), "triplets_per_s": round(B / t_g),
+                            "q_width": gstep.q_width, "doc_width": gstep.doc_width,
+                            "frac_f16_mfma_3x": round(3.0 * tok * FLOP_PER_TOKEN_TRAIN / t_g / 1e12 / MFMA_F16_PEAK_TFLOPS, 4)}
+        del gstep
+        lazy = tt.GraphedTrainStep(m, opt, batch=B, q_width=r32(q.shape[1]), doc_width=r32(max(p.shape[1], n.shape[1])), margin=0.5,
+                                   defer_check=True)     # step i's gate words read inside call i + 1
+        t_l = _time_gpu(lambda: lazy(qd, pd, nd), 5, 2)
+        lazy.flush()
+        train["graphed"]["deferred_check_ms_per_step"] = round(t_l * 1e3, 3)
+        train["graphed"]["deferred_check_triplets_per_s"] = round(B / t_l)
+        del lazy
+    except Exception as e:  # noqa: BLE001 -- the eager leg above is the record; say why the graph leg is missing
+        train["graphed"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     del opt
     torch.cuda.empty_cache()
     return enc, train, (table, q, p, n), m

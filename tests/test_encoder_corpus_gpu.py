@@ -55,7 +55,7 @@ def test_screened_search_over_encoder_outputs_is_bit_identical_to_the_oracle(ora
         st = ix.search_stats().cpu().numpy()
         flags = int(ix.fallback_flags.ne(0).sum().item())
         report[nq] = (float(st[:, 0].mean()), int(st[:, 0].max()), float(st[:, 1].mean()), int(st[:, 1].max()), flags)
-        # the proof's capacity limits (screen.hip: POOL_MAX 8192 pooled, SURV_MAX 256 survivors) are not reached, so no
+        # the proof's capacity limits (screen.hip: POOL_MAX 8192 pooled, SURV_MAX 1024 survivors) are not reached, so no
         # 32-query tile had to be recomputed by the exact kernel -- and every query kept at least its k
         assert flags == 0, report
         assert st[:, 1].min() >= 10 and st[:, 1].max() <= 256 and st[:, 0].max() <= 8192, report

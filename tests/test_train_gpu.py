@@ -389,6 +389,71 @@ def test_a_recurrence_time_out_redoes_the_step_on_the_one_workgroup_kernels():
     assert opt.step_count == 2
 
 
+def test_graphed_train_step_replays_the_eager_step_bit_for_bit():
+    """GraphedTrainStep: the whole direct step (two towers on two streams, loss, backwards, gate, clip + Adam with the step
+    number on the device) captured once and replayed.  Three steps with batches of different widths: parameters, moments, loss
+    and step number equal, bit for bit, those of the eager train_step on the same ids padded to the captured widths; a bad
+    batch raises the reference's exception out of the replay and leaves everything untouched; the next batch trains."""
+    import copy
+    import twotowermlretrieval_amd as tt
+    V, E, H, B = 300, 300, 256, 64
+    torch.manual_seed(9)
+    m = tt.TwoTowerModel({"VOCAB_SIZE": V, "EMBED_DIM": E, "HIDDEN_DIM": H}, synth.make_table(4, V, E)).cuda().train()
+    ref = copy.deepcopy(m)
+    opt = tt.FusedClipAdam(m.parameters(), lr=1e-3, max_norm=1.0)
+    ref_opt = tt.FusedClipAdam(ref.parameters(), lr=1e-3, max_norm=1.0)
+    before = opt.flat_params.clone()
+    step = tt.GraphedTrainStep(m, opt, batch=B, q_width=16, doc_width=48, margin=0.5)
+    torch.cuda.synchronize()
+    assert torch.equal(opt.flat_params, before) and opt.step_count == 0     # warm-up and capture ran on all-padding ids: gate closed
+
+    def padded(t, w):
+        out = torch.zeros((t.shape[0], w), dtype=torch.int64, device=t.device)
+        out[:, : t.shape[1]] = t
+        return out
+    for i, widths in enumerate(((7, 20, 25), (16, 48, 31), (3, 9, 48))):
+        ids = [torch.from_numpy(synth.make_ids(200 + 3 * i + s, B, T, V)).cuda() for s, T in enumerate(widths)]
+        loss = step(*ids)
+        ref_loss = tt.train_step(ref, ref_opt, padded(ids[0], 16), padded(ids[1], 48), padded(ids[2], 48), margin=0.5)
+        torch.cuda.synchronize()
+        assert float(loss) == float(ref_loss)
+        assert torch.equal(opt.flat_params, ref_opt.flat_params) and torch.equal(opt.exp_avg_sq, ref_opt.exp_avg_sq)
+        assert opt.step_count == ref_opt.step_count == i + 1
+    # the prepared-weight cache of the eval path follows the replayed updates
+    m.eval(); ref.eval()
+    with torch.no_grad():
+        assert torch.equal(m.encode_query(ids[0]), ref.encode_query(ids[0]))
+    m.train(); ref.train()
+    snap = (opt.flat_params.clone(), opt.exp_avg.clone(), opt.step_count)
+    bad = [t.clone() for t in ids]
+    bad[1][3, 0] = V + 5
+    with pytest.raises(IndexError):
+        step(*bad)
+    torch.cuda.synchronize()
+    assert torch.equal(opt.flat_params, snap[0]) and torch.equal(opt.exp_avg, snap[1]) and opt.step_count == snap[2]
+    with pytest.raises(ValueError):
+        step(ids[0], padded(ids[1], 64), ids[2])                           # wider than the capture
+    loss = step(*ids)
+    ref_loss = tt.train_step(ref, ref_opt, padded(ids[0], 16), padded(ids[1], 48), padded(ids[2], 48), margin=0.5)
+    torch.cuda.synchronize()
+    assert float(loss) == float(ref_loss) and torch.equal(opt.flat_params, ref_opt.flat_params)
+    # defer_check: the gate words of step i are looked at inside call i + 1, after step i + 1 has been enqueued -- the bad
+    # batch's exception comes out one call late, its step was not applied, the step behind it was
+    lazy = tt.GraphedTrainStep(m, opt, batch=B, q_width=16, doc_width=48, margin=0.5, defer_check=True)
+    n0 = opt.step_count
+    lazy(*ids)
+    lazy(*bad)                                  # no exception yet
+    with pytest.raises(IndexError):
+        lazy(*ids)                              # ... here, behind this (good, applied) step
+    lazy.flush()                                # the last step was fine
+    torch.cuda.synchronize()
+    assert opt.step_count == n0 + 2
+    for _ in range(2):
+        ref_loss = tt.train_step(ref, ref_opt, padded(ids[0], 16), padded(ids[1], 48), padded(ids[2], 48), margin=0.5)
+    torch.cuda.synchronize()
+    assert torch.equal(opt.flat_params, ref_opt.flat_params)
+
+
 def test_weight_gradient_kernel_against_the_tiled_one():
     """wgrad16 (256-row output tiles, K-major LDS images, one K slab per workgroup) and the tiled f16-split GEMM it replaced
     (the comparison build with TT_WGRAD_TILED=1) compute dW_ih / dW_hh from the same dGi / dGh with different slab partitions: they

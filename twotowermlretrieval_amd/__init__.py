@@ -7,10 +7,10 @@ from .index import (BruteForceIndex, GraphedSearch, PendingSearch, ShardedIndex,
 from .model import RNNEncoder, TwoTowerModel, triplet_loss_cosine
 from .query_inferencer import QueryInferencer
 from .tokenizer import PretrainedTokenizer
-from .trainer import DataParallelTrainer, FusedClipAdam, train_step
+from .trainer import DataParallelTrainer, FusedClipAdam, GraphedTrainStep, train_step
 
 __all__ = ["BruteForceIndex", "GraphedSearch", "ShardedIndex", "PendingSearch", "StreamedIndex", "score_topk", "topk_merge", "score_rank", "score_all", "shard_bounds",
            "RNNEncoder", "TwoTowerModel", "triplet_loss_cosine", "QueryInferencer", "PretrainedTokenizer",
-           "FusedClipAdam", "DataParallelTrainer", "train_step", "model", "trainer", "tokenizer", "query_inferencer",
+           "FusedClipAdam", "DataParallelTrainer", "train_step", "GraphedTrainStep", "model", "trainer", "tokenizer", "query_inferencer",
            "evaluators", "hybrid", "collective"]
 __version__ = "0.1.0"

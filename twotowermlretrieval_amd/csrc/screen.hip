@@ -60,7 +60,9 @@ constexpr int STILE_BYTES = 32 * 512; // 32 docs x 256 f16
 constexpr int SRING = 8;              // ring depth in tiles
 constexpr int STPB = 2;               // tiles per barrier interval (waves drift freely inside one)
 constexpr int SCAP = 128;             // candidate entries per (workgroup, query)
-constexpr int SURV_MAX = 256;         // survivors per query the finish kernel can rescore
+constexpr int SURV_MAX = 1024;        // survivors per query the finish kernel can rescore (256 until round 4: a cluster of ~200
+                                      // near-duplicates plus a group of exact duplicates overflowed it, and on a clustered
+                                      // corpus the predicated exact kernel then cost more than the screen saved: DESIGN K4s)
 constexpr int POOL_MAX = 8192;        // candidates per query the finish kernel can pool
 constexpr int FIN_MAX_CHUNKS = 2048;  // document chunks per query the finish kernel can pool
 
@@ -996,11 +998,12 @@ __global__ __launch_bounds__(256) void screen_finish_kernel(FinishParams p)
     }
     __syncthreads();
     const int ns = min(n_surv, SURV_MAX);
-    if (tid < ns) {
-        // one thread per survivor: the chain is sequential by definition, but the row's loads are not -- 16 of them
-        // (256 B) are issued back to back before the 64 fmaf that consume them, four batches per row (left to
-        // hipcc the loop waited for one 16-byte load per iteration: ~30 us of a 46 us kernel at k = 50)
-        const float *drow = p.D32 + (size_t)sv_x[tid] * 256;
+    for (int sidx = tid; sidx < ns; sidx += 256) {
+        // one thread per survivor (a second, third, fourth round only beyond 256 of them): the chain is sequential by
+        // definition, but the row's loads are not -- 16 of them (256 B) are issued back to back before the 64 fmaf that
+        // consume them, four batches per row (left to hipcc the loop waited for one 16-byte load per iteration: ~30 us of a
+        // 46 us kernel at k = 50)
+        const float *drow = p.D32 + (size_t)sv_x[sidx] * 256;
         float acc = 0.0f;
 #pragma unroll 1
         for (int x0 = 0; x0 < 256; x0 += 64) {
@@ -1016,7 +1019,7 @@ __global__ __launch_bounds__(256) void screen_finish_kernel(FinishParams p)
                 acc = fmaf(qs[x0 + 4 * i + 3], dv[i].w, acc);
             }
         }
-        sv_v[tid] = acc;
+        sv_v[sidx] = acc;
     }
     if (tid == 0) {
         p.stats[2 * row] = n_pool;
@@ -1026,9 +1029,9 @@ __global__ __launch_bounds__(256) void screen_finish_kernel(FinishParams p)
         atomicOr(p.flag + (row >> 5), 4);
     // ---- exact top-k of the survivors: every thread ranks its own survivor against all others ----
     __syncthreads();
-    if (tid < ns) {
-        const float mv = sv_v[tid];
-        const int mx = sv_x[tid];
+    for (int sidx = tid; sidx < ns; sidx += 256) {
+        const float mv = sv_v[sidx];
+        const int mx = sv_x[sidx];
         int rank = 0;
         for (int u = 0; u < ns; ++u)
             rank += before_f(sv_v[u], sv_x[u], mv, mx) ? 1 : 0;

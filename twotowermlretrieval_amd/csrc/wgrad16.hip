@@ -189,7 +189,14 @@ __global__ __launch_bounds__(512, 1) void wgrad16_kernel(SgemmParams p, int n_nt
     };
     auto commit_b = [&](char *stage, int j, f32x4v v) {
         u2v hi, lo;
+#ifdef TT_WG_EXP_B_PRESPLIT // TIMING EXPERIMENT ONLY (wrong numbers): the 16 loaded bytes taken as 4 hi + 4 lo halves, as if K1 and the
+                            // forward recurrence had left fp16 hi / lo images of X and h -- the same bytes per element, no
+                            // conversion instructions for B: the most VERDICT r03 item 4 could gain in this kernel
+        hi = (u2v){__float_as_uint(v[0]), __float_as_uint(v[1])};
+        lo = (u2v){__float_as_uint(v[2]), __float_as_uint(v[3])};
+#else
         split4(v, bscale[j], hi, lo);
+#endif
         *(u2v *)(stage + b_lds[j]) = hi;
         *(u2v *)(stage + WG_IMG + b_lds[j]) = lo;
     };

@@ -85,7 +85,8 @@ def embed_corpus(model, tokenizer, documents: Sequence[str], device: torch.devic
     n = len(documents)
     if n == 0:
         return torch.empty((0, 0), device=device)
-    cores = len(os.sched_getaffinity(0))
+    from .tokenizer import host_cores
+    cores = host_cores()
     if producers <= 0:
         producers = max(1, min(4, cores // 4))
     nt = max(1, min(16, cores // producers))

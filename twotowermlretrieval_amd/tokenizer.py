@@ -26,6 +26,28 @@ UNK = "<UNK>"
 _SCRATCH = threading.local()
 
 
+def host_cores() -> int:
+    """CPU cores this process may really use: the scheduler affinity, capped by the cgroup's CPU quota (a container on a
+    256-thread host with a 16-core share reports 256 in sched_getaffinity; 64 tokenizer threads on 16 cores thrash)."""
+    import os
+    n = len(os.sched_getaffinity(0))
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]) + 0.5)))
+            else:
+                quota = int(txt[0])
+                period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if quota > 0:
+                    n = min(n, max(1, int(quota / period + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
 def _scratch(name: str, n: int, dtype) -> np.ndarray:
     """A per-thread array of at least n elements that is REUSED from call to call (grown geometrically).  The ragged id
     buffer of one 16k-document batch is ~50 MB; as a fresh np.empty every call it is ~12k first-touch page faults, which cost
@@ -113,7 +135,7 @@ class PretrainedTokenizer:
         from . import _lib
         L = _lib.lib()
         n = len(texts)
-        nt = n_threads or min(16, len(os.sched_getaffinity(0)))
+        nt = n_threads or min(16, host_cores())
         # Fast form (every text a str, all ASCII, none holding a NUL -- the common case): ONE join + encode under the GIL, the
         # text boundaries are found natively (tt_tok_encode_sep).  What Python does per batch is then ~3 ms for 16k passages, which
         # is what bounds several producer threads (evaluators.embed_corpus) once the native part is spread over enough cores.

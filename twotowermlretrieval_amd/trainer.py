@@ -25,7 +25,7 @@ import torch
 from . import _lib
 from .model import TwoTowerModel, deferred_input_checks, triplet_loss_cosine
 
-__all__ = ["FusedClipAdam", "train_step", "DataParallelTrainer"]
+__all__ = ["FusedClipAdam", "train_step", "DataParallelTrainer", "GraphedTrainStep"]
 
 
 def _hip_clip_adam(flat_p, flat_g, m, v, step, lr, betas, eps, max_norm, grad_scale, total_norm, scratch):
@@ -169,6 +169,11 @@ class _FlatClipAdam:
         synchronisation): IndexError / RuntimeError as the reference raises them, model.SplitRecurrenceTimeout for a time-out,
         on every rank alike; parameters, moments and step number are then untouched."""
         self._collect()
+        return self._reduce_apply(self._fold_status(), check)
+
+    def _fold_status(self) -> bool:
+        """The pending status words -> the gate words behind the gradients (one launch, no host read).  Returns whether the step
+        is gated (status words were pending, or there is a process group)."""
         status = list(self._pending_status)
         self._pending_status.clear()  # (in place: the watched encoders hold this list)
         gated = bool(status) or self.world > 1
@@ -176,6 +181,9 @@ class _FlatClipAdam:
             self._gate_fn(status, self.gate)
         elif gated:
             self.gate.zero_()
+        return gated
+
+    def _reduce_apply(self, gated: bool, check: Optional[bool] = None) -> torch.Tensor:
         if self.world > 1:
             self._all_reduce(self._bucket)  # ONE bucket: 3.4 MB of gradients + the gate words
         args = (self.lr, self.betas, self.eps, self.max_norm, 1.0 / self.world, self.total_norm)
@@ -288,14 +296,23 @@ class _towers_in_flight:
         return False
 
 
-def _train_step_direct(model: TwoTowerModel, optimizer, queries, pos_docs, neg_docs, margin: float):
+def _train_step_direct(model: TwoTowerModel, optimizer, queries, pos_docs, neg_docs, margin: float, phase: str = "all",
+                       join_on_caller: bool = False, both: Optional[torch.Tensor] = None):
     """The same step without the autograd engine: tower forwards (train mode), the fused loss + gradient kernel, tower backwards
     written STRAIGHT into the optimizer's flat gradient buffer, optimizer step.  Every parameter receives its gradient exactly
     once (query tower once; positives and negatives as one 2B-row document-tower call), so nothing has to be zeroed or
     accumulated: what the autograd path adds per step -- grad_output plumbing around the loss, four accumulate-adds per
     tower, the 3.4 MB zero fill -- is ~0.1 ms of small launches on the document tower's critical path.  Returns None when the
     shortcut does not apply (another optimizer, a trainable embedding table, parameters without the optimizer's gradient
-    views): the caller then takes the autograd path, which computes the same numbers."""
+    views): the caller then takes the autograd path, which computes the same numbers.
+    phase: "all" = through optimizer.step(); "fold" = up to the gate words behind the gradients (optimizer._fold_status), the
+    caller reduces and applies (GraphedTrainStep with a process group: the all-reduce stays outside the captured graph).
+    join_on_caller: the towers' streams meet on the CALLER's stream (loss and optimizer run there) instead of on the document
+    tower's.  Eagerly that costs two hops per join on the critical path (~20 us each); under stream capture it is free (the hops
+    are graph edges) and it is the only form this ROCm can capture: a side stream that waits for ANOTHER side stream and then
+    goes on makes hipStreamEndCapture crash inside the runtime (tools/experiments/graph_pattern_probe.py: fork / join through
+    the origin stream is fine, side-to-side joins segfault, whatever the kernels).
+    both: the 2B-row document batch [pos_docs; neg_docs] already concatenated (GraphedTrainStep stages it outside the graph)."""
     if not isinstance(optimizer, _FlatClipAdam) or not torch.is_grad_enabled():
         return None
     # the document tower (2B rows of ~70 tokens) is the step's critical path: its launches go out FIRST, the query tower's
@@ -314,15 +331,27 @@ def _train_step_direct(model: TwoTowerModel, optimizer, queries, pos_docs, neg_d
     cur = torch.cuda.current_stream(dev)
     B = queries.shape[0]
     streams = _tower_streams(dev)[:2]
-    if pos_docs.dtype != torch.int64 or neg_docs.dtype != torch.int64:
+    if both is None and (pos_docs.dtype != torch.int64 or neg_docs.dtype != torch.int64):
         return None
     s_doc, s_qry = streams
+    s_main = cur if join_on_caller else s_doc     # where the towers meet: loss, optimizer
+
+    def join():   # s_main waits for both towers
+        s_main.wait_stream(s_qry)
+        if s_main is not s_doc:
+            s_main.wait_stream(s_doc)
+
+    def fork():   # both towers wait for s_main
+        s_qry.wait_stream(s_main)
+        if s_main is not s_doc:
+            s_doc.wait_stream(s_main)
     try:
         s_doc.wait_stream(cur)
-        with torch.cuda.stream(s_doc):  # (on the document tower's own stream: no hop from the caller's)
-            pos_docs.record_stream(s_doc)
-            neg_docs.record_stream(s_doc)
-            both = _concat_ids(pos_docs, neg_docs)
+        if both is None:
+            with torch.cuda.stream(s_doc):  # (on the document tower's own stream: no hop from the caller's)
+                pos_docs.record_stream(s_doc)
+                neg_docs.record_stream(s_doc)
+                both = _concat_ids(pos_docs, neg_docs)
         ids_of = (both, queries)
         # dropout seeds from torch's CPU generator in the order the autograd path draws them (query tower, then document tower)
         seeds = {id(enc): (int(torch.randint(0, 2 ** 62, (1,)).item()) if enc.dropout > 0.0 else 0)
@@ -343,28 +372,28 @@ def _train_step_direct(model: TwoTowerModel, optimizer, queries, pos_docs, neg_d
         pn, q = fw[0][0], fw[1][0]
         p, n = pn[:B], pn[B:]
         H = q.shape[1]
-        s_doc.wait_stream(s_qry)
-        with torch.cuda.stream(s_doc):
+        join()
+        with torch.cuda.stream(s_main):
             loss = torch.empty((), dtype=torch.float32, device=dev)
             dq = torch.empty_like(q)
             dpn = torch.empty_like(pn)
             rows = torch.empty(B, dtype=torch.float32, device=dev)
-            for t in (q, loss, dq, dpn, rows):
-                t.record_stream(s_doc)
+            for t in (q, pn, loss, dq, dpn, rows):
+                t.record_stream(s_main)
             with torch.cuda.device(dev):
                 _lib.check(_lib.lib().tt_triplet_loss_f32(q.data_ptr(), p.data_ptr(), n.data_ptr(), B, H, float(margin), loss.data_ptr(),
                                                           dq.data_ptr(), dpn[:B].data_ptr(), dpn[B:].data_ptr(), rows.data_ptr(),
-                                                          s_doc.cuda_stream))
-        s_qry.wait_stream(s_doc)
+                                                          s_main.cuda_stream))
+        fork()
         for enc, ids, s, f, d_out, grads in zip(encs, ids_of, streams, fw, (dpn, dq), into):
             with torch.cuda.stream(s):
                 d_out.record_stream(s)
                 # (a time-out of the split backward recurrence ORs bit 2 into the forward's word, which the optimizer reads)
                 enc._run_backward(ids.contiguous(), f[1], d_out, f[3], f[4], into=grads, status=f[2], opts=f[5])
-        s_doc.wait_stream(s_qry)
+        join()
         for p_, gv in zip(optimizer.params, optimizer._views):
             p_.grad = gv
-        with torch.cuda.stream(s_doc):
+        with torch.cuda.stream(s_main):
             # The optimizer is enqueued unconditionally: the towers' status words (zero-length rows / ids out of range raise as
             # in the reference; a column-split recurrence that gave up) are folded into the gate behind the gradients, reduced
             # over the ranks with them, and the device applies the step on every rank or on none.  The read of the reduced gate
@@ -372,8 +401,11 @@ def _train_step_direct(model: TwoTowerModel, optimizer, queries, pos_docs, neg_d
             # gradient buffer holds garbage, which the next step overwrites).
             for t in (optimizer.flat_params, optimizer._bucket, optimizer.exp_avg, optimizer.exp_avg_sq, optimizer.total_norm,
                       optimizer._scratch, optimizer._step_dev):
-                t.record_stream(s_doc)
-            optimizer.step()
+                t.record_stream(s_main)
+            if phase == "all":
+                optimizer.step()
+            else:
+                optimizer._fold_status()
     finally:
         # (also when step() raised: the caller's stream joins the towers' streams, nothing of this step is left running
         #  behind the caller's back)
@@ -480,3 +512,135 @@ class DataParallelTrainer:
     def step(self, queries, pos_docs, neg_docs) -> torch.Tensor:
         self.model.train()
         return train_step(self.model, self.optimizer, queries, pos_docs, neg_docs, self.margin)
+
+
+def _stage_ids(out: torch.Tensor, a: torch.Tensor, b: Optional[torch.Tensor] = None) -> None:
+    """out [Ba + Bb, T] <- rows of a, then rows of b, zero-padded to out's width: ONE launch (tt_concat_ids_i64) on the current
+    stream, into an existing buffer (GraphedTrainStep's static inputs)."""
+    a = a.contiguous()
+    b = b.contiguous() if b is not None else None
+    with torch.cuda.device(out.device):
+        _lib.check(_lib.lib().tt_concat_ids_i64(a.data_ptr(), a.shape[0], a.shape[1], b.data_ptr() if b is not None else None,
+                                                b.shape[0] if b is not None else 0, b.shape[1] if b is not None else 0,
+                                                out.data_ptr(), out.shape[1], torch.cuda.current_stream(out.device).cuda_stream))
+
+
+class GraphedTrainStep:
+    """The direct train step of ONE batch shape captured in a HIP graph and replayed: the ~40 launches of a step (two towers on
+    two streams, loss, two backwards, gate, clip + Adam) become one graph launch, so the host is out of the step's way -- what
+    is left per step is two staging launches (the batch's ids into static buffers, zero-padded), one hipGraphLaunch and the read
+    of the gate words (the eager step leaves the GPU idle for ~0.1 ms per step while the host enqueues the next step's launches
+    behind its one synchronisation).  Possible because nothing in the captured launches changes from step to step: the step number
+    and the bias corrections live on the device (tt_clip_adam_step_gated_f32), the failure decision is a device predicate (the
+    gate), and every library call is capture-clean (no allocation, no synchronisation, kernels instead of memsets: include/tt.h).
+
+        step = GraphedTrainStep(model, optimizer, batch=512, q_width=32, doc_width=128, margin=0.5)
+        loss = step(queries, pos_docs, neg_docs)      # ids [batch, <= width]
+
+    Padding columns of id 0 change nothing (lengths are counts of non-zero ids, backend/model.py:52): results are bit-identical
+    to train_step on ids padded to the same widths (the launch geometry -- slab partitions of the weight-gradient products --
+    follows the padded width, so against the UNPADDED eager step the last bits of a gradient sum may differ).
+    Failure semantics are train_step's: the reduced gate is read after the replay (the step's one synchronisation) and the
+    reference's exceptions are raised, on every rank, with the weights untouched; a recurrence time-out redoes the step eagerly
+    on the one-workgroup kernels.  defer_check=True moves that read one step back: step i's gate words are copied to pinned host
+    memory behind its replay and looked at inside call i + 1, AFTER step i + 1 has been enqueued -- the GPU never waits for the
+    host, and a bad batch's exception comes out of the NEXT call (or of flush()); its step was not applied, the following one
+    (already enqueued) is an ordinary step on the same weights.  With a process group the graph ends at the gate words and the
+    all-reduce + clip + Adam are issued eagerly behind it (RCCL inside a capture is not rehearsable here).  Needs: the
+    optimizer's own parameters on a GPU, GloVe-frozen tables, no inter-layer dropout (its seeds come from the host's generator),
+    input checking on (default)."""
+
+    def __init__(self, model: TwoTowerModel, optimizer: FusedClipAdam, batch: int, q_width: int, doc_width: int, margin: float = 0.2,
+                 defer_check: bool = False):
+        encs = (model.query_encoder, model.doc_encoder)
+        if not isinstance(optimizer, _FlatClipAdam) or optimizer._gated_step_fn is None:
+            raise TypeError("GraphedTrainStep needs a FusedClipAdam")
+        if any(e.dropout > 0.0 for e in encs):
+            raise ValueError("GraphedTrainStep: inter-layer dropout draws its seeds on the host every step; use train_step")
+        if not all(e.check_inputs for e in encs):
+            raise ValueError("GraphedTrainStep: input checking must be on (the gate is what keeps a bad batch from being applied)")
+        self.model, self.optimizer, self.margin = model, optimizer, float(margin)
+        self.B, self.q_width, self.doc_width = int(batch), int(q_width), int(doc_width)
+        self.defer_check = bool(defer_check)
+        dev = optimizer.flat_params.device
+        self.q = torch.zeros((self.B, self.q_width), dtype=torch.int64, device=dev)
+        self.both = torch.zeros((2 * self.B, self.doc_width), dtype=torch.int64, device=dev)
+        self._gate_host = [torch.zeros(optimizer.GATE, dtype=torch.float32).pin_memory() for _ in range(2)]
+        self._gate_ev = [torch.cuda.Event() for _ in range(2)]
+        self._pending = None     # deferred check: (slot, the batch it belongs to)
+        self._n = 0
+        self._phase = "all" if optimizer.world == 1 else "fold"
+        model.train()
+        keep_check, optimizer.check = optimizer.check, False        # (no host read inside a capture)
+        try:
+            # the static buffers hold id 0 only: every row is a zero-length row, the gate closes and neither the warm-up run nor
+            # anything else before the first real batch touches the weights
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                for _ in range(2):                                   # allocator pools, kernel attributes, lazy handles
+                    if self._run() is None:
+                        raise ValueError("GraphedTrainStep: the model / optimizer pair does not take the direct step "
+                                         "(trainer._train_step_direct)")
+                    if self._phase == "fold":
+                        optimizer.gate.zero_()
+            torch.cuda.current_stream(dev).wait_stream(side)
+            torch.cuda.synchronize(dev)
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.loss = self._run()
+        finally:
+            optimizer.check = keep_check
+            optimizer._pending_status.clear()
+
+    def _run(self):
+        rows = {self.model.query_encoder: self.B, self.model.doc_encoder: 2 * self.B}
+        with _towers_in_flight(self.model, self.optimizer, rows):
+            return _train_step_direct(self.model, self.optimizer, self.q, None, None, self.margin, phase=self._phase,
+                                      join_on_caller=True, both=self.both)
+
+    def _settle(self, pending):
+        """Look at a finished step's gate words (pinned copy) and raise what train_step would have raised for it."""
+        from .model import SplitRecurrenceTimeout
+        slot, batch = pending
+        self._gate_ev[slot].synchronize()
+        try:
+            self.optimizer.raise_for_gate(self._gate_host[slot].tolist())
+        except SplitRecurrenceTimeout:
+            return train_step(self.model, self.optimizer, *batch, self.margin)   # (eager; it takes the one-workgroup retry itself if it must)
+        return None
+
+    def flush(self) -> None:
+        """defer_check: settle the last step (raises its exception, if any)."""
+        pending, self._pending = self._pending, None
+        if pending is not None:
+            self._settle(pending)
+
+    def __call__(self, queries: torch.Tensor, pos_docs: torch.Tensor, neg_docs: torch.Tensor) -> torch.Tensor:
+        """Returns the step's loss (a static 0-d device tensor, valid until the next call)."""
+        for src, width, what in ((queries, self.q_width, "queries"), (pos_docs, self.doc_width, "pos_docs"), (neg_docs, self.doc_width, "neg_docs")):
+            if src.dim() != 2 or src.shape[0] != self.B or src.shape[1] > width or src.dtype != torch.int64:
+                raise ValueError(f"GraphedTrainStep was captured for int64 {what} [{self.B}, <= {width}], got {src.dtype} {tuple(src.shape)}")
+        opt = self.optimizer
+        _stage_ids(self.q, queries)
+        _stage_ids(self.both, pos_docs, neg_docs)
+        self.graph.replay()
+        if self._phase == "fold":
+            opt._reduce_apply(True, check=False)
+        opt.mark_params_changed()
+        if not opt.check:
+            return self.loss
+        slot = self._n & 1
+        self._n += 1
+        self._gate_host[slot].copy_(opt.gate, non_blocking=True)
+        self._gate_ev[slot].record(torch.cuda.current_stream(opt.gate.device))
+        mine = (slot, (queries, pos_docs, neg_docs))
+        if self.defer_check:
+            pending, self._pending = self._pending, mine
+            if pending is not None:
+                self._settle(pending)        # the PREVIOUS step's words: this step is already enqueued behind it
+        else:
+            redone = self._settle(mine)      # the step's one host synchronisation
+            if redone is not None:
+                return redone
+        return self.loss
