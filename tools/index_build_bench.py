@@ -28,6 +28,13 @@ table = (np.random.RandomState(1).standard_normal((tok.vocab_size(), E)) * 0.3).
 m = tt.TwoTowerModel({"HIDDEN_DIM": H, "VOCAB_SIZE": tok.vocab_size(), "EMBED_DIM": E}, table).to(dev).eval()
 embed_corpus(m, tok, docs[:20000], dev)
 torch.cuda.synchronize()
-t = time.time(); emb = embed_corpus(m, tok, docs, dev); torch.cuda.synchronize(); dt = time.time() - t
-print(json.dumps(dict(what="pipelined index build from strings", docs=n_docs, tokens=n_tok, s=round(dt, 3), docs_per_s=round(n_docs / dt),
-                      tok_per_s=round(n_tok / dt), shape=list(emb.shape))), flush=True)
+from twotowermlretrieval_amd.tokenizer import host_cores
+for prod in (0, 1, 2, 4):
+    st = {}
+    embed_corpus(m, tok, docs[:65536], dev, producers=prod)
+    torch.cuda.synchronize()
+    t = time.time(); emb = embed_corpus(m, tok, docs, dev, producers=prod, stats=st); torch.cuda.synchronize(); dt = time.time() - t
+    print(json.dumps(dict(what="pipelined index build from strings", producers_arg=prod, **st, docs=n_docs, tokens=n_tok, s=round(dt, 3),
+                          docs_per_s=round(n_docs / dt), tok_per_s=round(n_tok / dt), shape=list(emb.shape))), flush=True)
+print(json.dumps(dict(host_cores=host_cores(), affinity=len(__import__("os").sched_getaffinity(0)),
+                      cpu_max=open("/sys/fs/cgroup/cpu.max").read().strip() if __import__("os").path.exists("/sys/fs/cgroup/cpu.max") else None)))

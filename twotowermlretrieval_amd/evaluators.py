@@ -76,9 +76,10 @@ def embed_corpus(model, tokenizer, documents: Sequence[str], device: torch.devic
     order they finish in; ids cross PCIe with a non-blocking copy on a side stream; embeddings land in one preallocated
     [N, H] matrix.  Rows are independent, so neither the batch size nor the number of producers changes the result.
 
-    producers = 0: as many as the host's share allows, at most 4 -- ONE front-end thread tokenises ~80-115 M tokens/s and the
-    document tower takes ~240 M tokens/s, so a single producer (round 1-3) left the build host-bound by ~2x.  The native calls
-    split each batch over cores / producers threads.  stats (optional dict): receives what the build used."""
+    producers = 0: one per 16 cores of the host's share (cgroup quota respected), at most 4.  Round 1-3 ran ONE producer
+    that allocated a fresh pinned tensor per batch and tokenised through a four-array hash table: 93-115 M tokens/s against the
+    document tower's ~240 M.  With the staging ring below, the single-pass tokenizer and one join per batch the same single
+    producer feeds 234 M tokens/s on a 16-core share.  stats (optional dict): receives what the build used."""
     import collections
     import os
     from concurrent.futures import ThreadPoolExecutor
@@ -88,15 +89,30 @@ def embed_corpus(model, tokenizer, documents: Sequence[str], device: torch.devic
     from .tokenizer import host_cores
     cores = host_cores()
     if producers <= 0:
-        producers = max(1, min(4, cores // 4))
+        # every producer splits its batches over 16 native threads; a second producer only pays with cores to spare -- the
+        # Python part of a batch (one join + encode) holds the GIL, and producers that share cores mostly trade it back and forth
+        # (16-core share: 1 x 16 threads 3.35 M docs/s, 2 x 8 3.03 M, 4 x 4 2.6 M: profiles/r04_i_index_build.log)
+        producers = max(1, min(4, cores // 16))
     nt = max(1, min(16, cores // producers))
     starts = list(range(0, n, batch_size))
     window = producers + max(1, prefetch)          # batches tokenised or being tokenised ahead of the GPU
     if stats is not None:
         stats.update(producers=producers, threads_per_producer=nt, host_cores=cores, batch_size=batch_size)
 
+    # a ring of pinned staging buffers, kept across calls: page-locking a fresh 15-30 MB block per batch (what a pinned
+    # torch.empty does whenever the host allocator has no free block of that size) costs more than tokenising the batch
+    import queue
+    cap = batch_size * 160                      # int64 ids: ~21 MB per buffer at the default batch size
+    ring = _PINNED_RINGS.setdefault((str(device), cap), [])
+    while len(ring) < window + 3:
+        ring.append(torch.empty(cap, dtype=torch.int64, pin_memory=True))
+    free: "queue.SimpleQueue" = queue.SimpleQueue()
+    for buf in ring[:window + 3]:
+        free.put(buf)
+
     def make(i):
-        return tokenizer.encode_batch(documents[i:i + batch_size], pin=True, n_threads=nt)
+        buf = free.get()                        # (at most `window` jobs are outstanding and 3 batches in flight behind them)
+        return tokenizer.encode_batch(documents[i:i + batch_size], pin=True, n_threads=nt, out=buf), buf
 
     inflight = collections.deque()
     copy_stream = torch.cuda.Stream(device=device)
@@ -111,7 +127,7 @@ def embed_corpus(model, tokenizer, documents: Sequence[str], device: torch.devic
                 nxt += 1
             while pending:
                 i, fut = pending.popleft()
-                ids_host = fut.result()              # (re-raises a producer's exception here)
+                ids_host, buf = fut.result()         # (re-raises a producer's exception here)
                 if nxt < len(starts):
                     pending.append((starts[nxt], pool.submit(make, starts[nxt])))
                     nxt += 1
@@ -126,15 +142,20 @@ def embed_corpus(model, tokenizer, documents: Sequence[str], device: torch.devic
                 # a pinned batch must outlive its async copy; keep two batches in flight so the GPU never waits for the host
                 ev = torch.cuda.Event()
                 ev.record(cur)
-                inflight.append((ids_host, ev))
+                inflight.append((ids_host, ev, buf))
                 if len(inflight) > 2:
-                    inflight.popleft()[1].synchronize()
+                    done = inflight.popleft()
+                    done[1].synchronize()
+                    free.put(done[2])
         finally:
             for _, fut in pending:
                 fut.cancel()
     while inflight:
         inflight.popleft()[1].synchronize()
     return res
+
+
+_PINNED_RINGS: Dict = {}
 
 
 def corpus_recall_hit(query_emb: torch.Tensor, doc_embeddings: torch.Tensor, positives: Sequence[int],

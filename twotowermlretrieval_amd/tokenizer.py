@@ -119,9 +119,12 @@ class PretrainedTokenizer:
             except Exception:  # noqa: BLE001  (interpreter shutdown)
                 pass
 
-    def encode_batch(self, texts: Sequence, pin: bool = False, native: bool = True, n_threads: int = 0):
+    def encode_batch(self, texts: Sequence, pin: bool = False, native: bool = True, n_threads: int = 0, out=None):
         """texts -> right-padded int64 tensor [B, max_len] (at least one column when B > 0 ... zero columns for
-        all-empty batches, like pad_sequence)."""
+        all-empty batches, like pad_sequence).
+        out: a 1-D int64 tensor (typically pinned, reused by the caller: evaluators.embed_corpus keeps a ring of them) that
+        receives the batch when it is large enough; the result is then a view of it.  A fresh pinned tensor per batch costs a
+        page-locking allocation whenever the host allocator has no free block of that size."""
         import torch
         if not native:
             rows = [self.encode(t) for t in texts]
@@ -158,7 +161,10 @@ class PretrainedTokenizer:
         if fast is not None:
             off, ragged, lens = fast
             width = int(lens[:n].max())
-            t = torch.empty((n, width), dtype=torch.int64, pin_memory=bool(pin) and n * width > 0)
+            if out is not None and out.numel() >= n * width and out.dtype == torch.int64 and out.dim() == 1:
+                t = out[:n * width].view(n, width)
+            else:
+                t = torch.empty((n, width), dtype=torch.int64, pin_memory=bool(pin) and n * width > 0)
             if width:
                 _lib.check(L.tt_tok_pad(ragged.ctypes.data, off.ctypes.data, lens.ctypes.data, n, width, t.data_ptr(), nt))
             return t
