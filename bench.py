@@ -492,6 +492,11 @@ def encoder_legs(dev):
                      "input checking",
              "TFLOPs": round(tf, 2), "frac_f32_mfma": round(tf / MFMA_F32_PEAK_TFLOPS, 4),
              "frac_f16_mfma_3x": round(3.0 * tf / MFMA_F16_PEAK_TFLOPS, 4)}
+    # the eager step with the gate read one call late (no host synchronisation inside a step)
+    t_d = _time_gpu(lambda: tt.train_step(m, opt, qd, pd, nd, margin=0.5, defer_check=True), 5, 2)
+    opt.settle()
+    train["deferred_check_ms_per_step"] = round(t_d * 1e3, 3)
+    train["deferred_check_triplets_per_s"] = round(B / t_d)
     # the same step as ONE HIP graph launch (trainer.GraphedTrainStep: ids copied into static buffers padded to the next multiple
     # of 32 columns; same kernels, same failure semantics -- the gate words are read after every replay)
     r32 = lambda x: (int(x) + 31) // 32 * 32  # noqa: E731

@@ -270,6 +270,21 @@ def _bad_rank_worker(rank, world, port, tmp):
     assert all(np.array_equal(a, b) for a, b in zip(before[:3], after[:3])) and before[3] == after[3]
     l2 = tr.step(*mine(ids))                 # and a good batch trains as if nothing had happened
     torch.cuda.synchronize()
+    # the same through HIP graphs (GraphedTrainStep with a process group: the graph ends at the gate words, the all-reduce and the
+    # predicated optimizer follow eagerly): a good step, then rank 1's bad batch fails the step on both ranks
+    tr.graphs = True
+    tr.step(*mine(ids))
+    torch.cuda.synchronize()
+    g_before = snap()
+    try:
+        tr.step(*mine(cases[0]))
+        log.append("ok")
+    except IndexError:
+        log.append("IndexError")
+    torch.cuda.synchronize()
+    g_after = snap()
+    assert all(np.array_equal(a, b) for a, b in zip(g_before[:3], g_after[:3])) and g_before[3] == g_after[3] == 3
+    tr.graphs = False
     res["log"] = np.array(log)
     res["params"], res["m"], res["v"] = snap()[:3]
     res["steps"] = np.array(opt.step_count)
@@ -288,11 +303,11 @@ def test_a_bad_batch_on_one_rank_fails_the_step_on_both(tmp_path):
     and untouched, and the next good step trains -- identically to a two-rank run that never saw the bad batches."""
     mp.spawn(_bad_rank_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
     r0, r1 = np.load(tmp_path / "bad0.npz"), np.load(tmp_path / "bad1.npz")
-    want = ["IndexError", "RuntimeError", "IndexError", "IndexError"]
+    want = ["IndexError", "RuntimeError", "IndexError", "IndexError", "IndexError"]
     assert list(r0["log"]) == want and list(r1["log"]) == want
     for k in ("params", "m", "v"):
         assert np.array_equal(r0[k], r1[k]), k
-    assert int(r0["steps"]) == int(r1["steps"]) == 2
+    assert int(r0["steps"]) == int(r1["steps"]) == 3
     # one process on the concatenated batches, two good steps: the same trajectory up to the reduction order
     import twotowermlretrieval_amd as tt
     V, E, H, B = 300, 300, 256, 32
@@ -300,7 +315,7 @@ def test_a_bad_batch_on_one_rank_fails_the_step_on_both(tmp_path):
     m = tt.TwoTowerModel({"VOCAB_SIZE": V, "EMBED_DIM": E, "HIDDEN_DIM": H}, synth.make_table(4, V, E)).cuda().train()
     opt = tt.FusedClipAdam(m.parameters(), lr=1e-3, max_norm=1.0)
     ids = [torch.from_numpy(synth.make_ids(70 + s, 2 * B, T, V)).cuda() for s, T in enumerate((7, 20, 25))]
-    for _ in range(2):
+    for _ in range(3):
         loss = tt.train_step(m, opt, *ids, margin=0.5)
     torch.cuda.synchronize()
-    np.testing.assert_allclose(opt.flat_params.detach().cpu().numpy(), r0["params"], rtol=0, atol=5e-6)
+    np.testing.assert_allclose(opt.flat_params.detach().cpu().numpy(), r0["params"], rtol=0, atol=1e-5)

@@ -339,6 +339,34 @@ def test_a_bad_batch_raises_and_leaves_the_weights_untouched():
     assert float(l1) == float(l2) and torch.equal(opt.flat_params, ref_opt.flat_params)
 
 
+def test_deferred_check_raises_one_call_late_and_skips_only_the_bad_step():
+    """train_step(defer_check=True): the gate words of step i are copied to pinned memory behind the step and read inside call
+    i + 1, after step i + 1 has been enqueued -- no host synchronisation inside a step.  The device already decided that the bad
+    step is not applied; its exception comes out of the next call (or of optimizer.settle()), and the trajectory is the eager
+    one without the bad batch, bit for bit."""
+    import copy
+    import twotowermlretrieval_amd as tt
+    V, E, H, B = 300, 300, 256, 32
+    torch.manual_seed(3)
+    m = tt.TwoTowerModel({"VOCAB_SIZE": V, "EMBED_DIM": E, "HIDDEN_DIM": H}, synth.make_table(4, V, E)).cuda().train()
+    ref = copy.deepcopy(m)
+    opt = tt.FusedClipAdam(m.parameters(), lr=1e-3, max_norm=1.0)
+    ref_opt = tt.FusedClipAdam(ref.parameters(), lr=1e-3, max_norm=1.0)
+    good = [[torch.from_numpy(synth.make_ids(400 + 3 * i + s, B, T, V)).cuda() for s, T in enumerate((7, 20, 25))] for i in range(3)]
+    bad = [t.clone() for t in good[0]]
+    bad[2][1, 3] = -1
+    tt.train_step(m, opt, *good[0], margin=0.5, defer_check=True)
+    tt.train_step(m, opt, *bad, margin=0.5, defer_check=True)              # nothing raised yet
+    with pytest.raises(IndexError):
+        tt.train_step(m, opt, *good[1], margin=0.5, defer_check=True)      # the bad step's exception, behind this good step
+    tt.train_step(m, opt, *good[2], margin=0.5, defer_check=True)
+    assert opt.settle() is None                                             # the last step was fine
+    for g in good:
+        tt.train_step(ref, ref_opt, *g, margin=0.5)
+    torch.cuda.synchronize()
+    assert opt.step_count == 3 and torch.equal(opt.flat_params, ref_opt.flat_params) and torch.equal(opt.exp_avg_sq, ref_opt.exp_avg_sq)
+
+
 def test_a_recurrence_time_out_redoes_the_step_on_the_one_workgroup_kernels():
     """Status bit 2 (a column-split recurrence gave up waiting for a partner workgroup: CUs held by other work) is transient and
     rank-local.  It reaches the optimizer like the data errors -- through the gate behind the gradients, so every rank sees it --
@@ -452,6 +480,35 @@ def test_graphed_train_step_replays_the_eager_step_bit_for_bit():
         ref_loss = tt.train_step(ref, ref_opt, padded(ids[0], 16), padded(ids[1], 48), padded(ids[2], 48), margin=0.5)
     torch.cuda.synchronize()
     assert torch.equal(opt.flat_params, ref_opt.flat_params)
+
+
+def test_trainer_with_graphs_buckets_the_widths_and_equals_the_eager_trainer():
+    """DataParallelTrainer(graphs=True): one HIP graph per (batch, query width, document width) bucket of 32 columns, least
+    recently used evicted; every step equals, bit for bit, the eager trainer's step on ids padded to the bucket's widths."""
+    import copy
+    import twotowermlretrieval_amd as tt
+    V, E, H, B = 300, 300, 256, 32
+    torch.manual_seed(13)
+    m = tt.TwoTowerModel({"VOCAB_SIZE": V, "EMBED_DIM": E, "HIDDEN_DIM": H}, synth.make_table(4, V, E)).cuda()
+    ref = copy.deepcopy(m)
+    tr = tt.DataParallelTrainer(m, lr=1e-3, margin=0.5, graphs=True, max_graphs=2)
+    tr_ref = tt.DataParallelTrainer(ref, lr=1e-3, margin=0.5)
+
+    def padded(t, w):
+        out = torch.zeros((t.shape[0], w), dtype=torch.int64, device=t.device)
+        out[:, : t.shape[1]] = t
+        return out
+    seen = []
+    for i, widths in enumerate(((7, 20, 25), (9, 40, 33), (5, 30, 64), (7, 70, 20), (6, 31, 12))):
+        ids = [torch.from_numpy(synth.make_ids(300 + 3 * i + s, B, T, V)).cuda() for s, T in enumerate(widths)]
+        wq, wd = 32, -(-max(widths[1:]) // 32) * 32
+        loss = tr.step(*ids)
+        ref_loss = tr_ref.step(padded(ids[0], wq), padded(ids[1], wd), padded(ids[2], wd))
+        torch.cuda.synchronize()
+        assert float(loss) == float(ref_loss) and torch.equal(tr.optimizer.flat_params, tr_ref.optimizer.flat_params), i
+        seen.append((B, wq, wd))
+        assert list(tr._graphs)[-1] == (B, wq, wd) and len(tr._graphs) <= 2
+    assert len(set(seen)) == 3 and tr.optimizer.step_count == 5
 
 
 def test_weight_gradient_kernel_against_the_tiled_one():

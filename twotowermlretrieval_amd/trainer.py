@@ -106,6 +106,7 @@ class _FlatClipAdam:
         self._step_dev = torch.zeros(1, dtype=torch.int64, device=dev)  # steps applied (the gated kernel counts on the device)
         self._step_host = 0
         self._pending_status: list = []  # status words of the watched encoders' training calls since the last step()
+        self._gate_host, self._gate_ev, self._gate_n, self._deferred = None, None, 0, None   # (snapshot_gate / settle)
         self.check = True                # step() reads the reduced gate (one host synchronisation) and raises
         self._views = []
         off = 0
@@ -206,6 +207,41 @@ class _FlatClipAdam:
     def raise_for_gate(words) -> None:
         from .model import _raise_status
         _raise_status(sum(1 << b for b in range(3) if words[b] != 0))
+
+    # ---- the gate read, one step late (train_step(defer_check=True), GraphedTrainStep(defer_check=True)) --------------------
+    def snapshot_gate(self, redo: Optional[Callable] = None) -> None:
+        """Copy the (reduced) gate words of the step just enqueued to pinned host memory, asynchronously on the current stream, and
+        make them THE pending check of this optimizer; the previous pending check -- whose step has long finished -- is settled
+        first (it raises here, one call late).  redo: called instead of raising when the words say "recurrence time-out"."""
+        self.settle()
+        if self._gate_host is None:
+            self._gate_host = [torch.zeros(self.GATE, dtype=torch.float32).pin_memory() if self.gate.is_cuda
+                               else torch.zeros(self.GATE, dtype=torch.float32) for _ in range(2)]
+            self._gate_ev = [torch.cuda.Event() if self.gate.is_cuda else None for _ in range(2)]
+        slot = self._gate_n & 1
+        self._gate_n += 1
+        self._gate_host[slot].copy_(self.gate, non_blocking=True)
+        if self._gate_ev[slot] is not None:
+            self._gate_ev[slot].record(torch.cuda.current_stream(self.gate.device))
+        self._deferred = (slot, redo)
+
+    def settle(self):
+        """Look at the pending check, if any: raises what its step would have raised (IndexError / RuntimeError), or returns
+        redo()'s result after a recurrence time-out, or None."""
+        from .model import SplitRecurrenceTimeout
+        pending, self._deferred = self._deferred, None
+        if pending is None:
+            return None
+        slot, redo = pending
+        if self._gate_ev[slot] is not None:
+            self._gate_ev[slot].synchronize()
+        try:
+            self.raise_for_gate(self._gate_host[slot].tolist())
+        except SplitRecurrenceTimeout:
+            if redo is None:
+                raise
+            return redo()
+        return None
 
     def mark_params_changed(self) -> None:
         """Call after ANY write to `flat_params` that did not go through the parameters themselves (this class's own step,
@@ -466,7 +502,8 @@ def _train_step_once(model, optimizer, queries, pos_docs, neg_docs, margin, conc
 
 
 def train_step(model: TwoTowerModel, optimizer: FusedClipAdam, queries: torch.Tensor, pos_docs: torch.Tensor,
-               neg_docs: torch.Tensor, margin: float = 0.2, concurrent_towers: bool = True, direct: bool = True) -> torch.Tensor:
+               neg_docs: torch.Tensor, margin: float = 0.2, concurrent_towers: bool = True, direct: bool = True,
+               defer_check: bool = False) -> torch.Tensor:
     """One step of backend/main.py:244-259 on this rank's (equal-sized) share of the global batch.
     Returns the local loss as a 0-d device tensor (no .item(): the reference's per-step sync is dropped).
 
@@ -477,8 +514,23 @@ def train_step(model: TwoTowerModel, optimizer: FusedClipAdam, queries: torch.Te
     Failure is collective (FusedClipAdam): a zero-length row or an id out of range on ANY rank raises the reference's
     exception on EVERY rank, inside this call, with parameters, moments and step number untouched everywhere.  A time-out of a
     column-split recurrence (transient: CUs held by other work) does not raise: all ranks see it in the same reduced gate and
-    redo the step on the one-workgroup kernels (ordinary relaunch, same bits as the split forward)."""
+    redo the step on the one-workgroup kernels (ordinary relaunch, same bits as the split forward).
+
+    defer_check (FusedClipAdam only): the step's one host synchronisation -- the read of the reduced gate words -- moves one call
+    back: the words are copied to pinned memory behind the step and looked at inside the NEXT call (or optimizer.settle()), after
+    that step has been enqueued, so the host runs ahead of the GPU and the ~0.1 ms the GPU idles per step while the host
+    enqueues the next 40 launches is gone.  A bad batch's exception then comes out one call late; its step was not applied
+    (the device decided that), the step behind it is an ordinary step on the same weights."""
     from .model import SplitRecurrenceTimeout
+    if defer_check and isinstance(optimizer, _FlatClipAdam) and queries.is_cuda:
+        keep, optimizer.check = optimizer.check, False
+        try:
+            loss = train_step(model, optimizer, queries, pos_docs, neg_docs, margin, concurrent_towers, direct)
+        finally:
+            optimizer.check = keep
+        if keep:
+            optimizer.snapshot_gate(redo=lambda: train_step(model, optimizer, queries, pos_docs, neg_docs, margin, concurrent_towers, direct))
+        return loss
     encs = (model.query_encoder, model.doc_encoder)
     n_doc = pos_docs.shape[0] + neg_docs.shape[0] if (concurrent_towers and neg_docs.shape[0] == pos_docs.shape[0]) else max(
         pos_docs.shape[0], neg_docs.shape[0])
@@ -495,13 +547,22 @@ def train_step(model: TwoTowerModel, optimizer: FusedClipAdam, queries: torch.Te
 
 
 class DataParallelTrainer:
-    """Replicated model, per-rank batch shard, gradient all-reduce (with the step's failure gate) inside FusedClipAdam.step()."""
+    """Replicated model, per-rank batch shard, gradient all-reduce (with the step's failure gate) inside FusedClipAdam.step().
 
-    def __init__(self, model: TwoTowerModel, lr: float = 1e-4, margin: float = 0.2, max_norm: float = 1.0, group=None):
+    graphs=True: steps are replayed from HIP graphs (GraphedTrainStep), one per (batch, query width, document width) bucket --
+    widths rounded up to `width_step` columns, the `max_graphs` most recently used buckets kept (a graph owns its workspaces:
+    ~0.3 GB at 512 triplets x 128 columns).  A batch that does not fit the rules of GraphedTrainStep (dropout, unchecked inputs,
+    non-int64 ids) takes the eager train_step; results are the eager step's on ids padded to the bucket's widths.
+    defer_check: see GraphedTrainStep (exceptions one call late; call flush() after the last step)."""
+
+    def __init__(self, model: TwoTowerModel, lr: float = 1e-4, margin: float = 0.2, max_norm: float = 1.0, group=None,
+                 graphs: bool = False, width_step: int = 32, max_graphs: int = 4, defer_check: bool = False):
         self.model = model
         self.margin = margin
         self.optimizer = FusedClipAdam(model.parameters(), lr=lr, max_norm=max_norm, group=group)
         self.optimizer.watch(model)  # (a hand-written loop over self.model / self.optimizer fails collectively too)
+        self.graphs, self.width_step, self.max_graphs, self.defer_check = bool(graphs), int(width_step), int(max_graphs), bool(defer_check)
+        self._graphs: "dict" = {}
 
     def broadcast_parameters(self, src: int = 0) -> None:
         import torch.distributed as dist
@@ -509,9 +570,33 @@ class DataParallelTrainer:
             dist.broadcast(self.optimizer.flat_params, src=src, group=self.optimizer.group)
         self.optimizer.mark_params_changed()  # (the broadcast wrote the flat buffer, not the parameter tensors)
 
+    def _graph_for(self, queries, pos_docs, neg_docs) -> Optional["GraphedTrainStep"]:
+        encs = (self.model.query_encoder, self.model.doc_encoder)
+        if not (queries.is_cuda and queries.dtype == pos_docs.dtype == neg_docs.dtype == torch.int64
+                and queries.shape[0] == pos_docs.shape[0] == neg_docs.shape[0]
+                and all(e.check_inputs and e.dropout == 0.0 and not e.embedding.weight.requires_grad for e in encs)):
+            return None
+        up = lambda x: max(self.width_step, -(-int(x) // self.width_step) * self.width_step)  # noqa: E731
+        key = (queries.shape[0], up(queries.shape[1]), up(max(pos_docs.shape[1], neg_docs.shape[1])))
+        g = self._graphs.pop(key, None)
+        if g is None:
+            while len(self._graphs) >= self.max_graphs:           # least recently used first
+                self._graphs.pop(next(iter(self._graphs)))
+            g = GraphedTrainStep(self.model, self.optimizer, key[0], key[1], key[2], self.margin, defer_check=self.defer_check)
+        self._graphs[key] = g                                      # (re-inserted: most recently used last)
+        return g
+
+    def flush(self):
+        """defer_check: settle the last step's pending check."""
+        return self.optimizer.settle()
+
     def step(self, queries, pos_docs, neg_docs) -> torch.Tensor:
         self.model.train()
-        return train_step(self.model, self.optimizer, queries, pos_docs, neg_docs, self.margin)
+        if self.graphs:
+            g = self._graph_for(queries, pos_docs, neg_docs)
+            if g is not None:
+                return g(queries, pos_docs, neg_docs)
+        return train_step(self.model, self.optimizer, queries, pos_docs, neg_docs, self.margin, defer_check=self.defer_check)
 
 
 def _stage_ids(out: torch.Tensor, a: torch.Tensor, b: Optional[torch.Tensor] = None) -> None:
@@ -565,10 +650,6 @@ class GraphedTrainStep:
         dev = optimizer.flat_params.device
         self.q = torch.zeros((self.B, self.q_width), dtype=torch.int64, device=dev)
         self.both = torch.zeros((2 * self.B, self.doc_width), dtype=torch.int64, device=dev)
-        self._gate_host = [torch.zeros(optimizer.GATE, dtype=torch.float32).pin_memory() for _ in range(2)]
-        self._gate_ev = [torch.cuda.Event() for _ in range(2)]
-        self._pending = None     # deferred check: (slot, the batch it belongs to)
-        self._n = 0
         self._phase = "all" if optimizer.world == 1 else "fold"
         model.train()
         keep_check, optimizer.check = optimizer.check, False        # (no host read inside a capture)
@@ -599,22 +680,9 @@ class GraphedTrainStep:
             return _train_step_direct(self.model, self.optimizer, self.q, None, None, self.margin, phase=self._phase,
                                       join_on_caller=True, both=self.both)
 
-    def _settle(self, pending):
-        """Look at a finished step's gate words (pinned copy) and raise what train_step would have raised for it."""
-        from .model import SplitRecurrenceTimeout
-        slot, batch = pending
-        self._gate_ev[slot].synchronize()
-        try:
-            self.optimizer.raise_for_gate(self._gate_host[slot].tolist())
-        except SplitRecurrenceTimeout:
-            return train_step(self.model, self.optimizer, *batch, self.margin)   # (eager; it takes the one-workgroup retry itself if it must)
-        return None
-
-    def flush(self) -> None:
-        """defer_check: settle the last step (raises its exception, if any)."""
-        pending, self._pending = self._pending, None
-        if pending is not None:
-            self._settle(pending)
+    def flush(self):
+        """defer_check: settle the optimizer's pending check (raises that step's exception, if any)."""
+        return self.optimizer.settle()
 
     def __call__(self, queries: torch.Tensor, pos_docs: torch.Tensor, neg_docs: torch.Tensor) -> torch.Tensor:
         """Returns the step's loss (a static 0-d device tensor, valid until the next call)."""
@@ -630,17 +698,10 @@ class GraphedTrainStep:
         opt.mark_params_changed()
         if not opt.check:
             return self.loss
-        slot = self._n & 1
-        self._n += 1
-        self._gate_host[slot].copy_(opt.gate, non_blocking=True)
-        self._gate_ev[slot].record(torch.cuda.current_stream(opt.gate.device))
-        mine = (slot, (queries, pos_docs, neg_docs))
-        if self.defer_check:
-            pending, self._pending = self._pending, mine
-            if pending is not None:
-                self._settle(pending)        # the PREVIOUS step's words: this step is already enqueued behind it
-        else:
-            redone = self._settle(mine)      # the step's one host synchronisation
+        # (the eager redo takes the one-workgroup retry itself if it must)
+        opt.snapshot_gate(redo=lambda: train_step(self.model, opt, queries, pos_docs, neg_docs, self.margin))
+        if not self.defer_check:
+            redone = opt.settle()            # the step's one host synchronisation
             if redone is not None:
                 return redone
         return self.loss
