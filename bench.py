@@ -393,8 +393,8 @@ def index_build_from_strings_leg(dev, model, gpu_docs_per_s, n_docs=262_144, see
         p0 += L_
     n_tok = int(lens.sum())
     model.eval()
-    embed_corpus(model, tok, docs[:32768], dev)          # warm-up: vocabulary table, scratch arrays, pinned blocks
-    torch.cuda.synchronize()
+    embed_corpus(model, tok, docs, dev)                  # warm-up = one whole pass: vocabulary table, pinned ring, and the caching
+    torch.cuda.synchronize()                             # allocator's workspace blocks for every batch width (a 10M-100M build runs warm)
     stats = {}
     t0 = time.perf_counter()
     emb = embed_corpus(model, tok, docs, dev, stats=stats)

@@ -230,13 +230,31 @@ int tt_score_all_f32(const float *Q, int B, int d, const float *D, int64_t N, fl
  * TT_ENC_ONE_WORKGROUP, which keeps every recurrence on the one-workgroup kernels (no hand-off between workgroups, nothing to
  * wait for; results bit-identical to the column-split forward's).  The column-split kernels need every member of a row
  * group's team on a CU at the same time: ONE such launch always fits (checked against the device's CU count), a host that
- * keeps SEVERAL encoder calls in flight on different streams passes TT_ENC_ONE_WORKGROUP to all but the largest (what
- * trainer.train_step does for the query tower) -- or relies on the bounded wait and the retry above.
+ * keeps SEVERAL encoder calls in flight on different streams orders their recurrences with events (tt_enc_sync_t below: what
+ * trainer.train_step does), or passes TT_ENC_ONE_WORKGROUP to all but the largest -- or relies on the bounded wait and the
+ * retry above.
  * train: 0 inference, 1 training, 2 training with a trainable table, optionally | TT_ENC_ONE_WORKGROUP.  train != 0 keeps the
  * activations the backward pass needs inside the workspace: the SAME workspace (sized with the same train value) must then be
  * passed, untouched, to tt_encoder_backward_f32.  The library reads no environment variable on any call.
  * Supported: H multiple of 32 in [32,512], E multiple of 4, 1 <= num_layers <= 4.
  */
+/*
+ * Ordering the recurrences of calls that are in flight on DIFFERENT streams (nullable argument of the training calls).  A
+ * column-split recurrence launch takes one CU per workgroup and needs all of them resident at once; two such launches on two
+ * streams can ask for more CUs than the device has (query tower 128 + document tower 256 on 256 CUs).  Instead of hoping that
+ * dispatch order lets complete teams form, the host passes events (hipEvent_t, created by the host: tt_event_create serves hosts
+ * without a HIP binding):
+ *   record_after_recurrence  recorded on `stream` right behind the call's LAST recurrence launch
+ *   wait_before_recurrence   `stream` waits for it right in front of the call's FIRST recurrence launch
+ * so call A's recurrences have drained before call B's start while everything else of the two calls (gathers, projections,
+ * weight gradients) still overlaps.  The host must ISSUE the recording call before the waiting call (a wait on an event
+ * whose record has not been issued is a no-op).  Both are ordinary stream operations: asynchronous, capturable.
+ */
+typedef struct tt_enc_sync {
+    void *wait_before_recurrence;  /* hipEvent_t or NULL */
+    void *record_after_recurrence; /* hipEvent_t or NULL */
+} tt_enc_sync_t;
+
 #define TT_ENC_TRAIN_MASK 0xff
 #define TT_ENC_ONE_WORKGROUP 0x100 /* option bit of `train` / `opts`: recurrences on one workgroup per 16-row group */
 /* CUs the column-split recurrence of one call of this shape occupies (one workgroup each, all resident at once); 0 = the call
@@ -250,7 +268,7 @@ int tt_encoder_forward_f32(const int64_t *ids, int B, int T, const float *table,
                            int num_layers, int bidirectional, int rnn_type, const float *const *weights /*host array*/,
                            const float *proj_w, const float *proj_b, int normalize, int train, float dropout_p,
                            uint64_t dropout_seed, float *out, void *workspace, size_t workspace_bytes,
-                           int32_t *status, tt_stream_t stream);
+                           int32_t *status, const tt_enc_sync_t *sync /*nullable*/, tt_stream_t stream);
 
 /*
  * Inference with the weights converted ONCE.  tt_encoder_forward_f32 re-derives, on every call, what its kernels read
@@ -301,7 +319,8 @@ int tt_encoder_backward_f32(const int64_t *ids, int B, int T, const float *table
                             const float *proj_w, const float *proj_b, int normalize, float dropout_p,
                             uint64_t dropout_seed, const float *d_out, float *const *grads /*host array*/,
                             float *g_proj_w, float *g_proj_b, float *g_table /*nullable*/, void *workspace,
-                            size_t workspace_bytes, int opts, int32_t *status /*nullable*/, tt_stream_t stream);
+                            size_t workspace_bytes, int opts, int32_t *status /*nullable*/,
+                            const tt_enc_sync_t *sync /*nullable*/, tt_stream_t stream);
 
 /* ------------------------------------------------------------------ */
 /* Training step pieces                                                */

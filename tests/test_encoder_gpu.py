@@ -421,7 +421,7 @@ def test_status_word_is_written_not_accumulated(B, T):
         with torch.cuda.device(0):
             _lib.check(L.tt_encoder_forward_f32(ids.data_ptr(), B, T, table.data_ptr(), V, E, H, 1, 0, enc._cell, wptr, None,
                                                 None, 1, 0, 0.0, 0, out.data_ptr(), ws.data_ptr(), ws.numel(),
-                                                status.data_ptr(), _stream(ids.device)))
+                                                status.data_ptr(), None, _stream(ids.device)))
         torch.cuda.synchronize()
         return int(status.item())
 
@@ -567,11 +567,12 @@ def test_k1_tail_split_writes_the_same_bits(B, T):
 def test_train_step_keeps_the_split_recurrences_within_the_cus():
     """The train step launches the query tower and the 2B-row document tower on two streams.  Both column-split would be 32 + 64
     teams = 384 one-per-CU workgroups for 256 CUs: members of some teams would wait for a CU while their partners already sweep
-    for them, and progress would rest on dispatch order.  trainer._towers_in_flight keeps the sum within the CU count instead
-    (the smaller tower runs the one-workgroup recurrences, same bits forward): checked here on the options the tower calls
-    really got.  Three steps: with the split forward alone the parameters are the all-one-workgroup run's bit for bit; with the
-    document tower's backward split too the run repeats itself bit for bit and its last gradient agrees with the one-workgroup
-    run's to the gradient tolerance."""
+    for them, and progress would rest on dispatch order.  trainer._towers_in_flight makes co-residency a matter of construction:
+    the direct step ORDERS the two towers' recurrence launches with events inside the calls (tt_enc_sync_t: the query tower's
+    first in the forward, last in the backward), the autograd path -- whose calls cannot carry events -- gives the smaller tower
+    the one-workgroup recurrences.  Checked here on what the tower calls really got.  Three steps: with the split forward alone
+    the parameters are the all-one-workgroup run's bit for bit; with the backwards split too the run repeats itself bit for bit
+    and its last gradient agrees with the one-workgroup run's to the gradient tolerance; direct and autograd paths agree."""
     import copy
     import twotowermlretrieval_amd as tt
     from twotowermlretrieval_amd import _lib
@@ -580,7 +581,9 @@ def test_train_step_keeps_the_split_recurrences_within_the_cus():
     m0 = tt.TwoTowerModel({"VOCAB_SIZE": V, "EMBED_DIM": E, "HIDDEN_DIM": H}, synth.make_table(4, V, E)).cuda().train()
     cus = torch.cuda.get_device_properties(0).multi_processor_count
     runs = {}
-    for name, (flag, bwd) in {"one": (False, False), "fwd": (True, False), "both": (True, True), "both2": (True, True)}.items():
+    cases = {"one": (False, False, True), "fwd": (True, False, True), "both": (True, True, True), "both2": (True, True, True),
+             "both_autograd": (True, True, False)}
+    for name, (flag, bwd, direct) in cases.items():
         m = copy.deepcopy(m0)
         o = tt.FusedClipAdam(m.parameters(), lr=1e-5, max_norm=1.0)
         seen = []
@@ -588,25 +591,33 @@ def test_train_step_keeps_the_split_recurrences_within_the_cus():
             fwd0 = enc._run_forward
 
             def spy(x, train, *a, _f=fwd0, _e=enc, **k):
-                seen.append((_e, x.shape[0], _e._opts(), _e._opts_bwd()))
+                sy = k.get("sync")
+                seen.append((_e, x.shape[0], _e._opts(), _e._opts_bwd(), None if sy is None else (bool(sy.wait_before_recurrence),
+                                                                                                bool(sy.record_after_recurrence))))
                 return _f(x, train, *a, **k)
             enc._run_forward = spy
         losses = []
         for step in range(3):
             ids = [torch.from_numpy(synth.make_ids(60 + 3 * step + s, B, T, V)).cuda() for s, T in enumerate((9, 60, 70))]
-            losses.append(float(_with_split(m, flag, lambda: tt.train_step(m, o, *ids, margin=0.5), bwd).item()))
+            losses.append(float(_with_split(m, flag, lambda: tt.train_step(m, o, *ids, margin=0.5, direct=direct), bwd).item()))
             torch.cuda.synchronize()
         runs[name] = (losses, o.flat_params.clone(), o.flat_grads.clone())
-        # what was in flight together never asked for more CUs than the device has
+        # what was in flight together never asked for more CUs than the device has -- or its recurrences were ordered
         for i in range(0, len(seen), 2):
-            want = sum(_lib.lib().tt_encoder_split_workgroups(b, H, 0, 0) for e, b, of, ob in seen[i:i + 2]
-                       if not (of and ob))
-            assert want <= cus, (name, seen[i:i + 2])
-        if name == "both" and cus < 384:
+            pair = seen[i:i + 2]
+            want = sum(_lib.lib().tt_encoder_split_workgroups(b, H, 0, 0) for e, b, of, ob, sy in pair if not (of and ob))
+            ordered = sorted(sy for *_, sy in pair if sy is not None) == [(False, True), (True, False)]   # one records, one waits
+            assert want <= cus or ordered, (name, pair)
+            if ordered:   # the recording call (the query tower) was issued first
+                assert pair[0][0] is m.query_encoder and pair[0][4] == (False, True), (name, pair)
+        if cus < 384 and name == "both":
+            assert all(sy is not None and not of for *_, of, ob, sy in seen), seen          # both towers split, ordered by events
+        if cus < 384 and name == "both_autograd":
             q_calls = [t for t in seen if t[0] is m.query_encoder]
-            d_calls = [t for t in seen if t[0] is m.doc_encoder]
-            assert all(of and ob for _, _, of, ob in q_calls) and all(not of and not ob for _, _, of, ob in d_calls)
+            assert all(of and ob and sy is None for *_, of, ob, sy in q_calls), seen         # the smaller tower: one workgroup
     assert runs["one"][0] == runs["fwd"][0] and torch.equal(runs["one"][1], runs["fwd"][1])
     assert runs["both"][0] == runs["both2"][0] and torch.equal(runs["both"][1], runs["both2"][1])
     np.testing.assert_allclose(runs["both"][0], runs["one"][0], atol=2e-6)
     assert_grad_close(runs["both"][2].cpu().numpy(), runs["one"][2].cpu().numpy())
+    np.testing.assert_allclose(runs["both_autograd"][0], runs["both"][0], atol=2e-6)
+    assert_grad_close(runs["both_autograd"][2].cpu().numpy(), runs["both"][2].cpu().numpy())

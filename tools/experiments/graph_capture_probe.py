@@ -7,7 +7,7 @@ import json, subprocess, sys, time
 from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent.parent
 sys.path.insert(0, str(ROOT))
-VARIANTS = ["eager2", "two"]
+VARIANTS = ["eager2", "two", "eager2_qone", "two_qone", "eager2", "two"]
 
 
 def one(variant):
@@ -24,12 +24,15 @@ def one(variant):
     q, p, n = q.to(dev), p.to(dev), n.to(dev)
     opt = tt.FusedClipAdam(m.parameters(), lr=5e-5, max_norm=1.0)
     opt.check = False
+    if variant.endswith("_qone"):     # the first co-residency plan: the query tower on the one-workgroup recurrences, no ordering
+        m.query_encoder.one_workgroup = True
+        variant = variant[:-5]
     rows = {m.query_encoder: B, m.doc_encoder: 2 * B}
     if variant == "two_norecord":
         torch.Tensor.record_stream = lambda self, s: None
 
     def run():
-        with T._towers_in_flight(m, opt, rows):
+        with T._towers_in_flight(m, opt, rows) as plan:
             if variant.startswith("fwd"):
                 with torch.no_grad():
                     pass
@@ -45,7 +48,7 @@ def one(variant):
                     cur.wait_stream(s)
                 opt._pending_status.clear()
                 return outs[0]
-            return T._train_step_direct(m, opt, q, p, n, 0.5, join_on_caller=(variant != "eager2"))
+            return T._train_step_direct(m, opt, q, p, n, 0.5, join_on_caller=(variant != "eager2"), plan=plan)
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):

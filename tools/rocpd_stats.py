@@ -4,7 +4,7 @@
 `--output-format csv` would put in *_kernel_stats.csv, with ONE ROW PER (kernel, grid, duration cluster).  A bench run
 launches the same kernel at several shapes -- the 10M-document step, the 2M-document encoder-corpus leg, the screened
 search's predicated no-op launches of the exact kernel, all with the same grid -- and an average over all of them says
-nothing about any: durations of one (kernel, grid) are sorted and a new cluster starts wherever one is more than 2.5x the
+nothing about any: durations of one (kernel, grid) are sorted and a new cluster starts wherever one is more than 1.6x the
 one before.   python tools/rocpd_stats.py DB [out.csv]"""
 import csv
 import re
@@ -24,7 +24,7 @@ for (name, gx, gy), ds in by.items():
     ds.sort()
     cl = [[ds[0]]]
     for d in ds[1:]:
-        if d > 2.5 * cl[-1][-1]:
+        if d > 1.6 * cl[-1][-1]:
             cl.append([])
         cl[-1].append(d)
     for i, c in enumerate(cl):

@@ -11,6 +11,11 @@ LIB_PATH = _PKG / "libtt.so"
 TT_OK, TT_ERR_BAD_SHAPE, TT_ERR_BAD_INDEX, TT_ERR_ZERO_LENGTH, TT_ERR_UNSUPPORTED, TT_ERR_WORKSPACE, TT_ERR_HIP = range(7)
 TT_ENC_ONE_WORKGROUP = 0x100  # option bit of the encoder calls (include/tt.h)
 TT_STEP_GATE_WORDS = 4
+
+
+class EncSync(C.Structure):
+    """tt_enc_sync_t (include/tt.h): events that order the recurrences of encoder calls on different streams."""
+    _fields_ = [("wait_before_recurrence", C.c_void_p), ("record_after_recurrence", C.c_void_p)]
 TT_TOPK_INVALID_INDEX = 1 << 62
 
 
@@ -54,14 +59,14 @@ SIGNATURES = {
     "tt_encoder_split_workgroups": (_i, [_i, _i, _i, _i]),
     "tt_encoder_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i, _i, _i]),
     "tt_encoder_forward_f32": (_i, [_vp, _i, _i, _vp, _i64, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _f, _u64, _vp, _vp,
-                                    _sz, _vp, _vp]),
+                                    _sz, _vp, _vp, _vp]),
     "tt_concat_ids_i64": (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _i, _vp]),
     "tt_encoder_prepared_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "tt_encoder_prepare_f32": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "tt_encoder_forward_prepared_f32": (_i, [_vp, _i, _i, _vp, _i64, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp,
                                              _sz, _vp, _vp]),
     "tt_encoder_backward_f32": (_i, [_vp, _i, _i, _vp, _i64, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _f, _u64, _vp, _vp,
-                                     _vp, _vp, _vp, _vp, _sz, _i, _vp, _vp]),
+                                     _vp, _vp, _vp, _vp, _sz, _i, _vp, _vp, _vp]),
     "tt_triplet_loss_f32": (_i, [_vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
     "tt_allgather_topk": (_i, [_vp, _vp, _vp, _sz, _vp]),
     "tt_allreduce_grads": (_i, [_vp, _vp, _i64, _vp]),

@@ -675,7 +675,7 @@ static int encoder_forward(const char *who, const int64_t *ids, int B, int T, co
                            int num_layers, int bidirectional, int rnn_type, const float *const *weights,
                            const void *prepared, const float *proj_w, const float *proj_b, int normalize, int train,
                            float dropout_p, uint64_t dropout_seed, float *out, void *workspace, size_t workspace_bytes,
-                           int32_t *status, hipStream_t st)
+                           int32_t *status, hipStream_t st, const tt_enc_sync_t *sync = nullptr)
 {
     int rc = enc_check_shape(who, B, T, E, H, num_layers, V);
     if (rc != TT_OK)
@@ -832,6 +832,8 @@ static int encoder_forward(const char *who, const int64_t *ids, int B, int T, co
         }
         if (ndir == 1)
             gp.dir[1] = gp.dir[0];
+        if (l == 0 && sync && sync->wait_before_recurrence) // (include/tt.h: the host orders this call's recurrences behind another call's)
+            TT_HIP_CHECK(hipStreamWaitEvent(st, (hipEvent_t)sync->wait_before_recurrence, 0));
         if (use16 && lo.xch && !one_wg && gru16x4_usable(B, H, ndir)) {
             // a row group's gate columns on four CUs (gru16x4.hip): same bits out, ~half the time per step
             rc = gru16x4_launch(gp, ndir, ws + lo.xch, status, st, /*xch_zeroed=*/l == 0 && split0);
@@ -849,6 +851,8 @@ static int encoder_forward(const char *who, const int64_t *ids, int B, int T, co
                 return rc;
         }
         TT_LAUNCH_CHECK();
+        if (last && sync && sync->record_after_recurrence)
+            TT_HIP_CHECK(hipEventRecord((hipEvent_t)sync->record_after_recurrence, st));
         if (drop && !last) { // nn.GRU's dropout sits on the outputs of every layer but the last
             hipLaunchKernelGGL(dropout_apply_kernel, dim3(B), dim3(256), 0, st, (const float *)xout,
                                (float *)(ws + lo.xd[l + 1]), len, tok_off, T, ndir * H, l, dropout_p, dropout_seed);
@@ -906,11 +910,11 @@ TT_EXPORT int tt_encoder_forward_f32(const int64_t *ids, int B, int T, const flo
                                      int num_layers, int bidirectional, int rnn_type, const float *const *weights,
                                      const float *proj_w, const float *proj_b, int normalize, int train,
                                      float dropout_p, uint64_t dropout_seed, float *out, void *workspace,
-                                     size_t workspace_bytes, int32_t *status, tt_stream_t stream)
+                                     size_t workspace_bytes, int32_t *status, const tt_enc_sync_t *sync, tt_stream_t stream)
 {
     return encoder_forward("tt_encoder_forward_f32", ids, B, T, table, V, E, H, num_layers, bidirectional, rnn_type, weights,
                            nullptr, proj_w, proj_b, normalize, train, dropout_p, dropout_seed, out, workspace,
-                           workspace_bytes, status, (hipStream_t)stream);
+                           workspace_bytes, status, (hipStream_t)stream, sync);
 }
 
 TT_EXPORT int tt_encoder_forward_prepared_f32(const int64_t *ids, int B, int T, const float *table, int64_t V, int E, int H,

@@ -426,7 +426,8 @@ TT_EXPORT int tt_encoder_backward_f32(const int64_t *ids, int B, int T, const fl
                                       const float *proj_w, const float *proj_b, int normalize, float dropout_p,
                                       uint64_t dropout_seed, const float *d_out, float *const *grads,
                                       float *g_proj_w, float *g_proj_b, float *g_table, void *workspace,
-                                      size_t workspace_bytes, int opts, int32_t *status, tt_stream_t stream)
+                                      size_t workspace_bytes, int opts, int32_t *status, const tt_enc_sync_t *sync,
+                                      tt_stream_t stream)
 {
     (void)ids;
     (void)proj_b;
@@ -577,6 +578,8 @@ TT_EXPORT int tt_encoder_backward_f32(const int64_t *ids, int B, int T, const fl
         }
         if (ndir == 1)
             bp.dir[1] = bp.dir[0];
+        if (l == num_layers - 1 && sync && sync->wait_before_recurrence) // (the first recurrence launch of the call)
+            TT_HIP_CHECK(hipStreamWaitEvent(st, (hipEvent_t)sync->wait_before_recurrence, 0));
         if (use16 && fused_bias && lo.xchb && !one_wg && gru16x4_bwd_usable(B, H, ndir)) {
             // a row group's reduction over the gate columns on four CUs (gru16x4.hip); a time-out ORs bit 2 into `status`
             rc = gru16x4_bwd_launch(bp, ndir, ws + lo.xchb, status, st);
@@ -589,6 +592,8 @@ TT_EXPORT int tt_encoder_backward_f32(const int64_t *ids, int B, int T, const fl
         }
         if (rc != TT_OK)
             return rc;
+        if (l == 0 && sync && sync->record_after_recurrence) // (the last recurrence launch of the call)
+            TT_HIP_CHECK(hipEventRecord((hipEvent_t)sync->record_after_recurrence, st));
         if (fused_bias) {
             // the recurrence kernel left one partial sum per row group in the split-K scratch: reduce them (row-group order:
             // deterministic) for BOTH directions before the first weight-gradient product reuses that scratch

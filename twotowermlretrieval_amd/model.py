@@ -263,7 +263,9 @@ class RNNEncoder(nn.Module):
             self._prep[device] = (key, blob, ent[1] if ent is not None else None)
         return blob
 
-    def _run_forward(self, x: torch.Tensor, train: bool, dropout_p: float = 0.0, dropout_seed: int = 0, opts: Optional[int] = None):
+    def _run_forward(self, x: torch.Tensor, train: bool, dropout_p: float = 0.0, dropout_seed: int = 0, opts: Optional[int] = None,
+                     sync=None):
+        """sync: an _lib.EncSync (tt_enc_sync_t) that orders this call's recurrences against another stream's (training calls)."""
         L = _lib.lib()
         opts = self._opts() if opts is None else opts
         ids = x.contiguous()
@@ -307,7 +309,7 @@ class RNNEncoder(nn.Module):
                     self._cell, wptr, pw.data_ptr() if pw is not None else None,
                     pb.data_ptr() if pb is not None else None, int(self.normalize_output), train_mode | opts,
                     float(dropout_p), int(dropout_seed), out.data_ptr(), ws.data_ptr(), ws.numel(), status.data_ptr(),
-                    _stream(ids.device)))
+                    C.byref(sync) if sync is not None else None, _stream(ids.device)))
         if self.check_inputs:
             if self._deferred_status is not None:
                 self._deferred_status.append(status)  # the caller reads them once, after enqueuing its other calls
@@ -318,13 +320,13 @@ class RNNEncoder(nn.Module):
                 if (st & 7) == 4 and not train and not (opts & _lib.TT_ENC_ONE_WORKGROUP):
                     # inference: a transient time-out of the column-split recurrence and nothing wrong with the data -- the
                     # same call on the one-workgroup kernels (same bits, nothing to wait for)
-                    return self._run_forward(x, train, dropout_p, dropout_seed, opts | _lib.TT_ENC_ONE_WORKGROUP)
+                    return self._run_forward(x, train, dropout_p, dropout_seed, opts | _lib.TT_ENC_ONE_WORKGROUP, sync)
                 _raise_status(st)
         return out, ws, status
 
     def _run_backward(self, ids: torch.Tensor, ws: torch.Tensor, d_out: torch.Tensor, dropout_p: float = 0.0,
                       dropout_seed: int = 0, into: Optional[list] = None, status: Optional[torch.Tensor] = None,
-                      opts: Optional[int] = None):
+                      opts: Optional[int] = None, sync=None):
         """into: contiguous float32 tensors, one per _flat_params() entry, that receive the gradients (the C entry point
         OVERWRITES its gradient buffers): trainer.train_step hands over the optimizer's gradient views.
         status: the forward call's status word; a time-out of the column-split backward recurrence ORs bit 2 into it."""
@@ -351,7 +353,8 @@ class RNNEncoder(nn.Module):
                 grads[nq].data_ptr() if pw is not None else None,
                 grads[nq + 1].data_ptr() if pb is not None else None,
                 g_table.data_ptr() if g_table is not None else None, ws.data_ptr(), ws.numel(), opts,
-                status.data_ptr() if status is not None else None, _stream(ids.device)))
+                status.data_ptr() if status is not None else None, C.byref(sync) if sync is not None else None,
+                _stream(ids.device)))
         return grads + ([g_table] if g_table is not None else [])
 
     # ---- public -----------------------------------------------------------------

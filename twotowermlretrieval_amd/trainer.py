@@ -275,6 +275,9 @@ _TOWER_STREAMS = {}
 def _tower_streams(device):
     key = (device.type, device.index)
     if key not in _TOWER_STREAMS:
+        # [0] document tower, [1] query tower, [2] a third tower call of the autograd path.  (A high-priority query stream was
+        # tried: its split recurrence still only gets whole CUs when the document tower's input projection ends -- that kernel's
+        # workgroups are resident for its whole duration -- 161 us against 148 without, profiles/r04_l_train_timeline.txt.)
         _TOWER_STREAMS[key] = [torch.cuda.Stream(device=device) for _ in range(3)]
     return _TOWER_STREAMS[key]
 
@@ -292,37 +295,84 @@ def _concat_ids(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     return out
 
 
+_ORDER_EVENTS = {}
+
+
+def _order_events(device):
+    """Two hipEvents per device (tt_event_create: plain HIP events the C calls record / wait on, include/tt.h tt_enc_sync_t)."""
+    import ctypes as C
+    key = (device.type, device.index)
+    if key not in _ORDER_EVENTS:
+        evs = []
+        with torch.cuda.device(device):
+            for _ in range(2):
+                e = C.c_void_p()
+                _lib.check(_lib.lib().tt_event_create(C.byref(e)))
+                evs.append(e.value)
+        _ORDER_EVENTS[key] = tuple(evs)
+    return _ORDER_EVENTS[key]
+
+
 class _towers_in_flight:
     """For the duration of one train step: (1) the model's encoders hand their status words to `optimizer` (watch), so that
     the step's failure is decided in optimizer.step(), by all ranks together; (2) the towers that are in flight at the same time
-    keep their column-split recurrences within the device's CUs -- a split launch needs every member of every team resident at
-    once (one workgroup per CU), which ONE launch guarantees against the CU count and two launches on two streams do not: the
-    smaller towers run the one-workgroup recurrences (TT_ENC_ONE_WORKGROUP: same bits, no hand-off) until the sum fits.  Then
-    every resident workgroup either waits for nobody or waits for partners that get a CU as soon as independent workgroups
-    drain: co-residency is guaranteed by construction, not observed (csrc/gru16x4.hip, include/tt.h)."""
+    never have more column-split workgroups in flight than the device has CUs.  A split launch needs every member of every
+    team resident at once (one workgroup per CU), which ONE launch guarantees against the CU count and two launches on two
+    streams do not (query tower 128 + document tower 256 on 256 CUs: round 3 rested on in-order dispatch).  Two ways out, both
+    co-residency BY CONSTRUCTION:
+      * ordered (the direct step), FORWARD: the towers' recurrence launches are ordered by an event inside the calls
+        (tt_enc_sync_t): the query tower's recurrence (64 us) first -- it has drained before the document tower's input
+        projection has finished -- and everything else of the two towers still overlaps.  BACKWARD: the smaller tower runs the
+        one-workgroup recurrence (its workgroups wait for nobody).  Ordering the backwards too was measured and dropped: the query
+        tower's split recurrence behind the document tower's lands under the document tower's weight-gradient kernels, whose
+        one-per-CU workgroups keep it off the CUs until they end (graph replay 1.146 -> 1.207 ms), and in front of it it would
+        add its ~100 us to the critical path;
+      * one_workgroup (the autograd path, whose calls cannot carry events): the smaller towers run the one-workgroup
+        recurrences (TT_ENC_ONE_WORKGROUP: same bits, no hand-off) until the sum fits.  Measured (profiles/
+        r04_j_train_timeline.txt): the query tower then holds 32 CUs for 280 + 390 us and 32 of the document tower's split
+        workgroups wait for them -- correct (nobody waits for a workgroup that cannot be scheduled), ~60 us per step slower.
+    (csrc/gru16x4.hip, include/tt.h)"""
 
     def __init__(self, model: TwoTowerModel, optimizer, rows: dict, force_one_workgroup: bool = False):
         self.model, self.optimizer, self.rows, self.force = model, optimizer, rows, force_one_workgroup
+        self.needs_order = False
 
     def __enter__(self):
         encs = [self.model.query_encoder, self.model.doc_encoder]
         self._saved = [(e, e.one_workgroup, e.one_workgroup_bwd, e._status_sink) for e in encs]
         if isinstance(self.optimizer, _FlatClipAdam):
             self.optimizer.watch(*encs)
+        self._need = {}
         if self.force:
             for e in encs:
                 e.one_workgroup, e.one_workgroup_bwd = True, None
         elif self.rows and encs[0].embedding.weight.is_cuda:
             L = _lib.lib()
             cus = torch.cuda.get_device_properties(encs[0].embedding.weight.device).multi_processor_count
-            need = {e: (0 if (e.one_workgroup and e.one_workgroup_bwd is not False) else L.tt_encoder_split_workgroups(int(B), e.hidden_dim, int(e.bidirectional), e._cell))
-                    for e, B in self.rows.items()}
-            for e in sorted(need, key=lambda e: need[e]):  # smallest first
-                if sum(need.values()) <= cus:
-                    break
-                if need[e]:
-                    e.one_workgroup, e.one_workgroup_bwd, need[e] = True, None, 0
+            self._need = {e: (0 if (e.one_workgroup and e.one_workgroup_bwd is not False) else L.tt_encoder_split_workgroups(
+                int(B), e.hidden_dim, int(e.bidirectional), e._cell)) for e, B in self.rows.items()}
+            self.needs_order = sum(self._need.values()) > cus
+            if self.needs_order:   # the backward: the smaller towers on the one-workgroup recurrence until the sum fits
+                left = dict(self._need)
+                for e in sorted(left, key=lambda e: left[e]):
+                    if sum(left.values()) <= cus:
+                        break
+                    if left[e]:
+                        e.one_workgroup_bwd, left[e] = True, 0
         return self
+
+    def use_one_workgroup(self) -> None:
+        """The plan for calls that cannot carry events: the smaller towers on the one-workgroup recurrences until the sum fits."""
+        if not self.needs_order:
+            return
+        cus = torch.cuda.get_device_properties(self.model.query_encoder.embedding.weight.device).multi_processor_count
+        need = self._need
+        for e in sorted(need, key=lambda e: need[e]):  # smallest first
+            if sum(need.values()) <= cus:
+                break
+            if need[e]:
+                e.one_workgroup, e.one_workgroup_bwd, need[e] = True, None, 0
+        self.needs_order = False
 
     def __exit__(self, exc_type, exc, tb):
         for e, one, one_bwd, sink in self._saved:
@@ -333,7 +383,7 @@ class _towers_in_flight:
 
 
 def _train_step_direct(model: TwoTowerModel, optimizer, queries, pos_docs, neg_docs, margin: float, phase: str = "all",
-                       join_on_caller: bool = False, both: Optional[torch.Tensor] = None):
+                       join_on_caller: bool = False, both: Optional[torch.Tensor] = None, plan: Optional[_towers_in_flight] = None):
     """The same step without the autograd engine: tower forwards (train mode), the fused loss + gradient kernel, tower backwards
     written STRAIGHT into the optimizer's flat gradient buffer, optimizer step.  Every parameter receives its gradient exactly
     once (query tower once; positives and negatives as one 2B-row document-tower call), so nothing has to be zeroed or
@@ -348,11 +398,11 @@ def _train_step_direct(model: TwoTowerModel, optimizer, queries, pos_docs, neg_d
     are graph edges) and it is the only form this ROCm can capture: a side stream that waits for ANOTHER side stream and then
     goes on makes hipStreamEndCapture crash inside the runtime (tools/experiments/graph_pattern_probe.py: fork / join through
     the origin stream is fine, side-to-side joins segfault, whatever the kernels).
-    both: the 2B-row document batch [pos_docs; neg_docs] already concatenated (GraphedTrainStep stages it outside the graph)."""
+    both: the 2B-row document batch [pos_docs; neg_docs] already concatenated (GraphedTrainStep stages it outside the graph).
+    plan: the step's _towers_in_flight; when the two towers' split recurrences do not fit the device together their recurrence
+    launches are ordered with events (query tower's first in the forward, last in the backward)."""
     if not isinstance(optimizer, _FlatClipAdam) or not torch.is_grad_enabled():
         return None
-    # the document tower (2B rows of ~70 tokens) is the step's critical path: its launches go out FIRST, the query tower's
-    # ~15 small launches then overlap it instead of delaying it by the ~0.1 ms the host needs to issue them
     encs = (model.doc_encoder, model.query_encoder)
     views = {id(p): gv for p, gv in zip(optimizer.params, optimizer._views)}
     into = []
@@ -370,17 +420,29 @@ def _train_step_direct(model: TwoTowerModel, optimizer, queries, pos_docs, neg_d
     if both is None and (pos_docs.dtype != torch.int64 or neg_docs.dtype != torch.int64):
         return None
     s_doc, s_qry = streams
+    if join_on_caller and plan is not None:
+        # a capture: no ordering events (an event edge between the two tower streams is a side-to-side edge, which this ROCm
+        # cannot capture; with the query tower moved onto the capturing stream it can, but replays slower: 1.19-1.21 ms against
+        # 1.16 with the smaller tower on the one-workgroup recurrences, profiles/r04_m_graph_probe.log)
+        plan.use_one_workgroup()
     s_main = cur if join_on_caller else s_doc     # where the towers meet: loss, optimizer
+    ordered = plan is not None and plan.needs_order
+    sync_f = sync_b = {}
+    if ordered:
+        ev_f, ev_b = _order_events(dev)
+        q_enc, d_enc = model.query_encoder, model.doc_encoder
+        sync_f = {id(q_enc): _lib.EncSync(None, ev_f), id(d_enc): _lib.EncSync(ev_f, None)}   # query records, document waits
+        # (backward: no events -- the plan gave the smaller tower the one-workgroup recurrence, _towers_in_flight)
 
     def join():   # s_main waits for both towers
-        s_main.wait_stream(s_qry)
-        if s_main is not s_doc:
-            s_main.wait_stream(s_doc)
+        for t in (s_qry, s_doc):
+            if t is not s_main:
+                s_main.wait_stream(t)
 
     def fork():   # both towers wait for s_main
-        s_qry.wait_stream(s_main)
-        if s_main is not s_doc:
-            s_doc.wait_stream(s_main)
+        for t in (s_qry, s_doc):
+            if t is not s_main:
+                t.wait_stream(s_main)
     try:
         s_doc.wait_stream(cur)
         if both is None:
@@ -392,16 +454,22 @@ def _train_step_direct(model: TwoTowerModel, optimizer, queries, pos_docs, neg_d
         # dropout seeds from torch's CPU generator in the order the autograd path draws them (query tower, then document tower)
         seeds = {id(enc): (int(torch.randint(0, 2 ** 62, (1,)).item()) if enc.dropout > 0.0 else 0)
                  for enc in (model.query_encoder, model.doc_encoder)}
-        fw = []
-        for enc, ids, s in zip(encs, ids_of, streams):
-            s.wait_stream(cur)
+        # Issue order.  Unordered: the document tower (2B rows of ~70 tokens: the step's critical path) FIRST, the query tower's
+        # ~15 small launches then overlap it instead of delaying it by the ~0.1 ms the host needs to issue them.  Ordered: the
+        # call that RECORDS the ordering event must be issued before the call that waits for it (include/tt.h) -- the query
+        # tower first; its recurrence is over long before the document tower's projection is.
+        fw = [None, None]
+        for k in ((1, 0) if ordered else (0, 1)):
+            enc, ids, s = encs[k], ids_of[k], streams[k]
+            if s is not cur:
+                s.wait_stream(cur)
             with torch.cuda.stream(s):
                 ids.record_stream(s)
                 p_drop = enc.dropout
                 seed = seeds[id(enc)]
                 # (the encoders are watched -- _towers_in_flight -- so the status word goes to the optimizer instead of a read here)
-                out, ws, status = enc._run_forward(ids, train=True, dropout_p=p_drop, dropout_seed=seed)
-                fw.append((out, ws, status, p_drop, seed, enc._opts_bwd()))
+                out, ws, status = enc._run_forward(ids, train=True, dropout_p=p_drop, dropout_seed=seed, sync=sync_f.get(id(enc)))
+                fw[k] = (out, ws, status, p_drop, seed, enc._opts_bwd())
         # The document tower's stream carries the step's critical path from here on: the loss, the document backward and the
         # optimizer are enqueued on IT (a hop to the caller's stream and back cost ~20 us each way on that path: event wait +
         # launch); the query tower's stream joins for the loss and again before the optimizer.
@@ -425,7 +493,8 @@ def _train_step_direct(model: TwoTowerModel, optimizer, queries, pos_docs, neg_d
             with torch.cuda.stream(s):
                 d_out.record_stream(s)
                 # (a time-out of the split backward recurrence ORs bit 2 into the forward's word, which the optimizer reads)
-                enc._run_backward(ids.contiguous(), f[1], d_out, f[3], f[4], into=grads, status=f[2], opts=f[5])
+                enc._run_backward(ids.contiguous(), f[1], d_out, f[3], f[4], into=grads, status=f[2], opts=f[5],
+                                  sync=sync_b.get(id(enc)))
         join()
         for p_, gv in zip(optimizer.params, optimizer._views):
             p_.grad = gv
@@ -445,17 +514,20 @@ def _train_step_direct(model: TwoTowerModel, optimizer, queries, pos_docs, neg_d
     finally:
         # (also when step() raised: the caller's stream joins the towers' streams, nothing of this step is left running
         #  behind the caller's back)
-        cur.wait_stream(s_qry)
-        cur.wait_stream(s_doc)
+        for t in (s_qry, s_doc):
+            if t is not cur:
+                cur.wait_stream(t)
     loss.record_stream(cur)
     return loss
 
 
-def _train_step_once(model, optimizer, queries, pos_docs, neg_docs, margin, concurrent_towers, direct):
+def _train_step_once(model, optimizer, queries, pos_docs, neg_docs, margin, concurrent_towers, direct, plan=None):
     if direct and concurrent_towers and queries.is_cuda and neg_docs.shape[0] == pos_docs.shape[0] == queries.shape[0]:
-        loss = _train_step_direct(model, optimizer, queries, pos_docs, neg_docs, margin)
+        loss = _train_step_direct(model, optimizer, queries, pos_docs, neg_docs, margin, plan=plan)
         if loss is not None:
             return loss
+    if plan is not None:
+        plan.use_one_workgroup()   # (autograd calls cannot carry the ordering events)
     optimizer.zero_grad()
     watched = isinstance(optimizer, _FlatClipAdam)
     if concurrent_towers and queries.is_cuda:
@@ -537,13 +609,13 @@ def train_step(model: TwoTowerModel, optimizer: FusedClipAdam, queries: torch.Te
     rows = {model.query_encoder: queries.shape[0], model.doc_encoder: n_doc} if concurrent_towers else {}
     rng = torch.get_rng_state() if any(e.dropout > 0.0 and e.training for e in encs) else None
     try:
-        with _towers_in_flight(model, optimizer, rows if queries.is_cuda else {}):
-            return _train_step_once(model, optimizer, queries, pos_docs, neg_docs, margin, concurrent_towers, direct)
+        with _towers_in_flight(model, optimizer, rows if queries.is_cuda else {}) as plan:
+            return _train_step_once(model, optimizer, queries, pos_docs, neg_docs, margin, concurrent_towers, direct, plan)
     except SplitRecurrenceTimeout:
         if rng is not None:
             torch.set_rng_state(rng)  # (the redone step draws the dropout seeds the failed attempt drew)
-        with _towers_in_flight(model, optimizer, {}, force_one_workgroup=True):
-            return _train_step_once(model, optimizer, queries, pos_docs, neg_docs, margin, concurrent_towers, direct)
+        with _towers_in_flight(model, optimizer, {}, force_one_workgroup=True) as plan:
+            return _train_step_once(model, optimizer, queries, pos_docs, neg_docs, margin, concurrent_towers, direct, plan)
 
 
 class DataParallelTrainer:
@@ -676,9 +748,9 @@ class GraphedTrainStep:
 
     def _run(self):
         rows = {self.model.query_encoder: self.B, self.model.doc_encoder: 2 * self.B}
-        with _towers_in_flight(self.model, self.optimizer, rows):
+        with _towers_in_flight(self.model, self.optimizer, rows) as plan:
             return _train_step_direct(self.model, self.optimizer, self.q, None, None, self.margin, phase=self._phase,
-                                      join_on_caller=True, both=self.both)
+                                      join_on_caller=True, both=self.both, plan=plan)
 
     def flush(self):
         """defer_check: settle the optimizer's pending check (raises that step's exception, if any)."""
