@@ -8,7 +8,7 @@ import numpy as np, torch
 import twotowermlretrieval_amd as tt
 from twotowermlretrieval_amd.evaluators import embed_corpus
 n_docs = int(sys.argv[1]) if len(sys.argv) > 1 else 400_000
-V = 50_000
+V = int(sys.argv[2]) if len(sys.argv) > 2 else 50_000
 words = ["the", ",", ".", "of", "and"] + [f"w{i}" for i in range(5, V)]
 tok = tt.PretrainedTokenizer(word2idx={w: i for i, w in enumerate(words)})
 rs = np.random.RandomState(0)
@@ -29,11 +29,11 @@ m = tt.TwoTowerModel({"HIDDEN_DIM": H, "VOCAB_SIZE": tok.vocab_size(), "EMBED_DI
 embed_corpus(m, tok, docs[:20000], dev)
 torch.cuda.synchronize()
 from twotowermlretrieval_amd.tokenizer import host_cores
-for prod in (0, 1, 2, 4):
+for prod, tpp in ((0, 0), (1, 0), (2, 0), (4, 0), (2, 16), (3, 16), (2, 12)):
     st = {}
-    embed_corpus(m, tok, docs[:65536], dev, producers=prod)
+    embed_corpus(m, tok, docs, dev, producers=prod, threads_per_producer=tpp)
     torch.cuda.synchronize()
-    t = time.time(); emb = embed_corpus(m, tok, docs, dev, producers=prod, stats=st); torch.cuda.synchronize(); dt = time.time() - t
+    t = time.time(); emb = embed_corpus(m, tok, docs, dev, producers=prod, stats=st, threads_per_producer=tpp); torch.cuda.synchronize(); dt = time.time() - t
     print(json.dumps(dict(what="pipelined index build from strings", producers_arg=prod, **st, docs=n_docs, tokens=n_tok, s=round(dt, 3),
                           docs_per_s=round(n_docs / dt), tok_per_s=round(n_tok / dt), shape=list(emb.shape))), flush=True)
 print(json.dumps(dict(host_cores=host_cores(), affinity=len(__import__("os").sched_getaffinity(0)),

@@ -69,17 +69,18 @@ def embed_documents(model, tokenizer, documents: Sequence[str], device: torch.de
 
 
 def embed_corpus(model, tokenizer, documents: Sequence[str], device: torch.device, batch_size: int = 16384,
-                 prefetch: int = 2, out: torch.Tensor = None, producers: int = 0, stats: Dict = None) -> torch.Tensor:
+                 prefetch: int = 2, out: torch.Tensor = None, producers: int = 0, stats: Dict = None,
+                 threads_per_producer: int = 0) -> torch.Tensor:
     """Index build: the same rows as embed_documents, with the host front end off the critical path.
     `producers` host threads tokenise and pad batches natively (tt_tok_encode / tt_tok_pad release the GIL; each thread
     reuses its scratch arrays) into pinned memory while the GPU encodes; batches are consumed in document order whatever
     order they finish in; ids cross PCIe with a non-blocking copy on a side stream; embeddings land in one preallocated
     [N, H] matrix.  Rows are independent, so neither the batch size nor the number of producers changes the result.
 
-    producers = 0: one per 16 cores of the host's share (cgroup quota respected), at most 4.  Round 1-3 ran ONE producer
+    producers = 0: one per 8 cores of the host's share (cgroup quota respected), at most 4.  Round 1-3 ran ONE producer
     that allocated a fresh pinned tensor per batch and tokenised through a four-array hash table: 93-115 M tokens/s against the
-    document tower's ~240 M.  With the staging ring below, the single-pass tokenizer and one join per batch the same single
-    producer feeds 234 M tokens/s on a 16-core share.  stats (optional dict): receives what the build used."""
+    document tower's ~240 M.  With the staging ring below, the single-pass tokenizer and one join per batch two producers
+    feed 213-234 M tokens/s on a 16-core share.  stats (optional dict): receives what the build used."""
     import collections
     import os
     from concurrent.futures import ThreadPoolExecutor
@@ -89,11 +90,13 @@ def embed_corpus(model, tokenizer, documents: Sequence[str], device: torch.devic
     from .tokenizer import host_cores
     cores = host_cores()
     if producers <= 0:
-        # every producer splits its batches over 16 native threads; a second producer only pays with cores to spare -- the
-        # Python part of a batch (one join + encode) holds the GIL, and producers that share cores mostly trade it back and forth
-        # (16-core share: 1 x 16 threads 3.35 M docs/s, 2 x 8 3.03 M, 4 x 4 2.6 M: profiles/r04_i_index_build.log)
-        producers = max(1, min(4, cores // 16))
-    nt = max(1, min(16, cores // producers))
+        # two producers from 16 cores up: while one is in the Python part of its batch (one join + encode, under the GIL) the
+        # other is in the native part.  More producers than that mostly trade the GIL back and forth, fewer leave the cores idle
+        # during the Python part.  16-core share, 400 k passages: GloVe-size vocabulary 1 x 16 threads 2.5 M docs/s, 2 x 8 3.16 M,
+        # 2 x 16 3.05 M, 3 x 16 2.6 M, 4 x 4 2.5 M; 50 k-word vocabulary 1 x 16 3.35 M, 2 x 8 3.03 M, 4 x 4 2.6 M
+        # (profiles/r04_o_index_build_v400k.log, r04_i_index_build_producer_sweep.log)
+        producers = max(1, min(4, cores // 8))
+    nt = threads_per_producer if threads_per_producer > 0 else max(1, min(16, cores // producers))
     starts = list(range(0, n, batch_size))
     window = producers + max(1, prefetch)          # batches tokenised or being tokenised ahead of the GPU
     if stats is not None:

@@ -425,6 +425,12 @@ def _train_step_direct(model: TwoTowerModel, optimizer, queries, pos_docs, neg_d
         # cannot capture; with the query tower moved onto the capturing stream it can, but replays slower: 1.19-1.21 ms against
         # 1.16 with the smaller tower on the one-workgroup recurrences, profiles/r04_m_graph_probe.log)
         plan.use_one_workgroup()
+    elif plan is not None and plan.needs_order and optimizer.check and all(e.check_inputs for e in encs):
+        # a step that ENDS with a host read (the gate words) starts with the GPU idle: whichever tower is issued first starts
+        # first, and the ordered forward must issue the query tower first -- that costs the document tower the ~0.1 ms the host
+        # needs for the query tower's launches, more than the ordering saves (1.365 against 1.34 ms, profiles/r04_n_bench_n1.json
+        # / r04_j).  With the read deferred (or no read at all) the host runs ahead of the GPU and the order of issue is free.
+        plan.use_one_workgroup()
     s_main = cur if join_on_caller else s_doc     # where the towers meet: loss, optimizer
     ordered = plan is not None and plan.needs_order
     sync_f = sync_b = {}
