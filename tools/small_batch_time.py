@@ -26,12 +26,12 @@ def timeit(fn, iters=20, warm=3):
     return e0.elapsed_time(e1) / iters
 
 
-for B in (1, 32, 33, 64, 128, 129, 256, 257, 512, 1024):
+for B in (1, 8, 32, 33, 64, 65, 96, 128, 129, 192, 256, 257, 384, 512, 513, 768, 1024):
     q = bench.gen_queries(B, dev, seed=B)
     ve, ie = ix_e.search(q, 10)
     vs, is_ = ix_s.search(q, 10)
     same = bool(torch.equal(ve, vs) and torch.equal(ie, is_))
-    te = timeit(lambda: ix_e.search(q, 10))
+    te = timeit(lambda: ix_e.search(q, 10), iters=(5 if B > 64 else 20))
     ts = timeit(lambda: ix_s.search(q, 10))
     print(json.dumps(dict(B=B, docs=n, exact_ms=round(te, 4), screened_ms=round(ts, 4), identical=same,
                           screened_GBps=round(n * 512 / ts / 1e6, 1), flags=int(ix_s.fallback_flags.ne(0).sum().item()))), flush=True)

@@ -729,6 +729,8 @@ class GraphedTrainStep:
         self.q = torch.zeros((self.B, self.q_width), dtype=torch.int64, device=dev)
         self.both = torch.zeros((2 * self.B, self.doc_width), dtype=torch.int64, device=dev)
         self._phase = "all" if optimizer.world == 1 else "fold"
+        # (the optimizer's hyper-parameters are arguments of the captured launches: changing them means capturing again)
+        self._hyper = (optimizer.lr, optimizer.betas, optimizer.eps, optimizer.max_norm)
         model.train()
         keep_check, optimizer.check = optimizer.check, False        # (no host read inside a capture)
         try:
@@ -768,6 +770,9 @@ class GraphedTrainStep:
             if src.dim() != 2 or src.shape[0] != self.B or src.shape[1] > width or src.dtype != torch.int64:
                 raise ValueError(f"GraphedTrainStep was captured for int64 {what} [{self.B}, <= {width}], got {src.dtype} {tuple(src.shape)}")
         opt = self.optimizer
+        if self._phase == "all" and (opt.lr, opt.betas, opt.eps, opt.max_norm) != self._hyper:
+            raise ValueError("GraphedTrainStep: the optimizer's lr / betas / eps / max_norm changed since the capture (they are "
+                             "arguments of the captured launches); build a new GraphedTrainStep")
         _stage_ids(self.q, queries)
         _stage_ids(self.both, pos_docs, neg_docs)
         self.graph.replay()
