@@ -114,14 +114,21 @@ def embed_corpus(model, tokenizer, documents: Sequence[str], device: torch.devic
         free.put(buf)
 
     def make(i):
-        buf = free.get()                        # (at most `window` jobs are outstanding and 3 batches in flight behind them)
+        buf = free.get(timeout=120)             # (at most `window` jobs are outstanding and 3 batches in flight behind them; the
+        #                                         time-out only ends a job whose consumer died: the pool's threads outlive the call)
         return tokenizer.encode_batch(documents[i:i + batch_size], pin=True, n_threads=nt, out=buf), buf
 
     inflight = collections.deque()
     copy_stream = torch.cuda.Stream(device=device)
     cur = torch.cuda.current_stream(device)
     res = out
-    with ThreadPoolExecutor(max_workers=producers, thread_name_prefix="tt-tok") as pool, torch.no_grad():
+    # the producer threads are kept across calls: their per-thread scratch arrays (tokenizer._scratch: ~50 MB of ragged ids per
+    # batch) would otherwise be page-faulted in again by every call's fresh threads -- ~0.09 s per call, more than a 400 k-passage
+    # build takes
+    pool = _PRODUCER_POOLS.get(producers)
+    if pool is None:
+        pool = _PRODUCER_POOLS[producers] = ThreadPoolExecutor(max_workers=producers, thread_name_prefix="tt-tok")
+    with torch.no_grad():
         pending = collections.deque()
         nxt = 0
         try:
@@ -159,6 +166,7 @@ def embed_corpus(model, tokenizer, documents: Sequence[str], device: torch.devic
 
 
 _PINNED_RINGS: Dict = {}
+_PRODUCER_POOLS: Dict = {}
 
 
 def corpus_recall_hit(query_emb: torch.Tensor, doc_embeddings: torch.Tensor, positives: Sequence[int],
