@@ -31,7 +31,10 @@ def tt():
 
 
 @pytest.mark.parametrize("B,N,k", [(128, 5000, 10), (200, 33333, 10), (600, 20000, 16), (97, 1000, 1), (513, 4097, 5),
-                                   (130, 9000, 50), (96, 700000, 64), (33, 70000, 10), (250, 66000, 10), (256, 3000, 7)])
+                                   (130, 9000, 50), (96, 700000, 64), (33, 70000, 10), (250, 66000, 10), (256, 3000, 7),
+                                   # the 384-query groups (NSET = 3): one group, a ragged last wave, two and three groups
+                                   (257, 40000, 10), (384, 70001, 10), (300, 9000, 33), (768, 66000, 10), (700, 250000, 10),
+                                   (1025, 30000, 8)])
 def test_bit_exact_vs_oracle(tt, oracle, B, N, k):
     Q = synth.unit_rows(100 + B, B, 256)
     D = synth.unit_rows(200 + N, N, 256)

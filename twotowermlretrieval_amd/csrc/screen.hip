@@ -251,7 +251,10 @@ __global__ __launch_bounds__(128) void q_image_kernel(const float *__restrict__ 
 }
 
 // NSET = 16-query sets per wave: 4 (512 queries per workgroup) for large batches; 2 / 1 (256 / 128 queries per
-// workgroup) spread a mid-size batch over all eight waves instead of leaving most of them without queries.
+// workgroup) spread a mid-size batch over all eight waves instead of leaving most of them without queries; 3 (384 per
+// workgroup, round 4) for the batches a 512-query group would leave a quarter or more empty: B = 257 .. 384 (one group) and
+// 513 .. 768 (two groups of 384 instead of a full one and a nearly empty one -- a group costs a pass whatever it holds: B = 513
+// took 3.6 ms where 512 took 2.1, profiles/r04_p_batch_sweep.log).
 template <bool MAXONLY, int NSET>
 __global__ __launch_bounds__(SW * 64, 2) void screen_kernel(ScreenParams p)
 {
@@ -259,7 +262,7 @@ __global__ __launch_bounds__(SW * 64, 2) void screen_kernel(ScreenParams p)
     // NSET < 4 (B <= 256): one query group, so every tile is read once by one workgroup: nt policy like the streaming
     // form (TSTREAM_AUX; here -2.5 % at B = 33 .. 128, -1.5 % at 256, A/B on one box); NSET == 4 may have two groups per
     // chunk that share the tile through L2: default policy
-    constexpr int DMA_AUX = NSET < 4 ? 2 : 0;
+    constexpr int DMA_AUX = NSET < 3 ? 2 : 0;
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int chunk = blockIdx.x % p.n_chunks;
@@ -1171,7 +1174,12 @@ SPlan make_splan(int B, int64_t N, int k)
 {
     SPlan pl;
     pl.stream = B <= STREAM_MAX_B;
-    pl.nset = B <= SW * 16 ? 1 : (B <= SW * 32 ? 2 : 4);
+    if (B <= SW * 32) {
+        pl.nset = B <= SW * 16 ? 1 : 2;
+    } else { // as few groups as 512-query groups would need, as evenly filled as whole 16-query sets per wave allow
+        const int groups = (B + SW * 64 - 1) / (SW * 64);
+        pl.nset = (B + groups - 1) / groups <= SW * 48 ? 3 : 4;
+    }
     pl.q_per_block = pl.stream ? (B <= 32 ? 32 : 64) : SW * 16 * pl.nset;
     pl.n_qgroups = (B + pl.q_per_block - 1) / pl.q_per_block;
     pl.n_tiles = (int)((N + 31) / 32);
@@ -1400,6 +1408,11 @@ int screened_impl(const char *who, int phase, const float *Q, int B, int d, cons
                 hipLaunchKernelGGL((screen_kernel<true, 4>), dim3(blocks), dim3(SW * 64), pl.lds, st, a);
             else
                 hipLaunchKernelGGL((screen_kernel<false, 4>), dim3(blocks), dim3(SW * 64), pl.lds, st, a);
+        } else if (pl.nset == 3) {
+            if (maxonly)
+                hipLaunchKernelGGL((screen_kernel<true, 3>), dim3(blocks), dim3(SW * 64), pl.lds, st, a);
+            else
+                hipLaunchKernelGGL((screen_kernel<false, 3>), dim3(blocks), dim3(SW * 64), pl.lds, st, a);
         } else if (pl.nset == 2) {
             if (maxonly)
                 hipLaunchKernelGGL((screen_kernel<true, 2>), dim3(blocks), dim3(SW * 64), pl.lds, st, a);
@@ -1421,10 +1434,11 @@ int screened_impl(const char *who, int phase, const float *Q, int B, int d, cons
         TT_HIP_CHECK(hipFuncSetAttribute((const void *)screen_stream_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds));
         TT_HIP_CHECK(hipFuncSetAttribute((const void *)screen_stream_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds));
     } else {
-        const void *fns[6] = {(const void *)screen_kernel<false, 4>, (const void *)screen_kernel<true, 4>,
+        const void *fns[8] = {(const void *)screen_kernel<false, 4>, (const void *)screen_kernel<true, 4>,
                               (const void *)screen_kernel<false, 2>, (const void *)screen_kernel<true, 2>,
-                              (const void *)screen_kernel<false, 1>, (const void *)screen_kernel<true, 1>};
-        const int f0 = pl.nset == 4 ? 0 : (pl.nset == 2 ? 2 : 4);
+                              (const void *)screen_kernel<false, 1>, (const void *)screen_kernel<true, 1>,
+                              (const void *)screen_kernel<false, 3>, (const void *)screen_kernel<true, 3>};
+        const int f0 = pl.nset == 4 ? 0 : (pl.nset == 2 ? 2 : (pl.nset == 3 ? 6 : 4));
         TT_HIP_CHECK(hipFuncSetAttribute(fns[f0], hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds));
         TT_HIP_CHECK(hipFuncSetAttribute(fns[f0 + 1], hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds));
     }
