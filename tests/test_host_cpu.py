@@ -209,3 +209,21 @@ def test_load_config_reads_json(tmp_path):
     from twotowermlretrieval_amd.query_inferencer import load_config
     (tmp_path / "config.json").write_text('{"HIDDEN_DIM": 256, "RNN_TYPE": "GRU"}')
     assert load_config(str(tmp_path / "config.json")) == {"HIDDEN_DIM": 256, "RNN_TYPE": "GRU"}
+
+
+def test_seed_plan_of_a_sharded_search():
+    """How many seeds a rank lists and which rank of the union is taken (index.seed_plan): k per rank while world * k fits the
+    union kernel's 512-value tile, fewer per rank on wider jobs (the k-th of the union still has k distinct documents above
+    it), every shard for itself when even that does not fit, when the ranks did not agree to exchange, or beyond the screen's k."""
+    from twotowermlretrieval_amd.index import seed_plan
+    assert seed_plan(8, 10) == (10, 10) and seed_plan(1, 10) == (10, 10) and seed_plan(8, 64) == (64, 64)
+    assert seed_plan(16, 64) == (32, 64)          # 16 x 64 = 1024 > 512: 32 per rank, the 64th of 512
+    assert seed_plan(512, 64) == (1, 64) and seed_plan(512, 1) == (1, 1)
+    assert seed_plan(1024, 10) is None            # not even one value per rank fits
+    assert seed_plan(8, 65) is None and seed_plan(8, 10, exchange=False) is None
+    for world in (1, 2, 3, 7, 8, 16, 48, 100, 512):
+        for k in (1, 5, 10, 50, 64):
+            pl = seed_plan(world, k)
+            if pl is not None:
+                ks, kth = pl
+                assert 1 <= ks <= k and kth == k and world * ks <= 512 and world * ks >= k

@@ -330,6 +330,19 @@ def seed_union(lists: torch.Tensor, world: int, kth: Optional[int] = None) -> to
     return seed
 
 
+def seed_plan(world: int, k: int, exchange: bool = True):
+    """(list length per rank, rank taken from the union) of a sharded search's seed exchange, or None when the union does not
+    apply: world * list length is bounded by tt_seed_union_f32's tile (SEED_UNION_MAX values per query); a job too wide for k
+    values per rank lists fewer -- the k-th of the union is still reached by k distinct documents -- and one too wide even for
+    that (or a k beyond the screen's 64) seeds every shard by itself."""
+    if not exchange or k > 64 or world < 1:
+        return None
+    ks = min(k, SEED_UNION_MAX // world)
+    if ks < 1 or world * ks < k:
+        return None
+    return ks, k
+
+
 def _local_seed(lst: torch.Tensor) -> torch.Tensor:
     """No exchange: the union over one shard is that shard's own ks-th largest sample maximum."""
     return seed_union(lst.unsqueeze(0), 1)
@@ -424,16 +437,7 @@ class ShardedIndex:
         self._seed_exchange = bool(mine)  # the same on every rank
 
     def _seed_plan(self, k: int):
-        """(list length per rank, rank taken from the union) of the seed exchange, or None when the union does not apply:
-        world * list length is bounded by tt_seed_union_f32's tile; a job too wide for k values per rank lists fewer (the
-        k-th of the union is still reached by k distinct documents)."""
-        world = self._coll.world
-        if not self._seed_exchange or k > 64:
-            return None
-        ks = min(k, SEED_UNION_MAX // world)
-        if ks < 1 or world * ks < k:
-            return None
-        return ks, k
+        return seed_plan(self._coll.world, k, self._seed_exchange)
 
     def _local_search(self, q: torch.Tensor, kp: int, k: int, sl: "_Slot", comm_stream=None) -> None:
         """This shard's list for the exchange: up to kp = max(k, shard_k) entries, best first.  The screen is seeded for
