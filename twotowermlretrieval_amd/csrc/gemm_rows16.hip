@@ -312,7 +312,7 @@ int launch_rows16(const SgemmParams &p, hipStream_t st)
                                          C::LDS));
         attr_done = true;
     }
-    // resident workgroups (the kernel's rounds): two per CU for the narrow form, one for the wide one; TT_ROWS_SPLIT=0: no tail split
+    // resident workgroups (the kernel's rounds): two per CU for the narrow form, one for the wide one; the comparison build's TT_ROWS_SPLIT=0: no tail split
     static const int resident = [] {
         int dev = 0, cus = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) {

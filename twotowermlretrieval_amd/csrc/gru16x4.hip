@@ -17,11 +17,13 @@
 //     same order, so outputs, stash and final states are BIT-IDENTICAL to that kernel (tests/test_encoder_gpu.py).
 // Since round 3 a member is EIGHT waves, two per SIMD (gru_seq16x4p_kernel / gru_bwd16x4p_kernel below): a lone wave issues one
 // instruction per ~8.7 clocks whatever its kind, two waves on a SIMD each do (tools/experiments/valu_rate.hip), and a step of
-// these kernels is little more than its instruction count.  The four-wave members stay as the reference the tests compare
-// the eight-wave ones with (TT_GRU_SPLIT=4 / TT_GRU_SPLIT_BWD=4); everything said here about the protocol holds for both.
-// Co-residency: the grid is at most one workgroup per CU (the host only takes this path when 4 x row groups x directions
-// <= CUs); members of a team that is not resident yet are waited for with a BOUNDED sweep: a wave that exhausts its budget
-// raises bit 2 (value 4) of the call's status word and the team leaves the step loop -- it never spins forever.
+// these kernels is little more than its instruction count.  The four-wave members are compiled into the comparison build only
+// (-DTT_AB; TT_GRU_SPLIT=4 / TT_GRU_SPLIT_BWD=4 there) as the reference the tests compare the eight-wave ones with; everything
+// said here about the protocol holds for both.
+// Co-residency: the grid is at most one workgroup per CU (ONE launch is only taken when 4 x row groups x directions <= CUs; a host
+// that keeps two calls in flight orders their recurrences or gives the smaller one TT_ENC_ONE_WORKGROUP: include/tt.h,
+// trainer._towers_in_flight); members of a team that is not resident yet are waited for with a BOUNDED sweep: a wave that
+// exhausts its budget raises bit 2 (value 4) of the call's status word and the team leaves the step loop -- it never spins forever.
 #include "encoder.h"
 #include "sgemm.h"
 

@@ -78,7 +78,7 @@ int tt_gemm_rows16(const SgemmParams &p, hipStream_t st);
 
 // The weight-gradient products C[M][N] = A^T B summed over tokens (csrc/wgrad16.hip): p as for tt_sgemm16's (a_t, b_t) = (true,
 // true) form with C = the split-K slabs [z][M][N] (ldc = N, slab_stride = M N); writes nslabs slabs = tt_wgrad16_slabs(...),
-// which the caller reduces (tt_slab_reduce).  tt_wgrad16_supported: M a multiple of 256 (and TT_WGRAD_TILED unset).
+// which the caller reduces (tt_slab_reduce).  tt_wgrad16_supported: M a multiple of 256 (and, in the comparison build, TT_WGRAD_TILED unset).
 bool tt_wgrad16_supported(int M, int N, int64_t lda, int64_t ldb, int64_t b_rows);
 int tt_wgrad16_slabs(int M, int N, int cus, int max_slabs);
 int tt_wgrad16(const SgemmParams &p, int nslabs, hipStream_t st);

@@ -41,7 +41,7 @@
 // barrier.  HBM delivers only the unique 320 MB (TCC misses x 128 B; L2 hit rate 64 %: the XCD placement works).
 // Products and their order per element: (A hi)(B hi) + (A lo)(B hi) + (A hi)(B lo), token tiles ascending inside a slab, slabs
 // reduced in slab order by tt_slab_reduce: deterministic, fp32-grade; NOT bit-identical to the tiled kernel (another slab
-// partition).  TT_WGRAD_TILED=1 keeps the tiled kernel (A/B).
+// partition).  The comparison build (-DTT_AB) keeps the tiled kernel with TT_WGRAD_TILED=1 (A/B).
 #include "sgemm.h"
 
 namespace {
