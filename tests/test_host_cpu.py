@@ -123,7 +123,11 @@ def _dp_worker(rank, world, port, out):
         gr = np.random.RandomState(100 + 10 * step + rank)  # each rank: its own batch shard's gradient
         for prm in params:
             prm.grad.add_(torch.from_numpy(gr.standard_normal(tuple(prm.shape)).astype(np.float32)))
+        if step == 1:
+            opt.reduce_prefix(60)       # the first parameter's gradients go out early (the query tower's, in the train step);
+            assert opt._reduced_upto == 60   # step() then reduces the rest of the bucket, gate words included
         norms.append(float(opt.step()[0]))
+        assert opt._reduced_upto == 0
     out[rank] = (np.concatenate([p.detach().numpy().ravel() for p in params]), norms)
     dist.destroy_process_group()
 

@@ -107,6 +107,7 @@ class _FlatClipAdam:
         self._step_host = 0
         self._pending_status: list = []  # status words of the watched encoders' training calls since the last step()
         self._gate_host, self._gate_ev, self._gate_n, self._deferred = None, None, 0, None   # (snapshot_gate / settle)
+        self._reduced_upto = 0           # gradients [0, _reduced_upto) of this step have been all-reduced already (reduce_prefix)
         self.check = True                # step() reads the reduced gate (one host synchronisation) and raises
         self._views = []
         off = 0
@@ -184,9 +185,21 @@ class _FlatClipAdam:
             self.gate.zero_()
         return gated
 
+    def reduce_prefix(self, upto: int) -> None:
+        """Data-parallel only: all-reduce the bucket's first `upto` gradients NOW, on the current stream -- the part of the
+        bucket whose gradients are already complete (the query tower's, while the document tower's weight-gradient kernels still
+        run: the exchange of half the bucket hides under them).  _reduce_apply then reduces the rest, gate words included: the
+        failure decision still rides in the LAST all-reduce of the step.  Every rank must make the same calls in the same order
+        (a function of the model's structure only)."""
+        if self.world > 1 and 0 < upto <= self.flat_grads.numel() and self._reduced_upto == 0:
+            self._all_reduce(self._bucket[:upto])
+            self._reduced_upto = int(upto)
+
     def _reduce_apply(self, gated: bool, check: Optional[bool] = None) -> torch.Tensor:
         if self.world > 1:
-            self._all_reduce(self._bucket)  # ONE bucket: 3.4 MB of gradients + the gate words
+            # the bucket: 3.4 MB of gradients + the gate words (minus what reduce_prefix has sent already)
+            self._all_reduce(self._bucket[self._reduced_upto:] if self._reduced_upto else self._bucket)
+            self._reduced_upto = 0
         args = (self.lr, self.betas, self.eps, self.max_norm, 1.0 / self.world, self.total_norm)
         words = None
         if self._gated_step_fn is not None:
@@ -379,6 +392,7 @@ class _towers_in_flight:
             e.one_workgroup, e.one_workgroup_bwd, e._status_sink = one, one_bwd, sink
         if exc_type is not None and isinstance(self.optimizer, _FlatClipAdam):
             self.optimizer._pending_status.clear()  # (a step that died before optimizer.step(): its words are nobody's)
+            self.optimizer._reduced_upto = 0
         return False
 
 
@@ -501,6 +515,15 @@ def _train_step_direct(model: TwoTowerModel, optimizer, queries, pos_docs, neg_d
                 # (a time-out of the split backward recurrence ORs bit 2 into the forward's word, which the optimizer reads)
                 enc._run_backward(ids.contiguous(), f[1], d_out, f[3], f[4], into=grads, status=f[2], opts=f[5],
                                   sync=sync_b.get(id(enc)))
+                if enc is model.query_encoder and optimizer.world > 1 and not join_on_caller:
+                    # data-parallel: the query tower's gradients are complete long before the document tower's (its backward is
+                    # a tenth of the tokens) -- when they are the bucket's prefix their all-reduce goes out HERE, on the query
+                    # tower's stream, and runs under the document tower's weight-gradient kernels; the rest of the bucket (with
+                    # the gate words) follows in optimizer.step()
+                    base = optimizer.flat_grads.data_ptr()
+                    spans = sorted(((g.data_ptr() - base) // 4, g.numel()) for g in grads)
+                    if spans[0][0] == 0 and all(a + n == b for (a, n), (b, _) in zip(spans, spans[1:])):
+                        optimizer.reduce_prefix(spans[-1][0] + spans[-1][1])
         join()
         for p_, gv in zip(optimizer.params, optimizer._views):
             p_.grad = gv
