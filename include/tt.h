@@ -257,6 +257,13 @@ typedef struct tt_enc_sync {
 
 #define TT_ENC_TRAIN_MASK 0xff
 #define TT_ENC_ONE_WORKGROUP 0x100 /* option bit of `train` / `opts`: recurrences on one workgroup per 16-row group */
+/* tt_encoder_forward_f32 in two halves, so that a host can put ANOTHER call's launches between them: the same arguments and
+ * workspace twice, once with TT_ENC_PHASE_BEGIN (input checks, lengths, weight conversion, layer 0's input projection: everything
+ * in front of the first recurrence launch; `out` is not written) and once with TT_ENC_PHASE_FINISH (the recurrences and the
+ * head).  With tt_enc_sync_t a host orders call B's recurrences behind call A's without delaying B's projection: B BEGIN, A
+ * (records), B FINISH (waits) -- what trainer.train_step does with the document tower (B) and the query tower (A). */
+#define TT_ENC_PHASE_BEGIN 0x200
+#define TT_ENC_PHASE_FINISH 0x400
 /* CUs the column-split recurrence of one call of this shape occupies (one workgroup each, all resident at once); 0 = the call
  * runs the one-workgroup kernels whatever `train` says.  A host with several calls in flight keeps the sum within the device's
  * CU count by passing TT_ENC_ONE_WORKGROUP to the smaller ones. */

@@ -568,10 +568,11 @@ def test_train_step_keeps_the_split_recurrences_within_the_cus():
     """The train step launches the query tower and the 2B-row document tower on two streams.  Both column-split would be 32 + 64
     teams = 384 one-per-CU workgroups for 256 CUs: members of some teams would wait for a CU while their partners already sweep
     for them, and progress would rest on dispatch order.  trainer._towers_in_flight makes co-residency a matter of construction:
-    a direct step whose host runs ahead of the GPU (defer_check) ORDERS the two towers' forward recurrence launches with an event
-    inside the calls (tt_enc_sync_t: the query tower's first) and gives the smaller tower the one-workgroup BACKWARD recurrence; a
-    step that ends in a host read (the default), the autograd path and graph capture give the smaller tower the one-workgroup
-    recurrences in both directions.  Checked here on what the tower calls really got.  Three steps: with the split forward alone
+    the direct step ORDERS the two towers' forward recurrence launches with an event inside the calls (tt_enc_sync_t: the query
+    tower's first; the document tower's call goes out in two halves around the query tower's, TT_ENC_PHASE_BEGIN / _FINISH, so
+    that its projection is not delayed) and gives the smaller tower the one-workgroup BACKWARD recurrence; the autograd path and
+    graph capture give the smaller tower the one-workgroup recurrences in both directions.  Checked here on what the tower calls
+    really got.  Three steps: with the split forward alone
     the parameters are the all-one-workgroup run's bit for bit; with the backwards split too the run repeats itself bit for bit
     and its last gradient agrees with the one-workgroup run's to the gradient tolerance; direct and autograd paths agree."""
     import copy
@@ -587,14 +588,17 @@ def test_train_step_keeps_the_split_recurrences_within_the_cus():
     for name, (flag, bwd, direct, defer) in cases.items():
         m = copy.deepcopy(m0)
         o = tt.FusedClipAdam(m.parameters(), lr=1e-5, max_norm=1.0)
-        seen = []
+        seen, begun = [], []
         for enc in (m.query_encoder, m.doc_encoder):
             fwd0 = enc._run_forward
 
             def spy(x, train, *a, _f=fwd0, _e=enc, **k):
                 sy = k.get("sync")
-                seen.append((_e, x.shape[0], _e._opts(), _e._opts_bwd(), None if sy is None else (bool(sy.wait_before_recurrence),
-                                                                                                bool(sy.record_after_recurrence))))
+                if k.get("phase", 0) == _lib.TT_ENC_PHASE_BEGIN:
+                    begun.append(_e)          # (the first half of a two-phase call: prep + projection, no recurrence yet)
+                else:
+                    seen.append((_e, x.shape[0], _e._opts(), _e._opts_bwd(), None if sy is None else
+                                 (bool(sy.wait_before_recurrence), bool(sy.record_after_recurrence))))
                 return _f(x, train, *a, **k)
             enc._run_forward = spy
         losses = []
@@ -613,10 +617,11 @@ def test_train_step_keeps_the_split_recurrences_within_the_cus():
             assert want <= cus or ordered, (name, pair)
             if ordered:   # the recording call (the query tower) was issued first
                 assert pair[0][0] is m.query_encoder and pair[0][4] == (False, True), (name, pair)
-        if cus < 384 and name == "both":
+        if cus < 384 and name in ("both", "both_checked"):
             assert all(sy is not None and not of for *_, of, ob, sy in seen), seen          # both forwards split, ordered by events
             assert all(ob for e, _, of, ob, sy in seen if e is m.query_encoder), seen       # the smaller tower's backward: one workgroup
-        if cus < 384 and name in ("both_checked", "both_autograd"):
+            assert begun == [m.doc_encoder] * 3                                             # the document tower's call in two halves
+        if cus < 384 and name == "both_autograd":
             q_calls = [t for t in seen if t[0] is m.query_encoder]
             assert all(of and ob and sy is None for *_, of, ob, sy in q_calls), seen         # the smaller tower: one workgroup
     assert runs["one"][0] == runs["fwd"][0] and torch.equal(runs["one"][1], runs["fwd"][1])

@@ -680,9 +680,12 @@ static int encoder_forward(const char *who, const int64_t *ids, int B, int T, co
     int rc = enc_check_shape(who, B, T, E, H, num_layers, V);
     if (rc != TT_OK)
         return rc;
-    if (train < 0 || (train & ~(TT_ENC_TRAIN_MASK | TT_ENC_ONE_WORKGROUP)) || (train & TT_ENC_TRAIN_MASK) > 2)
-        return tt_fail(TT_ERR_BAD_SHAPE, "%s: train=0x%x (0, 1 or 2, optionally | TT_ENC_ONE_WORKGROUP)", who, train);
+    if (train < 0 || (train & ~(TT_ENC_TRAIN_MASK | TT_ENC_ONE_WORKGROUP | TT_ENC_PHASE_BEGIN | TT_ENC_PHASE_FINISH)) ||
+        (train & TT_ENC_TRAIN_MASK) > 2 || ((train & TT_ENC_PHASE_BEGIN) && (train & TT_ENC_PHASE_FINISH)))
+        return tt_fail(TT_ERR_BAD_SHAPE, "%s: train=0x%x (0, 1 or 2, optionally | TT_ENC_ONE_WORKGROUP | one TT_ENC_PHASE_*)", who, train);
     const bool one_wg = (train & TT_ENC_ONE_WORKGROUP) != 0; // the caller keeps the recurrences off the column-split kernels
+    // the call in two halves (include/tt.h): BEGIN = everything in front of the first recurrence launch, FINISH = the rest
+    const bool ph_begin = (train & TT_ENC_PHASE_BEGIN) != 0, ph_finish = (train & TT_ENC_PHASE_FINISH) != 0;
     train &= TT_ENC_TRAIN_MASK;
     if (!ids || !table || !weights || !out || (bidirectional && (!proj_w || !proj_b)))
         return tt_fail(TT_ERR_BAD_SHAPE, "%s: null pointer", who);
@@ -710,13 +713,15 @@ static int encoder_forward(const char *who, const int64_t *ids, int B, int T, co
     const bool use16_early = rnn_type == CELL_GRU && gru16_supported(H) && !enc_force_f32();
     const bool split0 = use16_early && lo.xch && !one_wg && gru16x4_usable(B, H, ndir);
     const bool fused_prep = B <= 1024 && (int64_t)B * T <= PREP_FUSED_MAX_IDS;
-    {
+    if (!ph_finish) {
         float *x1 = (num_layers == 1 && !train) ? nullptr : (float *)(ws + lo.x[1]);
         TT_RC_CHECK(tt_zero3_async(fused_prep ? nullptr : (void *)flag, fused_prep ? 0 : 256,
                                    train ? (void *)(x1 + (size_t)lo.MT * ndir * H) : nullptr, train ? sizeof(float) * ndir * H : 0,
                                    split0 ? (void *)(ws + lo.xch) : nullptr, split0 ? gru16x4_xch_bytes(B, H, ndir) : 0, st));
     }
-    if (fused_prep) {
+    if (ph_finish) {
+        // (the BEGIN half made lengths, packed ids, maps and layer 0's projections in this workspace)
+    } else if (fused_prep) {
         hipLaunchKernelGGL(prep_fused_kernel, dim3(1), dim3(1024), 0, st, ids, B, T, V, len, flag, tok_off, perm, idsp, status,
                            pm_fwd, pm_rev, (int)lo.MT);
         TT_LAUNCH_CHECK();
@@ -779,11 +784,15 @@ static int encoder_forward(const char *who, const int64_t *ids, int B, int T, co
                 wmax = (unsigned *)flag + 16 + 2 * l + d;
                 w16 = ws + lo.wih16[d];
                 wp = ws + lo.wp[d];
-                rc = enc_pack_weights(I, H, rnn_type, w, wih_max, wmax, w16, wp, st);
-                if (rc != TT_OK)
-                    return rc;
+                if (!(ph_finish && l == 0)) {
+                    rc = enc_pack_weights(I, H, rnn_type, w, wih_max, wmax, w16, wp, st);
+                    if (rc != TT_OK)
+                        return rc;
+                }
             }
-            if (!force_f32) {
+            if (ph_finish && l == 0) {
+                rc = TT_OK; // (layer 0's projection was launched by the BEGIN half)
+            } else if (!force_f32) {
                 // K1 on the f16 pipes (fp16 hi/lo split, fp32-grade; sgemm.h): W_ih is scaled by the power of two
                 // that puts its largest element in [2^13, 2^14); deeper layers' A rows are hidden states in (-1, 1) (times
                 // 1/(1-p) under dropout): 2^6; layer 0's are embedding vectors of ANY magnitude: the token-stationary
@@ -832,6 +841,10 @@ static int encoder_forward(const char *who, const int64_t *ids, int B, int T, co
         }
         if (ndir == 1)
             gp.dir[1] = gp.dir[0];
+        if (ph_begin) { // everything in front of the first recurrence launch is in the queue
+            TT_LAUNCH_CHECK();
+            return TT_OK;
+        }
         if (l == 0 && sync && sync->wait_before_recurrence) // (include/tt.h: the host orders this call's recurrences behind another call's)
             TT_HIP_CHECK(hipStreamWaitEvent(st, (hipEvent_t)sync->wait_before_recurrence, 0));
         if (use16 && lo.xch && !one_wg && gru16x4_usable(B, H, ndir)) {

@@ -264,8 +264,10 @@ class RNNEncoder(nn.Module):
         return blob
 
     def _run_forward(self, x: torch.Tensor, train: bool, dropout_p: float = 0.0, dropout_seed: int = 0, opts: Optional[int] = None,
-                     sync=None):
-        """sync: an _lib.EncSync (tt_enc_sync_t) that orders this call's recurrences against another stream's (training calls)."""
+                     sync=None, phase: int = 0, resume=None):
+        """sync: an _lib.EncSync (tt_enc_sync_t) that orders this call's recurrences against another stream's (training calls).
+        phase: 0 = the whole call; _lib.TT_ENC_PHASE_BEGIN = everything in front of the first recurrence launch (returns the
+        (out, ws, status) triple to pass back as `resume`); _lib.TT_ENC_PHASE_FINISH with resume = the rest (train mode only)."""
         L = _lib.lib()
         opts = self._opts() if opts is None else opts
         ids = x.contiguous()
@@ -285,11 +287,14 @@ class RNNEncoder(nn.Module):
         # autograd node owns it; in eval mode a per-call buffer keeps concurrent callers apart -- the reference serves
         # queries from a thread pool (frontend/main.py:103), and a buffer shared across threads or streams would be
         # overwritten by the next call's kernels while this call's are still queued.
-        ws = torch.empty(max(need, 256), dtype=torch.uint8, device=ids.device)
-        out = torch.empty((B, H), dtype=torch.float32, device=ids.device)
-        # (not zeroed: every call that returns TT_OK WRITES the word on the stream -- include/tt.h, `status` -- and a call that
-        #  does not raises below before anyone reads it; the fill was one more ~5 us launch in front of every tower call)
-        status = torch.empty(1, dtype=torch.int32, device=ids.device)
+        if resume is not None:
+            out, ws, status = resume
+        else:
+            ws = torch.empty(max(need, 256), dtype=torch.uint8, device=ids.device)
+            out = torch.empty((B, H), dtype=torch.float32, device=ids.device)
+            # (not zeroed: every call that returns TT_OK WRITES the word on the stream -- include/tt.h, `status` -- and a call that
+            #  does not raises below before anyone reads it; the fill was one more ~5 us launch in front of every tower call)
+            status = torch.empty(1, dtype=torch.int32, device=ids.device)
         quads = [w.detach().contiguous() for quad in self.rnn.quads() for w in quad]
         wptr = _ptr_array(quads)
         pw = self.projection.weight.detach().contiguous() if self.projection is not None else None
@@ -307,9 +312,11 @@ class RNNEncoder(nn.Module):
                 _lib.check(L.tt_encoder_forward_f32(
                     ids.data_ptr(), B, T, table.data_ptr(), V, E, H, self.num_layers, int(self.bidirectional),
                     self._cell, wptr, pw.data_ptr() if pw is not None else None,
-                    pb.data_ptr() if pb is not None else None, int(self.normalize_output), train_mode | opts,
+                    pb.data_ptr() if pb is not None else None, int(self.normalize_output), train_mode | opts | phase,
                     float(dropout_p), int(dropout_seed), out.data_ptr(), ws.data_ptr(), ws.numel(), status.data_ptr(),
                     C.byref(sync) if sync is not None else None, _stream(ids.device)))
+        if phase == _lib.TT_ENC_PHASE_BEGIN:
+            return out, ws, status   # (the status word is handed over / read when the FINISH half has been issued)
         if self.check_inputs:
             if self._deferred_status is not None:
                 self._deferred_status.append(status)  # the caller reads them once, after enqueuing its other calls

@@ -309,6 +309,7 @@ def _concat_ids(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
 
 
 _ORDER_EVENTS = {}
+_TWO_PHASE = True   # (tools/experiments: False issues the query tower first instead of splitting the document tower's call)
 
 
 def _order_events(device):
@@ -334,8 +335,9 @@ class _towers_in_flight:
     streams do not (query tower 128 + document tower 256 on 256 CUs: round 3 rested on in-order dispatch).  Two ways out, both
     co-residency BY CONSTRUCTION:
       * ordered (the direct step), FORWARD: the towers' recurrence launches are ordered by an event inside the calls
-        (tt_enc_sync_t): the query tower's recurrence (64 us) first -- it has drained before the document tower's input
-        projection has finished -- and everything else of the two towers still overlaps.  BACKWARD: the smaller tower runs the
+        (tt_enc_sync_t): the query tower's recurrence first, the document tower's behind it, everything else of the two towers
+        still overlaps; the document tower's call goes out in two halves around the query tower's (TT_ENC_PHASE_BEGIN / _FINISH),
+        so that the record is issued before the wait without the document tower's projection waiting for the host.  BACKWARD: the smaller tower runs the
         one-workgroup recurrence (its workgroups wait for nobody).  Ordering the backwards too was measured and dropped: the query
         tower's split recurrence behind the document tower's lands under the document tower's weight-gradient kernels, whose
         one-per-CU workgroups keep it off the CUs until they end (graph replay 1.146 -> 1.207 ms), and in front of it it would
@@ -439,12 +441,6 @@ def _train_step_direct(model: TwoTowerModel, optimizer, queries, pos_docs, neg_d
         # cannot capture; with the query tower moved onto the capturing stream it can, but replays slower: 1.19-1.21 ms against
         # 1.16 with the smaller tower on the one-workgroup recurrences, profiles/r04_m_graph_probe.log)
         plan.use_one_workgroup()
-    elif plan is not None and plan.needs_order and optimizer.check and all(e.check_inputs for e in encs):
-        # a step that ENDS with a host read (the gate words) starts with the GPU idle: whichever tower is issued first starts
-        # first, and the ordered forward must issue the query tower first -- that costs the document tower the ~0.1 ms the host
-        # needs for the query tower's launches, more than the ordering saves (1.365 against 1.34 ms, profiles/r04_n_bench_n1.json
-        # / r04_j).  With the read deferred (or no read at all) the host runs ahead of the GPU and the order of issue is free.
-        plan.use_one_workgroup()
     s_main = cur if join_on_caller else s_doc     # where the towers meet: loss, optimizer
     ordered = plan is not None and plan.needs_order
     sync_f = sync_b = {}
@@ -474,21 +470,29 @@ def _train_step_direct(model: TwoTowerModel, optimizer, queries, pos_docs, neg_d
         # dropout seeds from torch's CPU generator in the order the autograd path draws them (query tower, then document tower)
         seeds = {id(enc): (int(torch.randint(0, 2 ** 62, (1,)).item()) if enc.dropout > 0.0 else 0)
                  for enc in (model.query_encoder, model.doc_encoder)}
-        # Issue order.  Unordered: the document tower (2B rows of ~70 tokens: the step's critical path) FIRST, the query tower's
-        # ~15 small launches then overlap it instead of delaying it by the ~0.1 ms the host needs to issue them.  Ordered: the
-        # call that RECORDS the ordering event must be issued before the call that waits for it (include/tt.h) -- the query
-        # tower first; its recurrence is over long before the document tower's projection is.
+        # Issue order: the document tower (2B rows of ~70 tokens: the step's critical path) FIRST, the query tower's ~15 small
+        # launches then overlap it instead of delaying it by the ~0.1 ms the host needs to issue them.  Ordered recurrences: the
+        # call that RECORDS the ordering event must be issued before the WAIT for it (include/tt.h), so the document tower's call
+        # goes out in two halves around the query tower's: BEGIN (prep, weight conversion, input projection: 130 us of GPU
+        # work), the query tower (records behind its recurrence), FINISH (waits, then recurrence + head).
         fw = [None, None]
-        for k in ((1, 0) if ordered else (0, 1)):
+        begun = None
+        for k, half in (((0, _lib.TT_ENC_PHASE_BEGIN), (1, 0), (0, _lib.TT_ENC_PHASE_FINISH)) if (ordered and _TWO_PHASE) else
+                         (((1, 0), (0, 0)) if ordered else ((0, 0), (1, 0)))):
             enc, ids, s = encs[k], ids_of[k], streams[k]
-            if s is not cur:
+            if s is not cur and half != _lib.TT_ENC_PHASE_FINISH:
                 s.wait_stream(cur)
             with torch.cuda.stream(s):
                 ids.record_stream(s)
                 p_drop = enc.dropout
                 seed = seeds[id(enc)]
                 # (the encoders are watched -- _towers_in_flight -- so the status word goes to the optimizer instead of a read here)
-                out, ws, status = enc._run_forward(ids, train=True, dropout_p=p_drop, dropout_seed=seed, sync=sync_f.get(id(enc)))
+                res = enc._run_forward(ids, train=True, dropout_p=p_drop, dropout_seed=seed, sync=sync_f.get(id(enc)) if half != _lib.TT_ENC_PHASE_BEGIN else None,
+                                       phase=half, resume=begun if half == _lib.TT_ENC_PHASE_FINISH else None)
+                if half == _lib.TT_ENC_PHASE_BEGIN:
+                    begun = res
+                    continue
+                out, ws, status = res
                 fw[k] = (out, ws, status, p_drop, seed, enc._opts_bwd())
         # The document tower's stream carries the step's critical path from here on: the loss, the document backward and the
         # optimizer are enqueued on IT (a hop to the caller's stream and back cost ~20 us each way on that path: event wait +
