@@ -437,6 +437,12 @@ int tt_tok_encode(const void *handle, const char *text_blob, const int64_t *text
  * text i = blob[text_off_out[i], text_off_out[i + 1] - 1)), which saves a Python host its per-text length pass. */
 int tt_tok_encode_sep(const void *handle, const char *text_blob, int64_t blob_len, char sep, int64_t n_texts,
                       int64_t *text_off_out, int64_t *ragged_ids, int32_t *lens, int32_t *status, int n_threads);
+/* tt_tok_encode for texts that lie wherever the host keeps them: texts[i] points at text_len[i] bytes (no terminator needed).
+ * text_off_out [n_texts + 1] receives the running sum of the lengths; text i's ids go to ragged_ids[text_off_out[i] ...]
+ * (capacity: the sum of the lengths), which is the layout tt_tok_pad reads.  A host whose strings are separate objects (CPython
+ * str, Go string, Java byte[]) builds no blob: twotowermlretrieval_amd/csrc/pytext.c collects the pointers of a list of str. */
+int tt_tok_encode_ptrs(const void *handle, const char *const *texts, const int64_t *text_len, int64_t n_texts,
+                       int64_t *text_off_out, int64_t *ragged_ids, int32_t *lens, int32_t *status, int n_threads);
 int tt_tok_pad(const int64_t *ragged_ids, const int64_t *text_off, const int32_t *lens, int64_t n_texts,
                int64_t width, int64_t *out, int n_threads);
 

@@ -97,3 +97,88 @@ def test_host_cores_is_positive_and_at_most_the_affinity():
     import os
     from twotowermlretrieval_amd.tokenizer import host_cores
     assert 1 <= host_cores() <= len(os.sched_getaffinity(0))
+
+
+def _long_word_vocab(rs, n=4000):
+    """Words of 1 .. 40 bytes; many share their first 8 or 16 bytes (the native table keeps 8 key bytes in a slot and compares
+    the rest in the key blob; the scan takes words of up to 16 bytes from a 16-byte window and longer ones byte by byte)."""
+    alphabet = "abcdefghijklmnopqrstuvwxyz0123456789_"
+    stems = ["".join(rs.choice(alphabet) for _ in range(L)) for L in (8, 8, 16, 16, 7, 15, 9, 17)]
+    words = {}
+    while len(words) < n:
+        L = rs.choice([1, 2, 3, 5, 7, 8, 9, 12, 15, 16, 17, 18, 24, 31, 32, 33, 40])
+        w = "".join(rs.choice(alphabet) for _ in range(L))
+        if rs.random() < 0.4:
+            w = (rs.choice(stems) + w)[:max(L, 9)]
+        words.setdefault(w, len(words))
+    for p in ".,!?;":
+        words.setdefault(p, len(words))
+    return words
+
+
+def test_long_keys_shared_prefixes_and_every_window_alignment(monkeypatch):
+    from twotowermlretrieval_amd import tokenizer as T
+    rs = random.Random(11)
+    vocab = _long_word_vocab(rs)
+    vocab["big" + "x" * 20] = 7_000_000_000            # a long key whose id needs 64 bits
+    tok = PretrainedTokenizer(word2idx=vocab)
+    keys = list(vocab)
+    texts = []
+    for i in range(1500):
+        parts = [" " * rs.randint(0, 17)]               # every start offset inside a 16-byte window
+        for _ in range(rs.randint(0, 30)):
+            w = rs.choice(keys)
+            r = rs.random()
+            if r < 0.25:
+                w = w.upper()
+            elif r < 0.35:
+                w = w[:-1] + "Q" if len(w) > 1 else w   # near miss: same length, same prefix
+            elif r < 0.45:
+                w = w + "z"                             # near miss: one byte longer
+            parts.append(w + rs.choice([" ", "  ", ",", ". ", "-", "\t", "!?", ";", " " * 15, " " * 16, " " * 33]))
+        texts.append("".join(parts)[:rs.randint(0, 400)] if rs.random() < 0.3 else "".join(parts))
+    texts += ["a" * 16, "a" * 17, "a" * 16 + " " + "b" * 16, "x" * 31, "x" * 32, "x" * 33, "_" * 8, "9" * 9]
+    want = tok.encode_batch(texts, native=False)
+    got = tok.encode_batch(texts)                        # list of ASCII str: pointer form when csrc/pytext.c is built
+    assert got.shape == want.shape and bool((got == want).all())
+    assert bool((tok.encode_batch(tuple(texts), n_threads=3) == want).all())
+    monkeypatch.setattr(T, "_GATHER", None)              # the one-join form
+    assert bool((tok.encode_batch(texts) == want).all())
+    mixed = texts + [None, "é " + texts[3]]              # the offsets form (a non-str element, a non-ASCII text)
+    assert bool((tok.encode_batch(mixed) == tok.encode_batch(mixed, native=False)).all())
+
+
+def test_pointer_form_is_the_one_taken_for_lists_of_ascii_str():
+    """csrc/pytext.c is built by twotowermlretrieval_amd.build: lists and tuples of ASCII str are read in place (no join)."""
+    from twotowermlretrieval_amd import tokenizer as T
+    gather = T._pytext_gather()
+    assert gather is not None, "twotowermlretrieval_amd/_pytext*.so is missing: python -m twotowermlretrieval_amd.build"
+    ptrs, lens = np.zeros(4, np.uint64), np.zeros(4, np.int64)
+    assert gather(["ab", "", "cde"], ptrs.ctypes.data, lens.ctypes.data) == (3, 5) and lens[:3].tolist() == [2, 0, 3]
+    assert gather(["ab", "é", "cde"], ptrs.ctypes.data, lens.ctypes.data)[0] == 1      # stops at the first non-ASCII str
+    assert gather(("ab", 7), ptrs.ctypes.data, lens.ctypes.data)[0] == 1
+    import pytest
+    with pytest.raises(TypeError):
+        gather("ab", ptrs.ctypes.data, lens.ctypes.data)
+
+
+def test_a_key_listed_twice_resolves_to_the_later_id():
+    """tt_tok_create takes (keys, ids) arrays: a key that occurs twice -- a dict cannot hold one, a table built from a word list
+    can -- resolves to the LATER id, as a dict filled in order would; for short keys (id in the slot) and long ones (side table)."""
+    import ctypes as C
+    from twotowermlretrieval_amd import _lib
+    L = _lib.lib()
+    keys = [b"the", b"averyveryverylongword", b"mid_length_k", b"the", b"averyveryverylongword", b"mid_length_k", b"x"]
+    ids = np.asarray([1, 2, 3, 40, 50, 60, 7], dtype=np.int64)
+    off = np.zeros(len(keys) + 1, dtype=np.int64)
+    np.cumsum([len(k) for k in keys], out=off[1:])
+    blob = b"".join(keys)
+    h = C.c_void_p()
+    _lib.check(L.tt_tok_create(blob, off.ctypes.data, ids.ctypes.data, len(keys), 99, C.byref(h)))
+    text = b"The averyveryverylongword mid_length_k x averyveryverylongworD2 mid_length_"
+    toff = np.asarray([0, len(text)], dtype=np.int64)
+    ragged = np.zeros(len(text), dtype=np.int64)
+    n, st = np.zeros(1, np.int32), np.zeros(1, np.int32)
+    _lib.check(L.tt_tok_encode(h, text, toff.ctypes.data, 1, ragged.ctypes.data, n.ctypes.data, st.ctypes.data, 1))
+    L.tt_tok_destroy(h)
+    assert st[0] == 0 and ragged[:n[0]].tolist() == [40, 50, 60, 7, 99, 99]

@@ -47,6 +47,7 @@ def needs_build() -> bool:
 
 
 def build(force: bool = False, verbose: bool = False) -> Path:
+    build_pytext(force)
     if not force and not needs_build():
         return LIB
     objdir = PKG / "build"
@@ -76,6 +77,24 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stdout}")
     return LIB
+
+
+def build_pytext(force: bool = False) -> Path:
+    """twotowermlretrieval_amd/_pytext.*.so from csrc/pytext.c (CPython API, host compiler): the str-pointer gather in front of
+    tt_tok_encode_ptrs.  Not part of libtt.so; tokenizer.encode_batch falls back to its one-join form without it."""
+    import sysconfig
+    src = PKG / "csrc" / "pytext.c"
+    out = PKG / ("_pytext" + sysconfig.get_config_var("EXT_SUFFIX"))
+    if not force and out.exists() and out.stat().st_mtime > src.stat().st_mtime:
+        return out
+    cc = os.environ.get("CC") or shutil.which("gcc") or shutil.which("cc")
+    if cc is None:
+        raise RuntimeError("no C compiler for csrc/pytext.c")
+    r = subprocess.run([cc, "-O2", "-shared", "-fPIC", "-Wall", f"-I{sysconfig.get_paths()['include']}", str(src), "-o", str(out)],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode:
+        raise RuntimeError(f"{cc} failed on pytext.c:\n{r.stdout}")
+    return out
 
 
 def build_variant(name: str, defs, force: bool = False) -> Path:

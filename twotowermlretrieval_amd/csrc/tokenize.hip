@@ -9,104 +9,328 @@
 #include "tt_common.h"
 
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
+#include <sys/mman.h>
+#if defined(__SSE2__) && !defined(TT_TOK_NO_SIMD)
+#include <emmintrin.h>
+#endif
 #include <thread>
 #include <vector>
 
+// Build-time knobs (tools/experiments/tok_harness.sh times the variants on the host in question; none is read at run time)
+#ifndef TT_TOK_LAG
+#define TT_TOK_LAG 16        // tokens between a slot's prefetch and its read (4 ... 48 within 8 % of each other where measured)
+#endif
+#ifndef TT_TOK_HUGEPAGES
+#define TT_TOK_HUGEPAGES 1   // ask for transparent huge pages under the slot table
+#endif
+
 namespace {
 
-// One 16-byte slot per key: everything a probe needs sits in the slot's cache line (tag = high hash bits, length, where the
-// key's bytes are, the id) -- a hit costs the slot's line plus the key's bytes, a miss on an occupied slot only the slot (the
-// first table kept word numbers in the slots and looked length, bytes and id up in three more arrays: four dependent cache
-// misses per token on a 400 k-word GloVe vocabulary).
+// One 16-byte slot per key, four per cache line: tag_len = the hash's high bits with the key length (capped at 31) in the low five,
+// the key's first 8 bytes, and the id.  A token of up to 8 bytes -- most of a text -- is resolved from the slot alone; a longer
+// one whose tag, length and first 8 bytes agree is compared with the key's remaining bytes through `longs`.  A 400 k-word
+// vocabulary is a 16 MB table.  (The first table kept word numbers in the slots and looked length, bytes and id up in three more
+// arrays: four dependent cache misses per token; the second kept 16-byte slots and every key in the blob: two.)
 struct TokSlot {
-    uint32_t tag;   // hash >> 32
-    uint32_t off;   // offset of the key in blob
-    int32_t len;    // key length in bytes, -1 = empty slot
-    int32_t val;    // the id (ids32) or the word number (index into ids)
+    uint32_t tag_len; // 0 = empty slot (no key has length 0)
+    int32_t val;      // len <= 8: the id (ids32) or the word number (index into ids); len > 8: index into longs
+    uint64_t k0;      // the key's bytes 0 .. 7 (little-endian, zero-padded)
+};
+static_assert(sizeof(TokSlot) == 16, "four slots per cache line");
+struct LongKey {
+    uint32_t off, len; // the key in blob
+    int64_t id;
+};
+
+// The slot table on transparent huge pages where the kernel grants them (madvise mode included): with 4 KB pages nearly every
+// probe of a 16 MB table also misses the TLB, and a software prefetch that has to walk the page table first is no prefetch.
+template <class T>
+struct HugeArray {
+    T *p = nullptr;
+    size_t n = 0;
+    HugeArray() = default;
+    HugeArray(const HugeArray &) = delete;
+    HugeArray &operator=(const HugeArray &) = delete;
+    ~HugeArray() { std::free(p); }
+    bool assign(size_t count, const T &v)
+    {
+        std::free(p);
+        p = nullptr;
+        n = 0;
+        const size_t huge = (size_t)2 << 20, bytes = (count * sizeof(T) + huge - 1) / huge * huge;
+        void *q = nullptr;
+        if (posix_memalign(&q, huge, bytes) != 0)
+            return false;
+#if defined(MADV_HUGEPAGE) && TT_TOK_HUGEPAGES
+        madvise(q, bytes, MADV_HUGEPAGE); // (advice: refused or unsupported -> ordinary pages)
+#endif
+        p = (T *)q;
+        n = count;
+        for (size_t i = 0; i < count; ++i)
+            p[i] = v;
+        return true;
+    }
+    T &operator[](size_t i) { return p[i]; }
+    const T &operator[](size_t i) const { return p[i]; }
 };
 
 struct TokTable {
     std::vector<char> blob;          // all words, back to back
     std::vector<int64_t> ids;        // id of word i (only read when !ids32)
-    std::vector<TokSlot> slots;      // open addressing, linear probing
+    HugeArray<TokSlot> slots;        // open addressing, linear probing
+    std::vector<LongKey> longs;      // keys of more than 8 bytes
     uint64_t mask = 0;
     int64_t unk = 0;
     bool ids32 = true;               // every id fits an int32: ids live in the slots
 };
 
-constexpr uint64_t FNV_BASIS = 1469598103934665603ull, FNV_PRIME = 1099511628211ull;
-inline uint64_t fnv_finish(uint64_t h) { return h ^ (h >> 29); }
-inline uint64_t fnv1a(const char *p, size_t n)
+// The hash of a key: its bytes as little-endian 64-bit words (the last one zero-padded), one multiply per word -- a word of up
+// to 8 characters costs one round (a byte-serial FNV-1a was a chain of one 64-bit multiply PER BYTE).
+constexpr uint64_t HASH_SEED = 0x243f6a8885a308d3ull, HASH_MUL = 0x9e3779b97f4a7c15ull, HASH_MUL2 = 0xd6e8feb86659fd93ull;
+inline uint64_t load_le(const char *p, size_t n) // n <= 8 bytes, zero-padded
 {
-    uint64_t h = FNV_BASIS;
-    for (size_t i = 0; i < n; ++i) {
-        h ^= (unsigned char)p[i];
-        h *= FNV_PRIME;
-    }
-    return fnv_finish(h);
+    uint64_t v = 0;
+    std::memcpy(&v, p, n);
+    return v;
 }
-
-inline int64_t lookup_hashed(const TokTable &t, const char *p, size_t n, uint64_t h)
+inline uint64_t hash_round(uint64_t h, uint64_t w)
 {
-    const uint32_t tag = (uint32_t)(h >> 32);
-    uint64_t s = h & t.mask;
-    for (;;) {
-        const TokSlot &sl = t.slots[s];
-        if (sl.len < 0)
-            return t.unk;
-        if (sl.tag == tag && (size_t)sl.len == n && std::memcmp(t.blob.data() + sl.off, p, n) == 0)
-            return t.ids32 ? (int64_t)sl.val : t.ids[(size_t)sl.val];
-        s = (s + 1) & t.mask;
-    }
+    h = (h ^ w) * HASH_MUL;
+    return h ^ (h >> 32);
 }
-
-inline bool is_word(unsigned char c)
+inline uint64_t hash_finish(uint64_t h, size_t n)
 {
-    return (c >= 'a' && c <= 'z') || (c >= '0' && c <= '9') || c == '_' || (c >= 'A' && c <= 'Z');
+    h = (h ^ (uint64_t)n) * HASH_MUL2;
+    return h ^ (h >> 29);
 }
-inline bool is_punct(unsigned char c) { return c == '.' || c == ',' || c == '!' || c == '?' || c == ';'; }
-
-// one text -> ids at out[0..]; returns the token count, or -1 when the text is not pure ASCII
-int64_t encode_one(const TokTable &t, const char *s, size_t n, int64_t *out, std::vector<char> &lower)
+inline uint64_t hash_key(const char *p, size_t n)
 {
-    for (size_t i = 0; i < n; ++i)
-        if ((unsigned char)s[i] >= 0x80)
-            return -1;
-    int64_t cnt = 0;
+    uint64_t h = HASH_SEED;
     size_t i = 0;
-    char small[64];
+    for (; i + 8 <= n; i += 8)
+        h = hash_round(h, load_le(p + i, 8));
+    if (i < n)
+        h = hash_round(h, load_le(p + i, n - i));
+    return hash_finish(h, n);
+}
+
+// character classes of the reference's pattern  \w+|[.,!?;]  on lower-cased ASCII text (backend/tokenizer.py:41-43)
+enum : unsigned char { CH_OTHER = 0, CH_WORD = 1, CH_PUNCT = 2, CH_HIGH = 3 };
+struct CharTables {
+    unsigned char cls[256];
+    char low[256];
+    CharTables()
+    {
+        for (int c = 0; c < 256; ++c) {
+            const bool word = (c >= 'a' && c <= 'z') || (c >= '0' && c <= '9') || c == '_' || (c >= 'A' && c <= 'Z');
+            const bool punct = c == '.' || c == ',' || c == '!' || c == '?' || c == ';';
+            cls[c] = c >= 0x80 ? CH_HIGH : word ? CH_WORD : punct ? CH_PUNCT : CH_OTHER;
+            low[c] = (c >= 'A' && c <= 'Z') ? (char)(c + 32) : (char)c;
+        }
+    }
+};
+const CharTables g_chars;
+
+inline uint32_t tag_len_of(uint64_t h, size_t n) { return ((uint32_t)(h >> 32) & ~31u) | (uint32_t)(n < 31 ? n : 31); }
+inline int64_t short_value(const TokTable &t, const TokSlot &sl) { return t.ids32 ? (int64_t)sl.val : t.ids[(size_t)sl.val]; }
+
+// a key of more than 16 bytes (p: the whole lower-cased key)
+int64_t lookup_long(const TokTable &t, const char *p, size_t n, uint64_t h)
+{
+    const uint32_t tl = tag_len_of(h, n);
+    const uint64_t k0 = load_le(p, 8);
+    for (uint64_t s = h & t.mask;; s = (s + 1) & t.mask) {
+        const TokSlot &sl = t.slots[s];
+        if (sl.tag_len == 0)
+            return t.unk;
+        if (sl.tag_len == tl && sl.k0 == k0) {
+            const LongKey &lk = t.longs[(size_t)sl.val];
+            if (lk.len == n && std::memcmp(t.blob.data() + lk.off + 8, p + 8, n - 8) == 0)
+                return lk.id;
+        }
+    }
+}
+
+// Tokens of up to 16 bytes are looked up LATE: the scan computes a token's hash, asks for its slot's cache line and goes on
+// scanning; the slot is read LAG tokens later, when the line has arrived.  A 400 k-word vocabulary is a 16 MB table and MS MARCO
+// text hits it all over: looked up in place, every token waited ~70 ns for memory (14 M tokens/s per thread) while the core
+// could have ten such misses in flight.
+struct Pending {
+    uint64_t h, k0, k1;
+    int64_t *dst;
+    uint32_t len;
+};
+struct Lookups {
+    static constexpr unsigned RING = 64, LAG = TT_TOK_LAG;
+    const TokTable &t;
+    Pending ring[RING];
+    unsigned head = 0, tail = 0;
+    explicit Lookups(const TokTable &tab) : t(tab) {}
+    void resolve(const Pending &p)
+    {
+        const uint32_t tl = tag_len_of(p.h, p.len);
+        for (uint64_t s = p.h & t.mask;; s = (s + 1) & t.mask) {
+            const TokSlot &sl = t.slots[s];
+            if (sl.tag_len == 0) {
+                *p.dst = t.unk;
+                return;
+            }
+            if (sl.tag_len == tl && sl.k0 == p.k0) {
+                if (p.len <= 8) {
+                    *p.dst = short_value(t, sl);
+                    return;
+                }
+                const LongKey &lk = t.longs[(size_t)sl.val];
+                if (lk.len == p.len && load_le(t.blob.data() + lk.off + 8, p.len - 8) == p.k1) {
+                    *p.dst = lk.id;
+                    return;
+                }
+            }
+        }
+    }
+    void push(uint64_t h, uint64_t k0, uint64_t k1, uint32_t len, int64_t *dst)
+    {
+        __builtin_prefetch(&t.slots[h & t.mask]);
+        ring[head++ % RING] = Pending{h, k0, k1, dst, len};
+        if (head - tail > LAG)
+            resolve(ring[tail++ % RING]);
+    }
+    void flush()
+    {
+        while (tail != head)
+            resolve(ring[tail++ % RING]);
+    }
+};
+
+// one text -> ids at out[0..] (the short tokens' ids arrive by lk.flush() at the latest); returns the token count, or -1 when the
+// text is not pure ASCII (whatever was written to out is then meaningless)
+inline int64_t encode_tail(const TokTable &t, Lookups &lk, const char *s, size_t i, size_t n, int64_t *out, int64_t cnt, std::vector<char> &lower)
+{
+    const unsigned char *cls = g_chars.cls;
+    const char *low = g_chars.low;
     while (i < n) {
         const unsigned char c = (unsigned char)s[i];
-        if (is_word(c)) {
-            // lower-case copy and hash in ONE pass over the word (a stack buffer for words of up to 64 bytes)
+        const unsigned char k = cls[c];
+        if (k == CH_WORD) {
+            alignas(8) char buf[16] = {0};
             size_t j = i;
-            while (j < n && is_word((unsigned char)s[j]))
+            while (j < n && j - i < 16 && cls[(unsigned char)s[j]] == CH_WORD) {
+                buf[j - i] = low[(unsigned char)s[j]];
                 ++j;
-            const size_t len = j - i;
-            char *buf = small;
-            if (len > sizeof small) {
+            }
+            if (j < n && j - i == 16 && cls[(unsigned char)s[j]] == CH_WORD) { // a long word: lower-cased copy, looked up in place
+                while (j < n && cls[(unsigned char)s[j]] == CH_WORD)
+                    ++j;
+                const size_t len = j - i;
                 lower.resize(len);
-                buf = lower.data();
+                for (size_t q = 0; q < len; ++q)
+                    lower[q] = low[(unsigned char)s[i + q]];
+                out[cnt++] = lookup_long(t, lower.data(), len, hash_key(lower.data(), len));
+            } else {
+                const size_t len = j - i;
+                const uint64_t k0 = load_le(buf, 8), k1 = load_le(buf + 8, 8);
+                uint64_t h = hash_round(HASH_SEED, k0);
+                if (len > 8)
+                    h = hash_round(h, k1);
+                lk.push(hash_finish(h, len), k0, k1, (uint32_t)len, out + cnt++);
             }
-            uint64_t h = FNV_BASIS;
-            for (size_t q = 0; q < len; ++q) {
-                const char ch = s[i + q];
-                const char lc = (ch >= 'A' && ch <= 'Z') ? (char)(ch + 32) : ch;
-                buf[q] = lc;
-                h ^= (unsigned char)lc;
-                h *= FNV_PRIME;
-            }
-            out[cnt++] = lookup_hashed(t, buf, len, fnv_finish(h));
             i = j;
-        } else if (is_punct(c)) {
-            out[cnt++] = lookup_hashed(t, s + i, 1, fnv1a(s + i, 1));
+        } else if (k == CH_PUNCT) {
+            lk.push(hash_finish(hash_round(HASH_SEED, (uint64_t)c), 1), (uint64_t)c, 0, 1u, out + cnt++);
             ++i;
+        } else if (k == CH_HIGH) {
+            return -1;
         } else {
             ++i;
         }
     }
     return cnt;
+}
+
+inline uint64_t lower8(uint64_t x) // A-Z -> a-z in each byte < 0x80 (a byte >= 0x80 can only disturb the bytes ABOVE it)
+{
+    const uint64_t up = ((x + 0x3f3f3f3f3f3f3f3full) & ~(x + 0x2525252525252525ull)) & 0x8080808080808080ull;
+    return x | (up >> 2);
+}
+inline uint64_t load8(const char *p)
+{
+    uint64_t v;
+    std::memcpy(&v, p, 8);
+    return v;
+}
+
+int64_t encode_one(const TokTable &t, Lookups &lk, const char *s, size_t n, int64_t *out, std::vector<char> &lower)
+{
+    int64_t cnt = 0;
+    size_t i = 0;
+#if defined(__SSE2__) && !defined(TT_TOK_NO_SIMD)
+    // Windows of 16 bytes while 32 are left (a token's 16 key bytes are then readable wherever it starts in the window).  The
+    // classes of a window as bit masks; every token that ENDS inside the window is taken from the masks (no byte loop, no
+    // data-dependent load address between windows); a word that touches the window's end restarts the window at its first byte.
+    // A window starts at a token boundary: behind a full step its predecessor byte was no word byte.
+    const __m128i v_20 = _mm_set1_epi8(0x20), v_a1 = _mm_set1_epi8('a' - 1), v_z1 = _mm_set1_epi8('z' + 1), v_01 = _mm_set1_epi8('0' - 1),
+                  v_91 = _mm_set1_epi8('9' + 1), v_us = _mm_set1_epi8('_');
+    while (i + 32 <= n) {
+        const __m128i v = _mm_loadu_si128((const __m128i *)(s + i));
+        const __m128i lo = _mm_or_si128(v, v_20);  // (only the letter test reads it; signed compares: bytes >= 0x80 are negative)
+        const __m128i alpha = _mm_and_si128(_mm_cmpgt_epi8(lo, v_a1), _mm_cmpgt_epi8(v_z1, lo));
+        const __m128i digit = _mm_and_si128(_mm_cmpgt_epi8(v, v_01), _mm_cmpgt_epi8(v_91, v));
+        const __m128i wordv = _mm_or_si128(_mm_or_si128(alpha, digit), _mm_cmpeq_epi8(v, v_us));
+        const __m128i punct = _mm_or_si128(_mm_or_si128(_mm_cmpeq_epi8(v, _mm_set1_epi8('.')), _mm_cmpeq_epi8(v, _mm_set1_epi8(','))),
+                                           _mm_or_si128(_mm_or_si128(_mm_cmpeq_epi8(v, _mm_set1_epi8('!')), _mm_cmpeq_epi8(v, _mm_set1_epi8('?'))),
+                                                        _mm_cmpeq_epi8(v, _mm_set1_epi8(';'))));
+        const unsigned W = (unsigned)_mm_movemask_epi8(wordv), P = (unsigned)_mm_movemask_epi8(punct);
+        if (_mm_movemask_epi8(v))
+            return -1;
+        unsigned T = (W & ~(W << 1)) | P; // first bytes of the window's tokens
+        size_t step = 16;
+        while (T) {
+            const unsigned b = (unsigned)__builtin_ctz(T);
+            T &= T - 1;
+            const char *p = s + i + b;
+            if (P >> b & 1u) {
+                const uint64_t c = (unsigned char)*p;
+                lk.push(hash_finish(hash_round(HASH_SEED, c), 1), c, 0, 1u, out + cnt++);
+                continue;
+            }
+            const unsigned len = (unsigned)__builtin_ctz(~(W >> b)); // <= 16 - b: the bits above the window are clear in W
+            if (b + len == 16) {      // touches the end of the window (it is the window's last token)
+                if (b) {
+                    step = b;
+                    break;
+                }
+                if (g_chars.cls[(unsigned char)s[i + 16]] == CH_WORD) { // 17 bytes or more: lower-cased copy, looked up in place
+                    size_t j = i + 16;
+                    while (j < n && g_chars.cls[(unsigned char)s[j]] == CH_WORD)
+                        ++j;
+                    const size_t wl = j - i;
+                    lower.resize(wl);
+                    for (size_t q = 0; q < wl; ++q)
+                        lower[q] = g_chars.low[(unsigned char)s[i + q]];
+                    out[cnt++] = lookup_long(t, lower.data(), wl, hash_key(lower.data(), wl));
+                    step = wl;
+                    break;
+                }
+            }
+            uint64_t k0 = lower8(load8(p)), k1 = 0;
+            if (len < 8)
+                k0 &= ~0ull >> (64 - 8 * len);
+            else if (len > 8) {
+                k1 = lower8(load8(p + 8));
+                if (len < 16)
+                    k1 &= ~0ull >> (128 - 8 * len);
+            }
+            uint64_t h = hash_round(HASH_SEED, k0);
+            if (len > 8)
+                h = hash_round(h, k1);
+            lk.push(hash_finish(h, len), k0, k1, len, out + cnt++);
+        }
+        i += step;
+    }
+#endif
+    return encode_tail(t, lk, s, i, n, out, cnt, lower);
 }
 
 template <class F>
@@ -147,25 +371,44 @@ TT_EXPORT int tt_tok_create(const char *words_blob, const int64_t *word_off, con
     while (cap < (uint64_t)n_words * 2 + 1)
         cap <<= 1;
     t->mask = cap - 1;
-    t->slots.assign(cap, TokSlot{0u, 0u, -1, 0});
+    if (!t->slots.assign(cap, TokSlot{0u, 0, 0ull})) {
+        delete t;
+        return tt_fail(TT_ERR_WORKSPACE, "tt_tok_create: no memory for %llu slots", (unsigned long long)cap);
+    }
     for (int64_t w = 0; w < n_words; ++w) {
         const char *p = t->blob.data() + word_off[w];
         const size_t n = (size_t)(word_off[w + 1] - word_off[w]);
-        const uint64_t h = fnv1a(p, n);
-        const TokSlot fresh{(uint32_t)(h >> 32), (uint32_t)word_off[w], (int32_t)n, t->ids32 ? (int32_t)word_ids[w] : (int32_t)w};
+        if (n == 0)
+            continue; // (the empty string is no token of any text)
+        const uint64_t h = hash_key(p, n);
+        const uint32_t tl = tag_len_of(h, n);
+        const uint64_t k0 = load_le(p, n < 8 ? n : 8);
         uint64_t s = h & t->mask;
         bool dup = false;
-        while (t->slots[s].len >= 0) {
-            const TokSlot &o = t->slots[s];
-            if (o.tag == fresh.tag && (size_t)o.len == n && std::memcmp(t->blob.data() + o.off, p, n) == 0) {
-                dup = true; // the same key twice: the later entry wins, as in a dict built in order
-                t->slots[s] = fresh;
+        for (; t->slots[s].tag_len != 0; s = (s + 1) & t->mask) {
+            TokSlot &o = t->slots[s];
+            if (o.tag_len != tl || o.k0 != k0)
+                continue;
+            if (n <= 8) { // the same key twice: the later entry wins, as in a dict built in order
+                o.val = t->ids32 ? (int32_t)word_ids[w] : (int32_t)w;
+                dup = true;
                 break;
             }
-            s = (s + 1) & t->mask;
+            LongKey &lk = t->longs[(size_t)o.val];
+            if (lk.len == n && std::memcmp(t->blob.data() + lk.off, p, n) == 0) {
+                lk.id = word_ids[w];
+                dup = true;
+                break;
+            }
         }
-        if (!dup)
-            t->slots[s] = fresh;
+        if (dup)
+            continue;
+        if (n <= 8)
+            t->slots[s] = TokSlot{tl, t->ids32 ? (int32_t)word_ids[w] : (int32_t)w, k0};
+        else {
+            t->slots[s] = TokSlot{tl, (int32_t)t->longs.size(), k0};
+            t->longs.push_back(LongKey{(uint32_t)word_off[w], (uint32_t)n, word_ids[w]});
+        }
     }
     *handle = t;
     return TT_OK;
@@ -182,12 +425,14 @@ TT_EXPORT int tt_tok_encode(const void *handle, const char *text_blob, const int
     parallel_for(n_texts, n_threads, [&](int64_t lo, int64_t hi) {
         std::vector<char> lower;
         lower.reserve(64);
+        Lookups lk(t);
         for (int64_t i = lo; i < hi; ++i) {
-            const int64_t c = encode_one(t, text_blob + text_off[i], (size_t)(text_off[i + 1] - text_off[i]),
+            const int64_t c = encode_one(t, lk, text_blob + text_off[i], (size_t)(text_off[i + 1] - text_off[i]),
                                          ragged_ids + text_off[i], lower);
             status[i] = c < 0 ? 1 : 0;
             lens[i] = c < 0 ? 0 : (int32_t)c;
         }
+        lk.flush();
     });
     return TT_OK;
 }
@@ -223,12 +468,48 @@ TT_EXPORT int tt_tok_encode_sep(const void *handle, const char *text_blob, int64
     parallel_for(n_texts, n_threads, [&](int64_t lo, int64_t hi) {
         std::vector<char> lower;
         lower.reserve(64);
+        Lookups lk(t);
         for (int64_t i = lo; i < hi; ++i) {
-            const int64_t c = encode_one(t, text_blob + text_off_out[i], (size_t)(text_off_out[i + 1] - 1 - text_off_out[i]),
+            const int64_t c = encode_one(t, lk, text_blob + text_off_out[i], (size_t)(text_off_out[i + 1] - 1 - text_off_out[i]),
                                          ragged_ids + text_off_out[i], lower);
             status[i] = c < 0 ? 1 : 0;
             lens[i] = c < 0 ? 0 : (int32_t)c;
         }
+        lk.flush();
+    });
+    return TT_OK;
+}
+
+// The same for texts that lie wherever the host keeps them (one pointer and one byte length per text: a host whose strings are
+// separate objects -- CPython's str, Go's string, a Java byte[] -- hands them over without building a blob; what bounded several
+// Python producer threads was the join + encode under the interpreter lock, 2.7 ms per 16 k passages).  text_off_out [n_texts + 1]
+// receives the running sum of the lengths: text i's ids go to ragged_ids[text_off_out[i] ...] (capacity: the sum of the lengths),
+// the layout tt_tok_pad reads.
+TT_EXPORT int tt_tok_encode_ptrs(const void *handle, const char *const *texts, const int64_t *text_len, int64_t n_texts,
+                                 int64_t *text_off_out, int64_t *ragged_ids, int32_t *lens, int32_t *status, int n_threads)
+{
+    if (!handle || n_texts < 0 || (n_texts > 0 && (!texts || !text_len || !text_off_out || !ragged_ids || !lens || !status)))
+        return tt_fail(TT_ERR_BAD_SHAPE, "tt_tok_encode_ptrs: n_texts=%lld", (long long)n_texts);
+    int64_t run = 0;
+    for (int64_t i = 0; i < n_texts; ++i) {
+        if (text_len[i] < 0 || (text_len[i] > 0 && !texts[i]))
+            return tt_fail(TT_ERR_BAD_SHAPE, "tt_tok_encode_ptrs: text %lld: length %lld", (long long)i, (long long)text_len[i]);
+        text_off_out[i] = run;
+        run += text_len[i];
+    }
+    if (n_texts > 0)
+        text_off_out[n_texts] = run;
+    const TokTable &t = *(const TokTable *)handle;
+    parallel_for(n_texts, n_threads, [&](int64_t lo, int64_t hi) {
+        std::vector<char> lower;
+        lower.reserve(64);
+        Lookups lk(t);
+        for (int64_t i = lo; i < hi; ++i) {
+            const int64_t c = encode_one(t, lk, texts[i], (size_t)text_len[i], ragged_ids + text_off_out[i], lower);
+            status[i] = c < 0 ? 1 : 0;
+            lens[i] = c < 0 ? 0 : (int32_t)c;
+        }
+        lk.flush();
     });
     return TT_OK;
 }
