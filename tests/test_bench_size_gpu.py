@@ -111,3 +111,27 @@ def test_index_build_batch_b8192_rows_vs_oracle(oracle):
     want = oracle_par.forward(oracle, big.numpy()[rows], table, _quads(m, "doc_encoder"), bench.ENC_H)
     assert_fwd_close(y[rows], want, what="_index_build_b8192")
     np.testing.assert_allclose(np.linalg.norm(y, axis=1), 1.0, atol=1e-6)
+
+
+def test_two_tile_batch_b16384_rows_vs_oracle_and_vs_the_b8192_call(oracle):
+    """From four rounds of 16-row workgroups up (16 384 rows on 256 CUs: evaluators.embed_corpus's batch) the forward recurrence
+    takes TWO row tiles per workgroup (gru_seq16_kernel<256, 2>).  The 8192-passage batch twice -- the second copy in another
+    row order -- in one call: 64 rows against the oracle, and EVERY row the same bits as in the 8192-row call (one tile per
+    workgroup): a passage's embedding depends on nothing but the passage, whatever the batch it travels in."""
+    import bench
+    dev = torch.device("cuda:0")
+    inp = bench.make_encoder_inputs(dev)
+    m, table, big = inp["model"], inp["table"].numpy(), inp["big"]
+    m.eval()
+    perm = torch.from_numpy(np.random.RandomState(5).permutation(big.shape[0]))
+    both = torch.cat([big, big[perm]], 0)
+    assert both.shape[0] == 16384
+    with torch.no_grad():
+        y8 = m.encode_document(big.to(dev))
+        y16 = m.encode_document(both.to(dev))
+    assert torch.equal(y16[:8192], y8) and torch.equal(y16[8192:], y8[perm.to(dev)])
+    lens = (both.numpy() != 0).sum(1)
+    rs = np.random.RandomState(12)
+    rows = np.unique(np.concatenate([[int(lens.argmax()), int(lens.argmin()), 0, 16383], rs.choice(16384, 62, replace=False)]))[:64]
+    want = oracle_par.forward(oracle, both.numpy()[rows], table, _quads(m, "doc_encoder"), bench.ENC_H)
+    assert_fwd_close(y16.cpu().numpy()[rows], want, what="_two_tile_b16384")

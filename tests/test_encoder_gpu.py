@@ -503,6 +503,47 @@ def test_column_split_recurrence_vs_the_one_cu_kernels(B, T, layers, bi):
         assert_grad_close(a.cpu().numpy(), b.cpu().numpy())
 
 
+@pytest.mark.parametrize("B,T,layers,bi", [(70, 40, 1, False), (1, 7, 1, False), (33, 250, 1, False), (2000, 25, 1, False),
+                                          (300, 21, 2, True), (17, 9, 3, False)])
+def test_two_row_tiles_per_workgroup_vs_one(B, T, layers, bi):
+    """gru_seq16_kernel<256, 2> (big batches: a workgroup takes 32 rows, every streamed W_hh fragment multiplies both tiles' h
+    fragments) against the one-tile form: a row's products and their order are the same -> the SAME BITS, eval and train, stash
+    included (the backward pass of both runs is the same kernel: every gradient the same bits).  The product library takes two
+    tiles from four rounds of one-tile workgroups up (B >= 16 384 on 256 CUs: tests/test_bench_size_gpu.py runs that size
+    against the oracle); here the comparison build forces either form (TT_GRU16_RT = 3 / 1) on small shapes: a half-empty
+    second tile, a one-row batch, both directions in one launch, stacked layers, ragged lengths."""
+    from conftest import ab_library
+    V, E, H, seed = 400, 300, 256, 2100 + B
+    enc, table, sd = make_encoder(V, E, H, seed, layers, bi)
+    ids = torch.from_numpy(synth.make_ids(seed + 5, B, T, V, zero_inside=0.05)).cuda()
+    enc.cache_prepared = False
+    enc.one_workgroup = enc.one_workgroup_bwd = True      # (below 1 025 rows the column-split kernels would take the call)
+
+    def run(mode, train):
+        enc.train(train)
+        with ab_library(TT_GRU16_RT=mode):
+            if not train:
+                with torch.no_grad():
+                    y = enc(ids).clone()
+                torch.cuda.synchronize()
+                return y, []
+            enc.zero_grad()
+            y = enc(ids)
+            y.backward(d_out)
+            torch.cuda.synchronize()
+            return y.detach().clone(), [p.grad.clone() for p in enc._flat_params()]
+    d_out = torch.from_numpy(np.random.RandomState(seed).standard_normal((B, H)).astype(np.float32)).cuda()
+    y1, _ = run(1, False)
+    y2, _ = run(3, False)
+    assert torch.equal(y1, y2) and torch.isfinite(y2).all() and float(y2.norm(dim=1).min()) > 0.99
+    with torch.no_grad():
+        enc.eval()
+        assert torch.equal(enc(ids), y1)                  # the product library (one tile at these sizes)
+    t1, g1 = run(1, True)
+    t2, g2 = run(3, True)
+    assert torch.equal(t1, t2) and len(g1) == len(g2) > 0 and all(torch.equal(a, b) for a, b in zip(g1, g2))
+
+
 @pytest.mark.parametrize("B,T,layers,bi", [(70, 40, 1, False), (1024, 33, 1, False), (300, 21, 2, True), (1, 7, 1, False)])
 def test_eight_wave_members_vs_four_wave_members(B, T, layers, bi):
     """The split recurrences run a member as EIGHT waves (two per SIMD; gru_seq16x4p / gru_bwd16x4p_kernel) -- the four-wave

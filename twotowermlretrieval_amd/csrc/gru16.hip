@@ -48,20 +48,38 @@ constexpr int H_SHIFT = 10; // h is scaled by 2^10 before the split (|h| < 1)
 
 enum { K_REG = 0, K_LDS = 1, K_STR = 2 };
 
-template <int H>
+// RT = row tiles of 16 batch rows per workgroup.  RT = 1: the form described above.  RT = 2 (big batches, more row groups than
+// the chip runs at once): a streamed W_hh fragment is multiplied with BOTH tiles' h fragments, so a row costs half the L2 bytes --
+// with every CU streaming 60 fragments per wave and step the launch is bound by that stream (8.7 us per step against 2.2 us of
+// matrix work at B = 8192).  The accumulators, h registers and gi values of the second tile take the registers of 20 resident
+// fragments (R = 1; 7 spills 10 - 27 registers wherever the gi loads go; 11 in LDS behind the second pair of h images, 84
+// streamed: 42 per 16 rows instead of 60) and the gi values are asked for late in the multiply instead of up front.  A row's arithmetic
+// is the same instruction sequence on the same operands: results are BIT-IDENTICAL to RT = 1 (tests/test_encoder_gpu.py).
+template <int H, int RT = 1>
 struct G16 {
     static constexpr int NW = H / 32;       // waves: wave w owns hidden units [32w, 32w+32) of all three gates
     static constexpr int NK = H / 32;       // k-steps of 32
     static constexpr int NF = 12 * NK;      // B fragments per wave and step: NK x 6 column tiles x {hi, lo}
     static constexpr int LDH = H + 8;       // fp16 elements per row of an h image (row stride = 4 banks: A reads spread)
     static constexpr int IMG = 16 * LDH * 2;
-    static constexpr int H_BYTES = 4 * IMG; // [buffer 2][hi, lo]
+    static constexpr int H_BYTES = RT * 4 * IMG; // [row tile][buffer 2][hi, lo]
     static constexpr int LDS_CAP = ((160 * 1024 - H_BYTES) / NW) / 1024;
-    static constexpr int R = H == 256 ? TT_G16_R : 16;
+#ifndef TT_G16_R2
+#define TT_G16_R2 1
+#endif
+    static constexpr int R = RT == 2 ? (H == 256 ? TT_G16_R2 : 16) : (H == 256 ? TT_G16_R : 16);
     static constexpr int NL = NF - R < LDS_CAP ? NF - R : LDS_CAP;
     static constexpr int NS = NF - R - NL;
     static constexpr int NR = NS == 0 ? 1 : 6;
     static constexpr int LDS_BYTES = H_BYTES + NW * NL * 1024;
+#ifndef TT_G16_RT2_ROUNDS
+#define TT_G16_RT2_ROUNDS 4 // two tiles per workgroup from this many rounds of one-tile workgroups up
+#endif
+#ifndef TT_G16_GI_Q0
+#define TT_G16_GI_Q0 14
+#define TT_G16_GI_Q1 20
+#endif
+    static constexpr int GI_Q0 = TT_G16_GI_Q0, GI_Q1 = TT_G16_GI_Q1; // RT = 2: the multiply groups (of NK * 3 = 24) behind which the two tiles' gi loads go out
     static_assert(NS % NR == 0, "the ring must come round once per step");
     static_assert(NF <= 96, "plan tables are sized for H <= 256");
 };
@@ -125,27 +143,30 @@ __global__ __launch_bounds__(256) void pack_whh16_kernel(const float *__restrict
 __device__ __forceinline__ float fast_sigmoid16(float x) { return tt_fast_sigmoid(x); }
 __device__ __forceinline__ float fast_tanh16(float x) { return tt_fast_tanh(x); }
 
-template <int H>
-__global__ __launch_bounds__(G16<H>::NW * 64) void gru_seq16_kernel(GruParams p)
+template <int H, int RT>
+__global__ __launch_bounds__(H / 32 * 64) void gru_seq16_kernel(GruParams p)
 {
-    using C = G16<H>;
+    using C = G16<H, RT>;
     using P = PlanOf<C>;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const GruDir d = p.dir[blockIdx.y];
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 15, kq = lane >> 4;
-    const int row0 = blockIdx.x * ENC_RB;
+    const int row0 = blockIdx.x * ENC_RB * RT;
 
-    int len_e[4], off_e[4], rid_e[4];
+    int len_e[RT][4], off_e[RT][4];
+    int steps = 0;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const int br = row0 + kq * 4 + e;
-        rid_e[e] = br < p.B ? p.perm[br] : -1;
-        len_e[e] = rid_e[e] >= 0 ? p.len[rid_e[e]] : 0;
-        off_e[e] = rid_e[e] >= 0 ? p.tok_off[rid_e[e]] : 0;
-    }
-    int steps = max(max(len_e[0], len_e[1]), max(len_e[2], len_e[3])); // block-wide max length
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int br = row0 + rt * ENC_RB + kq * 4 + e;
+            const int rid = br < p.B ? p.perm[br] : -1;
+            len_e[rt][e] = rid >= 0 ? p.len[rid] : 0;
+            off_e[rt][e] = rid >= 0 ? p.tok_off[rid] : 0;
+            steps = max(steps, len_e[rt][e]); // block-wide max length
+        }
     steps = max(steps, __shfl_xor(steps, 16));
     steps = max(steps, __shfl_xor(steps, 32));
 
@@ -162,7 +183,14 @@ __global__ __launch_bounds__(G16<H>::NW * 64) void gru_seq16_kernel(GruParams p)
     }
     for (int i = threadIdx.x; i < C::H_BYTES / 4; i += C::NW * 64)
         ((int *)lds)[i] = 0; // h_0 = 0 in both buffers, both parts
-    float hreg[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+    float hreg[RT][2][4];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                hreg[rt][ct][e] = 0.0f;
 
     // ---- this wave's slice of W_hh: resident fragments into VGPRs / LDS, the ring's first NR streamed ones ----
     const __amdgpu_buffer_rsrc_t wsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -190,36 +218,52 @@ __global__ __launch_bounds__(G16<H>::NW * 64) void gru_seq16_kernel(GruParams p)
     const int H3 = 3 * H;
     int cur = 0;
     for (int s = 0; s < steps; ++s) {
-        bool act[4];
-        size_t tok[4];
-        float giv[3][2][4];
+        float giv[RT][3][2][4];
+        // this step's token of row e of tile rt (a valid token even when the row is done); RT = 2 recomputes it where it is used
+        // instead of keeping it through the multiply
+        auto token = [&](int rt, int e) {
+            const int t = d.reverse ? len_e[rt][e] - 1 - s : s;
+            return off_e[rt][e] + (s < len_e[rt][e] ? t : 0);
+        };
+        // the input projections of this step's tokens: RT = 1 asks for them up front (24 registers that wait through the whole
+        // multiply); RT = 2 has no registers for 48 of them there and asks late in the multiply (tile 0 behind group GI_Q0, tile 1
+        // behind GI_Q1: they arrive while the last groups run)
+        auto load_gi = [&](auto rtc) {
+            constexpr int rt = decltype(rtc)::value;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            act[e] = s < len_e[e];
-            const int t = d.reverse ? len_e[e] - 1 - s : s;
-            tok[e] = (size_t)(off_e[e] + (act[e] ? t : 0));
+            for (int e = 0; e < 4; ++e) {
+                const float *row = d.gi + (size_t)token(rt, e) * H3 + unit[0];
+#pragma unroll
+                for (int g = 0; g < 3; ++g)
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct)
+                        giv[rt][g][ct][e] = row[g * H + 16 * ct];
+            }
+        };
+        if constexpr (RT == 1)
+            load_gi(std::integral_constant<int, 0>{});
+        f32x4v acc[RT][6]; // tile t = 2 g + ct
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
             for (int g = 0; g < 3; ++g)
 #pragma unroll
                 for (int ct = 0; ct < 2; ++ct)
-                    giv[g][ct][e] = d.gi[tok[e] * H3 + g * H + unit[ct]]; // (a valid token even when the row is done)
-        }
-        f32x4v acc[6]; // tile t = 2 g + ct
-#pragma unroll
-        for (int g = 0; g < 3; ++g)
-#pragma unroll
-            for (int ct = 0; ct < 2; ++ct)
-                acc[2 * g + ct] = (f32x4v){bias[g][ct], bias[g][ct], bias[g][ct], bias[g][ct]};
+                    acc[rt][2 * g + ct] = (f32x4v){bias[g][ct], bias[g][ct], bias[g][ct], bias[g][ct]};
 
+        // row tile rt's images: [rt][buffer][hi, lo]
         const char *img = lds + cur * 2 * C::IMG + j * (C::LDH * 2) + kq * 16;
         // Consumption order: k-step s2, pair of column tiles, {hi t0, hi t1, lo t0, lo t1}.  Software pipeline, pinned
         // by scheduling fences (left alone, hipcc hoists every load of the step and spills): group q issues the LDS
         // reads of group q + 1 (its LDS-resident B fragments; the next k-step's A fragments one group early), then its
-        // own six MFMAs, then refills the ring slots it consumed.
-        h8 a_hi[2], a_lo[2]; // by k-step parity
-        h8 lbuf[2][4];       // LDS-resident B fragments of the current / next group
-        a_hi[0] = *(const h8 *)(img);
-        a_lo[0] = *(const h8 *)(img + C::IMG);
+        // own six MFMAs per row tile, then refills the ring slots it consumed.
+        h8 a_hi[2][RT], a_lo[2][RT]; // by k-step parity
+        h8 lbuf[2][4];               // LDS-resident B fragments of the current / next group
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            a_hi[0][rt] = *(const h8 *)(img + rt * 4 * C::IMG);
+            a_lo[0][rt] = *(const h8 *)(img + rt * 4 * C::IMG + C::IMG);
+        }
         static_for<0, 4>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
             constexpr int kind = P::value.kind[i], idx = P::value.idx[i];
@@ -237,8 +281,11 @@ __global__ __launch_bounds__(G16<H>::NW * 64) void gru_seq16_kernel(GruParams p)
                         lbuf[(q + 1) & 1][i] = *(const h8 *)(wlds + idx * 1024);
                 });
                 if constexpr (pair == 1 && s2 + 1 < C::NK) { // the next k-step's A fragments, 1.5 groups ahead
-                    a_hi[(s2 + 1) & 1] = *(const h8 *)(img + (s2 + 1) * 64);
-                    a_lo[(s2 + 1) & 1] = *(const h8 *)(img + C::IMG + (s2 + 1) * 64);
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) {
+                        a_hi[(s2 + 1) & 1][rt] = *(const h8 *)(img + rt * 4 * C::IMG + (s2 + 1) * 64);
+                        a_lo[(s2 + 1) & 1][rt] = *(const h8 *)(img + rt * 4 * C::IMG + C::IMG + (s2 + 1) * 64);
+                    }
                 }
             }
             h8 b[4];
@@ -253,14 +300,17 @@ __global__ __launch_bounds__(G16<H>::NW * 64) void gru_seq16_kernel(GruParams p)
                     b[i] = ring[idx % C::NR];
             });
             constexpr int t0 = 2 * pair, t1 = 2 * pair + 1;
-            acc[t0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[s2 & 1], b[0], acc[t0], 0, 0, 0);
-            acc[t1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[s2 & 1], b[1], acc[t1], 0, 0, 0);
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                acc[rt][t0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[s2 & 1][rt], b[0], acc[rt][t0], 0, 0, 0);
+                acc[rt][t1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[s2 & 1][rt], b[1], acc[rt][t1], 0, 0, 0);
 #if !(TT_MUTATE_DROP_LO & 1)
-            acc[t0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo[s2 & 1], b[0], acc[t0], 0, 0, 0);
-            acc[t1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo[s2 & 1], b[1], acc[t1], 0, 0, 0);
-            acc[t0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[s2 & 1], b[2], acc[t0], 0, 0, 0);
-            acc[t1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[s2 & 1], b[3], acc[t1], 0, 0, 0);
+                acc[rt][t0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo[s2 & 1][rt], b[0], acc[rt][t0], 0, 0, 0);
+                acc[rt][t1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo[s2 & 1][rt], b[1], acc[rt][t1], 0, 0, 0);
+                acc[rt][t0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[s2 & 1][rt], b[2], acc[rt][t0], 0, 0, 0);
+                acc[rt][t1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[s2 & 1][rt], b[3], acc[rt][t1], 0, 0, 0);
 #endif
+            }
             // refill the ring slots this group consumed: the fragment NR streamed fragments further on (the next
             // step's first ones near the end of this step -- W_hh does not change)
             static_for<0, 4>([&](auto ic) {
@@ -271,47 +321,59 @@ __global__ __launch_bounds__(G16<H>::NW * 64) void gru_seq16_kernel(GruParams p)
                     ring[idx % C::NR] = frag_load(wsrc, loff, off);
                 }
             });
+            if constexpr (RT == 2 && q == C::GI_Q0)
+                load_gi(std::integral_constant<int, 0>{});
+            if constexpr (RT == 2 && q == C::GI_Q1)
+                load_gi(std::integral_constant<int, RT - 1>{});
             __builtin_amdgcn_sched_barrier(0);
         });
 
-        char *nimg = lds + (cur ^ 1) * 2 * C::IMG;
 #pragma unroll
-        for (int ct = 0; ct < 2; ++ct)
+        for (int rt = 0; rt < RT; ++rt) {
+            char *nimg = lds + rt * 4 * C::IMG + (cur ^ 1) * 2 * C::IMG;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float r = fast_sigmoid16(giv[0][ct][e] + acc[ct][e] * down);
-                const float z = fast_sigmoid16(giv[1][ct][e] + acc[2 + ct][e] * down);
-                const float ghn = acc[4 + ct][e] * down;
-                const float n = fast_tanh16(giv[2][ct][e] + r * ghn);
-                const float hn = (hreg[ct][e] - n) * z + n;
-                if (act[e]) {
-                    hreg[ct][e] = hn;
-                    if (d.out_seq)
-                        d.out_seq[tok[e] * p.out_ld + d.out_col0 + unit[ct]] = hn;
-                    if (d.gates) {
-                        float *gs = d.gates + tok[e] * 4 * H + unit[ct];
-                        gs[0] = r;
-                        gs[H] = z;
-                        gs[2 * H] = n;
-                        gs[3 * H] = ghn;
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float r = fast_sigmoid16(giv[rt][0][ct][e] + acc[rt][ct][e] * down);
+                    const float z = fast_sigmoid16(giv[rt][1][ct][e] + acc[rt][2 + ct][e] * down);
+                    const float ghn = acc[rt][4 + ct][e] * down;
+                    const float n = fast_tanh16(giv[rt][2][ct][e] + r * ghn);
+                    const float hn = (hreg[rt][ct][e] - n) * z + n;
+                    if (s < len_e[rt][e]) {
+                        hreg[rt][ct][e] = hn;
+                        const size_t tok = (size_t)token(rt, e);
+                        if (d.out_seq)
+                            d.out_seq[tok * p.out_ld + d.out_col0 + unit[ct]] = hn;
+                        if (d.gates) {
+                            float *gs = d.gates + tok * 4 * H + unit[ct];
+                            gs[0] = r;
+                            gs[H] = z;
+                            gs[2 * H] = n;
+                            gs[3 * H] = ghn;
+                        }
                     }
+                    const float hs = hreg[rt][ct][e] * (float)(1 << H_SHIFT);
+                    const _Float16 hi = (_Float16)hs;
+                    const _Float16 lo = (_Float16)(hs - (float)hi);
+                    _Float16 *dst = (_Float16 *)nimg + (kq * 4 + e) * C::LDH + unit[ct];
+                    dst[0] = hi;
+                    dst[C::IMG / 2] = lo;
                 }
-                const float hs = hreg[ct][e] * (float)(1 << H_SHIFT);
-                const _Float16 hi = (_Float16)hs;
-                const _Float16 lo = (_Float16)(hs - (float)hi);
-                _Float16 *dst = (_Float16 *)nimg + (kq * 4 + e) * C::LDH + unit[ct];
-                dst[0] = hi;
-                dst[C::IMG / 2] = lo;
-            }
+        }
         __syncthreads();
         cur ^= 1;
     }
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct)
+    for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-            if (rid_e[e] >= 0)
-                d.h_final[(size_t)rid_e[e] * H + unit[ct]] = hreg[ct][e];
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int br = row0 + rt * ENC_RB + kq * 4 + e;
+                if (br < p.B)
+                    d.h_final[(size_t)p.perm[br] * H + unit[ct]] = hreg[rt][ct][e];
+            }
 }
 
 // ------------------------------------------------------------------ reverse-time recurrence (training)
@@ -641,12 +703,26 @@ __global__ __launch_bounds__(B16<H>::NW * 64) void gru_bwd16_kernel(GruBwdParams
     }
 }
 
-template <int H>
+// Two row tiles per workgroup when the launch is more than one round of one-tile workgroups anyway (one workgroup per CU: the
+// weights fill the LDS) -- fewer, fatter workgroups then cost nothing in parallelism and halve the W_hh stream per row.  Below
+// that every row group gets a CU of its own and finishes sooner alone.
+inline bool gru16_two_tiles(int B, int ndir)
+{
+    const int mode = TT_AB_SWITCH(TT_GRU16_RT, 2); // comparison build: 1 = never, 3 = always (tests, tools/experiments/gru16_rt.py)
+    if (mode != 2)
+        return mode > 2;
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+        return false;
+    return (long)((B + ENC_RB - 1) / ENC_RB) * ndir >= (long)TT_G16_RT2_ROUNDS * cus;
+}
+
+template <int H, int RT>
 int launch16(const GruParams &gp, int ndir, hipStream_t st)
 {
-    using C = G16<H>;
-    TT_HIP_CHECK(hipFuncSetAttribute((const void *)gru_seq16_kernel<H>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
-    hipLaunchKernelGGL(gru_seq16_kernel<H>, dim3((gp.B + ENC_RB - 1) / ENC_RB, ndir), dim3(C::NW * 64), C::LDS_BYTES, st, gp);
+    using C = G16<H, RT>;
+    TT_HIP_CHECK(hipFuncSetAttribute((const void *)gru_seq16_kernel<H, RT>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
+    hipLaunchKernelGGL((gru_seq16_kernel<H, RT>), dim3((gp.B + ENC_RB * RT - 1) / (ENC_RB * RT), ndir), dim3(C::NW * 64), C::LDS_BYTES, st, gp);
     TT_LAUNCH_CHECK();
     return TT_OK;
 }
@@ -666,10 +742,11 @@ int gru16_pack(const float *W_hh, int H, unsigned *absmax /*zeroed by the caller
 
 int gru16_launch(const GruParams &gp, int ndir, hipStream_t st)
 {
+    const bool two = gru16_two_tiles(gp.B, ndir);
     if (gp.H == 256)
-        return launch16<256>(gp, ndir, st);
+        return two ? launch16<256, 2>(gp, ndir, st) : launch16<256, 1>(gp, ndir, st);
     if (gp.H == 128)
-        return launch16<128>(gp, ndir, st);
+        return launch16<128, 1>(gp, ndir, st);
     return tt_fail(TT_ERR_UNSUPPORTED, "gru16_launch: H=%d", gp.H);
 }
 

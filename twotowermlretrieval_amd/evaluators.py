@@ -77,10 +77,15 @@ def embed_corpus(model, tokenizer, documents: Sequence[str], device: torch.devic
     order they finish in; ids cross PCIe with a non-blocking copy on a side stream; embeddings land in one preallocated
     [N, H] matrix.  Rows are independent, so neither the batch size nor the number of producers changes the result.
 
-    producers = 0: one per 8 cores of the host's share (cgroup quota respected), at most 4.  Round 1-3 ran ONE producer
-    that allocated a fresh pinned tensor per batch and tokenised through a four-array hash table: 93-115 M tokens/s against the
-    document tower's ~240 M.  With the staging ring below, the single-pass tokenizer and one join per batch two producers
-    feed 213-234 M tokens/s on a 16-core share.  stats (optional dict): receives what the build used."""
+    producers = 0: one, two from 32 cores of the host's share (cgroup quota respected) up.  History, 16-core share, GloVe-size
+    vocabulary: rounds 1-3 ONE producer that page-locked a fresh tensor per batch and tokenised through a four-array hash table:
+    93-115 M tokens/s against the document tower's ~240 M; round 4 (a): staging ring, single-pass tokenizer, one join per batch:
+    two producers x 8 threads 160-234 M tokens/s depending on the box (0.66-0.95 of the GPU's rate); round 4 (b): pipelined
+    table lookups, 16-byte slots on huge pages, the texts read in place (tt_tok_encode_ptrs: no join under the GIL): the native
+    part does 590 M tokens/s on 8 threads and 1 050 M on 16 (tools/experiments/tok_harness.sh), every producer setting from
+    1 x 16 to 4 x 4 builds at the GPU's rate (3.3-3.8 M passages/s, profiles/r04_w_index_build.log), and one producer with all
+    the threads is the fastest of them (fewer Python threads trading the GIL with the consumer).
+    stats (optional dict): receives what the build used."""
     import collections
     import os
     from concurrent.futures import ThreadPoolExecutor
@@ -90,12 +95,7 @@ def embed_corpus(model, tokenizer, documents: Sequence[str], device: torch.devic
     from .tokenizer import host_cores
     cores = host_cores()
     if producers <= 0:
-        # two producers from 16 cores up: while one is in the Python part of its batch (one join + encode, under the GIL) the
-        # other is in the native part.  More producers than that mostly trade the GIL back and forth, fewer leave the cores idle
-        # during the Python part.  16-core share, 400 k passages: GloVe-size vocabulary 1 x 16 threads 2.5 M docs/s, 2 x 8 3.16 M,
-        # 2 x 16 3.05 M, 3 x 16 2.6 M, 4 x 4 2.5 M; 50 k-word vocabulary 1 x 16 3.35 M, 2 x 8 3.03 M, 4 x 4 2.6 M
-        # (profiles/r04_o_index_build_v400k.log, r04_i_index_build_producer_sweep.log)
-        producers = max(1, min(4, cores // 8))
+        producers = 1 if cores < 32 else 2
     nt = threads_per_producer if threads_per_producer > 0 else max(1, min(16, cores // producers))
     starts = list(range(0, n, batch_size))
     window = producers + max(1, prefetch)          # batches tokenised or being tokenised ahead of the GPU
