@@ -48,13 +48,20 @@ constexpr int H_SHIFT = 10; // h is scaled by 2^10 before the split (|h| < 1)
 
 enum { K_REG = 0, K_LDS = 1, K_STR = 2 };
 
-// RT = row tiles of 16 batch rows per workgroup.  RT = 1: the form described above.  RT = 2 (big batches, more row groups than
-// the chip runs at once): a streamed W_hh fragment is multiplied with BOTH tiles' h fragments, so a row costs half the L2 bytes --
-// with every CU streaming 60 fragments per wave and step the launch is bound by that stream (8.7 us per step against 2.2 us of
-// matrix work at B = 8192).  The accumulators, h registers and gi values of the second tile take the registers of 20 resident
-// fragments (R = 1; 7 spills 10 - 27 registers wherever the gi loads go; 11 in LDS behind the second pair of h images, 84
-// streamed: 42 per 16 rows instead of 60) and the gi values are asked for late in the multiply instead of up front.  A row's arithmetic
-// is the same instruction sequence on the same operands: results are BIT-IDENTICAL to RT = 1 (tests/test_encoder_gpu.py).
+// RT = row tiles of 16 batch rows per workgroup.  RT = 1: the form described above.  RT = 2 (big batches: four rounds of one-tile
+// workgroups or more, e.g. evaluators.embed_corpus's 16 384 passages): a streamed W_hh fragment is multiplied with BOTH tiles' h
+// fragments.  The accumulators, h registers and gi values of the second tile take the registers of 20 resident fragments (R = 1;
+// 7 spills 10 - 27 registers wherever the gi loads go; 11 in LDS behind the second pair of h images, 84 streamed: 42 per 16 rows
+// instead of 60) and the gi values are asked for late in the multiply instead of up front.  A row's arithmetic is the same
+// instruction sequence on the same operands: results are BIT-IDENTICAL to RT = 1 (tests/test_encoder_gpu.py,
+// tests/test_bench_size_gpu.py).
+// What it buys is small, and why (round 4, profiles/r04_x_gru16_two_tiles.log, r04_x_gru16_ring_depth.log): document-tower call
+// 4.10 -> 3.98 ms at 16 384 passages, 8.00 -> 7.56 at 32 768 (+3 - 6 %); SLOWER below two rounds of two-tile workgroups (8 192:
+// equal; 4 096: 1.28 -> 1.58 ms, half the CUs idle), hence the threshold.  The W_hh stream is not what bounds the step: with 6
+// more fragments streamed per step (R = 15) the 8 192-passage call goes from 2.15 to 2.20 ms, a ring of 8, 11, 12 or 18 loads in
+// flight instead of 6 (at the expense of resident fragments) is 1 - 9 % SLOWER at every size -- the step (8.7 us at 8 192
+// passages for 2.2 us of matrix work) is its instruction stream (144 MFMAs + ~70 loads + the gate math of 8 elements per lane, two
+// waves per SIMD) at the clock the chip holds with every CU multiplying, and two tiles double that stream per workgroup.
 template <int H, int RT = 1>
 struct G16 {
     static constexpr int NW = H / 32;       // waves: wave w owns hidden units [32w, 32w+32) of all three gates
@@ -70,7 +77,10 @@ struct G16 {
     static constexpr int R = RT == 2 ? (H == 256 ? TT_G16_R2 : 16) : (H == 256 ? TT_G16_R : 16);
     static constexpr int NL = NF - R < LDS_CAP ? NF - R : LDS_CAP;
     static constexpr int NS = NF - R - NL;
-    static constexpr int NR = NS == 0 ? 1 : 6;
+#ifndef TT_G16_NR
+#define TT_G16_NR 6
+#endif
+    static constexpr int NR = NS == 0 ? 1 : (H == 256 && RT == 1 ? TT_G16_NR : 6); // streamed fragments in flight per wave
     static constexpr int LDS_BYTES = H_BYTES + NW * NL * 1024;
 #ifndef TT_G16_RT2_ROUNDS
 #define TT_G16_RT2_ROUNDS 4 // two tiles per workgroup from this many rounds of one-tile workgroups up
