@@ -162,10 +162,12 @@ class PretrainedTokenizer:
         gather = _pytext_gather()
         if n and gather is not None and type(texts) in (list, tuple):
             # Fastest form: the texts are read where the interpreter keeps them (csrc/pytext.c collects one pointer and one
-            # length per str, ~0.1 ms per 16 k passages under the GIL; tt_tok_encode_ptrs does the rest without it).  `texts`
-            # stays referenced by this frame for the duration of the call.
+            # length per str, ~0.25 ms per 16 k passages under the GIL; tt_tok_encode_ptrs does the rest without it).  The
+            # str objects stay referenced by this frame's tuple for the duration of the call.
             ptrs = _scratch("ptrs", n, np.uint64)
             tlen = _scratch("tlen", n, np.int64)
+            if type(texts) is list:
+                texts = tuple(texts)   # (the pointers stay valid even if another thread edits the caller's list meanwhile: ~40 us)
             n_ok, total = gather(texts, ptrs.ctypes.data, tlen.ctypes.data)
             if n_ok == n:
                 off = _scratch("off", n + 1, np.int64)
