@@ -264,8 +264,9 @@ typedef struct tt_enc_sync {
  * (records), B FINISH (waits) -- what trainer.train_step does with the document tower (B) and the query tower (A). */
 #define TT_ENC_PHASE_BEGIN 0x200
 #define TT_ENC_PHASE_FINISH 0x400
-/* CUs the column-split recurrence of one call of this shape occupies (one workgroup each, all resident at once); 0 = the call
- * runs the one-workgroup kernels whatever `train` says.  A host with several calls in flight keeps the sum within the device's
+/* CUs the column-split recurrence of one call of this shape occupies (one workgroup each, all resident at once; a bidirectional
+ * call whose two directions do not fit together runs them one launch after the other and this is ONE direction's count); 0 = the
+ * call runs the one-workgroup kernels whatever `train` says.  A host with several calls in flight keeps the sum within the device's
  * CU count by passing TT_ENC_ONE_WORKGROUP to the smaller ones. */
 int tt_encoder_split_workgroups(int B, int H, int bidirectional, int rnn_type);
 size_t tt_encoder_workspace_bytes(int B, int T, int E, int H, int num_layers, int bidirectional, int rnn_type,

@@ -463,14 +463,17 @@ def _with_split(mod, flag, fn, bwd=None):
 
 
 @pytest.mark.parametrize("B,T,layers,bi", [(70, 40, 1, False), (5, 250, 1, False), (1024, 33, 1, False), (1, 7, 1, False),
-                                          (300, 21, 2, True), (512, 12, 1, True), (17, 9, 3, False)])
+                                          (300, 21, 2, True), (512, 12, 1, True), (17, 9, 3, False),
+                                          (1024, 20, 1, True), (700, 15, 2, True)])   # (the last two: one launch per direction)
 def test_column_split_recurrence_vs_the_one_cu_kernels(B, T, layers, bi):
     """gru_seq16x4p_kernel (a row group's gate columns on four CUs, hidden state handed over through tagged granules every
     step) against gru_seq16_kernel (TT_ENC_ONE_WORKGROUP): same products in the same order -> the SAME BITS, in eval mode and in
     train mode, stash included: with the split forward and the one-CU backward every gradient is bit-identical to the all-one-CU
     run.  gru_bwd16x4p_kernel splits the REDUCTION (four partial chains per column, summed in member order): its gradients agree
     with the one-CU backward to the tests' gradient tolerance and are the same bits on every run.  Ragged lengths, one-row
-    batches, 64 teams (every CU taken), both directions in one launch, stacked layers."""
+    batches, 64 teams (every CU taken), both directions in one launch, stacked layers; bidirectional batches whose two directions
+    do not fit the device together run one launch per direction (gru16x4_launches == 2: the reference's default model shape at
+    512 triplets)."""
     V, E, H, seed = 400, 300, 256, 900 + B
     enc, table, sd = make_encoder(V, E, H, seed, layers, bi)
     ids = torch.from_numpy(synth.make_ids(seed + 5, B, T, V, zero_inside=0.05)).cuda()

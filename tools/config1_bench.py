@@ -23,7 +23,7 @@ def main():
     m = tt.TwoTowerModel({"VOCAB_SIZE": V, "EMBED_DIM": E, "HIDDEN_DIM": H, "NUM_LAYERS": 2, "BIDIRECTIONAL": True,
                           "DROPOUT": 0.2}, table).to(dev)
     for enc in (m.query_encoder, m.doc_encoder): enc.check_inputs = False
-    B = 512
+    B = int(sys.argv[1]) if len(sys.argv) > 1 else 512   # (64 = config.json's own BATCH_SIZE)
     q, qt = make_ids(rs, B, 6, 1, 30, V); p, pt = make_ids(rs, B, 70, 10, 250, V); n, nt = make_ids(rs, B, 70, 10, 250, V)
     q, p, n = q.to(dev), p.to(dev), n.to(dev)
     m.eval()
@@ -37,7 +37,7 @@ def main():
     print(json.dumps(dict(what="config.json shape: index build fwd", B=8192, tokens=bt, ms=round(t_big * 1e3, 3), tokens_per_s=round(bt / t_big))), flush=True)
     m.train()
     opt = tt.FusedClipAdam(m.parameters(), lr=5e-5, max_norm=1.0)
-    t_tr = timeit(lambda: tt.train_step(m, opt, q, p, n, margin=0.5, concurrent_towers=True), iters=5, warm=2)
+    t_tr = timeit(lambda: tt.train_step(m, opt, q, p, n, margin=0.5, concurrent_towers=True), iters=20, warm=3)
     print(json.dumps(dict(what="config.json shape: train step", triplets=B, tokens=qt + pt + nt, ms=round(t_tr * 1e3, 3), triplets_per_s=round(B / t_tr))), flush=True)
 
 if __name__ == "__main__":

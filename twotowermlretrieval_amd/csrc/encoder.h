@@ -73,7 +73,8 @@ __host__ __device__ static inline float tt_dropout_scale(uint64_t seed, int laye
 // gru16_launch.  gru16x4_xch_bytes: hand-off scratch for B rows (0 when H != 256; host-only arithmetic, no GPU call).
 size_t gru16x4_xch_bytes(int B, int H, int ndir);
 size_t gru16x4_bwd_xch_bytes(int B, int H, int ndir);
-bool gru16x4_usable(int B, int H, int ndir); // this device has a CU for every member of every team of ONE launch
+bool gru16x4_usable(int B, int H, int ndir); // this device has a CU for every member of every team of ONE launch (gru16x4_launches > 0)
+int gru16x4_launches(int B, int H, int ndir); // 1: both directions in one grid, 2: one launch per direction, 0: does not fit
 bool gru16x4_bwd_usable(int B, int H, int ndir);
 
 static inline EncLayout enc_layout(int B, int T, int E, int H, int L, int bidir, int train, int dropout = 0,

@@ -916,7 +916,7 @@ TT_EXPORT int tt_encoder_split_workgroups(int B, int H, int bidirectional, int r
     if (rnn_type != CELL_GRU || !gru16_supported(H) || enc_force_f32() || gru16x4_xch_bytes(B, H, ndir) == 0 ||
         !gru16x4_usable(B, H, ndir))
         return 0;
-    return ((B + ENC_RB - 1) / ENC_RB + 7) / 8 * 32 * ndir;
+    return ((B + ENC_RB - 1) / ENC_RB + 7) / 8 * 32 * (gru16x4_launches(B, H, ndir) == 2 ? 1 : ndir); // (per launch)
 }
 
 TT_EXPORT int tt_encoder_forward_f32(const int64_t *ids, int B, int T, const float *table, int64_t V, int E, int H,

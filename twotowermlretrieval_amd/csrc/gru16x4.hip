@@ -1500,13 +1500,22 @@ size_t gru16x4_xch_bytes(int B, int H, int ndir)
 
 // one workgroup per CU at most, so that every member of every team is resident (one wave per SIMD with the whole
 // register file: nothing else fits on a CU beside one of these workgroups)
-bool gru16x4_usable(int B, int H, int ndir)
+// Launches a call of this shape takes: 1 = both directions' teams in one grid, 2 = one launch per direction (a bidirectional
+// layer whose two directions together ask for more CUs than the device has while each alone fits: 1 024 rows x 2 directions on
+// 256 CUs -- the directions are independent recurrences, and one behind the other on four CUs per row group is faster than both
+// at once on one CU per row group: 2 x 231 against 709 us forward, 2 x 353 against 1 023 us backward for the reference's default
+// model shape at 512 triplets), 0 = the shape does not fit.
+int gru16x4_launches(int B, int H, int ndir)
 {
     if (!split_enabled() || H != X4_H || B <= 0)
-        return false;
-    const int nteams = (B + ENC_RB - 1) / ENC_RB;
-    return (nteams + 7) / 8 * 32 * ndir <= device_cus();
+        return 0;
+    const int per_dir = ((B + ENC_RB - 1) / ENC_RB + 7) / 8 * 32;
+    if (per_dir * ndir <= device_cus())
+        return 1;
+    return ndir == 2 && per_dir <= device_cus() ? 2 : 0;
 }
+
+bool gru16x4_usable(int B, int H, int ndir) { return gru16x4_launches(B, H, ndir) > 0; }
 
 size_t gru16x4_bwd_xch_bytes(int B, int H, int ndir)
 {
@@ -1555,6 +1564,14 @@ int gru16x4_bwd_launch(const GruBwdParams &bp, int ndir, void *xch, int32_t *sta
         hipLaunchKernelGGL(gru_bwd16x4_kernel, dim3((sp.nteams + 7) / 8 * 32, ndir), dim3(256), XB_LDS + 16, st, sp);
     else
 #endif
+    if (gru16x4_launches(bp.B, bp.H, ndir) == 2) { // one direction after the other, each with its own exchange slots
+        for (int d = 0; d < 2; ++d) {
+            GruSplitBwdParams one = sp;
+            one.g.dir[0] = bp.dir[d];
+            one.xch = (char *)xch + (size_t)d * gru16x4_bwd_xch_bytes(bp.B, bp.H, 1);
+            hipLaunchKernelGGL(gru_bwd16x4p_kernel, dim3((sp.nteams + 7) / 8 * 32, 1), dim3(512), XP_LDS + 16, st, one);
+        }
+    } else
         hipLaunchKernelGGL(gru_bwd16x4p_kernel, dim3((sp.nteams + 7) / 8 * 32, ndir), dim3(512), XP_LDS + 16, st, sp);
     TT_LAUNCH_CHECK();
     return TT_OK;
@@ -1594,6 +1611,14 @@ int gru16x4_launch(const GruParams &gp, int ndir, void *xch, int32_t *status, hi
         hipLaunchKernelGGL(gru_seq16x4_kernel, dim3((sp.nteams + 7) / 8 * 32, ndir), dim3(256), X4_LDS + 16, st, sp);
     else
 #endif
+    if (gru16x4_launches(gp.B, gp.H, ndir) == 2) { // one direction after the other, each with its own exchange slots
+        for (int d = 0; d < 2; ++d) {
+            GruSplitParams one = sp;
+            one.g.dir[0] = gp.dir[d];
+            one.xch = (char *)xch + (size_t)d * gru16x4_xch_bytes(gp.B, gp.H, 1);
+            hipLaunchKernelGGL(gru_seq16x4p_kernel, dim3((sp.nteams + 7) / 8 * 32, 1), dim3(512), XF_LDS + 16, st, one);
+        }
+    } else
         hipLaunchKernelGGL(gru_seq16x4p_kernel, dim3((sp.nteams + 7) / 8 * 32, ndir), dim3(512), XF_LDS + 16, st, sp);
     TT_LAUNCH_CHECK();
     return TT_OK;
