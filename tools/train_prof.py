@@ -11,9 +11,14 @@ from bench import make_ids
 def main():
     dev = torch.device("cuda"); rs = np.random.RandomState(0)
     V, E, H, B = 400003, 300, 256, 512
+    cfg = {"VOCAB_SIZE": V, "EMBED_DIM": E, "HIDDEN_DIM": H}
+    if len(sys.argv) > 2 and sys.argv[2] == "config1":   # the reference's default model (backend/config.json:13-17)
+        E = 200
+        cfg.update(EMBED_DIM=E, NUM_LAYERS=2, BIDIRECTIONAL=True, DROPOUT=0.2)
+        B = int(sys.argv[3]) if len(sys.argv) > 3 else B
     table = (rs.standard_normal((V, E)) * 0.3).astype(np.float32)
     torch.manual_seed(0)
-    m = tt.TwoTowerModel({"VOCAB_SIZE": V, "EMBED_DIM": E, "HIDDEN_DIM": H}, table).to(dev)
+    m = tt.TwoTowerModel(cfg, table).to(dev)
     for enc in (m.query_encoder, m.doc_encoder): enc.check_inputs = False
     q, qt = make_ids(rs, B, 6, 1, 30, V); p, pt = make_ids(rs, B, 70, 10, 250, V); n, nt = make_ids(rs, B, 70, 10, 250, V)
     q, p, n = q.to(dev), p.to(dev), n.to(dev)
