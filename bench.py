@@ -526,6 +526,25 @@ def encoder_legs(dev):
     except Exception as e:  # noqa: BLE001 -- the eager leg above is the record; say why the graph leg is missing
         train["graphed"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     del opt
+    # the reference's DEFAULT model (backend/config.json:13-17: E = 200, 2 layers, bidirectional, dropout 0.2 -- BASELINE
+    # configs[0]'s model) on the same triplets' shapes, at 512 triplets and at config.json's own BATCH_SIZE of 64
+    try:
+        import numpy as np
+        rs = np.random.RandomState(7)
+        tab1 = torch.from_numpy((rs.standard_normal((ENC_V, 200)) * 0.3).astype(np.float32))
+        torch.manual_seed(1)
+        m1 = tt.TwoTowerModel({"VOCAB_SIZE": ENC_V, "EMBED_DIM": 200, "HIDDEN_DIM": ENC_H, "NUM_LAYERS": 2, "BIDIRECTIONAL": True,
+                               "DROPOUT": 0.2}, tab1).to(dev)
+        m1.train()
+        opt1 = tt.FusedClipAdam(m1.parameters(), lr=5e-5, max_norm=1.0)
+        t512 = _time_gpu(lambda: tt.train_step(m1, opt1, qd, pd, nd, margin=0.5), 4, 2)
+        t64 = _time_gpu(lambda: tt.train_step(m1, opt1, qd[:64], pd[:64], nd[:64], margin=0.5), 8, 2)
+        train["config_json_model"] = {"model": "E=200, H=256, 2 layers, bidirectional, dropout 0.2 (backend/config.json:13-17)",
+                                      "ms_per_step_512_triplets": round(t512 * 1e3, 3), "triplets_per_s_512": round(512 / t512),
+                                      "ms_per_step_64_triplets": round(t64 * 1e3, 3), "triplets_per_s_64": round(64 / t64)}
+        del opt1, m1, tab1
+    except Exception as e:  # noqa: BLE001
+        train["config_json_model"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     torch.cuda.empty_cache()
     return enc, train, (table, q, p, n), m
 
