@@ -367,9 +367,15 @@ class _towers_in_flight:
             self._need = {e: (0 if (e.one_workgroup and e.one_workgroup_bwd is not False) else L.tt_encoder_split_workgroups(
                 int(B), e.hidden_dim, int(e.bidirectional), e._cell)) for e, B in self.rows.items()}
             self.needs_order = sum(self._need.values()) > cus
+            if self.needs_order and any(e.num_layers > 1 for e in encs):
+                # stacked layers: the ordering event is recorded behind a call's LAST recurrence launch, i.e. behind ALL the layers
+                # of the smaller tower -- the document tower's first layer would wait for the whole query tower (207 us of a
+                # 5.5 ms step at the reference's default shape, profiles/r04_z_config1_train_timeline.txt).  The smaller tower
+                # on the one-workgroup recurrences instead: its few short sequences cost it ~90 us off the critical path.
+                self.use_one_workgroup()
             if self.needs_order:   # the backward: the smaller towers on the one-workgroup recurrence until the sum fits
                 left = dict(self._need)
-                for e in sorted(left, key=lambda e: left[e]):
+                for e in sorted(left, key=lambda e: (left[e], self.rows.get(e, 0))):
                     if sum(left.values()) <= cus:
                         break
                     if left[e]:
@@ -382,7 +388,7 @@ class _towers_in_flight:
             return
         cus = torch.cuda.get_device_properties(self.model.query_encoder.embedding.weight.device).multi_processor_count
         need = self._need
-        for e in sorted(need, key=lambda e: need[e]):  # smallest first
+        for e in sorted(need, key=lambda e: (need[e], self.rows.get(e, 0))):  # smallest first (fewest rows among equals)
             if sum(need.values()) <= cus:
                 break
             if need[e]:
