@@ -542,7 +542,14 @@ def encoder_legs(dev):
         train["config_json_model"] = {"model": "E=200, H=256, 2 layers, bidirectional, dropout 0.2 (backend/config.json:13-17)",
                                       "ms_per_step_512_triplets": round(t512 * 1e3, 3), "triplets_per_s_512": round(512 / t512),
                                       "ms_per_step_64_triplets": round(t64 * 1e3, 3), "triplets_per_s_64": round(64 / t64)}
-        del opt1, m1, tab1
+        q64, p64, n64 = qd[:64].contiguous(), pd[:64].contiguous(), nd[:64].contiguous()
+        g64 = tt.GraphedTrainStep(m1, opt1, batch=64, q_width=r32(q64.shape[1]), doc_width=r32(max(p64.shape[1], n64.shape[1])),
+                                  margin=0.5, defer_check=True)    # (dropout seeds as device words: include/tt.h TT_ENC_SEED_ON_DEVICE)
+        tg = _time_gpu(lambda: g64(q64, p64, n64), 8, 2)
+        g64.flush()
+        train["config_json_model"]["graphed_deferred_ms_per_step_64_triplets"] = round(tg * 1e3, 3)
+        train["config_json_model"]["graphed_deferred_triplets_per_s_64"] = round(64 / tg)
+        del g64, opt1, m1, tab1
     except Exception as e:  # noqa: BLE001
         train["config_json_model"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     torch.cuda.empty_cache()

@@ -264,6 +264,11 @@ typedef struct tt_enc_sync {
  * (records), B FINISH (waits) -- what trainer.train_step does with the document tower (B) and the query tower (A). */
 #define TT_ENC_PHASE_BEGIN 0x200
 #define TT_ENC_PHASE_FINISH 0x400
+/* Option bit of `train` (forward) and `opts` (backward): `dropout_seed` is the ADDRESS of a device uint64 that holds the seed; the
+ * kernels read it when they run.  A host that captures a train step into a HIP graph writes a new seed there before every replay
+ * (trainer.GraphedTrainStep); passing the value instead would freeze one mask into the graph.  Forward and backward of a step must
+ * see the same value. */
+#define TT_ENC_SEED_ON_DEVICE 0x800
 /* CUs the column-split recurrence of one call of this shape occupies (one workgroup each, all resident at once; a bidirectional
  * call whose two directions do not fit together runs them one launch after the other and this is ONE direction's count); 0 = the
  * call runs the one-workgroup kernels whatever `train` says.  A host with several calls in flight keeps the sum within the device's

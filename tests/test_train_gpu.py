@@ -482,6 +482,47 @@ def test_graphed_train_step_replays_the_eager_step_bit_for_bit():
     assert torch.equal(opt.flat_params, ref_opt.flat_params)
 
 
+def test_graphed_train_step_with_inter_layer_dropout_replays_the_eager_step():
+    """The reference's default model (backend/config.json:13-17: 2 layers, bidirectional, dropout 0.2) in a HIP graph: the dropout
+    seeds are device words the captured kernels read when they run (TT_ENC_SEED_ON_DEVICE), drawn per call from torch's CPU
+    generator in the eager step's order.  With the generator in the same state a replay computes the eager step's bits --
+    loss, parameters, moments -- for three different batches (different masks every step), and a replay with another generator
+    state computes something else (the mask is not frozen into the graph)."""
+    import copy
+    import twotowermlretrieval_amd as tt
+    V, E, H, B = 300, 200, 256, 64
+    torch.manual_seed(19)
+    cfg = {"VOCAB_SIZE": V, "EMBED_DIM": E, "HIDDEN_DIM": H, "NUM_LAYERS": 2, "BIDIRECTIONAL": True, "DROPOUT": 0.2}
+    m = tt.TwoTowerModel(cfg, synth.make_table(4, V, E)).cuda().train()
+    ref = copy.deepcopy(m)
+    opt = tt.FusedClipAdam(m.parameters(), lr=1e-3, max_norm=1.0)
+    ref_opt = tt.FusedClipAdam(ref.parameters(), lr=1e-3, max_norm=1.0)
+    step = tt.GraphedTrainStep(m, opt, batch=B, q_width=16, doc_width=48, margin=0.5)
+
+    def padded(t, w):
+        out = torch.zeros((t.shape[0], w), dtype=torch.int64, device=t.device)
+        out[:, : t.shape[1]] = t
+        return out
+    losses = []
+    for i, widths in enumerate(((7, 20, 25), (16, 48, 31), (3, 9, 48))):
+        ids = [torch.from_numpy(synth.make_ids(700 + 3 * i + s, B, T, V)).cuda() for s, T in enumerate(widths)]
+        torch.manual_seed(500 + i)
+        loss = step(*ids)
+        torch.manual_seed(500 + i)
+        ref_loss = tt.train_step(ref, ref_opt, padded(ids[0], 16), padded(ids[1], 48), padded(ids[2], 48), margin=0.5)
+        torch.cuda.synchronize()
+        assert float(loss) == float(ref_loss)
+        assert torch.equal(opt.flat_params, ref_opt.flat_params) and torch.equal(opt.exp_avg_sq, ref_opt.exp_avg_sq)
+        assert opt.step_count == ref_opt.step_count == i + 1
+        losses.append(float(loss))
+    # the same batch twice with different generator states: different masks, different losses
+    torch.manual_seed(1)
+    a = float(step(*ids))
+    torch.manual_seed(2)
+    b = float(step(*ids))
+    assert a != b
+
+
 def test_trainer_with_graphs_buckets_the_widths_and_equals_the_eager_trainer():
     """DataParallelTrainer(graphs=True): one HIP graph per (batch, query width, document width) bucket of 32 columns, least
     recently used evicted; every step equals, bit for bit, the eager trainer's step on ids padded to the bucket's widths."""

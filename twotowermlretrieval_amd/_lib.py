@@ -11,6 +11,7 @@ LIB_PATH = _PKG / "libtt.so"
 TT_OK, TT_ERR_BAD_SHAPE, TT_ERR_BAD_INDEX, TT_ERR_ZERO_LENGTH, TT_ERR_UNSUPPORTED, TT_ERR_WORKSPACE, TT_ERR_HIP = range(7)
 TT_ENC_ONE_WORKGROUP = 0x100  # option bit of the encoder calls (include/tt.h)
 TT_ENC_PHASE_BEGIN, TT_ENC_PHASE_FINISH = 0x200, 0x400  # tt_encoder_forward_f32 in two halves
+TT_ENC_SEED_ON_DEVICE = 0x800  # dropout_seed is the address of a device uint64
 TT_STEP_GATE_WORDS = 4
 
 

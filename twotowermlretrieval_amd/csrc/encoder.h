@@ -246,6 +246,7 @@ struct GruBwdParams {
     // inter-layer dropout on this layer's OUTPUT: d_seq is the gradient w.r.t. the dropped sequence
     float drop_p;
     uint64_t drop_seed;
+    const uint64_t *drop_seed_ptr = nullptr; // TT_ENC_SEED_ON_DEVICE: the seed is read from here by the kernel (include/tt.h)
     int drop_layer, T;
 };
 

@@ -467,8 +467,10 @@ int launch_seq(const GruParams &gp, int B, int H, int ndir, size_t lds, hipStrea
 __global__ __launch_bounds__(256) void dropout_apply_kernel(const float *__restrict__ x, float *__restrict__ xd,
                                                             const int32_t *__restrict__ len,
                                                             const int32_t *__restrict__ tok_off, int T, int ld,
-                                                            int layer, float p, uint64_t seed)
+                                                            int layer, float p, uint64_t seed_value,
+                                                            const uint64_t *__restrict__ seed_ptr)
 {
+    const uint64_t seed = seed_ptr ? *seed_ptr : seed_value; // (TT_ENC_SEED_ON_DEVICE: read when the kernel runs)
     const int b = blockIdx.x;
     const int L = len[b], o = tok_off[b];
     for (int i = threadIdx.x; i < L * ld; i += 256) {
@@ -680,12 +682,14 @@ static int encoder_forward(const char *who, const int64_t *ids, int B, int T, co
     int rc = enc_check_shape(who, B, T, E, H, num_layers, V);
     if (rc != TT_OK)
         return rc;
-    if (train < 0 || (train & ~(TT_ENC_TRAIN_MASK | TT_ENC_ONE_WORKGROUP | TT_ENC_PHASE_BEGIN | TT_ENC_PHASE_FINISH)) ||
+    if (train < 0 || (train & ~(TT_ENC_TRAIN_MASK | TT_ENC_ONE_WORKGROUP | TT_ENC_PHASE_BEGIN | TT_ENC_PHASE_FINISH | TT_ENC_SEED_ON_DEVICE)) ||
         (train & TT_ENC_TRAIN_MASK) > 2 || ((train & TT_ENC_PHASE_BEGIN) && (train & TT_ENC_PHASE_FINISH)))
         return tt_fail(TT_ERR_BAD_SHAPE, "%s: train=0x%x (0, 1 or 2, optionally | TT_ENC_ONE_WORKGROUP | one TT_ENC_PHASE_*)", who, train);
     const bool one_wg = (train & TT_ENC_ONE_WORKGROUP) != 0; // the caller keeps the recurrences off the column-split kernels
     // the call in two halves (include/tt.h): BEGIN = everything in front of the first recurrence launch, FINISH = the rest
     const bool ph_begin = (train & TT_ENC_PHASE_BEGIN) != 0, ph_finish = (train & TT_ENC_PHASE_FINISH) != 0;
+    // the dropout seed as the address of a device word the kernels read when they run (a captured step replays with new masks)
+    const uint64_t *seed_dev = (train & TT_ENC_SEED_ON_DEVICE) ? (const uint64_t *)(uintptr_t)dropout_seed : nullptr;
     train &= TT_ENC_TRAIN_MASK;
     if (!ids || !table || !weights || !out || (bidirectional && (!proj_w || !proj_b)))
         return tt_fail(TT_ERR_BAD_SHAPE, "%s: null pointer", who);
@@ -868,7 +872,8 @@ static int encoder_forward(const char *who, const int64_t *ids, int B, int T, co
             TT_HIP_CHECK(hipEventRecord((hipEvent_t)sync->record_after_recurrence, st));
         if (drop && !last) { // nn.GRU's dropout sits on the outputs of every layer but the last
             hipLaunchKernelGGL(dropout_apply_kernel, dim3(B), dim3(256), 0, st, (const float *)xout,
-                               (float *)(ws + lo.xd[l + 1]), len, tok_off, T, ndir * H, l, dropout_p, dropout_seed);
+                               (float *)(ws + lo.xd[l + 1]), len, tok_off, T, ndir * H, l, dropout_p, seed_dev ? 0ull : dropout_seed,
+                               seed_dev);
             TT_RC_CHECK(tt_zero_async((float *)(ws + lo.xd[l + 1]) + (size_t)lo.MT * ndir * H, sizeof(float) * ndir * H, st));
             TT_LAUNCH_CHECK();
         }

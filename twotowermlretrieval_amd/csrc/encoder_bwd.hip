@@ -134,6 +134,7 @@ __global__ __launch_bounds__(256) void pack_whh_t_kernel(const float *__restrict
 template <int MAXW, int CELL>
 __global__ __launch_bounds__(MAXW * 64) void gru_bwd_seq_kernel(GruBwdParams p)
 {
+    const uint64_t drop_seed_v = (p.drop_p > 0.0f && p.drop_seed_ptr) ? *p.drop_seed_ptr : p.drop_seed;
     constexpr int NG = CELL == CELL_LSTM ? 4 : (CELL == CELL_RNN ? 1 : 3);
     extern __shared__ __attribute__((aligned(16))) float gt[]; // [16][NG*H+4]
     const GruBwdDir d = p.dir[blockIdx.y];
@@ -227,7 +228,7 @@ __global__ __launch_bounds__(MAXW * 64) void gru_bwd_seq_kernel(GruBwdParams p)
                 if (act[e]) {
                     float dsv = cur_st.dsv[ct][e];
                     if (d.d_seq && p.drop_p > 0.0f)
-                        dsv *= tt_dropout_scale(p.drop_seed, p.drop_layer,
+                        dsv *= tt_dropout_scale(drop_seed_v, p.drop_layer,
                                                 ((uint64_t)rid_e[e] * p.T + t) * p.ld + d.col0 + u, p.drop_p);
                     const float dhv = dh[ct][e] + dsv;
                     float *go = d.dgi + tok * HG + u;
@@ -435,8 +436,8 @@ TT_EXPORT int tt_encoder_backward_f32(const int64_t *ids, int B, int T, const fl
     int rc = enc_check_shape("tt_encoder_backward_f32", B, T, E, H, num_layers, V);
     if (rc != TT_OK)
         return rc;
-    if (opts & ~TT_ENC_ONE_WORKGROUP)
-        return tt_fail(TT_ERR_BAD_SHAPE, "tt_encoder_backward_f32: opts=0x%x (0 or TT_ENC_ONE_WORKGROUP)", opts);
+    if (opts & ~(TT_ENC_ONE_WORKGROUP | TT_ENC_SEED_ON_DEVICE))
+        return tt_fail(TT_ERR_BAD_SHAPE, "tt_encoder_backward_f32: opts=0x%x (0, TT_ENC_ONE_WORKGROUP, TT_ENC_SEED_ON_DEVICE)", opts);
     const bool one_wg = (opts & TT_ENC_ONE_WORKGROUP) != 0;
     if (!table || !weights || !d_out || !grads || (bidirectional && (!proj_w || !g_proj_w || !g_proj_b)))
         return tt_fail(TT_ERR_BAD_SHAPE, "tt_encoder_backward_f32: null pointer");
@@ -546,7 +547,8 @@ TT_EXPORT int tt_encoder_backward_f32(const int64_t *ids, int B, int T, const fl
         bp.H = H;
         bp.ld = ndir * H;
         bp.drop_p = (drop && !top) ? dropout_p : 0.0f;
-        bp.drop_seed = dropout_seed;
+        bp.drop_seed = (opts & TT_ENC_SEED_ON_DEVICE) ? 0ull : dropout_seed;
+        bp.drop_seed_ptr = (opts & TT_ENC_SEED_ON_DEVICE) ? (const uint64_t *)(uintptr_t)dropout_seed : nullptr;
         bp.drop_layer = l;
         bp.T = T;
         for (int d = 0; d < ndir; ++d) {

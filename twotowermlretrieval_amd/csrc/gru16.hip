@@ -444,6 +444,7 @@ __global__ __launch_bounds__(256) void pack_whh16_t_kernel(const float *__restri
 template <int H>
 __global__ __launch_bounds__(B16<H>::NW * 64) void gru_bwd16_kernel(GruBwdParams p)
 {
+    const uint64_t drop_seed_v = (p.drop_p > 0.0f && p.drop_seed_ptr) ? *p.drop_seed_ptr : p.drop_seed;
     using C = B16<H>;
     using P = PlanOf<C>;
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -554,7 +555,7 @@ __global__ __launch_bounds__(B16<H>::NW * 64) void gru_bwd16_kernel(GruBwdParams
                     const float hp = cur_st.hp[ct][e];
                     float dsv = cur_st.dsv[ct][e];
                     if (d.d_seq && p.drop_p > 0.0f)
-                        dsv *= tt_dropout_scale(p.drop_seed, p.drop_layer,
+                        dsv *= tt_dropout_scale(drop_seed_v, p.drop_layer,
                                                 ((uint64_t)rid_e[e] * p.T + t) * p.ld + d.col0 + u, p.drop_p);
                     const float dhv = dh[ct][e] + dsv;
                     const float dn_pre = dhv * (1.0f - z) * (1.0f - n * n);

@@ -740,6 +740,7 @@ __global__ __launch_bounds__(256, 1) void gru_bwd16x4_kernel(GruSplitBwdParams s
     extern __shared__ __attribute__((aligned(16))) char lds[];
     int &abort_flag = *(int *)(lds + XB_LDS);
     const GruBwdParams &p = sp.g;
+    const uint64_t drop_seed_v = (p.drop_p > 0.0f && p.drop_seed_ptr) ? *p.drop_seed_ptr : p.drop_seed;
     const int chunk = blockIdx.x >> 5, r32 = blockIdx.x & 31;
     const int m = __builtin_amdgcn_readfirstlane(r32 >> 3), team = chunk * 8 + (r32 & 7);
     if (team >= sp.nteams)
@@ -858,7 +859,7 @@ __global__ __launch_bounds__(256, 1) void gru_bwd16x4_kernel(GruSplitBwdParams s
             const float r = cur_st.r[e], z = cur_st.z[e], n = cur_st.n[e], ghn = cur_st.ghn[e], hp = cur_st.hp[e];
             float dsv = cur_st.dsv[e];
             if (d.d_seq && p.drop_p > 0.0f) // (uniform)
-                dsv *= tt_dropout_scale(p.drop_seed, p.drop_layer, ((uint64_t)(rid_e[e] < 0 ? 0 : rid_e[e]) * p.T + t) * p.ld + cu,
+                dsv *= tt_dropout_scale(drop_seed_v, p.drop_layer, ((uint64_t)(rid_e[e] < 0 ? 0 : rid_e[e]) * p.T + t) * p.ld + cu,
                                         p.drop_p);
             const float dhv = dh[e] + dsv;
             const float dn_pre = dhv * (1.0f - z) * (1.0f - n * n);
@@ -1105,6 +1106,7 @@ __global__ __launch_bounds__(512, 1) void gru_bwd16x4p_kernel(GruSplitBwdParams 
     extern __shared__ __attribute__((aligned(16))) char lds[];
     int &abort_flag = *(int *)(lds + XP_LDS);
     const GruBwdParams &p = sp.g;
+    const uint64_t drop_seed_v = (p.drop_p > 0.0f && p.drop_seed_ptr) ? *p.drop_seed_ptr : p.drop_seed;
     const int chunk = blockIdx.x >> 5, r32 = blockIdx.x & 31;
     const int m = __builtin_amdgcn_readfirstlane(r32 >> 3), team = chunk * 8 + (r32 & 7);
     if (team >= sp.nteams)
@@ -1232,7 +1234,7 @@ __global__ __launch_bounds__(512, 1) void gru_bwd16x4p_kernel(GruSplitBwdParams 
             const float r = cur_st.r[e], z = cur_st.z[e], n = cur_st.n[e], ghn = cur_st.ghn[e], hp = cur_st.hp[e];
             float dsv = cur_st.dsv[e];
             if (d.d_seq && p.drop_p > 0.0f) // (uniform)
-                dsv *= tt_dropout_scale(p.drop_seed, p.drop_layer, ((uint64_t)(rid_e[e] < 0 ? 0 : rid_e[e]) * p.T + t) * p.ld + cu,
+                dsv *= tt_dropout_scale(drop_seed_v, p.drop_layer, ((uint64_t)(rid_e[e] < 0 ? 0 : rid_e[e]) * p.T + t) * p.ld + cu,
                                         p.drop_p);
             const float dhv = dh[e] + dsv;
             const float dn_pre = dhv * (1.0f - z) * (1.0f - n * n);

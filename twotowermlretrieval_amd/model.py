@@ -270,6 +270,10 @@ class RNNEncoder(nn.Module):
         (out, ws, status) triple to pass back as `resume`); _lib.TT_ENC_PHASE_FINISH with resume = the rest (train mode only)."""
         L = _lib.lib()
         opts = self._opts() if opts is None else opts
+        if isinstance(dropout_seed, torch.Tensor):   # a device int64: the kernels read the seed when they run (captured steps)
+            seed_arg, opts = int(dropout_seed.data_ptr()), opts | _lib.TT_ENC_SEED_ON_DEVICE
+        else:
+            seed_arg = int(dropout_seed)
         ids = x.contiguous()
         if ids.dtype != torch.int64:
             ids = ids.to(torch.int64)
@@ -313,7 +317,7 @@ class RNNEncoder(nn.Module):
                     ids.data_ptr(), B, T, table.data_ptr(), V, E, H, self.num_layers, int(self.bidirectional),
                     self._cell, wptr, pw.data_ptr() if pw is not None else None,
                     pb.data_ptr() if pb is not None else None, int(self.normalize_output), train_mode | opts | phase,
-                    float(dropout_p), int(dropout_seed), out.data_ptr(), ws.data_ptr(), ws.numel(), status.data_ptr(),
+                    float(dropout_p), seed_arg, out.data_ptr(), ws.data_ptr(), ws.numel(), status.data_ptr(),
                     C.byref(sync) if sync is not None else None, _stream(ids.device)))
         if phase == _lib.TT_ENC_PHASE_BEGIN:
             return out, ws, status   # (the status word is handed over / read when the FINISH half has been issued)
@@ -339,6 +343,10 @@ class RNNEncoder(nn.Module):
         status: the forward call's status word; a time-out of the column-split backward recurrence ORs bit 2 into it."""
         L = _lib.lib()
         opts = self._opts_bwd() if opts is None else opts
+        if isinstance(dropout_seed, torch.Tensor):
+            seed_arg, opts = int(dropout_seed.data_ptr()), opts | _lib.TT_ENC_SEED_ON_DEVICE
+        else:
+            seed_arg = int(dropout_seed)
         B, T = ids.shape
         V, E = self.embedding.weight.shape
         H = self.hidden_dim
@@ -356,7 +364,7 @@ class RNNEncoder(nn.Module):
                 ids.contiguous().data_ptr(), B, T, self.embedding.weight.detach().data_ptr(), V, E, H,
                 self.num_layers, int(self.bidirectional), self._cell, wptr, pw.data_ptr() if pw is not None else None,
                 pb.data_ptr() if pb is not None else None, int(self.normalize_output), float(dropout_p),
-                int(dropout_seed), d_out.data_ptr(), gptr,
+                seed_arg, d_out.data_ptr(), gptr,
                 grads[nq].data_ptr() if pw is not None else None,
                 grads[nq + 1].data_ptr() if pb is not None else None,
                 g_table.data_ptr() if g_table is not None else None, ws.data_ptr(), ws.numel(), opts,

@@ -405,7 +405,8 @@ class _towers_in_flight:
 
 
 def _train_step_direct(model: TwoTowerModel, optimizer, queries, pos_docs, neg_docs, margin: float, phase: str = "all",
-                       join_on_caller: bool = False, both: Optional[torch.Tensor] = None, plan: Optional[_towers_in_flight] = None):
+                       join_on_caller: bool = False, both: Optional[torch.Tensor] = None, plan: Optional[_towers_in_flight] = None,
+                       seed_words: Optional[dict] = None):
     """The same step without the autograd engine: tower forwards (train mode), the fused loss + gradient kernel, tower backwards
     written STRAIGHT into the optimizer's flat gradient buffer, optimizer step.  Every parameter receives its gradient exactly
     once (query tower once; positives and negatives as one 2B-row document-tower call), so nothing has to be zeroed or
@@ -422,7 +423,9 @@ def _train_step_direct(model: TwoTowerModel, optimizer, queries, pos_docs, neg_d
     the origin stream is fine, side-to-side joins segfault, whatever the kernels).
     both: the 2B-row document batch [pos_docs; neg_docs] already concatenated (GraphedTrainStep stages it outside the graph).
     plan: the step's _towers_in_flight; when the two towers' split recurrences do not fit the device together their recurrence
-    launches are ordered with events (query tower's first in the forward, last in the backward)."""
+    launches are ordered with events (query tower's first in the forward, last in the backward).
+    seed_words: {id(encoder): device int64[1]} -- the towers' dropout seeds as device words the kernels read when they run
+    (TT_ENC_SEED_ON_DEVICE: GraphedTrainStep writes a fresh seed there before every replay); default: drawn here, passed by value."""
     if not isinstance(optimizer, _FlatClipAdam) or not torch.is_grad_enabled():
         return None
     encs = (model.doc_encoder, model.query_encoder)
@@ -474,8 +477,7 @@ def _train_step_direct(model: TwoTowerModel, optimizer, queries, pos_docs, neg_d
                 both = _concat_ids(pos_docs, neg_docs)
         ids_of = (both, queries)
         # dropout seeds from torch's CPU generator in the order the autograd path draws them (query tower, then document tower)
-        seeds = {id(enc): (int(torch.randint(0, 2 ** 62, (1,)).item()) if enc.dropout > 0.0 else 0)
-                 for enc in (model.query_encoder, model.doc_encoder)}
+        seeds = seed_words if seed_words is not None else _draw_dropout_seeds(model)
         # Issue order: the document tower (2B rows of ~70 tokens: the step's critical path) FIRST, the query tower's ~15 small
         # launches then overlap it instead of delaying it by the ~0.1 ms the host needs to issue them.  Ordered recurrences: the
         # call that RECORDS the ordering event must be issued before the WAIT for it (include/tt.h), so the document tower's call
@@ -558,6 +560,13 @@ def _train_step_direct(model: TwoTowerModel, optimizer, queries, pos_docs, neg_d
                 cur.wait_stream(t)
     loss.record_stream(cur)
     return loss
+
+
+def _draw_dropout_seeds(model: TwoTowerModel) -> dict:
+    """{id(encoder): seed} from torch's CPU generator in the order the autograd path draws them (query tower, then document
+    tower); 0 for a tower without inter-layer dropout (nothing is drawn for it)."""
+    return {id(enc): (int(torch.randint(0, 2 ** 62, (1,)).item()) if enc.dropout > 0.0 else 0)
+            for enc in (model.query_encoder, model.doc_encoder)}
 
 
 def _train_step_once(model, optimizer, queries, pos_docs, neg_docs, margin, concurrent_towers, direct, plan=None):
@@ -662,8 +671,8 @@ class DataParallelTrainer:
 
     graphs=True: steps are replayed from HIP graphs (GraphedTrainStep), one per (batch, query width, document width) bucket --
     widths rounded up to `width_step` columns, the `max_graphs` most recently used buckets kept (a graph owns its workspaces:
-    ~0.3 GB at 512 triplets x 128 columns).  A batch that does not fit the rules of GraphedTrainStep (dropout, unchecked inputs,
-    non-int64 ids) takes the eager train_step; results are the eager step's on ids padded to the bucket's widths.
+    ~0.3 GB at 512 triplets x 128 columns).  A batch that does not fit the rules of GraphedTrainStep (unchecked inputs,
+    non-int64 ids, a trainable table) takes the eager train_step; results are the eager step's on ids padded to the bucket's widths.
     defer_check: see GraphedTrainStep (exceptions one call late; call flush() after the last step)."""
 
     def __init__(self, model: TwoTowerModel, lr: float = 1e-4, margin: float = 0.2, max_norm: float = 1.0, group=None,
@@ -685,7 +694,7 @@ class DataParallelTrainer:
         encs = (self.model.query_encoder, self.model.doc_encoder)
         if not (queries.is_cuda and queries.dtype == pos_docs.dtype == neg_docs.dtype == torch.int64
                 and queries.shape[0] == pos_docs.shape[0] == neg_docs.shape[0]
-                and all(e.check_inputs and e.dropout == 0.0 and not e.embedding.weight.requires_grad for e in encs)):
+                and all(e.check_inputs and not e.embedding.weight.requires_grad for e in encs)):
             return None
         up = lambda x: max(self.width_step, -(-int(x) // self.width_step) * self.width_step)  # noqa: E731
         key = (queries.shape[0], up(queries.shape[1]), up(max(pos_docs.shape[1], neg_docs.shape[1])))
@@ -743,16 +752,16 @@ class GraphedTrainStep:
     host, and a bad batch's exception comes out of the NEXT call (or of flush()); its step was not applied, the following one
     (already enqueued) is an ordinary step on the same weights.  With a process group the graph ends at the gate words and the
     all-reduce + clip + Adam are issued eagerly behind it (RCCL inside a capture is not rehearsable here).  Needs: the
-    optimizer's own parameters on a GPU, GloVe-frozen tables, no inter-layer dropout (its seeds come from the host's generator),
-    input checking on (default)."""
+    optimizer's own parameters on a GPU, GloVe-frozen tables, input checking on (default).  Inter-layer dropout (the reference's
+    default model has it) is captured with its seeds as device words (TT_ENC_SEED_ON_DEVICE, include/tt.h): every call draws them
+    from torch's CPU generator in the eager step's order and copies them in front of the replay, so a replay computes what the
+    eager step would have computed with the generator in the same state."""
 
     def __init__(self, model: TwoTowerModel, optimizer: FusedClipAdam, batch: int, q_width: int, doc_width: int, margin: float = 0.2,
                  defer_check: bool = False):
         encs = (model.query_encoder, model.doc_encoder)
         if not isinstance(optimizer, _FlatClipAdam) or optimizer._gated_step_fn is None:
             raise TypeError("GraphedTrainStep needs a FusedClipAdam")
-        if any(e.dropout > 0.0 for e in encs):
-            raise ValueError("GraphedTrainStep: inter-layer dropout draws its seeds on the host every step; use train_step")
         if not all(e.check_inputs for e in encs):
             raise ValueError("GraphedTrainStep: input checking must be on (the gate is what keeps a bad batch from being applied)")
         self.model, self.optimizer, self.margin = model, optimizer, float(margin)
@@ -761,6 +770,11 @@ class GraphedTrainStep:
         dev = optimizer.flat_params.device
         self.q = torch.zeros((self.B, self.q_width), dtype=torch.int64, device=dev)
         self.both = torch.zeros((2 * self.B, self.doc_width), dtype=torch.int64, device=dev)
+        # inter-layer dropout: the seeds are device words the captured kernels read when they run (TT_ENC_SEED_ON_DEVICE); every
+        # call draws them from torch's CPU generator exactly as the eager step does and copies them here in front of the replay
+        self._seed_words = torch.zeros(2, dtype=torch.int64, device=dev) if any(e.dropout > 0.0 for e in encs) else None
+        self._seed_host = torch.zeros((8, 2), dtype=torch.int64).pin_memory() if self._seed_words is not None else None
+        self._seed_events, self._seed_step = [None] * 8, 0
         self._phase = "all" if optimizer.world == 1 else "fold"
         # (the optimizer's hyper-parameters are arguments of the captured launches: changing them means capturing again)
         self._hyper = (optimizer.lr, optimizer.betas, optimizer.eps, optimizer.max_norm)
@@ -789,9 +803,12 @@ class GraphedTrainStep:
 
     def _run(self):
         rows = {self.model.query_encoder: self.B, self.model.doc_encoder: 2 * self.B}
+        words = None
+        if self._seed_words is not None:
+            words = {id(self.model.query_encoder): self._seed_words[0:1], id(self.model.doc_encoder): self._seed_words[1:2]}
         with _towers_in_flight(self.model, self.optimizer, rows) as plan:
             return _train_step_direct(self.model, self.optimizer, self.q, None, None, self.margin, phase=self._phase,
-                                      join_on_caller=True, both=self.both, plan=plan)
+                                      join_on_caller=True, both=self.both, plan=plan, seed_words=words)
 
     def flush(self):
         """defer_check: settle the optimizer's pending check (raises that step's exception, if any)."""
@@ -808,6 +825,16 @@ class GraphedTrainStep:
                              "arguments of the captured launches); build a new GraphedTrainStep")
         _stage_ids(self.q, queries)
         _stage_ids(self.both, pos_docs, neg_docs)
+        if self._seed_words is not None:
+            drawn = _draw_dropout_seeds(self.model)
+            k = self._seed_step % self._seed_host.shape[0]
+            self._seed_step += 1
+            if self._seed_events[k] is not None:
+                self._seed_events[k].synchronize()   # (this pinned pair was a copy's source eight calls ago: long done)
+            self._seed_host[k, 0], self._seed_host[k, 1] = drawn[id(self.model.query_encoder)], drawn[id(self.model.doc_encoder)]
+            self._seed_words.copy_(self._seed_host[k], non_blocking=True)
+            self._seed_events[k] = torch.cuda.Event()
+            self._seed_events[k].record()
         self.graph.replay()
         if self._phase == "fold":
             opt._reduce_apply(True, check=False)
