@@ -59,12 +59,15 @@ struct HugeArray {
         std::free(p);
         p = nullptr;
         n = 0;
-        const size_t huge = (size_t)2 << 20, bytes = (count * sizeof(T) + huge - 1) / huge * huge;
+        const size_t huge = (size_t)2 << 20, raw = count * sizeof(T);
+        const bool big = raw >= huge;             // (a toy vocabulary gets an ordinary allocation, not a 2 MB page)
+        const size_t align = big ? huge : 64, bytes = (raw + align - 1) / align * align;
         void *q = nullptr;
-        if (posix_memalign(&q, huge, bytes) != 0)
+        if (posix_memalign(&q, align, bytes ? bytes : align) != 0)
             return false;
 #if defined(MADV_HUGEPAGE) && TT_TOK_HUGEPAGES
-        madvise(q, bytes, MADV_HUGEPAGE); // (advice: refused or unsupported -> ordinary pages)
+        if (big)
+            madvise(q, bytes, MADV_HUGEPAGE); // (advice: refused or unsupported -> ordinary pages)
 #endif
         p = (T *)q;
         n = count;
