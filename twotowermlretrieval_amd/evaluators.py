@@ -97,7 +97,15 @@ def embed_corpus(model, tokenizer, documents: Sequence[str], device: torch.devic
     if producers <= 0:
         producers = 1 if cores < 32 else 2
     nt = threads_per_producer if threads_per_producer > 0 else max(1, min(16, cores // producers))
-    starts = list(range(0, n, batch_size))
+    # the pipeline's fill: the first two batches are a quarter and a half of a batch, so the GPU starts after a quarter of a
+    # batch's tokenising instead of a whole one (rows are independent: any batching gives the same rows)
+    bounds, pos = [], 0
+    for size in (batch_size // 4, batch_size // 2):
+        if size >= 1024 and n - pos > 2 * batch_size:
+            bounds.append((pos, pos + size))
+            pos += size
+    bounds += [(i, min(i + batch_size, n)) for i in range(pos, n, batch_size)]
+    starts = bounds
     window = producers + max(1, prefetch)          # batches tokenised or being tokenised ahead of the GPU
     if stats is not None:
         stats.update(producers=producers, threads_per_producer=nt, host_cores=cores, batch_size=batch_size)
@@ -116,7 +124,7 @@ def embed_corpus(model, tokenizer, documents: Sequence[str], device: torch.devic
     def make(i):
         buf = free.get(timeout=120)             # (at most `window` jobs are outstanding and 3 batches in flight behind them; the
         #                                         time-out only ends a job whose consumer died: the pool's threads outlive the call)
-        return tokenizer.encode_batch(documents[i:i + batch_size], pin=True, n_threads=nt, out=buf), buf
+        return tokenizer.encode_batch(documents[i[0]:i[1]], pin=True, n_threads=nt, out=buf), buf
 
     inflight = collections.deque()
     copy_stream = torch.cuda.Stream(device=device)
@@ -148,7 +156,7 @@ def embed_corpus(model, tokenizer, documents: Sequence[str], device: torch.devic
                 emb = model.encode_document(ids)
                 if res is None:
                     res = torch.empty((n, emb.shape[1]), dtype=torch.float32, device=device)
-                res[i:i + emb.shape[0]].copy_(emb)
+                res[i[0]:i[0] + emb.shape[0]].copy_(emb)
                 # a pinned batch must outlive its async copy; keep two batches in flight so the GPU never waits for the host
                 ev = torch.cuda.Event()
                 ev.record(cur)
