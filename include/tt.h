@@ -449,6 +449,15 @@ int tt_tok_encode_sep(const void *handle, const char *text_blob, int64_t blob_le
  * str, Go string, Java byte[]) builds no blob: twotowermlretrieval_amd/csrc/pytext.c collects the pointers of a list of str. */
 int tt_tok_encode_ptrs(const void *handle, const char *const *texts, const int64_t *text_len, int64_t n_texts,
                        int64_t *text_off_out, int64_t *ragged_ids, int32_t *lens, int32_t *status, int n_threads);
+/* Text beyond ASCII, tokenised here with the HOST's Unicode tables so that the ids are the host's by construction.
+ * tt_tok_set_unicode: low[cp] = the code point's lower-case code point (0xffffffff: no context-free single-code-point answer --
+ * U+0130, U+03A3 in CPython -- a text that holds it gets status 1), cls[cp] = 0 other / 1 word (\w) / 2 one of .,!?; -- n_cp
+ * entries each (at most 0x110000), copied.  tt_tok_encode_units = tt_tok_encode_ptrs for texts of 1-, 2- or 4-byte code units (one
+ * code point per unit: CPython's compact str kinds): unit_bytes[i] = 0: text_len[i] ASCII bytes; 1 / 2 / 4: units of that size.
+ * A token's key is the UTF-8 encoding of its lower-cased code points (what tt_tok_create's keys are). */
+int tt_tok_set_unicode(void *handle, const uint32_t *low, const uint8_t *cls, int64_t n_cp);
+int tt_tok_encode_units(const void *handle, const void *const *texts, const int64_t *text_len, const uint8_t *unit_bytes,
+                        int64_t n_texts, int64_t *text_off_out, int64_t *ragged_ids, int32_t *lens, int32_t *status, int n_threads);
 int tt_tok_pad(const int64_t *ragged_ids, const int64_t *text_off, const int32_t *lens, int64_t n_texts,
                int64_t width, int64_t *out, int n_threads);
 

@@ -148,18 +148,60 @@ def test_long_keys_shared_prefixes_and_every_window_alignment(monkeypatch):
     assert bool((tok.encode_batch(mixed) == tok.encode_batch(mixed, native=False)).all())
 
 
-def test_pointer_form_is_the_one_taken_for_lists_of_ascii_str():
-    """csrc/pytext.c is built by twotowermlretrieval_amd.build: lists and tuples of ASCII str are read in place (no join)."""
+def test_pointer_form_is_the_one_taken_for_lists_of_str():
+    """csrc/pytext.c is built by twotowermlretrieval_amd.build: lists and tuples of str are read in place (no join): where the
+    code units lie, how many, and their size (0 = ASCII bytes, 1 / 2 / 4 = Latin-1 / UCS-2 / UCS-4)."""
     from twotowermlretrieval_amd import tokenizer as T
     gather = T._pytext_gather()
     assert gather is not None, "twotowermlretrieval_amd/_pytext*.so is missing: python -m twotowermlretrieval_amd.build"
-    ptrs, lens = np.zeros(4, np.uint64), np.zeros(4, np.int64)
-    assert gather(["ab", "", "cde"], ptrs.ctypes.data, lens.ctypes.data) == (3, 5) and lens[:3].tolist() == [2, 0, 3]
-    assert gather(["ab", "é", "cde"], ptrs.ctypes.data, lens.ctypes.data)[0] == 1      # stops at the first non-ASCII str
-    assert gather(("ab", 7), ptrs.ctypes.data, lens.ctypes.data)[0] == 1
+    ptrs, lens, units = np.zeros(5, np.uint64), np.zeros(5, np.int64), np.zeros(5, np.uint8)
+    a = (ptrs.ctypes.data, lens.ctypes.data, units.ctypes.data)
+    assert gather(["ab", "", "cde"], *a) == (3, 5, 0) and lens[:3].tolist() == [2, 0, 3] and units[:3].tolist() == [0, 0, 0]
+    assert gather(["ab", "é", "\u2019x", "\U0001F600"], *a) == (4, 6, 3) and units[:4].tolist() == [0, 1, 2, 4]
+    assert gather(("ab", 7), *a)[0] == 1                               # stops at the first item that is not a str
     import pytest
     with pytest.raises(TypeError):
-        gather("ab", ptrs.ctypes.data, lens.ctypes.data)
+        gather("ab", *a)
+
+
+def test_text_beyond_ascii_is_tokenised_natively_with_the_interpreters_own_tables():
+    """Non-ASCII texts no longer send a batch through Python: tt_tok_encode_units reads CPython's 1-, 2- and 4-byte code units and
+    classifies / lower-cases with tables made from THIS interpreter's str.lower() and str.isalnum() (tokenizer._unicode_tables), so
+    the ids equal re.findall(r"\\w+|[.,!?;]", text.lower()) -> word2idx by construction -- checked here on Latin-1, Greek (capital
+    sigma: context-dependent lower case -> that text goes through Python), Cyrillic, CJK, digits of other scripts, combining
+    marks, typographic punctuation, U+0130 (lower-cases to two code points -> Python), astral code points, lone surrogates."""
+    import re
+    from twotowermlretrieval_amd import tokenizer as T
+    low, cls = T._unicode_tables()
+    rs = random.Random(21)
+    for cp in rs.sample(range(0x110000), 30000) + list(range(0x2000)):
+        if 0xD800 <= cp <= 0xDFFF:
+            continue
+        ch = chr(cp)
+        lw = ch.lower()
+        assert (low[cp] == 0xFFFFFFFF) == (len(lw) != 1 or cp == 0x3A3)
+        assert bool(cls[cp] == 1) == bool(re.fullmatch(r"\w", ch)), hex(cp)
+    pieces = ["the", "Straße", "STRASSE", "naïve", "NAÏVE", "Ελληνικά", "ΟΔΟΣ", "σίγμα", "Привет", "МИР", "日本語", "テスト", "한국어",
+              "٣٤٥", "x²", "İstanbul", "ǅ", "ǆ", "ẞ", "ﬁ", "e\u0301", "don\u2019t", "\u201cquoted\u201d", "a\u2013b", "😀", "𝔘𝔫𝔦", "𐐀𐐨",
+              "_under_", "MiXeD123", "…", "¿qué?", "50%", "a.b,c!d?e;f", "\ud800", "w" * 20, "Ω" * 9, "é" * 17, "\u00a0", "\u3000"]
+    vocab = {}
+    for w in pieces + ["don", "t", "quoted", "a", "b", "qué", "50", "c", "d", "e", "f", "e\u0301".lower(), "😀"]:
+        for tok in re.findall(r"\w+|[.,!?;]", w.lower()):
+            vocab.setdefault(tok, len(vocab))
+    vocab = {k: v for k, v in vocab.items() if "\ud800" not in k}
+    tok = PretrainedTokenizer(word2idx=vocab)
+    seps = [" ", "  ", ", ", ".", "!", "\t", "\u2014", "\u00a0", "-", "/", "(", ")", "\n", "\u3000", "?"]
+    texts = []
+    for i in range(3000):
+        texts.append("".join(rs.choice(pieces) + rs.choice(seps) for _ in range(rs.randint(0, 25))))
+    texts += ["", "é", "Σ", "ΑΣ ΑΣΑ", "İ", "\U0001F600", "ascii only text, here."]
+    want = tok.encode_batch(texts, native=False)
+    got = tok.encode_batch(texts)
+    assert got.shape == want.shape and bool((got == want).all())
+    assert bool((tok.encode_batch(tuple(texts), n_threads=3) == want).all())
+    assert getattr(tok, "_tok_unicode", False)                           # the native Unicode path was taken
+    mixed = texts + [None]                                               # a non-str element: the general form, same ids
+    assert bool((tok.encode_batch(mixed) == tok.encode_batch(mixed, native=False)).all())
 
 
 def test_a_key_listed_twice_resolves_to_the_later_id():

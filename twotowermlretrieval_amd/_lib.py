@@ -58,6 +58,8 @@ SIGNATURES = {
     "tt_tok_encode": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _i]),
     "tt_tok_encode_sep": (_i, [_vp, _vp, _i64, C.c_char, _i64, _vp, _vp, _vp, _vp, _i]),
     "tt_tok_encode_ptrs": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i]),
+    "tt_tok_set_unicode": (_i, [_vp, _vp, _vp, _i64]),
+    "tt_tok_encode_units": (_i, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i]),
     "tt_tok_pad": (_i, [_vp, _vp, _vp, _i64, _i64, _vp, _i]),
     "tt_encoder_split_workgroups": (_i, [_i, _i, _i, _i]),
     "tt_encoder_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i, _i, _i]),

@@ -1,11 +1,12 @@
 // Host-side text front end of the index build: tokenise -> ids -> right-padded int64 batch, so that
 // feeding the document tower (about 100 M tokens/s on one MI355X) is not bound by a Python loop.  No device code.
 //
-// Semantics: exactly PretrainedTokenizer.encode of the reference (backend/tokenizer.py:41-43) for ASCII text:
+// Semantics: exactly PretrainedTokenizer.encode of the reference (backend/tokenizer.py:41-43):
 //     tokens = re.findall(r"\w+|[.,!?;]", str(text).lower());  ids = word2idx.get(token, unk_id)
-// For ASCII, lower() maps A-Z to a-z and \w is [A-Za-z0-9_].  A text holding any byte >= 0x80 is NOT tokenised
-// here (Unicode \w and case mapping are Python's business): its status is set to 1 and the Python caller encodes
-// that one text itself, so results are identical by construction (tests/test_tokenize_native_cpu.py).
+// For ASCII, lower() maps A-Z to a-z and \w is [A-Za-z0-9_]: the byte entry points (tt_tok_encode, _sep, _ptrs) tokenise ASCII
+// text and hand a text with any byte >= 0x80 back (status 1: the Python caller encodes that one text itself).  Beyond ASCII the
+// answers are the host interpreter's: tt_tok_set_unicode takes ITS lower-case and word-class tables and tt_tok_encode_units reads
+// its strings' 1-, 2- or 4-byte code units in place -- identical ids by construction either way (tests/test_tokenize_native_cpu.py).
 #include "tt_common.h"
 
 #include <cstdint>
@@ -87,7 +88,13 @@ struct TokTable {
     uint64_t mask = 0;
     int64_t unk = 0;
     bool ids32 = true;               // every id fits an int32: ids live in the slots
+    // Unicode (tt_tok_set_unicode: the host's OWN tables, so that the ids are the host's by construction): code point -> its
+    // lower-case code point (TOK_NO_LOWER: no single-code-point answer without context -- U+0130, U+03A3: the text is handed back)
+    // and the class (CH_WORD / CH_PUNCT / CH_OTHER) of every code point.  Empty until set: non-ASCII texts are handed back.
+    std::vector<uint32_t> ulow;
+    std::vector<unsigned char> ucls;
 };
+constexpr uint32_t TOK_NO_LOWER = 0xffffffffu;
 
 // The hash of a key: its bytes as little-endian 64-bit words (the last one zero-padded), one multiply per word -- a word of up
 // to 8 characters costs one round (a byte-serial FNV-1a was a chain of one 64-bit multiply PER BYTE).
@@ -336,6 +343,74 @@ int64_t encode_one(const TokTable &t, Lookups &lk, const char *s, size_t n, int6
     return encode_tail(t, lk, s, i, n, out, cnt, lower);
 }
 
+// A text with code points beyond ASCII, as the host's string holds it: one code point per 1-, 2- or 4-byte unit (CPython's
+// compact str kinds: Latin-1, UCS-2, UCS-4).  Per code point: the host's lower-case mapping, then the host's class of the result
+// -- the reference lower-cases the text before it matches \w+|[.,!?;] (backend/tokenizer.py:41-43) -- and a token's key is the
+// UTF-8 encoding of its lower-cased code points (what the vocabulary's keys are).  Returns the token count, or -1 when the text
+// holds a code point whose lower case depends on context (the caller tokenises that text itself).
+template <class U>
+int64_t encode_units(const TokTable &t, Lookups &lk, const U *s, size_t n, int64_t *out, std::vector<char> &tok)
+{
+    const size_t n_cp = t.ulow.size();
+    if (n_cp == 0)
+        return -1;
+    int64_t cnt = 0;
+    tok.clear();
+    auto flush = [&] {
+        const size_t len = tok.size();
+        if (len == 0)
+            return;
+        if (len <= 16) {
+            char buf[16] = {0};
+            std::memcpy(buf, tok.data(), len);
+            const uint64_t k0 = load_le(buf, 8), k1 = load_le(buf + 8, 8);
+            uint64_t h = hash_round(HASH_SEED, k0);
+            if (len > 8)
+                h = hash_round(h, k1);
+            lk.push(hash_finish(h, len), k0, k1, (uint32_t)len, out + cnt++);
+        } else {
+            out[cnt++] = lookup_long(t, tok.data(), len, hash_key(tok.data(), len));
+        }
+        tok.clear();
+    };
+    for (size_t i = 0; i < n; ++i) {
+        const uint32_t cp = (uint32_t)s[i];
+        if (cp >= n_cp) { // (not a code point: no class)
+            flush();
+            continue;
+        }
+        const uint32_t lw = t.ulow[cp];
+        if (lw == TOK_NO_LOWER)
+            return -1;
+        const unsigned char c = lw < n_cp ? t.ucls[lw] : (unsigned char)CH_OTHER;
+        if (c == CH_WORD) {
+            if (lw < 0x80) {
+                tok.push_back((char)lw);
+            } else if (lw < 0x800) {
+                tok.push_back((char)(0xc0 | (lw >> 6)));
+                tok.push_back((char)(0x80 | (lw & 0x3f)));
+            } else if (lw < 0x10000) {
+                tok.push_back((char)(0xe0 | (lw >> 12)));
+                tok.push_back((char)(0x80 | ((lw >> 6) & 0x3f)));
+                tok.push_back((char)(0x80 | (lw & 0x3f)));
+            } else {
+                tok.push_back((char)(0xf0 | (lw >> 18)));
+                tok.push_back((char)(0x80 | ((lw >> 12) & 0x3f)));
+                tok.push_back((char)(0x80 | ((lw >> 6) & 0x3f)));
+                tok.push_back((char)(0x80 | (lw & 0x3f)));
+            }
+        } else {
+            flush();
+            if (c == CH_PUNCT) {
+                const uint64_t k0 = (uint64_t)lw; // (the five punctuation marks are ASCII)
+                lk.push(hash_finish(hash_round(HASH_SEED, k0), 1), k0, 0, 1u, out + cnt++);
+            }
+        }
+    }
+    flush();
+    return cnt;
+}
+
 template <class F>
 void parallel_for(int64_t n, int n_threads, F &&f)
 {
@@ -509,6 +584,61 @@ TT_EXPORT int tt_tok_encode_ptrs(const void *handle, const char *const *texts, c
         Lookups lk(t);
         for (int64_t i = lo; i < hi; ++i) {
             const int64_t c = encode_one(t, lk, texts[i], (size_t)text_len[i], ragged_ids + text_off_out[i], lower);
+            status[i] = c < 0 ? 1 : 0;
+            lens[i] = c < 0 ? 0 : (int32_t)c;
+        }
+        lk.flush();
+    });
+    return TT_OK;
+}
+
+// The host's Unicode tables (see TokTable): low [n_cp] uint32 (0xffffffff = context-dependent: hand the text back), cls [n_cp]
+// (0 other, 1 word, 2 one of .,!?;) -- copied.
+TT_EXPORT int tt_tok_set_unicode(void *handle, const uint32_t *low, const uint8_t *cls, int64_t n_cp)
+{
+    if (!handle || n_cp < 128 || n_cp > 0x110000 || !low || !cls)
+        return tt_fail(TT_ERR_BAD_SHAPE, "tt_tok_set_unicode: n_cp=%lld", (long long)n_cp);
+    TokTable *t = (TokTable *)handle;
+    t->ulow.assign(low, low + n_cp);
+    t->ucls.assign(cls, cls + n_cp);
+    return TT_OK;
+}
+
+// tt_tok_encode_ptrs for texts of 1-, 2- or 4-byte CODE UNITS (one code point each): unit_bytes[i] = 0: text i is text_len[i]
+// ASCII bytes (the fast scan); 1 / 2 / 4: text_len[i] units of that many bytes (needs tt_tok_set_unicode; without it, or for a text
+// with a context-dependent lower case, status[i] = 1 and the caller tokenises it).  ragged_ids / text_off_out as tt_tok_encode_ptrs
+// (a text never has more tokens than units).
+TT_EXPORT int tt_tok_encode_units(const void *handle, const void *const *texts, const int64_t *text_len, const uint8_t *unit_bytes,
+                                  int64_t n_texts, int64_t *text_off_out, int64_t *ragged_ids, int32_t *lens, int32_t *status,
+                                  int n_threads)
+{
+    if (!handle || n_texts < 0 || (n_texts > 0 && (!texts || !text_len || !unit_bytes || !text_off_out || !ragged_ids || !lens || !status)))
+        return tt_fail(TT_ERR_BAD_SHAPE, "tt_tok_encode_units: n_texts=%lld", (long long)n_texts);
+    int64_t run = 0;
+    for (int64_t i = 0; i < n_texts; ++i) {
+        const int ub = unit_bytes[i];
+        if (text_len[i] < 0 || (text_len[i] > 0 && !texts[i]) || !(ub == 0 || ub == 1 || ub == 2 || ub == 4))
+            return tt_fail(TT_ERR_BAD_SHAPE, "tt_tok_encode_units: text %lld: length %lld, unit %d", (long long)i, (long long)text_len[i], ub);
+        text_off_out[i] = run;
+        run += text_len[i];
+    }
+    if (n_texts > 0)
+        text_off_out[n_texts] = run;
+    const TokTable &t = *(const TokTable *)handle;
+    parallel_for(n_texts, n_threads, [&](int64_t lo, int64_t hi) {
+        std::vector<char> lower;
+        lower.reserve(64);
+        Lookups lk(t);
+        for (int64_t i = lo; i < hi; ++i) {
+            int64_t *dst = ragged_ids + text_off_out[i];
+            const size_t n = (size_t)text_len[i];
+            int64_t c;
+            switch (unit_bytes[i]) {
+            case 0: c = encode_one(t, lk, (const char *)texts[i], n, dst, lower); break;
+            case 1: c = encode_units(t, lk, (const unsigned char *)texts[i], n, dst, lower); break;
+            case 2: c = encode_units(t, lk, (const uint16_t *)texts[i], n, dst, lower); break;
+            default: c = encode_units(t, lk, (const uint32_t *)texts[i], n, dst, lower); break;
+            }
             status[i] = c < 0 ? 1 : 0;
             lens[i] = c < 0 ? 0 : (int32_t)c;
         }

@@ -64,6 +64,40 @@ def _pytext_gather():
     return _GATHER
 
 
+_UNICODE_TABLES = None
+
+
+def _unicode_tables():
+    """(low uint32 [0x110000], cls uint8 [0x110000]) -- THIS interpreter's answers, made once per process (~0.7 s), for
+    tt_tok_set_unicode: low[cp] = ord(chr(cp).lower()) (0xffffffff where str.lower() has no context-free single-code-point
+    answer: U+0130 lower-cases to two code points, U+03A3's lower case depends on its position in the word), cls[cp] = 1 where
+    re's \\w matches chr(cp) (str.isalnum() or '_': sre's definition), 2 for the five marks of the pattern .,!?; , else 0.
+    The native tokenizer then classifies exactly as re.findall(r"\\w+|[.,!?;]", text.lower()) does."""
+    global _UNICODE_TABLES
+    if _UNICODE_TABLES is None:
+        n = 0x110000
+        low = np.arange(n, dtype=np.uint32)
+        cls = np.zeros(n, dtype=np.uint8)
+        for cp in range(n):
+            if 0xD800 <= cp <= 0xDFFF:
+                continue   # (a lone surrogate: no case, no class)
+            ch = chr(cp)
+            lw = ch.lower()
+            if len(lw) == 1:
+                if lw != ch:
+                    low[cp] = ord(lw)
+            else:
+                low[cp] = 0xFFFFFFFF
+            if ch.isalnum():
+                cls[cp] = 1
+        low[0x3A3] = 0xFFFFFFFF          # capital sigma: 'σ' or 'ς' by context (Final_Sigma)
+        cls[ord("_")] = 1
+        for ch in ".,!?;":
+            cls[ord(ch)] = 2
+        _UNICODE_TABLES = (low, cls)
+    return _UNICODE_TABLES
+
+
 def _scratch(name: str, n: int, dtype) -> np.ndarray:
     """A per-thread array of at least n elements that is REUSED from call to call (grown geometrically).  The ragged id
     buffer of one 16k-document batch is ~50 MB; as a fresh np.empty every call it is ~12k first-touch page faults, which cost
@@ -160,23 +194,36 @@ class PretrainedTokenizer:
         # is what bounds several producer threads (evaluators.embed_corpus) once the native part is spread over enough cores.
         fast = None
         gather = _pytext_gather()
+        slow_texts = None
         if n and gather is not None and type(texts) in (list, tuple):
-            # Fastest form: the texts are read where the interpreter keeps them (csrc/pytext.c collects one pointer and one
-            # length per str, ~0.25 ms per 16 k passages under the GIL; tt_tok_encode_ptrs does the rest without it).  The
-            # str objects stay referenced by this frame's tuple for the duration of the call.
+            # Fastest form: the texts are read where the interpreter keeps them (csrc/pytext.c collects one pointer, one
+            # length and the code-unit size per str, ~0.25 ms per 16 k passages under the GIL; tt_tok_encode_units does the rest
+            # without it).  The str objects stay referenced by this frame's tuple for the duration of the call.  Texts beyond
+            # ASCII are tokenised natively too, with this interpreter's own Unicode tables (_unicode_tables); the few that
+            # hold a code point whose lower case depends on context come back with status 1 and go through self.encode.
             ptrs = _scratch("ptrs", n, np.uint64)
             tlen = _scratch("tlen", n, np.int64)
+            units = _scratch("units", n, np.uint8)
             if type(texts) is list:
                 texts = tuple(texts)   # (the pointers stay valid even if another thread edits the caller's list meanwhile: ~40 us)
-            n_ok, total = gather(texts, ptrs.ctypes.data, tlen.ctypes.data)
+            n_ok, total, beyond = gather(texts, ptrs.ctypes.data, tlen.ctypes.data, units.ctypes.data)
             if n_ok == n:
+                if beyond and not getattr(self, "_tok_unicode", False):
+                    low, cls = _unicode_tables()
+                    _lib.check(L.tt_tok_set_unicode(self._native(), low.ctypes.data, cls.ctypes.data, low.shape[0]))
+                    self._tok_unicode = True
                 off = _scratch("off", n + 1, np.int64)
-                ragged = _scratch("ragged", total + 1, np.int64)   # (a text never has more tokens than bytes)
+                ragged = _scratch("ragged", total + 1, np.int64)   # (a text never has more tokens than code points)
                 lens = _scratch("lens", n, np.int32)
                 status = _scratch("status", n, np.int32)
-                _lib.check(L.tt_tok_encode_ptrs(self._native(), ptrs.ctypes.data, tlen.ctypes.data, n, off.ctypes.data,
-                                                ragged.ctypes.data, lens.ctypes.data, status.ctypes.data, nt))
-                fast = (off, ragged, lens)   # (compact ASCII str only: no status can be set)
+                _lib.check(L.tt_tok_encode_units(self._native(), ptrs.ctypes.data, tlen.ctypes.data, units.ctypes.data, n,
+                                                 off.ctypes.data, ragged.ctypes.data, lens.ctypes.data, status.ctypes.data, nt))
+                if beyond:
+                    for i in np.flatnonzero(status[:n]):   # context-dependent lower case: Python's own str.lower() and re
+                        ids = self.encode(texts[i])
+                        lens[i] = len(ids)
+                        ragged[off[i]:off[i] + len(ids)] = ids
+                fast = (off, ragged, lens)
         if n and fast is None:
             try:
                 blob = "\x00".join(texts).encode("ascii")
@@ -210,7 +257,7 @@ class PretrainedTokenizer:
             if n:
                 np.cumsum(np.fromiter(map(len, strs), dtype=np.int64, count=n), out=off[1:])
         except UnicodeEncodeError:
-            enc = [t.encode("utf-8") for t in strs]
+            enc = [t.encode("utf-8", "surrogatepass") for t in strs]   # (any byte >= 0x80 sends the text to self.encode anyway)
             if n:
                 np.cumsum([len(b) for b in enc], out=off[1:])
             blob = b"".join(enc)
