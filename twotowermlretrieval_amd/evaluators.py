@@ -97,15 +97,10 @@ def embed_corpus(model, tokenizer, documents: Sequence[str], device: torch.devic
     if producers <= 0:
         producers = 1 if cores < 32 else 2
     nt = threads_per_producer if threads_per_producer > 0 else max(1, min(16, cores // producers))
-    # the pipeline's fill: the first two batches are a quarter and a half of a batch, so the GPU starts after a quarter of a
-    # batch's tokenising instead of a whole one (rows are independent: any batching gives the same rows)
-    bounds, pos = [], 0
-    for size in (batch_size // 4, batch_size // 2):
-        if size >= 1024 and n - pos > 2 * batch_size:
-            bounds.append((pos, pos + size))
-            pos += size
-    bounds += [(i, min(i + batch_size, n)) for i in range(pos, n, batch_size)]
-    starts = bounds
+    # (a quarter- and a half-size first batch, so that the GPU starts sooner, was measured and dropped: 0.844 -> 0.848 of the
+    #  GPU-only rate; what is left of the gap is the copies running beside the kernels -- 62 ms resident, 67 ms with the pinned
+    #  batches copied on the side stream, 74 ms with the tokenising: tools/experiments/index_build_gap.py)
+    starts = [(i, min(i + batch_size, n)) for i in range(0, n, batch_size)]
     window = producers + max(1, prefetch)          # batches tokenised or being tokenised ahead of the GPU
     if stats is not None:
         stats.update(producers=producers, threads_per_producer=nt, host_cores=cores, batch_size=batch_size)
