@@ -449,6 +449,9 @@ int tt_tok_encode_sep(const void *handle, const char *text_blob, int64_t blob_le
  * str, Go string, Java byte[]) builds no blob: twotowermlretrieval_amd/csrc/pytext.c collects the pointers of a list of str. */
 int tt_tok_encode_ptrs(const void *handle, const char *const *texts, const int64_t *text_len, int64_t n_texts,
                        int64_t *text_off_out, int64_t *ragged_ids, int32_t *lens, int32_t *status, int n_threads);
+/* tt_tok_pad with 4-byte ids (half the bytes to copy to the device; TT_ERR_BAD_INDEX when an id does not fit an int32). */
+int tt_tok_pad_i32(const int64_t *ragged_ids, const int64_t *text_off, const int32_t *lens, int64_t n_texts,
+                   int64_t width, int32_t *out, int n_threads);
 /* Text beyond ASCII, tokenised here with the HOST's Unicode tables so that the ids are the host's by construction.
  * tt_tok_set_unicode: low[cp] = the code point's lower-case code point (0xffffffff: no context-free single-code-point answer --
  * U+0130, U+03A3 in CPython -- a text that holds it gets status 1), cls[cp] = 0 other / 1 word (\w) / 2 one of .,!?; -- n_cp

@@ -224,3 +224,17 @@ def test_a_key_listed_twice_resolves_to_the_later_id():
     _lib.check(L.tt_tok_encode(h, text, toff.ctypes.data, 1, ragged.ctypes.data, n.ctypes.data, st.ctypes.data, 1))
     L.tt_tok_destroy(h)
     assert st[0] == 0 and ragged[:n[0]].tolist() == [40, 50, 60, 7, 99, 99]
+
+
+def test_int32_batches_in_the_callers_block():
+    """encode_batch(out=pinned block, ids32=True): the padded batch as int32 in the caller's block (half the bytes for the copy
+    to the device; evaluators.embed_corpus widens it there); a vocabulary with an id beyond int32 gets the int64 batch."""
+    import torch
+    tok = PretrainedTokenizer(word2idx={"the": 0, "a": 1, "cat": 2})
+    buf = torch.zeros(64, dtype=torch.int64)
+    texts = ["the cat", "a a a cat zz", ""]
+    t = tok.encode_batch(texts, out=buf, ids32=True)
+    assert t.dtype == torch.int32 and t.data_ptr() == buf.data_ptr() and t.tolist() == tok.encode_batch(texts).tolist()
+    big = PretrainedTokenizer(word2idx={"the": 0, "a": 5_000_000_000})
+    t = big.encode_batch(["the a"], out=buf, ids32=True)
+    assert t.dtype == torch.int64 and t.tolist() == [[0, 5_000_000_000]]

@@ -61,6 +61,7 @@ SIGNATURES = {
     "tt_tok_set_unicode": (_i, [_vp, _vp, _vp, _i64]),
     "tt_tok_encode_units": (_i, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i]),
     "tt_tok_pad": (_i, [_vp, _vp, _vp, _i64, _i64, _vp, _i]),
+    "tt_tok_pad_i32": (_i, [_vp, _vp, _vp, _i64, _i64, _vp, _i]),
     "tt_encoder_split_workgroups": (_i, [_i, _i, _i, _i]),
     "tt_encoder_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i, _i, _i]),
     "tt_encoder_forward_f32": (_i, [_vp, _i, _i, _vp, _i64, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _f, _u64, _vp, _vp,

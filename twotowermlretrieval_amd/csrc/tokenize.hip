@@ -592,6 +592,38 @@ TT_EXPORT int tt_tok_encode_ptrs(const void *handle, const char *const *texts, c
     return TT_OK;
 }
 
+// tt_tok_pad with 4-byte ids: half the bytes for the host-to-device copy of a batch (on this platform that copy is a shader
+// kernel that runs beside -- and in the way of -- the encoder's kernels; the device widens the batch again in ~10 us).  Fails with
+// TT_ERR_BAD_INDEX when an id does not fit an int32 (the caller takes tt_tok_pad).
+TT_EXPORT int tt_tok_pad_i32(const int64_t *ragged_ids, const int64_t *text_off, const int32_t *lens, int64_t n_texts,
+                             int64_t width, int32_t *out, int n_threads)
+{
+    if (n_texts < 0 || width < 0 || (n_texts > 0 && (!ragged_ids || !text_off || !lens || (width > 0 && !out))))
+        return tt_fail(TT_ERR_BAD_SHAPE, "tt_tok_pad_i32: n_texts=%lld width=%lld", (long long)n_texts, (long long)width);
+    for (int64_t i = 0; i < n_texts; ++i)
+        if (lens[i] > width)
+            return tt_fail(TT_ERR_BAD_SHAPE, "tt_tok_pad_i32: row %lld has %d tokens > width %lld", (long long)i, lens[i], (long long)width);
+    std::vector<int> bad((size_t)(n_threads > 1 ? n_threads : 1) + 1, 0);
+    const int64_t per = n_threads > 1 ? (n_texts + n_threads - 1) / n_threads : n_texts;
+    parallel_for(n_texts, n_threads, [&](int64_t lo, int64_t hi) {
+        int wide = 0;
+        for (int64_t i = lo; i < hi; ++i) {
+            int32_t *row = out + i * width;
+            const int64_t *src = ragged_ids + text_off[i];
+            for (int32_t k = 0; k < lens[i]; ++k) {
+                wide |= src[k] < INT32_MIN || src[k] > INT32_MAX;
+                row[k] = (int32_t)src[k];
+            }
+            std::memset(row + lens[i], 0, sizeof(int32_t) * (size_t)(width - lens[i]));
+        }
+        bad[(size_t)(per > 0 ? lo / per : 0)] = wide;
+    });
+    for (int b : bad)
+        if (b)
+            return tt_fail(TT_ERR_BAD_INDEX, "tt_tok_pad_i32: an id does not fit 32 bits");
+    return TT_OK;
+}
+
 // The host's Unicode tables (see TokTable): low [n_cp] uint32 (0xffffffff = context-dependent: hand the text back), cls [n_cp]
 // (0 other, 1 word, 2 one of .,!?;) -- copied.
 TT_EXPORT int tt_tok_set_unicode(void *handle, const uint32_t *low, const uint8_t *cls, int64_t n_cp)

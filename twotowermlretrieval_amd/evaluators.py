@@ -119,7 +119,7 @@ def embed_corpus(model, tokenizer, documents: Sequence[str], device: torch.devic
     def make(i):
         buf = free.get(timeout=120)             # (at most `window` jobs are outstanding and 3 batches in flight behind them; the
         #                                         time-out only ends a job whose consumer died: the pool's threads outlive the call)
-        return tokenizer.encode_batch(documents[i[0]:i[1]], pin=True, n_threads=nt, out=buf), buf
+        return tokenizer.encode_batch(documents[i[0]:i[1]], pin=True, n_threads=nt, out=buf, ids32=True), buf
 
     inflight = collections.deque()
     copy_stream = torch.cuda.Stream(device=device)
@@ -145,9 +145,12 @@ def embed_corpus(model, tokenizer, documents: Sequence[str], device: torch.devic
                     pending.append((starts[nxt], pool.submit(make, starts[nxt])))
                     nxt += 1
                 with torch.cuda.stream(copy_stream):
-                    ids = ids_host.to(device, non_blocking=True)
+                    ids = ids_host.to(device, non_blocking=True)   # (int32 when the vocabulary allows: on this platform the copy
+                    #                                               is a shader kernel that competes with the encoder's for CUs)
                 cur.wait_stream(copy_stream)
                 ids.record_stream(cur)
+                if ids.dtype != torch.int64:
+                    ids = ids.to(torch.int64)                      # widened on the device: ~10 us
                 emb = model.encode_document(ids)
                 if res is None:
                     res = torch.empty((n, emb.shape[1]), dtype=torch.float32, device=device)

@@ -169,12 +169,13 @@ class PretrainedTokenizer:
             except Exception:  # noqa: BLE001  (interpreter shutdown)
                 pass
 
-    def encode_batch(self, texts: Sequence, pin: bool = False, native: bool = True, n_threads: int = 0, out=None):
+    def encode_batch(self, texts: Sequence, pin: bool = False, native: bool = True, n_threads: int = 0, out=None, ids32: bool = False):
         """texts -> right-padded int64 tensor [B, max_len] (at least one column when B > 0 ... zero columns for
         all-empty batches, like pad_sequence).
         out: a 1-D int64 tensor (typically pinned, reused by the caller: evaluators.embed_corpus keeps a ring of them) that
         receives the batch when it is large enough; the result is then a view of it.  A fresh pinned tensor per batch costs a
-        page-locking allocation whenever the host allocator has no free block of that size."""
+        page-locking allocation whenever the host allocator has no free block of that size.
+        ids32 (with `out`, fast forms only): the batch as int32 in the caller's block when every id fits (else int64 as usual)."""
         import torch
         if not native:
             rows = [self.encode(t) for t in texts]
@@ -242,6 +243,15 @@ class PretrainedTokenizer:
         if fast is not None:
             off, ragged, lens = fast
             width = int(lens[:n].max())
+            if ids32 and width and out is not None and out.dtype == torch.int64 and out.dim() == 1 and 2 * out.numel() >= n * width:
+                # 4-byte ids into the caller's (pinned) block: half the bytes for the copy to the device (embed_corpus widens
+                # them there); a vocabulary with ids beyond int32 takes the 8-byte form below
+                t32 = out.view(torch.int32)[:n * width].view(n, width)
+                rc = L.tt_tok_pad_i32(ragged.ctypes.data, off.ctypes.data, lens.ctypes.data, n, width, t32.data_ptr(), nt)
+                if rc == _lib.TT_OK:
+                    return t32
+                if rc != _lib.TT_ERR_BAD_INDEX:
+                    _lib.check(rc)
             if out is not None and out.numel() >= n * width and out.dtype == torch.int64 and out.dim() == 1:
                 t = out[:n * width].view(n, width)
             else:
