@@ -65,6 +65,7 @@ def _pytext_gather():
 
 
 _UNICODE_TABLES = None
+_UNICODE_LOCK = threading.RLock()   # (re-entrant: encode_batch takes it around _native(), which takes it too)
 
 
 def _unicode_tables():
@@ -146,6 +147,13 @@ class PretrainedTokenizer:
     def _native(self):
         """Handle of the native vocabulary table (built once, on first use)."""
         if getattr(self, "_tok_handle", None) is None:
+            with _UNICODE_LOCK:   # (one table per tokenizer even when several producer threads get here together)
+                if getattr(self, "_tok_handle", None) is None:
+                    self._tok_handle = self._make_native()
+        return self._tok_handle
+
+    def _make_native(self):
+        if True:
             import ctypes as C
             from . import _lib
             words = list(self.word2idx.keys())
@@ -157,8 +165,7 @@ class PretrainedTokenizer:
             h = C.c_void_p()
             _lib.check(_lib.lib().tt_tok_create(blob, off.ctypes.data, ids.ctypes.data, len(enc), int(self.unk_token_id),
                                                 C.byref(h)))
-            self._tok_handle = h
-        return self._tok_handle
+            return h
 
     def __del__(self):
         h = getattr(self, "_tok_handle", None)
@@ -195,7 +202,6 @@ class PretrainedTokenizer:
         # is what bounds several producer threads (evaluators.embed_corpus) once the native part is spread over enough cores.
         fast = None
         gather = _pytext_gather()
-        slow_texts = None
         if n and gather is not None and type(texts) in (list, tuple):
             # Fastest form: the texts are read where the interpreter keeps them (csrc/pytext.c collects one pointer, one
             # length and the code-unit size per str, ~0.25 ms per 16 k passages under the GIL; tt_tok_encode_units does the rest
@@ -210,9 +216,11 @@ class PretrainedTokenizer:
             n_ok, total, beyond = gather(texts, ptrs.ctypes.data, tlen.ctypes.data, units.ctypes.data)
             if n_ok == n:
                 if beyond and not getattr(self, "_tok_unicode", False):
-                    low, cls = _unicode_tables()
-                    _lib.check(L.tt_tok_set_unicode(self._native(), low.ctypes.data, cls.ctypes.data, low.shape[0]))
-                    self._tok_unicode = True
+                    with _UNICODE_LOCK:   # (producer threads share a tokenizer: the tables are handed over once, by one of them)
+                        if not getattr(self, "_tok_unicode", False):
+                            low, cls = _unicode_tables()
+                            _lib.check(L.tt_tok_set_unicode(self._native(), low.ctypes.data, cls.ctypes.data, low.shape[0]))
+                            self._tok_unicode = True
                 off = _scratch("off", n + 1, np.int64)
                 ragged = _scratch("ragged", total + 1, np.int64)   # (a text never has more tokens than code points)
                 lens = _scratch("lens", n, np.int32)
