@@ -238,3 +238,25 @@ def test_int32_batches_in_the_callers_block():
     big = PretrainedTokenizer(word2idx={"the": 0, "a": 5_000_000_000})
     t = big.encode_batch(["the a"], out=buf, ids32=True)
     assert t.dtype == torch.int64 and t.tolist() == [[0, 5_000_000_000]]
+
+
+def test_concurrent_producers_share_one_tokenizer():
+    """Several threads take a FRESH tokenizer through its first calls at once (evaluators.embed_corpus's producers): one native
+    table and one Unicode hand-over, same ids as the Python path from every thread, and nobody deadlocks."""
+    import threading
+    vocab = {"the": 0, "café": 1, "a": 2}
+    texts = ["the café a", "a the", "café’s"] * 200
+    want = PretrainedTokenizer(word2idx=vocab).encode_batch(texts, native=False).tolist()
+    tok = PretrainedTokenizer(word2idx=vocab)
+    wrong = []
+
+    def work():
+        for _ in range(10):
+            if tok.encode_batch(texts, n_threads=2).tolist() != want:
+                wrong.append(1)
+    threads = [threading.Thread(target=work, daemon=True) for _ in range(6)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(60)
+    assert not any(t.is_alive() for t in threads) and not wrong
