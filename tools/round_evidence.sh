@@ -10,6 +10,8 @@ OUT=gpurun_out
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 timeout -k 10 600 python -m pytest tests -m gpu -x -q > $OUT/${TAG}_tests.log 2>&1; rc=$?; tail -3 $OUT/${TAG}_tests.log; [ $rc = 0 ] || exit 2
 cp $OUT/tolerance_report.json $OUT/${TAG}_tolerance_report.json 2>/dev/null
+timeout -k 10 300 python3 -c "import __graft_entry__ as g; g.smoke()" > $OUT/${TAG}_smoke.log 2>&1 || { tail -5 $OUT/${TAG}_smoke.log; exit 6; }
+tail -1 $OUT/${TAG}_smoke.log
 timeout -k 10 900 python3 bench.py > $OUT/${TAG}_bench_n1.json 2> $OUT/${TAG}_bench_n1.err || exit 3
 python3 -c "
 import json; d = json.load(open('$OUT/${TAG}_bench_n1.json')); L = d['roofline']['legs']
