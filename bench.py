@@ -409,7 +409,7 @@ def index_build_from_strings_leg(dev, model, gpu_docs_per_s, n_docs=262_144, see
     # the same build with typographic / accented characters in 5 % of the passages (MS MARCO has them): tokenised natively from
     # CPython's code units with the interpreter's own Unicode tables (tt_tok_encode_units) -- no Python fallback, no cliff
     docs5 = [d.replace(" ", " \u2019s caf\u00e9 ", 2) if i % 20 == 0 else d for i, d in enumerate(docs)]
-    embed_corpus(model, tok, docs5[:65536], dev)
+    embed_corpus(model, tok, docs5, dev)     # (a whole pass again: other batch widths, other workspace blocks; Unicode tables)
     torch.cuda.synchronize()
     t2 = time.perf_counter()
     embed_corpus(model, tok, docs5, dev)
