@@ -396,6 +396,7 @@ def index_build_from_strings_leg(dev, model, gpu_docs_per_s, n_docs=262_144, see
     embed_corpus(model, tok, docs, dev)                  # warm-up = one whole pass: vocabulary table, pinned ring, and the caching
     torch.cuda.synchronize()                             # allocator's workspace blocks for every batch width (a 10M-100M build runs warm)
     stats = {}
+    _settle_gc()    # (a generation-2 collection inside a 75 ms timed region -- 262 k fresh strings invite one -- is a third of it)
     t0 = time.perf_counter()
     emb = embed_corpus(model, tok, docs, dev, stats=stats)
     torch.cuda.synchronize()
@@ -411,6 +412,7 @@ def index_build_from_strings_leg(dev, model, gpu_docs_per_s, n_docs=262_144, see
     docs5 = [d.replace(" ", " \u2019s caf\u00e9 ", 2) if i % 20 == 0 else d for i, d in enumerate(docs)]
     embed_corpus(model, tok, docs5, dev)     # (a whole pass again: other batch widths, other workspace blocks; Unicode tables)
     torch.cuda.synchronize()
+    _settle_gc()
     t2 = time.perf_counter()
     embed_corpus(model, tok, docs5, dev)
     torch.cuda.synchronize()
