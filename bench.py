@@ -745,7 +745,10 @@ def main():
         #   encoder, train  SURVEY 8d's secondary metrics (tower / index-build tokens/s, training triplets/s)
         roof["legs"] = {"hbm_screen": roof_hbm, "hbm_exact_f32": roof_hbm_f32, "mfma_exact_f32": roof_f32}
         enc_inputs = None
-        if not a.no_secondary:
+        # N = 1 only: these legs build optimizers and trainers on rank 0 alone, and with a process group up every such object is
+        # a COLLECTIVE construction (FusedClipAdam(group=None) means the default group, as DDP's does): rank 0 would wait for
+        # peers that are already at the closing barrier.  (They are single-GPU figures anyway.)
+        if not a.no_secondary and world == 1:
             del index, local_index
             torch.cuda.empty_cache()
             roof["legs"]["encoder"], roof["legs"]["train"], enc_inputs, model = encoder_legs(dev)
