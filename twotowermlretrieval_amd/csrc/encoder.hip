@@ -473,10 +473,13 @@ __global__ __launch_bounds__(256) void dropout_apply_kernel(const float *__restr
     const uint64_t seed = seed_ptr ? *seed_ptr : seed_value; // (TT_ENC_SEED_ON_DEVICE: read when the kernel runs)
     const int b = blockIdx.x;
     const int L = len[b], o = tok_off[b];
-    for (int i = threadIdx.x; i < L * ld; i += 256) {
-        const int t = i / ld, c = i - t * ld;
+    // grid.y blocks share a row (a small batch is few rows: one block per row left most of the chip idle); a thread takes whole
+    // tokens' columns c, c + 256, ... so that no index is divided
+    for (int t = blockIdx.y; t < L; t += gridDim.y) {
         const size_t tok = (size_t)(o + t);
-        xd[tok * ld + c] = x[tok * ld + c] * tt_dropout_scale(seed, layer, ((uint64_t)b * T + t) * ld + c, p);
+        const uint64_t base = ((uint64_t)b * T + t) * ld;
+        for (int c = threadIdx.x; c < ld; c += 256)
+            xd[tok * ld + c] = x[tok * ld + c] * tt_dropout_scale(seed, layer, base + c, p);
     }
 }
 
@@ -871,7 +874,7 @@ static int encoder_forward(const char *who, const int64_t *ids, int B, int T, co
         if (last && sync && sync->record_after_recurrence)
             TT_HIP_CHECK(hipEventRecord((hipEvent_t)sync->record_after_recurrence, st));
         if (drop && !last) { // nn.GRU's dropout sits on the outputs of every layer but the last
-            hipLaunchKernelGGL(dropout_apply_kernel, dim3(B), dim3(256), 0, st, (const float *)xout,
+            hipLaunchKernelGGL(dropout_apply_kernel, dim3(B, B >= 2048 ? 1 : (B >= 512 ? 4 : 16)), dim3(256), 0, st, (const float *)xout,
                                (float *)(ws + lo.xd[l + 1]), len, tok_off, T, ndir * H, l, dropout_p, seed_dev ? 0ull : dropout_seed,
                                seed_dev);
             TT_RC_CHECK(tt_zero_async((float *)(ws + lo.xd[l + 1]) + (size_t)lo.MT * ndir * H, sizeof(float) * ndir * H, st));
