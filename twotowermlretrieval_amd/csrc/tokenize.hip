@@ -593,7 +593,7 @@ TT_EXPORT int tt_tok_encode_ptrs(const void *handle, const char *const *texts, c
 }
 
 // tt_tok_pad with 4-byte ids: half the bytes for the host-to-device copy of a batch (on this platform that copy is a shader
-// kernel that runs beside -- and in the way of -- the encoder's kernels; the device widens the batch again in ~10 us).  Fails with
+// kernel whose time adds to the encoder's; the device widens the batch again in ~10 us).  Fails with
 // TT_ERR_BAD_INDEX when an id does not fit an int32 (the caller takes tt_tok_pad).
 TT_EXPORT int tt_tok_pad_i32(const int64_t *ragged_ids, const int64_t *text_off, const int32_t *lens, int64_t n_texts,
                              int64_t width, int32_t *out, int n_threads)

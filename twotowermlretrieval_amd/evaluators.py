@@ -146,7 +146,7 @@ def embed_corpus(model, tokenizer, documents: Sequence[str], device: torch.devic
                     nxt += 1
                 with torch.cuda.stream(copy_stream):
                     ids = ids_host.to(device, non_blocking=True)   # (int32 when the vocabulary allows: on this platform the copy
-                    #                                               is a shader kernel that competes with the encoder's for CUs)
+                    #                                               is a shader kernel whose time adds to the encoder's)
                 cur.wait_stream(copy_stream)
                 ids.record_stream(cur)
                 if ids.dtype != torch.int64:
