@@ -4,7 +4,8 @@
   b        copy(k) on a side stream right in front of encode(k), encode waits for it
   b_early  ALL copies issued first (own buffers, own events), then the encodes, each waiting for its copy's event
   b_nowait as b without the wait (a race: results meaningless, only the time counts)
-  b_sync   copy(k) with a BLOCKING copy on the compute stream (no side stream)"""
+  b_aheadD copy(k + D) issued in front of encode(k), encode(k) waits for copy(k)'s EVENT
+  b_same_stream   the copy on the compute stream itself (no side stream)"""
 import sys, json, time
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent.parent))
@@ -58,6 +59,22 @@ def b_early():
             model.encode_document(bufs[k])
 
 
+def b_ahead(d):
+    evs = {}
+    def issue(k):
+        with torch.cuda.stream(side):
+            bufs[k].copy_(host[k], non_blocking=True)
+            e = torch.cuda.Event(); e.record(side); evs[k] = e
+    with torch.no_grad():
+        for k in range(min(d, len(host))):
+            issue(k)
+        for k in range(len(host)):
+            if k + d < len(host):
+                issue(k + d)
+            cur.wait_event(evs[k])
+            model.encode_document(bufs[k])
+
+
 def b_sync():
     with torch.no_grad():
         for k, h in enumerate(host):
@@ -71,5 +88,5 @@ def copies_only():
             bufs[k].copy_(h, non_blocking=True)
 
 
-for name, fn in (("a", a), ("copies_only", copies_only), ("b", b), ("b_early", b_early), ("b_nowait", lambda: b(False)), ("b_same_stream", b_sync), ("a again", a)):
+for name, fn in (("a", a), ("copies_only", copies_only), ("b", b), ("b_early", b_early), ("b_ahead1", lambda: b_ahead(1)), ("b_ahead2", lambda: b_ahead(2)), ("b_ahead0_event", lambda: b_ahead(0)), ("b_nowait", lambda: b(False)), ("b_same_stream", b_sync), ("a again", a)):
     print(json.dumps({"what": name, "ms": timed(fn)}), flush=True)
