@@ -56,6 +56,9 @@ def b(copy_out=False):
 
 
 for name, fn in (("a resident ids", a), ("b pinned ids + side-stream copies", b), ("c b + result copy", lambda: b(True)),
-                 ("d embed_corpus", lambda: embed_corpus(model, tok, docs, dev)), ("a again", a)):
+                 ("d embed_corpus", lambda: embed_corpus(model, tok, docs, dev)),
+                 ("d0 embed_corpus, copies not ahead", lambda: embed_corpus(model, tok, docs, dev, copy_ahead=0)),
+                 ("d embed_corpus again", lambda: embed_corpus(model, tok, docs, dev)),
+                 ("d0 again", lambda: embed_corpus(model, tok, docs, dev, copy_ahead=0)), ("a again", a)):
     t = timed(fn)
     print(json.dumps({"what": name, "ms": round(t * 1e3, 2), "docs_per_s": round(n_docs / t)}), flush=True)

@@ -70,7 +70,7 @@ def embed_documents(model, tokenizer, documents: Sequence[str], device: torch.de
 
 def embed_corpus(model, tokenizer, documents: Sequence[str], device: torch.device, batch_size: int = 16384,
                  prefetch: int = 2, out: torch.Tensor = None, producers: int = 0, stats: Dict = None,
-                 threads_per_producer: int = 0) -> torch.Tensor:
+                 threads_per_producer: int = 0, copy_ahead: int = 2) -> torch.Tensor:
     """Index build: the same rows as embed_documents, with the host front end off the critical path.
     `producers` host threads tokenise and pad batches natively (tt_tok_encode / tt_tok_pad release the GIL; each thread
     reuses its scratch arrays) into pinned memory while the GPU encodes; batches are consumed in document order whatever
@@ -164,7 +164,7 @@ def embed_corpus(model, tokenizer, documents: Sequence[str], device: torch.devic
                 # A copy issued BEHIND an encode call's launches does not start before they have run (0.25 ms per batch that
                 # then adds to the build: tools/experiments/copy_order.py -- 67.6 ms against 64.4 with the copy one batch
                 # ahead, 63.4 with the ids resident), so the next batches' copies go out IN FRONT of this batch's launches
-                while len(staged) < 3 and stage(False):
+                while len(staged) < 1 + copy_ahead and stage(False):
                     pass
                 i, ids, ev_c, ids_host, buf = staged.popleft()
                 cur.wait_event(ev_c)
