@@ -59,6 +59,11 @@ for name, fn in (("a resident ids", a), ("b pinned ids + side-stream copies", b)
                  ("d embed_corpus", lambda: embed_corpus(model, tok, docs, dev)),
                  ("d0 embed_corpus, copies not ahead", lambda: embed_corpus(model, tok, docs, dev, copy_ahead=0)),
                  ("d embed_corpus again", lambda: embed_corpus(model, tok, docs, dev)),
-                 ("d0 again", lambda: embed_corpus(model, tok, docs, dev, copy_ahead=0)), ("a again", a)):
+                 ("d0 again", lambda: embed_corpus(model, tok, docs, dev, copy_ahead=0)),
+                 ("d 14 threads", lambda: embed_corpus(model, tok, docs, dev, threads_per_producer=14)),
+                 ("d 12 threads", lambda: embed_corpus(model, tok, docs, dev, threads_per_producer=12)),
+                 ("d 8 threads", lambda: embed_corpus(model, tok, docs, dev, threads_per_producer=8)),
+                 ("d 2 producers x 7", lambda: embed_corpus(model, tok, docs, dev, producers=2, threads_per_producer=7)),
+                 ("d 16 threads", lambda: embed_corpus(model, tok, docs, dev)), ("a again", a)):
     t = timed(fn)
     print(json.dumps({"what": name, "ms": round(t * 1e3, 2), "docs_per_s": round(n_docs / t)}), flush=True)
