@@ -46,3 +46,22 @@ for nt in (8, 16):
                 T[k] += d
     print(json.dumps({"threads": nt, "tokens": int(lens.sum()), "gather_ms": round(T[0] / reps * 1e3, 3), "encode_units_ms": round(T[1] / reps * 1e3, 3),
                       "pad_i32_ms": round(T[2] / reps * 1e3, 3), "encode_batch_ms": round(T[3] / reps * 1e3, 3), "slice_ms": round(T[4] / reps * 1e3, 3)}), flush=True)
+
+# --- why is tt_tok_encode_units twice as slow here as in tok_harness (same tokens, same threads)?
+import ctypes as C
+print(open("/proc/self/smaps_rollup").read().split("AnonHugePages:")[1].split("\n")[0].strip(), "of anonymous huge pages in this process", flush=True)
+blob = "\0".join(docs).encode("ascii")
+base = C.cast(C.c_char_p(blob), C.c_void_p).value
+offs = np.zeros(n, np.int64); offs[1:] = np.cumsum(tlen[:n - 1] + 1)
+ptrs_c = (offs + base).astype(np.uint64)
+for name, pp in (("scattered str objects", ptrs), ("one contiguous blob", ptrs_c), ("scattered str objects", ptrs)):
+    ts = []
+    for _ in range(10):
+        t0 = time.perf_counter()
+        L.tt_tok_encode_units(h, pp.ctypes.data, tlen.ctypes.data, units.ctypes.data, n, off.ctypes.data, ragged.ctypes.data, lens.ctypes.data, status.ctypes.data, 16)
+        ts.append((time.perf_counter() - t0) * 1e3)
+    print(json.dumps({"texts": name, "threads": 16, "encode_units_ms_min": round(min(ts), 3), "median": round(sorted(ts)[5], 3)}), flush=True)
+for nt in (1, 4):
+    t0 = time.perf_counter()
+    L.tt_tok_encode_units(h, ptrs.ctypes.data, tlen.ctypes.data, units.ctypes.data, n, off.ctypes.data, ragged.ctypes.data, lens.ctypes.data, status.ctypes.data, nt)
+    print(json.dumps({"threads": nt, "encode_units_ms": round((time.perf_counter() - t0) * 1e3, 3)}), flush=True)
