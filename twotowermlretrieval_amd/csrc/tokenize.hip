@@ -16,6 +16,10 @@
 #if defined(__SSE2__) && !defined(TT_TOK_NO_SIMD)
 #include <emmintrin.h>
 #endif
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <pthread.h>
 #include <thread>
 #include <vector>
 
@@ -411,6 +415,83 @@ int64_t encode_units(const TokTable &t, Lookups &lk, const U *s, size_t n, int64
     return cnt;
 }
 
+// Workers that outlive the call.  A batch is two parallel loops (encode, pad) of ~1 ms each; sixteen std::thread constructions and
+// joins per loop were a quarter of that.  One pool per process, grown on demand, leaked on purpose (its detached workers wait on
+// its condition variable until the process ends); a loop that finds the pool busy -- two producers at once -- spawns threads as
+// before; a forked child starts with no pool.
+class WorkerPool {
+    std::mutex m;
+    std::condition_variable work_cv, done_cv;
+    const std::function<void(int)> *job = nullptr;
+    int chunks = 0, next_chunk = 0, unfinished = 0, workers = 0;
+    uint64_t generation = 0;
+    std::mutex busy; // one loop at a time
+
+    void worker()
+    {
+        uint64_t seen = 0;
+        std::unique_lock<std::mutex> lk(m);
+        for (;;) {
+            work_cv.wait(lk, [&] { return generation != seen && next_chunk < chunks; });
+            seen = generation;
+            while (next_chunk < chunks) {
+                const int c = next_chunk++;
+                const std::function<void(int)> *j = job;
+                lk.unlock();
+                (*j)(c);
+                lk.lock();
+                if (--unfinished == 0)
+                    done_cv.notify_all();
+            }
+        }
+    }
+
+public:
+    // runs fn(0 .. k - 1), the caller taking chunks too; false = the pool is in use (the caller spawns its own threads)
+    bool run(int k, const std::function<void(int)> &fn)
+    {
+        std::unique_lock<std::mutex> one(busy, std::try_to_lock);
+        if (!one.owns_lock())
+            return false;
+        std::unique_lock<std::mutex> lk(m);
+        while (workers < k - 1 && workers < 63) {
+            std::thread([this] { worker(); }).detach();
+            ++workers;
+        }
+        job = &fn;
+        chunks = k;
+        next_chunk = 0;
+        unfinished = k;
+        ++generation;
+        work_cv.notify_all();
+        while (next_chunk < chunks) { // the caller works as well
+            const int c = next_chunk++;
+            lk.unlock();
+            fn(c);
+            lk.lock();
+            --unfinished;
+        }
+        done_cv.wait(lk, [&] { return unfinished == 0; });
+        job = nullptr;
+        chunks = 0;
+        return true;
+    }
+};
+
+WorkerPool *g_pool = nullptr;
+std::once_flag g_pool_atfork;
+std::mutex g_pool_make;
+
+WorkerPool *worker_pool()
+{
+    std::lock_guard<std::mutex> lk(g_pool_make);
+    if (!g_pool) {
+        std::call_once(g_pool_atfork, [] { pthread_atfork(nullptr, nullptr, [] { g_pool = nullptr; }); });
+        g_pool = new WorkerPool; // (leaked: see above)
+    }
+    return g_pool;
+}
+
 template <class F>
 void parallel_for(int64_t n, int n_threads, F &&f)
 {
@@ -418,14 +499,18 @@ void parallel_for(int64_t n, int n_threads, F &&f)
         f(0, n);
         return;
     }
-    std::vector<std::thread> th;
     const int64_t per = (n + n_threads - 1) / n_threads;
-    for (int t = 0; t < n_threads; ++t) {
+    const int k = (int)((n + per - 1) / per);
+    const std::function<void(int)> chunk = [&](int t) {
         const int64_t lo = t * per, hi = lo + per < n ? lo + per : n;
-        if (lo >= hi)
-            break;
-        th.emplace_back([&f, lo, hi] { f(lo, hi); });
-    }
+        if (lo < hi)
+            f(lo, hi);
+    };
+    if (worker_pool()->run(k, chunk))
+        return;
+    std::vector<std::thread> th;
+    for (int t = 0; t < k; ++t)
+        th.emplace_back([&chunk, t] { chunk(t); });
     for (auto &x : th)
         x.join();
 }
