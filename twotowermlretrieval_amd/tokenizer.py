@@ -153,19 +153,17 @@ class PretrainedTokenizer:
         return self._tok_handle
 
     def _make_native(self):
-        if True:
-            import ctypes as C
-            from . import _lib
-            words = list(self.word2idx.keys())
-            enc = [w.encode("utf-8") if isinstance(w, str) else str(w).encode("utf-8") for w in words]
-            off = np.zeros(len(enc) + 1, dtype=np.int64)
-            np.cumsum([len(b) for b in enc], out=off[1:])
-            blob = b"".join(enc)
-            ids = np.asarray([self.word2idx[w] for w in words], dtype=np.int64)
-            h = C.c_void_p()
-            _lib.check(_lib.lib().tt_tok_create(blob, off.ctypes.data, ids.ctypes.data, len(enc), int(self.unk_token_id),
-                                                C.byref(h)))
-            return h
+        import ctypes as C
+        from . import _lib
+        words = list(self.word2idx.keys())
+        enc = [w.encode("utf-8") if isinstance(w, str) else str(w).encode("utf-8") for w in words]
+        off = np.zeros(len(enc) + 1, dtype=np.int64)
+        np.cumsum([len(b) for b in enc], out=off[1:])
+        blob = b"".join(enc)
+        ids = np.asarray([self.word2idx[w] for w in words], dtype=np.int64)
+        h = C.c_void_p()
+        _lib.check(_lib.lib().tt_tok_create(blob, off.ctypes.data, ids.ctypes.data, len(enc), int(self.unk_token_id), C.byref(h)))
+        return h
 
     def __del__(self):
         h = getattr(self, "_tok_handle", None)
