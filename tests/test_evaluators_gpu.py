@@ -150,6 +150,37 @@ def test_embed_corpus_pipeline_equals_batch_of_64_loop():
     assert a.shape == b.shape == (1000, H) and torch.equal(a, b)
 
 
+def test_embed_corpus_with_text_beyond_ascii_copy_ahead_and_wide_ids():
+    """The index build's host side, every form at once: passages with typographic quotes, accents, CJK and an emoji (tokenised natively
+    from CPython's code units), a Greek capital sigma and U+0130 (those two texts go through Python), two producers and copies issued
+    ahead -- int32 batches on the way to the device; and the same corpus under a vocabulary whose ids do not fit an int32 (int64
+    batches).  Rows equal the 64-document loop's, bit for bit."""
+    import twotowermlretrieval_amd as tt
+    from twotowermlretrieval_amd.evaluators import embed_corpus, embed_documents
+    words = [f"w{i}" for i in range(5, 300)] + ["café", "naïve", "日本語", "ος", "i̇stanbul"]
+    vocab = {w: i for i, w in enumerate(["the", ",", ".", "of", "and"] + words)}
+    tok = tt.PretrainedTokenizer(word2idx=vocab)
+    V, E, H = tok.vocab_size(), 20, 64
+    torch.manual_seed(0)
+    m = tt.TwoTowerModel({"HIDDEN_DIM": H, "NUM_LAYERS": 1, "BIDIRECTIONAL": False, "VOCAB_SIZE": V, "EMBED_DIM": E},
+                         synth.make_table(5, V, E)).cuda().eval()
+    rs = np.random.RandomState(4)
+    extras = ["", " \u2019s café", " “naïve”", " 日本語 —", " 😀", " ΟΣ", " İstanbul"]
+    docs = [" ".join(words[rs.randint(0, len(words))] + ("," if rs.rand() < 0.1 else "") for _ in range(rs.randint(1, 40)))
+            + extras[rs.randint(0, len(extras)) if rs.rand() < 0.3 else 0] for _ in range(2000)]
+    dev = torch.device("cuda")
+    a = embed_documents(m, tok, docs, dev, batch_size=64)
+    for kw in (dict(batch_size=300), dict(batch_size=256, producers=2, threads_per_producer=2, copy_ahead=2), dict(batch_size=512, copy_ahead=0)):
+        b = embed_corpus(m, tok, docs, dev, **kw)
+        torch.cuda.synchronize()
+        assert a.shape == b.shape == (2000, H) and torch.equal(a, b), kw
+    # ids beyond int32: a table cannot be that long, so the wide ids are mapped back by the tower's own vocabulary size here --
+    # the point is the int64 batch path of encode_batch / embed_corpus, compared with the same tokenizer's Python path
+    wide = tt.PretrainedTokenizer(word2idx={w: i + (1 << 33) for w, i in vocab.items()})
+    x = wide.encode_batch(docs[:300], out=torch.empty(300 * 64, dtype=torch.int64), ids32=True)
+    assert x.dtype == torch.int64 and torch.equal(x, wide.encode_batch(docs[:300], native=False))
+
+
 class _TextStub:
     """Towers for the G14 fixture: a text 'q<i>' / 'd<j>' is ONE token id, the embedding is the recorded row."""
 
