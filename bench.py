@@ -477,6 +477,79 @@ def make_encoder_inputs(dev, with_index_batch=True):
     return {"table": table, "model": m, "B": B, "q": q, "p": p, "n": n, "big": big, "qt": qt, "pt": pt, "nt": nt, "bt": bt}
 
 
+def graph_legs(dev):
+    """The HIP-graph legs, run in a process of their own (graph_legs_child): the whole direct train step as ONE graph launch
+    (trainer.GraphedTrainStep: ids copied into static buffers padded to the next multiple of 32 columns; same kernels, same failure
+    semantics -- the gate words are read after every replay), with and without the deferred read, for the north-star model at 512
+    triplets and for the reference's default model (config.json: 2 layers, bidirectional, dropout -- seeds as device words) at 64."""
+    import numpy as np
+    import twotowermlretrieval_amd as tt
+    inp = make_encoder_inputs(dev, with_index_batch=False)
+    m, B = inp["model"], inp["B"]
+    q, p, n = inp["q"], inp["p"], inp["n"]
+    qd, pd, nd = q.to(dev), p.to(dev), n.to(dev)
+    tok = inp["qt"] + inp["pt"] + inp["nt"]
+    r32 = lambda x: (int(x) + 31) // 32 * 32  # noqa: E731
+    out = {}
+    m.train()
+    opt = tt.FusedClipAdam(m.parameters(), lr=5e-5, max_norm=1.0)
+    try:
+        gstep = tt.GraphedTrainStep(m, opt, batch=B, q_width=r32(q.shape[1]), doc_width=r32(max(p.shape[1], n.shape[1])), margin=0.5)
+        t_g = _time_gpu(lambda: gstep(qd, pd, nd), 5, 2)
+        out["graphed"] = {"ms_per_step": round(t_g * 1e3, 3), "triplets_per_s": round(B / t_g),
+                          "q_width": gstep.q_width, "doc_width": gstep.doc_width,
+                          "frac_f16_mfma_3x": round(3.0 * tok * FLOP_PER_TOKEN_TRAIN / t_g / 1e12 / MFMA_F16_PEAK_TFLOPS, 4)}
+        del gstep
+        lazy = tt.GraphedTrainStep(m, opt, batch=B, q_width=r32(q.shape[1]), doc_width=r32(max(p.shape[1], n.shape[1])), margin=0.5,
+                                   defer_check=True)     # step i's gate words read inside call i + 1
+        t_l = _time_gpu(lambda: lazy(qd, pd, nd), 5, 2)
+        lazy.flush()
+        out["graphed"]["deferred_check_ms_per_step"] = round(t_l * 1e3, 3)
+        out["graphed"]["deferred_check_triplets_per_s"] = round(B / t_l)
+        del lazy
+    except Exception as e:  # noqa: BLE001 -- the eager leg is the record; say why the graph leg is missing
+        out["graphed"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+    del opt, m
+    try:
+        rs = np.random.RandomState(7)
+        tab1 = torch.from_numpy((rs.standard_normal((ENC_V, 200)) * 0.3).astype(np.float32))
+        torch.manual_seed(1)
+        m1 = tt.TwoTowerModel({"VOCAB_SIZE": ENC_V, "EMBED_DIM": 200, "HIDDEN_DIM": ENC_H, "NUM_LAYERS": 2, "BIDIRECTIONAL": True,
+                               "DROPOUT": 0.2}, tab1).to(dev)
+        m1.train()
+        opt1 = tt.FusedClipAdam(m1.parameters(), lr=5e-5, max_norm=1.0)
+        q64, p64, n64 = qd[:64].contiguous(), pd[:64].contiguous(), nd[:64].contiguous()
+        g64 = tt.GraphedTrainStep(m1, opt1, batch=64, q_width=r32(q64.shape[1]), doc_width=r32(max(p64.shape[1], n64.shape[1])),
+                                  margin=0.5, defer_check=True)    # (dropout seeds as device words: include/tt.h TT_ENC_SEED_ON_DEVICE)
+        tg = _time_gpu(lambda: g64(q64, p64, n64), 8, 2)
+        g64.flush()
+        out["config_json_model"] = {"graphed_deferred_ms_per_step_64_triplets": round(tg * 1e3, 3),
+                                    "graphed_deferred_triplets_per_s_64": round(64 / tg)}
+    except Exception as e:  # noqa: BLE001
+        out["config_json_model"] = {"graphed_error": f"{type(e).__name__}: {e}"[:300]}
+    return out
+
+
+def graph_legs_child(timeout_s: int = 600):
+    """graph_legs() in a child process (`bench.py --graph-legs-child`, one JSON line on stdout).  Stream capture is the one part
+    of the bench that has taken a process down before -- a ROCm runtime fault inside hipStreamEndCapture for some stream patterns,
+    DESIGN 4 -- and a fault there must cost the line these keys, not the line.  A started child is never exec'd over: it is an
+    ordinary subprocess of this (GPU-initialised) process."""
+    import subprocess
+    # (a profiler around this process stays with this process: its preloaded library would open a second trace for the child)
+    env = {k: v for k, v in os.environ.items() if k != "LD_PRELOAD" and not k.startswith(("ROCP", "ROCPROF"))}
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--graph-legs-child"], stdout=subprocess.PIPE,
+                           stderr=subprocess.PIPE, text=True, timeout=timeout_s, env=env)
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        if r.returncode == 0 and lines:
+            return json.loads(lines[-1])
+        why = f"child exit code {r.returncode}: {r.stderr.strip()[-240:]}"
+    except Exception as e:  # noqa: BLE001  (time-out, no interpreter, unparsable output)
+        why = f"{type(e).__name__}: {e}"[:300]
+    return {"graphed": {"error": why}, "config_json_model": {"graphed_error": why}}
+
+
 def encoder_legs(dev):
     """Tower forward (B=512), index build (B=8192) and the train step (512 triplets) on this rank's GPU.
     Returns (encoder dict, train dict, inputs for the CPU legs)."""
@@ -519,25 +592,9 @@ def encoder_legs(dev):
     opt.settle()
     train["deferred_check_ms_per_step"] = round(t_d * 1e3, 3)
     train["deferred_check_triplets_per_s"] = round(B / t_d)
-    # the same step as ONE HIP graph launch (trainer.GraphedTrainStep: ids copied into static buffers padded to the next multiple
-    # of 32 columns; same kernels, same failure semantics -- the gate words are read after every replay)
-    r32 = lambda x: (int(x) + 31) // 32 * 32  # noqa: E731
-    try:
-        gstep = tt.GraphedTrainStep(m, opt, batch=B, q_width=r32(q.shape[1]), doc_width=r32(max(p.shape[1], n.shape[1])), margin=0.5)
-        t_g = _time_gpu(lambda: gstep(qd, pd, nd), 5, 2)
-        train["graphed"] = {"ms_per_step": round(t_g * 1e3, 3), "triplets_per_s": round(B / t_g),
-                            "q_width": gstep.q_width, "doc_width": gstep.doc_width,
-                            "frac_f16_mfma_3x": round(3.0 * tok * FLOP_PER_TOKEN_TRAIN / t_g / 1e12 / MFMA_F16_PEAK_TFLOPS, 4)}
-        del gstep
-        lazy = tt.GraphedTrainStep(m, opt, batch=B, q_width=r32(q.shape[1]), doc_width=r32(max(p.shape[1], n.shape[1])), margin=0.5,
-                                   defer_check=True)     # step i's gate words read inside call i + 1
-        t_l = _time_gpu(lambda: lazy(qd, pd, nd), 5, 2)
-        lazy.flush()
-        train["graphed"]["deferred_check_ms_per_step"] = round(t_l * 1e3, 3)
-        train["graphed"]["deferred_check_triplets_per_s"] = round(B / t_l)
-        del lazy
-    except Exception as e:  # noqa: BLE001 -- the eager leg above is the record; say why the graph leg is missing
-        train["graphed"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+    # the same step as ONE HIP graph launch, and the reference's default model's: measured in a CHILD process (graph_legs_child)
+    graphs = graph_legs_child()
+    train["graphed"] = graphs.get("graphed", {"error": "no result"})
     del opt
     # the reference's DEFAULT model (backend/config.json:13-17: E = 200, 2 layers, bidirectional, dropout 0.2 -- BASELINE
     # configs[0]'s model) on the same triplets' shapes, at 512 triplets and at config.json's own BATCH_SIZE of 64
@@ -555,14 +612,8 @@ def encoder_legs(dev):
         train["config_json_model"] = {"model": "E=200, H=256, 2 layers, bidirectional, dropout 0.2 (backend/config.json:13-17)",
                                       "ms_per_step_512_triplets": round(t512 * 1e3, 3), "triplets_per_s_512": round(512 / t512),
                                       "ms_per_step_64_triplets": round(t64 * 1e3, 3), "triplets_per_s_64": round(64 / t64)}
-        q64, p64, n64 = qd[:64].contiguous(), pd[:64].contiguous(), nd[:64].contiguous()
-        g64 = tt.GraphedTrainStep(m1, opt1, batch=64, q_width=r32(q64.shape[1]), doc_width=r32(max(p64.shape[1], n64.shape[1])),
-                                  margin=0.5, defer_check=True)    # (dropout seeds as device words: include/tt.h TT_ENC_SEED_ON_DEVICE)
-        tg = _time_gpu(lambda: g64(q64, p64, n64), 8, 2)
-        g64.flush()
-        train["config_json_model"]["graphed_deferred_ms_per_step_64_triplets"] = round(tg * 1e3, 3)
-        train["config_json_model"]["graphed_deferred_triplets_per_s_64"] = round(64 / tg)
-        del g64, opt1, m1, tab1
+        train["config_json_model"].update(graphs.get("config_json_model", {"graphed_error": "no result"}))
+        del opt1, m1, tab1
     except Exception as e:  # noqa: BLE001
         train["config_json_model"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     torch.cuda.empty_cache()
@@ -606,7 +657,13 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the encoder / train / encoder-corpus legs")
     ap.add_argument("--no-encoder-corpus", action="store_true", help="skip the encoder-produced-corpus leg (~20 s)")
+    ap.add_argument("--graph-legs-child", action="store_true", help="internal: graph_legs() on cuda:0, one JSON line")
     a = ap.parse_args()
+
+    if a.graph_legs_child:
+        torch.cuda.set_device(0)
+        print(json.dumps(graph_legs(torch.device("cuda", 0))), flush=True)
+        return
 
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
         sys.exit(launch_ranks(a.gpus))
