@@ -537,7 +537,8 @@ def graph_legs_child(timeout_s: int = 600):
     ordinary subprocess of this (GPU-initialised) process."""
     import subprocess
     # (a profiler around this process stays with this process: its preloaded library would open a second trace for the child)
-    env = {k: v for k, v in os.environ.items() if k != "LD_PRELOAD" and not k.startswith(("ROCP", "ROCPROF"))}
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("LD_PRELOAD", "HSA_TOOLS_LIB", "HSA_TOOLS_REPORT_LOAD_FAILURE") and not k.startswith(("ROCP", "ROCPROF"))}
     try:
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "--graph-legs-child"], stdout=subprocess.PIPE,
                            stderr=subprocess.PIPE, text=True, timeout=timeout_s, env=env)
