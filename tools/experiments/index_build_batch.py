@@ -24,7 +24,7 @@ for L_ in lens:
     docs.append(" ".join(map(words.__getitem__, z[p0:p0 + L_]))); p0 += L_
 ref = None
 for rep in range(2):
-    for bs in (16384, 32768, 8192):
+    for bs in (32768, 65536, 49152, 16384):
         embed_corpus(model, tok, docs, dev, batch_size=bs)
         torch.cuda.synchronize()
         bench._settle_gc()
