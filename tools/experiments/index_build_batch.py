@@ -16,7 +16,7 @@ V = bench.ENC_V
 words = ["the", ",", ".", "of", "and"] + [f"w{i}" for i in range(5, V - 1)]
 tok = tt.PretrainedTokenizer(word2idx={w: i for i, w in enumerate(words)})
 rs = np.random.RandomState(3)
-n_docs = 524_288
+n_docs = int(sys.argv[1]) if len(sys.argv) > 1 else 524_288
 lens = np.clip(rs.poisson(70, n_docs), 10, 250)
 z = rs.zipf(1.07, int(lens.sum())) % (V - 1)
 docs, p0 = [], 0
@@ -24,7 +24,7 @@ for L_ in lens:
     docs.append(" ".join(map(words.__getitem__, z[p0:p0 + L_]))); p0 += L_
 ref = None
 for rep in range(2):
-    for bs in (32768, 65536, 49152, 16384):
+    for bs in (16384, 32768):
         embed_corpus(model, tok, docs, dev, batch_size=bs)
         torch.cuda.synchronize()
         bench._settle_gc()
