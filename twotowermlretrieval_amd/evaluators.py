@@ -68,7 +68,7 @@ def embed_documents(model, tokenizer, documents: Sequence[str], device: torch.de
     return torch.cat(out) if out else torch.empty((0, 0), device=device)
 
 
-def embed_corpus(model, tokenizer, documents: Sequence[str], device: torch.device, batch_size: int = 16384,
+def embed_corpus(model, tokenizer, documents: Sequence[str], device: torch.device, batch_size: int = 32768,
                  prefetch: int = 2, out: torch.Tensor = None, producers: int = 0, stats: Dict = None,
                  threads_per_producer: int = 0, copy_ahead: int = 2) -> torch.Tensor:
     """Index build: the same rows as embed_documents, with the host front end off the critical path.
@@ -85,6 +85,9 @@ def embed_corpus(model, tokenizer, documents: Sequence[str], device: torch.devic
     part does 590 M tokens/s on 8 threads and 1 050 M on 16 (tools/experiments/tok_harness.sh), every producer setting from
     1 x 16 to 4 x 4 builds at the GPU's rate (3.3-3.8 M passages/s, profiles/r04_w_index_build.log), and one producer with all
     the threads is the fastest of them (fewer Python threads trading the GIL with the consumer).
+    batch_size 32 768: per-batch costs (launches, the copy's place in the queue, the recurrence's tail, two row tiles per workgroup
+    from 16 384 passages up) amortise -- 1 M passages 3.55-3.67 M passages/s at 16 384 per batch, 3.89-3.92 M at 32 768, 3.83-3.90 at
+    49 152 / 65 536 (tools/experiments/index_build_batch.py); 377 MB of pinned staging, ~10 GB of workspace.
     stats (optional dict): receives what the build used."""
     import collections
     import os
