@@ -374,7 +374,7 @@ def _lib_ws_bytes(B, N):
     return _lib.lib().tt_score_topk_workspace_bytes(B, N, DIM, TOPK)
 
 
-def index_build_from_strings_leg(dev, model, gpu_docs_per_s, n_docs=262_144, seed=3):
+def index_build_from_strings_leg(dev, model, gpu_docs_per_s, n_docs=524_288, seed=3):
     """Index build from STRINGS (backend/main.py:125-138 over tokenizer.py:41-43): synthetic Zipf passages as text ->
     native tokeniser on several producer threads -> pinned batches -> document tower (evaluators.embed_corpus), against the
     GPU-only rate of the `index_build_b8192` leg (ids already on the device)."""
@@ -418,8 +418,8 @@ def index_build_from_strings_leg(dev, model, gpu_docs_per_s, n_docs=262_144, see
     torch.cuda.synchronize()
     dt5 = time.perf_counter() - t2
     del docs5
-    # the GPU's own rate on THESE passages at the build's batch size (ids resident: 16 consecutive batches of 16 384)
-    bs = stats.get("batch_size", 16384)
+    # the GPU's own rate on THESE passages at the build's batch size (ids resident: 16 consecutive batches of 32 768)
+    bs = stats.get("batch_size", 32768)
     resident = [tok.encode_batch(docs[i:i + bs]).to(dev) for i in range(0, n_docs, bs)]
     with torch.no_grad():
         t_gpu = _time_gpu(lambda: [model.encode_document(x) for x in resident], 2, 1)
