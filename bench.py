@@ -621,6 +621,151 @@ def encoder_legs(dev):
     return enc, train, (table, q, p, n), m
 
 
+# ---- legs EVERY rank executes (their constructors and steps are collectives): same order on every rank ------------------------
+PCIE_PEAK_GBPS = 64.0     # PCIe Gen5 x16 per direction (MI355X_MICROARCH.md: 63 GB/s spec)
+STREAM_DOCS_PER_GPU = 12_500_000   # BASELINE configs[4]: 100M x 256 bf16 over 8 GPUs
+
+
+def _max_over_ranks(x: float, dev, world: int) -> float:
+    if world == 1:
+        return x
+    t = torch.tensor([x], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def _fence(world: int):
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+
+
+def streamed_leg(dev, rank, world, n_shard=STREAM_DOCS_PER_GPU, iters=3):
+    """BASELINE configs[4] as stated: every GPU owns n_shard = 12.5M rows of a bf16 corpus (N x 12.5M rows in all: at N = 8 the
+    100M-passage corpus) that stay in PINNED host memory; one pass = every rank streams its shard through its GPU in 1M-row
+    blocks (copy stream: hipMemcpyAsync, compute stream: widen + screened search of the block + running top-k), then the usual
+    per-shard top-50 all-gather + merge to the global top-10 (ShardedIndex over a StreamedIndex).  Weak scaling: the shard per
+    GPU is fixed, the corpus grows with N.  PCIe binds (6.4 GB per pass and GPU), so the figure is GB/s per GPU against the
+    64 GB/s of a Gen5 x16 link; beside it the same shard widened once into HBM (it is 19.2 GB of 288) and searched resident."""
+    import twotowermlretrieval_amd as tt
+    lo = rank * n_shard
+    host = torch.empty((n_shard, DIM), dtype=torch.bfloat16).pin_memory()
+    for b0 in range(0, n_shard, GEN_BLOCK):
+        b1 = min(n_shard, b0 + GEN_BLOCK)
+        g = torch.Generator(device=dev).manual_seed(5000 + (lo + b0) // GEN_BLOCK)
+        x = torch.randn((b1 - b0, DIM), dtype=torch.float32, device=dev, generator=g)
+        x /= x.norm(dim=1, keepdim=True).clamp_min(1e-12)
+        host[b0:b1].copy_(x.to(torch.bfloat16))
+        del x
+    torch.cuda.synchronize()
+    q = gen_queries(BATCH, dev, seed=8)
+    six = tt.StreamedIndex(host, block_docs=1 << 20, device=dev, idx_offset=lo)
+    sh = tt.ShardedIndex(six, lo, shard_k=SHARD_K)
+
+    def timed(fn, n, warm=1):
+        for _ in range(warm):
+            out = fn()
+        _fence(world)
+        t0 = time.perf_counter()
+        for _ in range(n):
+            out = fn()
+        _fence(world)
+        return _max_over_ranks((time.perf_counter() - t0) / n, dev, world), out
+
+    t_s, (sv, si) = timed(lambda: sh.search(q, TOPK), iters)
+    q32 = q[:32].contiguous()
+    t_s32, _ = timed(lambda: sh.search(q32, TOPK), iters)
+    res = six.resident()                                     # widened once into HBM (fp32 rows + fp16 shadow)
+    rsh = tt.ShardedIndex(res.docs, lo, shard_k=SHARD_K, screen=True)
+    del res
+    t_r, (rv, ri) = timed(lambda: rsh.search(q, TOPK), 10, warm=2)
+    same = bool(torch.equal(sv, rv) and torch.equal(si, ri))
+    byts = n_shard * DIM * 2
+    out = {"workload": f"BASELINE configs[4]: exact top-{TOPK} of B={BATCH} queries over {world} x {n_shard} x {DIM} bf16 passages, "
+                       f"each GPU's shard in pinned host DRAM streamed in 1M-row blocks (async HIP copies on a copy stream "
+                       f"under the block searches), per-shard top-{SHARD_K} + all-gather + merge",
+           "docs_per_gpu": n_shard, "docs_total": world * n_shard, "scaling": "weak", "bound": "pcie",
+           "ms_per_pass": round(t_s * 1e3, 2), "queries_per_s": round(BATCH / t_s, 1),
+           "achieved": round(byts / t_s / 1e9, 2), "peak": PCIE_PEAK_GBPS, "unit": "GB/s per GPU", "frac": round(byts / t_s / 1e9 / PCIE_PEAK_GBPS, 4),
+           "b32_ms_per_pass": round(t_s32 * 1e3, 2), "b32_queries_per_s": round(32 / t_s32, 1),
+           "resident": {"what": f"the same shards widened once into HBM (fp32 rows + fp16 shadow = {n_shard * DIM * 6 / 1e9:.1f} GB per GPU), same exchange",
+                        "ms_per_pass": round(t_r * 1e3, 3), "queries_per_s": round(BATCH / t_r, 1)},
+           "identical_to_resident": same, "collective": sh.collective if world > 1 else None}
+    del sh, rsh, six, host
+    torch.cuda.empty_cache()
+    return out
+
+
+def dp_train_leg(dev, rank, world, steps=5, warm=2):
+    """BASELINE configs[2]: triplet training data-parallel over the ranks (backend/main.py:244-259 per rank; SURVEY 8e: ONE
+    summing all-reduce of the flat gradient bucket, x 1/W, then clip, then Adam).  512 triplets per GPU (4096 at N = 8) of one
+    seeded global batch, north-star model (GloVe-300-shaped frozen table, 1-layer GRU, H = 256).  Every rank constructs the
+    trainer and runs the same steps; the time is the slowest rank's.  The all-reduce's share is event-timed on the bucket."""
+    import numpy as np
+    import twotowermlretrieval_amd as tt
+    per = 512
+    g = torch.Generator(device=dev).manual_seed(5)
+    table = (torch.randn((ENC_V, ENC_E), dtype=torch.float32, device=dev, generator=g) * 0.3).cpu()
+    torch.manual_seed(0)
+    m = tt.TwoTowerModel({"VOCAB_SIZE": ENC_V, "EMBED_DIM": ENC_E, "HIDDEN_DIM": ENC_H}, table.numpy()).to(dev)
+    del table
+    rs = np.random.RandomState(0)
+    G = per * world
+    ids = [make_ids_bulk(rs, G, mean, lo_, hi_, ENC_V) for mean, lo_, hi_ in ((6, 1, 30), (70, 10, 250), (70, 10, 250))]
+    mine = [x[rank * per:(rank + 1) * per] for x in ids]
+    mine = [x[:, :max(int((x != 0).sum(1).max()), 1)].contiguous().to(dev) for x in mine]   # (the shard's own widest row)
+    tok_global = int(sum((x != 0).sum() for x in ids))
+    tr = tt.trainer.DataParallelTrainer(m, lr=5e-5, margin=0.5)
+    tr.broadcast_parameters()
+    opt = tr.optimizer
+
+    def timed(n, w):
+        for _ in range(w):
+            tr.step(*mine)
+        tr.flush()
+        _fence(world)
+        t0 = time.perf_counter()
+        for _ in range(n):
+            tr.step(*mine)
+        tr.flush()
+        _fence(world)
+        return _max_over_ranks((time.perf_counter() - t0) / n, dev, world)
+
+    _settle_gc()
+    t = timed(steps, warm)
+    opt.reduce_timing = []
+    timed(steps, 0)
+    torch.cuda.synchronize()
+    red_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in opt.reduce_timing) / steps if opt.reduce_timing else 0.0
+    red_bytes = sum(b for _, _, b in opt.reduce_timing) // steps if opt.reduce_timing else 0
+    n_red = len(opt.reduce_timing) // steps
+    opt.reduce_timing = None
+    tr.defer_check = True
+    t_d = timed(steps, warm)
+    out = {"workload": f"BASELINE configs[2]: {G} triplets per step = {per} per GPU x {world} (4096 at N = 8), GloVe-300-shaped frozen "
+                       f"table V={ENC_V}, GRU H={ENC_H}; per rank: 3 tower forwards + triplet loss + backward, then ONE flat "
+                       f"all-reduce (query tower's prefix early), x 1/W, clip_grad_norm_(1.0), Adam (main.py:244-259)",
+           "scaling": "weak", "triplets_per_s": round(G / t), "ms_per_step": round(t * 1e3, 3), "triplets_per_step": G,
+           "tokens_per_step": tok_global,
+           "allreduce_ms_per_step_rank0": round(red_ms, 4), "allreduce_share_of_step": round(red_ms / (t * 1e3), 4),
+           "allreduce_calls_per_step": n_red, "allreduce_bytes_per_step": int(red_bytes),
+           "deferred_check_ms_per_step": round(t_d * 1e3, 3), "deferred_check_triplets_per_s": round(G / t_d),
+           "collective": opt._coll.via if world > 1 else None}
+    del tr, opt, m
+    torch.cuda.empty_cache()
+    return out
+
+
+def collective_legs(dev, rank, world, a):
+    legs = {}
+    if not a.no_streamed:
+        legs["streamed_bf16"] = streamed_leg(dev, rank, world, n_shard=a.stream_docs)
+    if not a.no_secondary:
+        legs["dp_train"] = dp_train_leg(dev, rank, world)
+    return legs
+
+
 def launch_ranks(n: int) -> int:
     """`python bench.py --gpus N` from a bare shell: this parent makes NO GPU call; it starts N fresh rank processes
     (never an exec of itself), relays rank 0's JSON line and fails if any rank fails."""
@@ -658,6 +803,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the encoder / train / encoder-corpus legs")
     ap.add_argument("--no-encoder-corpus", action="store_true", help="skip the encoder-produced-corpus leg (~20 s)")
+    ap.add_argument("--no-streamed", action="store_true", help="skip the configs[4] leg (6.4 GB of pinned host memory per rank)")
+    ap.add_argument("--stream-docs", type=int, default=STREAM_DOCS_PER_GPU, help="rows per GPU of the configs[4] leg (rehearsals)")
     ap.add_argument("--graph-legs-child", action="store_true", help="internal: graph_legs() on cuda:0, one JSON line")
     a = ap.parse_args()
 
@@ -738,6 +885,8 @@ def main():
     assert vals.shape == (BATCH, TOPK) and bool((vals[:, 1:] <= vals[:, :-1]).all()) and int(idx.min()) >= 0
 
     flags = int(local_index.fallback_flags.ne(0).sum().item())
+    # the legs that are collectives (configs[4] streamed shards, configs[2] data-parallel training): all ranks, same order
+    shared_legs = collective_legs(dev, rank, world, a)
     if rank == 0:
         n_shard = hi - lo
         kp = TOPK if world == 1 else SHARD_K
@@ -801,7 +950,7 @@ def main():
         #   clustered_corpus  ... over clustered rows with groups of exact duplicates: fallback count and the all-fallback rate
         #   index_build_from_strings  text -> tokeniser threads -> document tower, as a fraction of the GPU-only rate
         #   encoder, train  SURVEY 8d's secondary metrics (tower / index-build tokens/s, training triplets/s)
-        roof["legs"] = {"hbm_screen": roof_hbm, "hbm_exact_f32": roof_hbm_f32, "mfma_exact_f32": roof_f32}
+        roof["legs"] = {"hbm_screen": roof_hbm, "hbm_exact_f32": roof_hbm_f32, "mfma_exact_f32": roof_f32, **shared_legs}
         enc_inputs = None
         # N = 1 only: these legs build optimizers and trainers on rank 0 alone, and with a process group up every such object is
         # a COLLECTIVE construction (FusedClipAdam(group=None) means the default group, as DDP's does): rank 0 would wait for

@@ -68,3 +68,78 @@ def test_streamed_index_at_shard_scale_4m_rows(oracle):
         got = list(ex.map(lambda r: oracle.score_topk(Q[r:r + 1].cpu().numpy(), d_np, 10, idx_offset=7), rows))
     for r, (ov, oi) in zip(rows, got):
         assert np.array_equal(si[r].cpu().numpy(), oi[0]) and np.array_equal(sv[r].cpu().numpy(), ov[0]), r
+
+
+def test_streamed_shard_at_configs4_size_12_5m_rows(oracle):
+    """BASELINE configs[4] at ITS size for one GPU: 100M x 256 bf16 over 8 GPUs = a 12.5M-row shard (6.4 GB) in PINNED host
+    memory, streamed in 1M-row blocks (13 of them, the last ragged), here as rank 5 of the 8 (row offset 62.5M).  For a bench
+    batch (B = 1024) and a serving batch (B = 32): streamed == the same shard widened once into HBM == the plain fp32 kernel,
+    bit for bit; the shard's list as the sharded search exchanges it (ShardedIndex over the streamed shard, per-shard
+    top-50 -> top-10) gives the same top-10; four queries (two of them copies of documents of the first and of the last,
+    ragged block) == the CPU oracle over all 12.5M rows."""
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+    import twotowermlretrieval_amd as tt
+    dev = torch.device("cuda:0")
+    N, OFF = 12_500_000, 62_500_000
+    host = torch.empty((N, 256), dtype=torch.bfloat16).pin_memory()
+    g = torch.Generator(device=dev).manual_seed(23)
+    for lo in range(0, N, 1_000_000):
+        hi = min(N, lo + 1_000_000)
+        x = torch.randn((hi - lo, 256), device=dev, generator=g)
+        x /= x.norm(dim=1, keepdim=True)
+        host[lo:hi].copy_(x.to(torch.bfloat16))
+    del x
+    torch.cuda.synchronize()
+    Q = torch.randn((1024, 256), device=dev, generator=g)
+    Q /= Q.norm(dim=1, keepdim=True)
+    for r, doc in ((3, 12_499_990), (17, 5)):
+        Q[r] = host[doc].to(dev).to(torch.float32)
+        Q[r] /= Q[r].norm()
+    ix = tt.StreamedIndex(host, block_docs=1 << 20, idx_offset=OFF)
+    assert ix.host.is_pinned() and ix._d16[0] is not None and ix.host.data_ptr() == host.data_ptr()
+    sh = tt.ShardedIndex(ix, OFF, shard_k=50)                 # one rank, no process group: the exchange is a copy
+    assert sh.streamed and sh._seed_exchange is False
+    res = ix.resident()
+    full32 = res.docs
+    kept = {}
+    for B in (1024, 32):
+        q = Q[:B].contiguous()
+        sv, si = ix.search(q, 10)
+        rv, ri = res.search(q, 10)
+        ev, ei = tt.score_topk(q, full32, 10, idx_offset=OFF)
+        hv, hi_ = sh.search(q, 10)
+        torch.cuda.synchronize()
+        assert torch.equal(si, ri) and torch.equal(sv, rv), B
+        assert torch.equal(si, ei) and torch.equal(sv, ev), B
+        assert torch.equal(hi_, si) and torch.equal(hv, sv), B
+        assert int(si[3, 0]) == OFF + 12_499_990 and int(si[17, 0]) == OFF + 5
+        kept[B] = (sv.cpu().numpy(), si.cpu().numpy())
+    pv, pi = sh.submit(Q, 10).result()                        # the pipelined form over a streamed shard
+    torch.cuda.synchronize()
+    assert np.array_equal(pi.cpu().numpy(), kept[1024][1]) and np.array_equal(pv.cpu().numpy(), kept[1024][0])
+    rows = [0, 3, 17, 1023]
+    d_np = full32.cpu().numpy()
+    del res, full32, ix, sh
+    torch.cuda.empty_cache()
+    with ThreadPoolExecutor(min(4, len(os.sched_getaffinity(0)))) as ex:
+        got = list(ex.map(lambda r: oracle.score_topk(Q[r:r + 1].cpu().numpy(), d_np, 10, idx_offset=OFF), rows))
+    for r, (ov, oi) in zip(rows, got):
+        assert np.array_equal(kept[1024][1][r], oi[0]) and np.array_equal(kept[1024][0][r], ov[0]), r
+        if r < 32:
+            assert np.array_equal(kept[32][1][r], oi[0]) and np.array_equal(kept[32][0][r], ov[0]), r
+
+
+def test_streamed_search_rejects_what_it_cannot_answer():
+    import twotowermlretrieval_amd as tt
+    D = torch.from_numpy(synth.unit_rows(5, 300, 256)).to(torch.bfloat16)
+    ix = tt.StreamedIndex(D, block_docs=128)
+    with pytest.raises(ValueError):
+        ix.search(torch.zeros((2, 128), device="cuda"), 5)          # other width
+    with pytest.raises(RuntimeError):
+        ix.search(torch.zeros((2, 256)), 5)                         # CPU queries: no fallback
+    with pytest.raises(ValueError):
+        tt.ShardedIndex(ix, 9)                                      # row numbering of the index and of the shard disagree
+    empty = tt.StreamedIndex(D[:0], block_docs=128, idx_offset=4)   # a rank whose shard is empty lists only padding
+    v, i = empty.search(torch.from_numpy(synth.unit_rows(6, 3, 256)).cuda(), 4)
+    assert bool((i == -1).all()) and bool(torch.isinf(v).all())

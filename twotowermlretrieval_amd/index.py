@@ -173,6 +173,10 @@ class BruteForceIndex:
     def ntotal(self) -> int:
         return self.docs.shape[0]
 
+    @property
+    def device(self) -> torch.device:
+        return self.docs.device
+
     def search_stats(self) -> Optional[torch.Tensor]:
         """int32 [B,2] = (pooled candidates, survivors rescored exactly) per query of the most recent screened search made
         with keep_stats = True, or None.  Diagnostic: what the fp16 filter let through on this corpus."""
@@ -414,22 +418,44 @@ class ShardedIndex:
     copy and at least SCREEN_MIN_DOCS rows, or no rank exchanges seeds -- a rank-local decision (shard sizes straddling the
     minimum, one shard outside the fp16 range) would leave some ranks in an all-gather the others never enter."""
 
-    def __init__(self, local_docs: torch.Tensor, row_offset: int, group=None, shard_k: int = 50, screen: bool = False,
-                 comm=None):
+    def __init__(self, local_docs, row_offset: int, group=None, shard_k: int = 50, screen: bool = False,
+                 comm=None, block_docs: int = 1 << 20, device=None):
+        """local_docs: this rank's rows [row_offset, row_offset + n) of the corpus, as
+          * a device fp32 [n,d] tensor: resident shard (BruteForceIndex; BASELINE configs[3]), or
+          * a CPU bfloat16 [n,d] tensor / a StreamedIndex: the shard stays in pinned host DRAM and every search streams it
+            through the GPU in blocks of block_docs rows (BASELINE configs[4]: 100M x 256 bf16 over 8 GPUs = 12.5M rows,
+            6.4 GB per rank, PCIe-bound).  The streamed shard's list is the exact top-k' of its rows (bf16 -> fp32 is exact),
+            so the exchange and the merge are the resident path's, unchanged.
+        A job may mix the two kinds (a rank that has the HBM keeps its shard resident).  The seed exchange is a property of the
+        whole job: with ANY streamed shard no rank exchanges seeds.  (A streamed shard searches block by block, each block
+        seeded by its own sample pass, which is valid on its own; a union seed would need the sample maxima of the whole
+        shard before the first block is screened, i.e. one more pass over PCIe, which is what binds.)"""
         from .collective import Collective
         self.group = group
         self.row_offset = int(row_offset)
         self.shard_k = int(shard_k)
-        self._index = BruteForceIndex(local_docs, idx_offset=row_offset, screen=screen)
-        self._coll = Collective(group, self._index.docs.device, comm=comm)
+        if isinstance(local_docs, StreamedIndex):
+            if local_docs.idx_offset != self.row_offset:
+                raise ValueError(f"the StreamedIndex numbers its rows from {local_docs.idx_offset}, the shard starts at {row_offset}")
+            self._index = local_docs
+        elif not local_docs.is_cuda and local_docs.dtype == torch.bfloat16:
+            self._index = StreamedIndex(local_docs, block_docs=block_docs, device=device, idx_offset=row_offset, screen=True)
+        else:
+            self._index = BruteForceIndex(local_docs, idx_offset=row_offset, screen=screen)
+        self.streamed = isinstance(self._index, StreamedIndex)
+        self._dev = self._index.device
+        self._coll = Collective(group, self._dev, comm=comm)
         self._slots = {}
         self._n_submitted = 0
         self._xs: Optional[torch.cuda.Stream] = None
         self._deferred = None  # (slot, B, kp, k) of the last submit(): its list exchange goes out behind the next seed gather
-        N, d = self._index.docs.shape
-        mine = int(self._index.docs16 is not None and d == 256 and N >= SCREEN_MIN_DOCS)
+        if self.streamed:
+            mine = 0
+        else:
+            N, d = self._index.docs.shape
+            mine = int(self._index.docs16 is not None and d == 256 and N >= SCREEN_MIN_DOCS)
         if self._coll.world > 1:
-            dev = self._index.docs.device
+            dev = self._dev
             send = torch.tensor([mine], dtype=torch.int64, device=dev)
             recv = torch.empty(self._coll.world, dtype=torch.int64, device=dev)
             self._coll.all_gather_blocks(send.view(torch.uint8), recv.view(torch.uint8))
@@ -454,7 +480,7 @@ class ShardedIndex:
         coll, world = self._coll, self._coll.world
         plan = self._seed_plan(k)
         B = q.shape[0]
-        padded = self._index.docs.shape[1] != 256
+        padded = (not self.streamed) and self._index.docs.shape[1] != 256
         screens = plan is not None and B >= (SCREEN_MIN_BATCH if not padded else SCREEN_PADDED_MIN_BATCH)  # (BruteForceIndex.search's rule)
         if not screens or (world == 1 and kp == k):
             # no seed exchange on any rank (agreed in the constructor; B and k are the same everywhere): the shard's own search
@@ -500,6 +526,16 @@ class ShardedIndex:
         return cls(docs[lo:hi], lo, group=group, **kw)
 
     @classmethod
+    def from_host_bf16(cls, host_docs: torch.Tensor, group=None, **kw) -> "ShardedIndex":
+        """BASELINE configs[4]: `host_docs` is the WHOLE bf16 corpus [N,d] in host memory (an np.memmap-backed tensor will do:
+        only this rank's rows are touched); rank r pins and streams rows [r*N/W, (r+1)*N/W) only."""
+        import torch.distributed as dist
+        world = dist.get_world_size(group) if dist.is_initialized() else 1
+        rank = dist.get_rank(group) if dist.is_initialized() else 0
+        lo, hi = shard_bounds(host_docs.shape[0], rank, world)
+        return cls(host_docs[lo:hi], lo, group=group, **kw)
+
+    @classmethod
     def from_documents(cls, model, tokenizer, documents, device, group=None, **kw) -> "ShardedIndex":
         """Index build across ranks (third row: embarrassingly parallel over documents, no collective): every rank
         holds the same document list (documents.pkl order, backend/main.py:134-136), embeds ONLY its contiguous shard
@@ -527,7 +563,7 @@ class ShardedIndex:
                 old = self._slots.pop(next(iter(self._slots)))
                 for sl in old:
                     sl.merged.synchronize()
-            self._slots[key] = [_Slot(B, kp, k, self._coll.world, self._index.docs.device) for _ in range(3)]
+            self._slots[key] = [_Slot(B, kp, k, self._coll.world, self._dev) for _ in range(3)]
         return self._slots[key][which]
 
     def _flush(self, only: Optional[_Slot] = None) -> None:
@@ -605,7 +641,7 @@ class StreamedIndex:
                  screen: bool = True):
         if host_docs.is_cuda or host_docs.dtype != torch.bfloat16 or host_docs.dim() != 2:
             raise ValueError("StreamedIndex wants a CPU bfloat16 [N,d] tensor (pinned for full PCIe speed)")
-        self.host = host_docs if host_docs.is_pinned() else host_docs.pin_memory()
+        self.host = host_docs if (host_docs.shape[0] == 0 or host_docs.is_pinned()) else host_docs.pin_memory()
         self.N, self.d = self.host.shape
         self.block = int(min(block_docs, max(self.N, 1)))
         self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
@@ -663,11 +699,20 @@ class StreamedIndex:
         self._walk(visit)
         return BruteForceIndex._from_buffers(d32, d16, self.dmax_norm, self.idx_offset)
 
-    def search(self, q: torch.Tensor, k: int = 10) -> Tuple[torch.Tensor, torch.Tensor]:
+    @property
+    def ntotal(self) -> int:
+        return self.N
+
+    def search(self, q: torch.Tensor, k: int = 10, out=None) -> Tuple[torch.Tensor, torch.Tensor]:
+        """out: optional (vals f32 [B,k], idx int64 [B,k]) device tensors to write the result into (ShardedIndex's send block)."""
         _need_cuda(q)
         if q.dim() == 1:  # a single query vector: squeezed result, like BruteForceIndex
             v, i = self.search(q.unsqueeze(0), k)
             return v[0], i[0]
+        if q.device != self.device:
+            raise ValueError(f"queries on {q.device} but the index streams through {self.device}")
+        if q.shape[1] != self.d:
+            raise ValueError(f"shape mismatch: q {tuple(q.shape)} vs docs {(self.N, self.d)}")
         q = _f32c(q)
         run = [None, None]
 
@@ -682,6 +727,10 @@ class StreamedIndex:
 
         self._walk(visit)
         if run[0] is None:
-            return (torch.full((q.shape[0], k), float("-inf"), device=q.device),
-                    torch.full((q.shape[0], k), -1, dtype=torch.int64, device=q.device))
+            run = [torch.full((q.shape[0], k), float("-inf"), device=q.device),
+                   torch.full((q.shape[0], k), -1, dtype=torch.int64, device=q.device)]
+        if out is not None:
+            out[0].copy_(run[0])
+            out[1].copy_(run[1])
+            return out
         return run[0], run[1]

@@ -108,6 +108,7 @@ class _FlatClipAdam:
         self._pending_status: list = []  # status words of the watched encoders' training calls since the last step()
         self._gate_host, self._gate_ev, self._gate_n, self._deferred = None, None, 0, None   # (snapshot_gate / settle)
         self._reduced_upto = 0           # gradients [0, _reduced_upto) of this step have been all-reduced already (reduce_prefix)
+        self.reduce_timing: Optional[list] = None   # a list: every all-reduce appends (event before, event after, bytes) -- bench.py
         self.check = True                # step() reads the reduced gate (one host synchronisation) and raises
         self._views = []
         off = 0
@@ -192,13 +193,25 @@ class _FlatClipAdam:
         failure decision still rides in the LAST all-reduce of the step.  Every rank must make the same calls in the same order
         (a function of the model's structure only)."""
         if self.world > 1 and 0 < upto <= self.flat_grads.numel() and self._reduced_upto == 0:
-            self._all_reduce(self._bucket[:upto])
+            self._timed_all_reduce(self._bucket[:upto])
             self._reduced_upto = int(upto)
+
+    def _timed_all_reduce(self, part: torch.Tensor) -> None:
+        """The all-reduce of one part of the bucket on the current stream; with `reduce_timing` set, bracketed by two timing
+        events on that stream (what the collective costs THIS rank, its wait for the slowest peer included)."""
+        if self.reduce_timing is None or not part.is_cuda:
+            self._all_reduce(part)
+            return
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        self._all_reduce(part)
+        e1.record()
+        self.reduce_timing.append((e0, e1, part.numel() * 4))
 
     def _reduce_apply(self, gated: bool, check: Optional[bool] = None) -> torch.Tensor:
         if self.world > 1:
             # the bucket: 3.4 MB of gradients + the gate words (minus what reduce_prefix has sent already)
-            self._all_reduce(self._bucket[self._reduced_upto:] if self._reduced_upto else self._bucket)
+            self._timed_all_reduce(self._bucket[self._reduced_upto:] if self._reduced_upto else self._bucket)
             self._reduced_upto = 0
         args = (self.lr, self.betas, self.eps, self.max_norm, 1.0 / self.world, self.total_norm)
         words = None
