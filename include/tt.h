@@ -269,6 +269,15 @@ typedef struct tt_enc_sync {
  * (trainer.GraphedTrainStep); passing the value instead would freeze one mask into the graph.  Forward and backward of a step must
  * see the same value. */
 #define TT_ENC_SEED_ON_DEVICE 0x800
+/* Option bit of `train` (forward), `opts` (prepared forward, backward): the REFERENCE'S OWN ARITHMETIC.  By default the GRU towers
+ * with H = 128 / 256 take every matrix product as three f16 MFMAs on fp16 hi/lo splits of the fp32 operands (fp32-grade: ~4e-7 on
+ * unit-norm outputs; csrc/gru16.hip has the error argument).  With TT_ENC_F32 every product of the call runs on the fp32-MFMA
+ * kernels instead -- plain fp32 multiply-adds, as nn.GRU computes them (backend/model.py:31-37, :59-62) -- at several times the
+ * cost.  A training step passes it to the forward AND the backward (the backward reads the workspace the forward filled);
+ * tt_encoder_forward_prepared_f32 accepts it and then derives the fp32 kernels' weight forms per call (the prepared images are
+ * the f16-split kernels'); no call with this bit is column-split (tt_encoder_split_workgroups counts without it), and the
+ * projected table does not exist for it. */
+#define TT_ENC_F32 0x1000
 /* CUs the column-split recurrence of one call of this shape occupies (one workgroup each, all resident at once; a bidirectional
  * call whose two directions do not fit together runs them one launch after the other and this is ONE direction's count); 0 = the
  * call runs the one-workgroup kernels whatever `train` says.  A host with several calls in flight keeps the sum within the device's
@@ -291,7 +300,7 @@ int tt_encoder_forward_f32(const int64_t *ids, int B, int T, const float *table,
  *   tt_encoder_prepared_bytes(...)  size of the caller-owned device buffer `prepared` (256-B aligned)
  *   tt_encoder_prepare_f32(...)     fills it from `weights` on `stream`; call again after the weights change
  *   tt_encoder_forward_prepared_f32 = tt_encoder_forward_f32 with train = 0 | opts reading `prepared` (same results, bit for
- *                                     bit); opts: 0 or TT_ENC_ONE_WORKGROUP
+ *                                     bit); opts: 0, TT_ENC_ONE_WORKGROUP, TT_ENC_F32
  */
 size_t tt_encoder_prepared_bytes(int E, int H, int num_layers, int bidirectional, int rnn_type);
 int tt_encoder_prepare_f32(int E, int H, int num_layers, int bidirectional, int rnn_type,
@@ -302,6 +311,32 @@ int tt_encoder_forward_prepared_f32(const int64_t *ids, int B, int T, const floa
                                     const float *const *weights /*host array*/, const void *prepared,
                                     const float *proj_w, const float *proj_b, int normalize, int opts, float *out,
                                     void *workspace, size_t workspace_bytes, int32_t *status, tt_stream_t stream);
+
+/*
+ * Inference without the input projection (the PROJECTED TABLE).  With GloVe loaded the embedding table is frozen
+ * (backend/model.py:25-27) and at inference W_ih / b_ih are fixed too (the premise of tt_encoder_prepare_f32), so layer 0's
+ * Gi = table[id] W_ih^T + b_ih of a token (model.py:49, :59-62: nn.Embedding, then nn.GRU's first half) depends on its id
+ * alone.  A serving / index-building host computes it ONCE for every vocabulary row:
+ *   tt_encoder_projected_bytes(...)    size of the caller-owned device buffer `projected` (256-B aligned): V x 3H floats per
+ *                                      direction, 1.23 GB for V = 400 003, H = 256; 0 = this configuration has none
+ *                                      (f16-split GRU only: H = 128 or 256)
+ *   tt_encoder_project_table_f32(...)  fills it: the launch tt_encoder_forward_prepared_f32 makes for layer 0, over the rows
+ *                                      0 .. V-1 in order (needs `prepared`; call again after the table or the weights change)
+ *   tt_encoder_forward_projected_f32   = tt_encoder_forward_prepared_f32 without that launch: the recurrence kernels gather a
+ *                                      step's projections from projected[id].  Same results, bit for bit.  No `table`
+ *                                      argument: the call never reads it.
+ * Workspace: tt_encoder_workspace_bytes(..., train = 0 | TT_ENC_PROJECTED, 0) (a one-layer model then needs no
+ * [tokens][3H] scratch; the size for train = 0 is enough too).
+ */
+#define TT_ENC_PROJECTED 0x2000 /* tt_encoder_workspace_bytes only: size the workspace for tt_encoder_forward_projected_f32 */
+size_t tt_encoder_projected_bytes(int64_t V, int E, int H, int bidirectional, int rnn_type);
+int tt_encoder_project_table_f32(const float *table, int64_t V, int E, int H, int num_layers, int bidirectional, int rnn_type,
+                                 const float *const *weights /*host array*/, const void *prepared, void *projected,
+                                 size_t projected_bytes, tt_stream_t stream);
+int tt_encoder_forward_projected_f32(const int64_t *ids, int B, int T, const void *projected, int64_t V, int E, int H,
+                                     int num_layers, int bidirectional, int rnn_type, const float *const *weights /*host array*/,
+                                     const void *prepared, const float *proj_w, const float *proj_b, int normalize, int opts,
+                                     float *out, void *workspace, size_t workspace_bytes, int32_t *status, tt_stream_t stream);
 
 /*
  * Two padded id batches as one: out [Ba + Bb][T] (T >= max(Ta, Tb)), rows of a then rows of b, padded with id 0

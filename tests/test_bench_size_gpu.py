@@ -135,3 +135,33 @@ def test_two_tile_batch_b16384_rows_vs_oracle_and_vs_the_b8192_call(oracle):
     rows = np.unique(np.concatenate([[int(lens.argmax()), int(lens.argmin()), 0, 16383], rs.choice(16384, 62, replace=False)]))[:64]
     want = oracle_par.forward(oracle, both.numpy()[rows], table, _quads(m, "doc_encoder"), bench.ENC_H)
     assert_fwd_close(y16.cpu().numpy()[rows], want, what="_two_tile_b16384")
+
+
+@pytest.mark.parametrize("B", [1, 512, 8192, 32768])
+def test_projected_table_at_bench_sizes_is_bit_identical_to_the_projecting_call(B):
+    """The north-star towers (V = 400 003, E = 300, H = 256: a 1.23 GB projected table each) at the batch sizes of the bench's
+    encoder legs -- a serving query, the 512-query batch, the 8192-passage index-build batch (one row tile per workgroup) and the
+    32 768-passage batch of evaluators.embed_corpus (two row tiles): the call that gathers layer 0's projections from the
+    projected table returns the bits of the call that projects its own tokens (tt_encoder_forward_prepared_f32, checked against
+    the oracle at these sizes above), for every row."""
+    import bench
+    dev = torch.device("cuda:0")
+    inp = bench.make_encoder_inputs(dev, with_index_batch=B >= 8192)
+    m = inp["model"]
+    m.eval()
+    if B >= 8192:
+        big = inp["big"]
+        ids = torch.cat([big] * (B // 8192), 0) if B > 8192 else big
+        enc = m.doc_encoder
+    else:
+        ids, enc = inp["q"][:B], m.query_encoder
+    ids = ids.to(dev)
+    assert ids.shape[0] == B
+    with torch.no_grad():
+        enc.projected_table = False
+        plain = enc(ids).clone()
+        enc.projected_table = None                      # auto: the table is frozen and fits
+        proj = enc(ids)
+        torch.cuda.synchronize()
+    assert dev in enc._proj and enc._proj[dev][1].numel() == bench.ENC_V * 3 * bench.ENC_H * 4
+    assert torch.equal(proj, plain)

@@ -1,0 +1,168 @@
+"""The projected table (include/tt.h: tt_encoder_project_table_f32 / tt_encoder_forward_projected_f32): at inference layer 0's
+input projection of a token, table[id] W_ih^T + b_ih (backend/model.py:49, :59-62), depends on the id alone once the table is
+frozen (model.py:25-27), so it is computed once for every vocabulary row and the recurrence kernels gather it.  The contract is
+BIT-IDENTITY with the call that projects the batch's tokens itself, for every recurrence kernel that gathers (column-split,
+one tile per workgroup, two tiles per workgroup), every layer shape, and through every change of the weights."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+import synth
+from conftest import assert_fwd_close
+from test_encoder_gpu import make_encoder
+
+pytestmark = pytest.mark.gpu
+
+
+def both_ways(enc, ids):
+    """(projected, projecting per call) outputs of the same eval call; the encoder is left in auto mode."""
+    with torch.no_grad():
+        enc.projected_table = False
+        plain = enc(ids).clone()
+        enc.projected_table = True
+        proj = enc(ids).clone()
+    torch.cuda.synchronize()
+    assert ids.device in enc._proj, "the projected table was not built"
+    enc.projected_table = None
+    return proj, plain
+
+
+@pytest.mark.parametrize("B,T,E,H,layers,bi,one_wg", [
+    (1, 7, 300, 256, 1, False, False),      # a serving call: column-split recurrence
+    (70, 40, 300, 256, 1, False, False),
+    (70, 40, 300, 256, 1, False, True),     # the same on the one-workgroup kernel (one row tile)
+    (33, 17, 200, 256, 2, True, False),     # config.json's shape: both directions of layer 0 gather, layer 1 projects as before
+    (33, 17, 200, 256, 2, True, True),
+    (41, 30, 200, 128, 2, True, False),     # H = 128: one-workgroup kernel only
+    (1500, 12, 300, 256, 1, False, False),  # beyond the column-split kernel's batch: one tile per workgroup
+    (67, 21, 52, 128, 1, False, False),     # a shape the token-stationary K1 takes with few k-steps
+])
+def test_projected_forward_is_bit_identical(oracle, B, T, E, H, layers, bi, one_wg):
+    V, seed = 700, 4000 + B + H
+    enc, table, sd = make_encoder(V, E, H, seed, layers, bi)
+    enc.one_workgroup = one_wg
+    ids_np = synth.make_ids(seed + 3, B, T, V, zero_inside=0.05)
+    ids_np[0, 0] = V - 1                                    # the last row of the table is a row like any other
+    ids = torch.from_numpy(ids_np).cuda()
+    proj, plain = both_ways(enc, ids)
+    assert torch.equal(proj, plain)
+    if B <= 100:
+        o = oracle.encoder_forward(ids_np, table, synth.weight_quads(sd, layers, bi), H, layers, bi,
+                                   sd.get("projection.weight"), sd.get("projection.bias"), True)
+        assert_fwd_close(proj.cpu().numpy(), o, what="_projected")
+
+
+def test_auto_mode_projects_frozen_tables_only_and_follows_weight_changes():
+    import twotowermlretrieval_amd as tt
+    from twotowermlretrieval_amd.model import RNNEncoder
+    V, E, H = 300, 300, 256
+    enc, _, _ = make_encoder(V, E, H, 11)
+    ids = torch.from_numpy(synth.make_ids(12, 9, 14, V, zero_inside=0.05)).cuda()
+    assert enc.projected_table is None and not enc.embedding.weight.requires_grad
+    with torch.no_grad():
+        first = enc(ids).clone()
+    blob = enc._proj[ids.device][1]
+    assert blob.numel() == V * 3 * H * 4
+    with torch.no_grad():
+        assert torch.equal(enc(ids), first) and enc._proj[ids.device][1] is blob     # reused
+        enc.rnn.weight_ih_l0.mul_(0.5)                                                # W_ih changes: the table is stale
+        changed = enc(ids).clone()
+    assert enc._proj[ids.device][1] is not blob and not torch.equal(changed, first)
+    proj, plain = both_ways(enc, ids)
+    assert torch.equal(proj, plain) and torch.equal(proj, changed)
+    with torch.no_grad():
+        enc.embedding.weight[5:9] *= 1.5                                              # the table changes (in place: version counter)
+    proj2, plain2 = both_ways(enc, ids)
+    assert torch.equal(proj2, plain2)
+    # an optimizer step writes the weights through the flat buffer: noticed through mark_params_changed's version bump
+    enc.train()
+    opt = tt.FusedClipAdam(enc.parameters(), lr=1e-2, max_norm=1.0)
+    enc(ids).square().sum().backward()
+    opt.step()
+    enc.eval()
+    proj3, plain3 = both_ways(enc, ids)
+    assert torch.equal(proj3, plain3) and not torch.equal(proj3, proj2)
+    # a trainable table (no GloVe vectors, model.py:23-24) is not projected in auto mode, and other cells have no table at all
+    free = RNNEncoder(V, E, H).cuda().eval()
+    with torch.no_grad():
+        free(ids)
+    assert free.embedding.weight.requires_grad and not free._proj
+    lstm = RNNEncoder(V, E, H, pretrained_embeddings=synth.make_table(3, V, E), rnn_type="LSTM").cuda().eval()
+    lstm.projected_table = True
+    with torch.no_grad():
+        lstm(ids)
+    assert not lstm._proj
+
+
+def test_projected_call_reports_bad_input_like_the_reference_and_never_faults():
+    """ids outside [0,V) raise IndexError, a row of padding only raises RuntimeError (model.py:55-57) -- the gather reads
+    clamped rows meanwhile (include/tt.h: such rows produce finite garbage, never a fault)."""
+    V, E, H = 200, 300, 256
+    enc, _, _ = make_encoder(V, E, H, 21)
+    enc.projected_table = True
+    good = synth.make_ids(22, 40, 11, V)
+    with torch.no_grad():
+        enc(torch.from_numpy(good).cuda())
+        bad = good.copy(); bad[7, 2] = V + 1000
+        with pytest.raises(IndexError):
+            enc(torch.from_numpy(bad).cuda())
+        bad = good.copy(); bad[3, 1] = -5
+        with pytest.raises(IndexError):
+            enc(torch.from_numpy(bad).cuda())
+        empty = good.copy(); empty[39, :] = 0                     # the LAST row empty: its token offset is one past the packed ids
+        with pytest.raises(RuntimeError):
+            enc(torch.from_numpy(empty).cuda())
+        allpad = np.zeros((17, 6), dtype=np.int64); allpad[0, 0] = 3
+        with pytest.raises(RuntimeError):
+            enc(torch.from_numpy(allpad).cuda())
+        y = enc(torch.from_numpy(good).cuda())                    # and the next good call is unaffected
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(y).all())
+
+
+def test_projected_table_through_the_c_abi():
+    """The three exports as a C host would call them: sizes, build, forward; against tt_encoder_forward_prepared_f32."""
+    from twotowermlretrieval_amd import _lib
+    from twotowermlretrieval_amd.model import _ptr_array
+    L = _lib.lib()
+    V, E, H, B, T = 900, 300, 256, 37, 16
+    enc, _, _ = make_encoder(V, E, H, 31)
+    dev = torch.device("cuda:0")
+    st = torch.cuda.current_stream().cuda_stream
+    quads = [w.detach().contiguous() for quad in enc.rnn.quads() for w in quad]
+    wptr = _ptr_array(quads)
+    prepared = torch.empty(L.tt_encoder_prepared_bytes(E, H, 1, 0, 0), dtype=torch.uint8, device=dev)
+    _lib.check(L.tt_encoder_prepare_f32(E, H, 1, 0, 0, wptr, prepared.data_ptr(), prepared.numel(), st))
+    need = L.tt_encoder_projected_bytes(V, E, H, 0, 0)
+    assert need == V * 3 * H * 4 and L.tt_encoder_projected_bytes(V, E, 64, 0, 0) == 0 and L.tt_encoder_projected_bytes(V, E, H, 0, 1) == 0
+    P = torch.empty(need, dtype=torch.uint8, device=dev)
+    table = enc.embedding.weight.detach()
+    with pytest.raises(_lib.TTError):                              # too small a buffer is refused, not overrun
+        _lib.check(L.tt_encoder_project_table_f32(table.data_ptr(), V, E, H, 1, 0, 0, wptr, prepared.data_ptr(), P.data_ptr(), need - 256, st))
+    _lib.check(L.tt_encoder_project_table_f32(table.data_ptr(), V, E, H, 1, 0, 0, wptr, prepared.data_ptr(), P.data_ptr(), need, st))
+    # row v of the table = the projection K1 computes for a token with id v: check a few rows against fp64
+    Pf = P.view(torch.float32).view(V, 3 * H)
+    w_ih, b_ih = quads[0].double(), quads[2].double()
+    for v in (0, 1, V - 1, 431):
+        want = table[v].double() @ w_ih.t() + b_ih
+        assert float((Pf[v].double() - want).abs().max()) < 2e-6 * max(1.0, float(want.abs().max()))
+    ids = torch.from_numpy(synth.make_ids(32, B, T, V, zero_inside=0.05)).to(dev)
+    outs = []
+    for projected in (False, True):
+        ws_bytes = L.tt_encoder_workspace_bytes(B, T, E, H, 1, 0, 0, _lib.TT_ENC_PROJECTED if projected else 0, 0)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        out = torch.empty((B, H), dtype=torch.float32, device=dev)
+        status = torch.full((1,), 99, dtype=torch.int32, device=dev)
+        if projected:
+            _lib.check(L.tt_encoder_forward_projected_f32(ids.data_ptr(), B, T, P.data_ptr(), V, E, H, 1, 0, 0, wptr, prepared.data_ptr(),
+                                                          None, None, 1, 0, out.data_ptr(), ws.data_ptr(), ws.numel(), status.data_ptr(), st))
+        else:
+            _lib.check(L.tt_encoder_forward_prepared_f32(ids.data_ptr(), B, T, table.data_ptr(), V, E, H, 1, 0, 0, wptr, prepared.data_ptr(),
+                                                         None, None, 1, 0, out.data_ptr(), ws.data_ptr(), ws.numel(), status.data_ptr(), st))
+        torch.cuda.synchronize()
+        assert int(status.item()) == 0
+        outs.append((out, ws_bytes))
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert outs[1][1] < outs[0][1] - B * T * 3 * H * 4 + 4096        # a one-layer projected call needs no [tokens][3H] scratch

@@ -12,6 +12,8 @@ TT_OK, TT_ERR_BAD_SHAPE, TT_ERR_BAD_INDEX, TT_ERR_ZERO_LENGTH, TT_ERR_UNSUPPORTE
 TT_ENC_ONE_WORKGROUP = 0x100  # option bit of the encoder calls (include/tt.h)
 TT_ENC_PHASE_BEGIN, TT_ENC_PHASE_FINISH = 0x200, 0x400  # tt_encoder_forward_f32 in two halves
 TT_ENC_SEED_ON_DEVICE = 0x800  # dropout_seed is the address of a device uint64
+TT_ENC_F32 = 0x1000  # every product of the call on the fp32-MFMA kernels (the reference's own arithmetic)
+TT_ENC_PROJECTED = 0x2000  # tt_encoder_workspace_bytes: size for tt_encoder_forward_projected_f32
 TT_STEP_GATE_WORDS = 4
 
 
@@ -71,6 +73,10 @@ SIGNATURES = {
     "tt_encoder_prepare_f32": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "tt_encoder_forward_prepared_f32": (_i, [_vp, _i, _i, _vp, _i64, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp,
                                              _sz, _vp, _vp]),
+    "tt_encoder_projected_bytes": (_sz, [_i64, _i, _i, _i, _i]),
+    "tt_encoder_project_table_f32": (_i, [_vp, _i64, _i, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+    "tt_encoder_forward_projected_f32": (_i, [_vp, _i, _i, _vp, _i64, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp,
+                                              _sz, _vp, _vp]),
     "tt_encoder_backward_f32": (_i, [_vp, _i, _i, _vp, _i64, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _f, _u64, _vp, _vp,
                                      _vp, _vp, _vp, _vp, _sz, _i, _vp, _vp, _vp]),
     "tt_triplet_loss_f32": (_i, [_vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp]),

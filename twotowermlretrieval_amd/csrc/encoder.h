@@ -77,8 +77,10 @@ bool gru16x4_usable(int B, int H, int ndir); // this device has a CU for every m
 int gru16x4_launches(int B, int H, int ndir); // 1: both directions in one grid, 2: one launch per direction, 0: does not fit
 bool gru16x4_bwd_usable(int B, int H, int ndir);
 
+// projected: an inference call whose layer 0 reads its input projections from the projected table (encoder.hip): a
+// one-layer model then needs no [tokens][3H] scratch at all (11 GB at 32 768 passages)
 static inline EncLayout enc_layout(int B, int T, int E, int H, int L, int bidir, int train, int dropout = 0,
-                                   int cell = CELL_GRU)
+                                   int cell = CELL_GRU, bool projected = false)
 {
     EncLayout lo;
     lo.B = B; lo.T = T; lo.E = E; lo.H = H; lo.L = L; lo.ndir = bidir ? 2 : 1; lo.train = train;
@@ -114,7 +116,7 @@ static inline EncLayout enc_layout(int B, int T, int E, int H, int L, int bidir,
     lo.hfin = take(sizeof(float) * lo.ndir * B * H);
     lo.hid = take(sizeof(float) * B * H);
     for (int d = 0; d < 2; ++d) {
-        lo.gi[d] = d < lo.ndir ? take(sizeof(float) * lo.MT * ng * H) : 0;
+        lo.gi[d] = d < lo.ndir ? take((projected && !train && L == 1) ? 0 : sizeof(float) * lo.MT * ng * H) : 0;
         lo.wp[d] = d < lo.ndir ? take(sizeof(float) * ng * H * H) : 0;
         {
             const int in_w = E > lo.ndir * H ? E : lo.ndir * H;
@@ -219,6 +221,11 @@ struct GruParams {
     const int32_t *len, *tok_off, *perm;
     int B, H, out_ld;
     int slots; // workgroups resident at once (2 per CU): within one such round, long row groups pair with short ones
+    // Projected table (inference, layer 0; tt_encoder_project_table_f32): dir[].gi is then P[gi_rows][3H] = table W_ih^T + b_ih
+    // of EVERY vocabulary row and a token's projections are row gi_ids[packed token] of it (clamped to gi_rows - 1: the packed
+    // ids of a zero-length row are never written).  Null: dir[].gi is indexed by the packed token itself.  (f16-split GRU kernels only.)
+    const int32_t *gi_ids = nullptr;
+    unsigned gi_rows = 0;
 };
 
 struct GruBwdDir {

@@ -545,15 +545,17 @@ TT_EXPORT size_t tt_encoder_workspace_bytes(int B, int T, int E, int H, int num_
 {
     if (B <= 0 || T <= 0 || num_layers < 1 || num_layers > ENC_MAX_LAYERS || rnn_type < 0 || rnn_type > 2)
         return 0;
-    train = train < 0 ? 0 : (train & TT_ENC_TRAIN_MASK); // (the option bits above the mask do not change the layout)
-    return enc_layout(B, T, E, H, num_layers, bidirectional, train > 2 ? 2 : train, dropout, rnn_type).total;
+    const bool projected = train > 0 && (train & TT_ENC_PROJECTED) != 0;
+    train = train < 0 ? 0 : (train & TT_ENC_TRAIN_MASK); // (the other option bits above the mask do not change the layout)
+    return enc_layout(B, T, E, H, num_layers, bidirectional, train > 2 ? 2 : train, dropout, rnn_type, projected && train == 0).total;
 }
 
 // H = 128 / 256: the recurrence runs on the f16 matrix pipes with both operands split into fp16 hi + lo parts
-// (gru16.hip; fp32-grade accuracy at 3/16 of the fp32 MFMA time).  TT_GRU_F32=1 keeps the fp32-MFMA kernels.
-static bool enc_force_f32()
+// (gru16.hip; fp32-grade accuracy at 3/16 of the fp32 MFMA time).  The option bit TT_ENC_F32 of a call (include/tt.h) keeps
+// every product of that call on the fp32-MFMA kernels instead: the reference's own arithmetic (nn.GRU in fp32, model.py:31-37).
+static bool enc_force_f32(int flags = 0)
 {
-    return TT_AB_SWITCH(TT_GRU_F32, 0) != 0;
+    return (flags & TT_ENC_F32) != 0 || TT_AB_SWITCH(TT_GRU_F32, 0) != 0;
 }
 static bool enc_tiled_k1() // A/B switch: the tiled f16 GEMM instead of the token-stationary one
 {
@@ -579,10 +581,11 @@ __global__ __launch_bounds__(256) void pack2_kernel(const float *__restrict__ Wi
 } // namespace
 
 static int enc_pack_weights(int I, int H, int rnn_type, const float *const *w, unsigned *wih_max, unsigned *wmax, char *w16,
-                            char *wp, hipStream_t st)
+                            char *wp, hipStream_t st, bool f32 = false)
 {
     const int NGH = enc_gates(rnn_type) * H;
-    if (!enc_force_f32() && rnn_type == CELL_GRU && gru16_supported(H) && enc_rows16(NGH, I) && (I + 15) / 16 <= 19) {
+    f32 = f32 || enc_force_f32();
+    if (!f32 && rnn_type == CELL_GRU && gru16_supported(H) && enc_rows16(NGH, I) && (I + 15) / 16 <= 19) {
         // the north-star shape: two launches instead of four (both maxima, then both conversions)
         TT_RC_CHECK(tt_absmax2(w[0], (int64_t)NGH * I, wih_max, w[1], (int64_t)3 * H * H, wmax, st));
         const int nks = (I + 15) / 16;
@@ -591,7 +594,7 @@ static int enc_pack_weights(int I, int H, int rnn_type, const float *const *w, u
         TT_LAUNCH_CHECK();
         return TT_OK;
     }
-    if (!enc_force_f32()) {
+    if (!f32) {
         TT_RC_CHECK(tt_absmax(w[0], (int64_t)NGH * I, wih_max, st));
         if (enc_rows16(NGH, I)) {
             TT_RC_CHECK(tt_pack_frag16(w[0], NGH, I, wih_max, w16, st));
@@ -601,7 +604,7 @@ static int enc_pack_weights(int I, int H, int rnn_type, const float *const *w, u
             TT_RC_CHECK(tt_pack_rows16(w[0], NGH, I, wih_max, w16, w16 + (size_t)NGH * Kp * sizeof(uint16_t), st));
         }
     }
-    if (rnn_type == CELL_GRU && gru16_supported(H) && !enc_force_f32()) {
+    if (rnn_type == CELL_GRU && gru16_supported(H) && !f32) {
         TT_RC_CHECK(gru16_pack(w[1], H, wmax, wp, st));
     } else {
         hipLaunchKernelGGL(pack_whh_kernel, dim3(96), dim3(256), 0, st, w[1], H, enc_gates(rnn_type), (float *)wp);
@@ -676,33 +679,56 @@ TT_EXPORT int tt_encoder_prepare_f32(int E, int H, int num_layers, int bidirecti
     return TT_OK;
 }
 
+
+// ------------------------------------------------------------------ the projected table (inference)
+// With GloVe loaded the table is frozen (backend/model.py:25-27) and at inference W_ih is fixed too, so layer 0's input
+// projection of a token depends on its id alone: P[v] = table[v] W_ih^T + b_ih for every vocabulary row v, V x 3H floats per
+// direction (400 003 x 768 x 4 B = 1.23 GB for the north-star tower).  It is built by the launch the forward itself would make
+// (same kernel, same weight images and scale words, rows taken in order instead of through the packed ids; the token-stationary
+// kernel scales every row by its own power of two), so row v holds the bits K1 writes for a token with id v, and the
+// recurrence kernels gather their step's rows from it (GruParams::gi_ids): K1 -- half the index build's GPU time, and a
+// [tokens][3H] buffer written and read back -- is gone from inference.
+static bool enc_projected_supported(int H, int rnn_type)
+{
+    return rnn_type == CELL_GRU && gru16_supported(H) && !enc_force_f32();
+}
+static size_t enc_projected_dir_bytes(int64_t V, int H, int rnn_type)
+{
+    return tt_align_up(sizeof(float) * (size_t)V * enc_gates(rnn_type) * H, 256);
+}
+
 static int encoder_forward(const char *who, const int64_t *ids, int B, int T, const float *table, int64_t V, int E, int H,
                            int num_layers, int bidirectional, int rnn_type, const float *const *weights,
                            const void *prepared, const float *proj_w, const float *proj_b, int normalize, int train,
                            float dropout_p, uint64_t dropout_seed, float *out, void *workspace, size_t workspace_bytes,
-                           int32_t *status, hipStream_t st, const tt_enc_sync_t *sync = nullptr)
+                           int32_t *status, hipStream_t st, const tt_enc_sync_t *sync = nullptr, const void *projected = nullptr)
 {
     int rc = enc_check_shape(who, B, T, E, H, num_layers, V);
     if (rc != TT_OK)
         return rc;
-    if (train < 0 || (train & ~(TT_ENC_TRAIN_MASK | TT_ENC_ONE_WORKGROUP | TT_ENC_PHASE_BEGIN | TT_ENC_PHASE_FINISH | TT_ENC_SEED_ON_DEVICE)) ||
+    if (train < 0 || (train & ~(TT_ENC_TRAIN_MASK | TT_ENC_ONE_WORKGROUP | TT_ENC_PHASE_BEGIN | TT_ENC_PHASE_FINISH | TT_ENC_SEED_ON_DEVICE | TT_ENC_F32)) ||
         (train & TT_ENC_TRAIN_MASK) > 2 || ((train & TT_ENC_PHASE_BEGIN) && (train & TT_ENC_PHASE_FINISH)))
-        return tt_fail(TT_ERR_BAD_SHAPE, "%s: train=0x%x (0, 1 or 2, optionally | TT_ENC_ONE_WORKGROUP | one TT_ENC_PHASE_*)", who, train);
+        return tt_fail(TT_ERR_BAD_SHAPE, "%s: train=0x%x (0, 1 or 2, optionally | TT_ENC_ONE_WORKGROUP | one TT_ENC_PHASE_* | TT_ENC_F32)", who, train);
+    const bool force_f32 = enc_force_f32(train); // every product of this call on the fp32-MFMA kernels
+    if (force_f32)
+        prepared = nullptr; // (the prepared images are the f16-split kernels'; this path derives its own in the workspace)
     const bool one_wg = (train & TT_ENC_ONE_WORKGROUP) != 0; // the caller keeps the recurrences off the column-split kernels
     // the call in two halves (include/tt.h): BEGIN = everything in front of the first recurrence launch, FINISH = the rest
     const bool ph_begin = (train & TT_ENC_PHASE_BEGIN) != 0, ph_finish = (train & TT_ENC_PHASE_FINISH) != 0;
     // the dropout seed as the address of a device word the kernels read when they run (a captured step replays with new masks)
     const uint64_t *seed_dev = (train & TT_ENC_SEED_ON_DEVICE) ? (const uint64_t *)(uintptr_t)dropout_seed : nullptr;
     train &= TT_ENC_TRAIN_MASK;
-    if (!ids || !table || !weights || !out || (bidirectional && (!proj_w || !proj_b)))
+    if (!ids || (!table && !projected) || !weights || !out || (bidirectional && (!proj_w || !proj_b)))
         return tt_fail(TT_ERR_BAD_SHAPE, "%s: null pointer", who);
+    if (projected && (train || ph_begin || ph_finish || force_f32 || !enc_projected_supported(H, rnn_type)))
+        return tt_fail(TT_ERR_UNSUPPORTED, "%s: a projected table serves inference calls of the f16-split GRU (H = 128, 256) only", who);
     if (!(dropout_p >= 0.0f && dropout_p < 1.0f))
         return tt_fail(TT_ERR_BAD_SHAPE, "%s: dropout_p=%g", who, dropout_p);
     if (rnn_type < CELL_GRU || rnn_type > CELL_RNN)
         return tt_fail(TT_ERR_UNSUPPORTED, "%s: rnn_type=%d (0 GRU, 1 LSTM, 2 RNN)", who, rnn_type);
     const int NGH = enc_gates(rnn_type) * H;
     const bool drop = train && dropout_p > 0.0f && num_layers > 1;
-    const EncLayout lo = enc_layout(B, T, E, H, num_layers, bidirectional, train, drop, rnn_type);
+    const EncLayout lo = enc_layout(B, T, E, H, num_layers, bidirectional, train, drop, rnn_type, projected != nullptr);
     if (!workspace || workspace_bytes < lo.total || ((uintptr_t)workspace & 255))
         return tt_fail(TT_ERR_WORKSPACE, "%s: workspace %zu < %zu bytes (or not 256-B aligned)", who, workspace_bytes,
                        lo.total);
@@ -717,7 +743,7 @@ static int encoder_forward(const char *who, const int64_t *ids, int B, int T, co
     // Layer 0's zero fills ride on ONE launch in front of the prep kernels (each was its own ~5 us launch on the call's chain):
     // the status flags (when the prep kernels do not clear them themselves), the all-zero row behind layer 0's output
     // (training) and the split recurrence's hand-off slots.
-    const bool use16_early = rnn_type == CELL_GRU && gru16_supported(H) && !enc_force_f32();
+    const bool use16_early = rnn_type == CELL_GRU && gru16_supported(H) && !force_f32;
     const bool split0 = use16_early && lo.xch && !one_wg && gru16x4_usable(B, H, ndir);
     const bool fused_prep = B <= 1024 && (int64_t)B * T <= PREP_FUSED_MAX_IDS;
     if (!ph_finish) {
@@ -741,7 +767,6 @@ static int encoder_forward(const char *who, const int64_t *ids, int B, int T, co
     }
 
     const size_t lds = sizeof(float) * 2 * ENC_RB * (H + 4);
-    const bool force_f32 = enc_force_f32();
     const bool use16 = rnn_type == CELL_GRU && gru16_supported(H) && !force_f32;
     const EncPrepared pl = enc_prepared_layout(E, H, num_layers, bidirectional, rnn_type);
     const char *pb = (const char *)prepared;
@@ -792,13 +817,15 @@ static int encoder_forward(const char *who, const int64_t *ids, int B, int T, co
                 w16 = ws + lo.wih16[d];
                 wp = ws + lo.wp[d];
                 if (!(ph_finish && l == 0)) {
-                    rc = enc_pack_weights(I, H, rnn_type, w, wih_max, wmax, w16, wp, st);
+                    rc = enc_pack_weights(I, H, rnn_type, w, wih_max, wmax, w16, wp, st, force_f32);
                     if (rc != TT_OK)
                         return rc;
                 }
             }
             if (ph_finish && l == 0) {
                 rc = TT_OK; // (layer 0's projection was launched by the BEGIN half)
+            } else if (projected && l == 0) {
+                rc = TT_OK; // (every vocabulary row's projection is in the table: the recurrence gathers them by token id)
             } else if (!force_f32) {
                 // K1 on the f16 pipes (fp16 hi/lo split, fp32-grade; sgemm.h): W_ih is scaled by the power of two
                 // that puts its largest element in [2^13, 2^14); deeper layers' A rows are hidden states in (-1, 1) (times
@@ -831,6 +858,11 @@ static int encoder_forward(const char *who, const int64_t *ids, int B, int T, co
             if (rc != TT_OK)
                 return rc;
             gp.dir[d].gi = (const float *)(ws + lo.gi[d]);
+            if (projected && l == 0) {
+                gp.dir[d].gi = (const float *)((const char *)projected + (size_t)d * enc_projected_dir_bytes(V, H, rnn_type));
+                gp.gi_ids = idsp;
+                gp.gi_rows = (unsigned)V;
+            }
             gp.dir[d].wp = (const float *)wp;
             gp.dir[d].wmax = wmax;
             gp.dir[d].b_hh = w[3];
@@ -946,9 +978,92 @@ TT_EXPORT int tt_encoder_forward_prepared_f32(const int64_t *ids, int B, int T, 
 {
     if (!prepared || ((uintptr_t)prepared & 255))
         return tt_fail(TT_ERR_WORKSPACE, "tt_encoder_forward_prepared_f32: prepared buffer null or not 256-B aligned");
-    if (opts & ~TT_ENC_ONE_WORKGROUP)
-        return tt_fail(TT_ERR_BAD_SHAPE, "tt_encoder_forward_prepared_f32: opts=0x%x (0 or TT_ENC_ONE_WORKGROUP)", opts);
+    if (opts & ~(TT_ENC_ONE_WORKGROUP | TT_ENC_F32))
+        return tt_fail(TT_ERR_BAD_SHAPE, "tt_encoder_forward_prepared_f32: opts=0x%x (0, TT_ENC_ONE_WORKGROUP, TT_ENC_F32)", opts);
     return encoder_forward("tt_encoder_forward_prepared_f32", ids, B, T, table, V, E, H, num_layers, bidirectional, rnn_type,
                            weights, prepared, proj_w, proj_b, normalize, /*train=*/0 | opts, 0.0f, 0, out, workspace,
                            workspace_bytes, status, (hipStream_t)stream);
+}
+
+TT_EXPORT size_t tt_encoder_projected_bytes(int64_t V, int E, int H, int bidirectional, int rnn_type)
+{
+    if (V <= 0 || V >= INT_MAX || E < 4 || (E & 3) || rnn_type < 0 || rnn_type > 2 || !enc_projected_supported(H, rnn_type))
+        return 0;
+    return (bidirectional ? 2 : 1) * enc_projected_dir_bytes(V, H, rnn_type);
+}
+
+TT_EXPORT int tt_encoder_project_table_f32(const float *table, int64_t V, int E, int H, int num_layers, int bidirectional,
+                                           int rnn_type, const float *const *weights, const void *prepared, void *projected,
+                                           size_t projected_bytes, tt_stream_t stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    int rc = enc_check_shape("tt_encoder_project_table_f32", 1, 1, E, H, num_layers, V);
+    if (rc != TT_OK)
+        return rc;
+    const size_t need = tt_encoder_projected_bytes(V, E, H, bidirectional, rnn_type);
+    if (need == 0)
+        return tt_fail(TT_ERR_UNSUPPORTED, "tt_encoder_project_table_f32: rnn_type=%d H=%d has no projected table (f16-split GRU: H = 128, 256)", rnn_type, H);
+    if (!table || !weights || !prepared || ((uintptr_t)prepared & 255))
+        return tt_fail(TT_ERR_BAD_SHAPE, "tt_encoder_project_table_f32: null pointer (or prepared not 256-B aligned)");
+    if (!projected || projected_bytes < need || ((uintptr_t)projected & 255))
+        return tt_fail(TT_ERR_WORKSPACE, "tt_encoder_project_table_f32: buffer %zu < %zu bytes (or null / not 256-B aligned)",
+                       projected_bytes, need);
+    const int ndir = bidirectional ? 2 : 1, NGH = enc_gates(rnn_type) * H;
+    const EncPrepared pl = enc_prepared_layout(E, H, num_layers, bidirectional, rnn_type);
+    const char *pb = (const char *)prepared;
+    for (int d = 0; d < ndir; ++d) {
+        const float *const *w = weights + (size_t)d * 4; // layer 0
+        SgemmParams g;
+        g.A = table;
+        g.a_map = nullptr; // rows in order: row v of the result is what a token with id v gets
+        g.B = w[0];
+        g.b_map = nullptr;
+        g.C = (float *)((char *)projected + (size_t)d * enc_projected_dir_bytes(V, H, rnn_type));
+        g.bias = w[2];
+        g.m_dyn = nullptr;
+        g.k_dyn = nullptr;
+        g.M = (int)V;
+        g.N = NGH;
+        g.K = E;
+        g.lda = E;
+        g.ldb = E;
+        g.ldc = NGH;
+        g.slab_stride = 0;
+        g.accumulate = 0;
+        g.a_absmax = nullptr;
+        g.a_exp = 0;
+        g.b_absmax = (const unsigned *)pb + 2 * d; // layer 0, direction d: max |W_ih| (tt_encoder_prepare_f32)
+        g.b_exp = 0;
+        g.b_hi16 = pb + pl.wih[0][d];
+        if (enc_rows16(NGH, E)) {
+            g.b_lo16 = nullptr;
+            g.ldb16 = 0;
+            g.a_row_scale = 1;
+            g.a_absmax_out = nullptr;
+            rc = tt_gemm_rows16(g, st);
+        } else {
+            const int Kp = (E + 31) / 32 * 32;
+            g.b_lo16 = pb + pl.wih[0][d] + (size_t)NGH * Kp * sizeof(uint16_t);
+            g.ldb16 = Kp;
+            rc = tt_sgemm16(g, false, false, 1, st);
+        }
+        if (rc != TT_OK)
+            return rc;
+    }
+    return TT_OK;
+}
+
+TT_EXPORT int tt_encoder_forward_projected_f32(const int64_t *ids, int B, int T, const void *projected, int64_t V, int E, int H,
+                                               int num_layers, int bidirectional, int rnn_type,
+                                               const float *const *weights, const void *prepared, const float *proj_w,
+                                               const float *proj_b, int normalize, int opts, float *out, void *workspace,
+                                               size_t workspace_bytes, int32_t *status, tt_stream_t stream)
+{
+    if (!prepared || ((uintptr_t)prepared & 255) || !projected || ((uintptr_t)projected & 255))
+        return tt_fail(TT_ERR_WORKSPACE, "tt_encoder_forward_projected_f32: prepared / projected buffer null or not 256-B aligned");
+    if (opts & ~TT_ENC_ONE_WORKGROUP)
+        return tt_fail(TT_ERR_BAD_SHAPE, "tt_encoder_forward_projected_f32: opts=0x%x (0 or TT_ENC_ONE_WORKGROUP)", opts);
+    return encoder_forward("tt_encoder_forward_projected_f32", ids, B, T, nullptr, V, E, H, num_layers, bidirectional, rnn_type,
+                           weights, prepared, proj_w, proj_b, normalize, /*train=*/0 | opts, 0.0f, 0, out, workspace,
+                           workspace_bytes, status, (hipStream_t)stream, nullptr, projected);
 }

@@ -436,8 +436,8 @@ TT_EXPORT int tt_encoder_backward_f32(const int64_t *ids, int B, int T, const fl
     int rc = enc_check_shape("tt_encoder_backward_f32", B, T, E, H, num_layers, V);
     if (rc != TT_OK)
         return rc;
-    if (opts & ~(TT_ENC_ONE_WORKGROUP | TT_ENC_SEED_ON_DEVICE))
-        return tt_fail(TT_ERR_BAD_SHAPE, "tt_encoder_backward_f32: opts=0x%x (0, TT_ENC_ONE_WORKGROUP, TT_ENC_SEED_ON_DEVICE)", opts);
+    if (opts & ~(TT_ENC_ONE_WORKGROUP | TT_ENC_SEED_ON_DEVICE | TT_ENC_F32))
+        return tt_fail(TT_ERR_BAD_SHAPE, "tt_encoder_backward_f32: opts=0x%x (0, TT_ENC_ONE_WORKGROUP, TT_ENC_SEED_ON_DEVICE, TT_ENC_F32)", opts);
     const bool one_wg = (opts & TT_ENC_ONE_WORKGROUP) != 0;
     if (!table || !weights || !d_out || !grads || (bidirectional && (!proj_w || !g_proj_w || !g_proj_b)))
         return tt_fail(TT_ERR_BAD_SHAPE, "tt_encoder_backward_f32: null pointer");
@@ -528,7 +528,7 @@ TT_EXPORT int tt_encoder_backward_f32(const int64_t *ids, int B, int T, const fl
     // (the "previous token" maps were made by the training forward's prep: csrc/encoder.hip)
 
     const size_t lds = sizeof(float) * ENC_RB * (H3 + 4);
-    const bool force_f32 = TT_AB_SWITCH(TT_GRU_F32, 0) != 0;
+    const bool force_f32 = (opts & TT_ENC_F32) != 0 || TT_AB_SWITCH(TT_GRU_F32, 0) != 0; // as the forward that filled the workspace
     const bool use16 = rnn_type == CELL_GRU && gru16_supported(H) && !force_f32; // (gru16.hip)
     const int n_rowgroups = (B + ENC_RB - 1) / ENC_RB;
     // the recurrence kernel's bias partial sums live in the split-K scratch (free while it runs): they must fit

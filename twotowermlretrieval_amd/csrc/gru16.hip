@@ -153,7 +153,11 @@ __global__ __launch_bounds__(256) void pack_whh16_kernel(const float *__restrict
 __device__ __forceinline__ float fast_sigmoid16(float x) { return tt_fast_sigmoid(x); }
 __device__ __forceinline__ float fast_tanh16(float x) { return tt_fast_tanh(x); }
 
-template <int H, int RT>
+// GATHER: the projections come from the projected table (GruParams::gi_ids): one more dependent load per row and step, the
+// id, asked for well ahead of the row loads that need it -- RT = 1: during the previous step (4 registers across the step
+// boundary); RT = 2: GI_AHEAD multiply groups in front of the tile's projection loads (no registers to spare at the boundary).
+// The arithmetic does not change: outputs are bit-identical to the same rows read from a [tokens][3H] buffer.
+template <int H, int RT, bool GATHER>
 __global__ __launch_bounds__(H / 32 * 64) void gru_seq16_kernel(GruParams p)
 {
     using C = G16<H, RT>;
@@ -227,14 +231,28 @@ __global__ __launch_bounds__(H / 32 * 64) void gru_seq16_kernel(GruParams p)
 
     const int H3 = 3 * H;
     int cur = 0;
+    // GATHER: grow = the projected-table rows of the step whose projections are loaded next
+    constexpr int GI_AHEAD = 5;
+    int grow[RT][4];
+    auto tok_at = [&](int rt, int e, int ss) {
+        const int t = d.reverse ? len_e[rt][e] - 1 - ss : ss;
+        return off_e[rt][e] + (ss < len_e[rt][e] ? t : 0);
+    };
+    auto load_ids = [&](auto rtc, int ss) {
+        constexpr int rt = decltype(rtc)::value;
+        if constexpr (GATHER) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                grow[rt][e] = p.gi_ids[tok_at(rt, e, ss)];
+        }
+    };
+    if constexpr (GATHER && RT == 1)
+        load_ids(std::integral_constant<int, 0>{}, 0);
     for (int s = 0; s < steps; ++s) {
         float giv[RT][3][2][4];
         // this step's token of row e of tile rt (a valid token even when the row is done); RT = 2 recomputes it where it is used
         // instead of keeping it through the multiply
-        auto token = [&](int rt, int e) {
-            const int t = d.reverse ? len_e[rt][e] - 1 - s : s;
-            return off_e[rt][e] + (s < len_e[rt][e] ? t : 0);
-        };
+        auto token = [&](int rt, int e) { return tok_at(rt, e, s); };
         // the input projections of this step's tokens: RT = 1 asks for them up front (24 registers that wait through the whole
         // multiply); RT = 2 has no registers for 48 of them there and asks late in the multiply (tile 0 behind group GI_Q0, tile 1
         // behind GI_Q1: they arrive while the last groups run)
@@ -242,7 +260,8 @@ __global__ __launch_bounds__(H / 32 * 64) void gru_seq16_kernel(GruParams p)
             constexpr int rt = decltype(rtc)::value;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float *row = d.gi + (size_t)token(rt, e) * H3 + unit[0];
+                const size_t gr = GATHER ? (size_t)min((unsigned)grow[rt][e], p.gi_rows - 1u) : (size_t)token(rt, e);
+                const float *row = d.gi + gr * H3 + unit[0];
 #pragma unroll
                 for (int g = 0; g < 3; ++g)
 #pragma unroll
@@ -250,8 +269,10 @@ __global__ __launch_bounds__(H / 32 * 64) void gru_seq16_kernel(GruParams p)
                         giv[rt][g][ct][e] = row[g * H + 16 * ct];
             }
         };
-        if constexpr (RT == 1)
+        if constexpr (RT == 1) {
             load_gi(std::integral_constant<int, 0>{});
+            load_ids(std::integral_constant<int, 0>{}, s + 1); // (GATHER) the next step's rows; s + 1 == steps reads a valid token's id
+        }
         f32x4v acc[RT][6]; // tile t = 2 g + ct
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt)
@@ -331,6 +352,10 @@ __global__ __launch_bounds__(H / 32 * 64) void gru_seq16_kernel(GruParams p)
                     ring[idx % C::NR] = frag_load(wsrc, loff, off);
                 }
             });
+            if constexpr (RT == 2 && q == C::GI_Q0 - GI_AHEAD)
+                load_ids(std::integral_constant<int, 0>{}, s);
+            if constexpr (RT == 2 && q == C::GI_Q1 - GI_AHEAD)
+                load_ids(std::integral_constant<int, RT - 1>{}, s);
             if constexpr (RT == 2 && q == C::GI_Q0)
                 load_gi(std::integral_constant<int, 0>{});
             if constexpr (RT == 2 && q == C::GI_Q1)
@@ -728,14 +753,22 @@ inline bool gru16_two_tiles(int B, int ndir)
     return (long)((B + ENC_RB - 1) / ENC_RB) * ndir >= (long)TT_G16_RT2_ROUNDS * cus;
 }
 
+template <int H, int RT, bool GATHER>
+int launch16g(const GruParams &gp, int ndir, hipStream_t st)
+{
+    using C = G16<H, RT>;
+    TT_HIP_CHECK(hipFuncSetAttribute((const void *)gru_seq16_kernel<H, RT, GATHER>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
+    hipLaunchKernelGGL((gru_seq16_kernel<H, RT, GATHER>), dim3((gp.B + ENC_RB * RT - 1) / (ENC_RB * RT), ndir), dim3(C::NW * 64), C::LDS_BYTES, st, gp);
+    TT_LAUNCH_CHECK();
+    return TT_OK;
+}
+
 template <int H, int RT>
 int launch16(const GruParams &gp, int ndir, hipStream_t st)
 {
-    using C = G16<H, RT>;
-    TT_HIP_CHECK(hipFuncSetAttribute((const void *)gru_seq16_kernel<H, RT>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
-    hipLaunchKernelGGL((gru_seq16_kernel<H, RT>), dim3((gp.B + ENC_RB * RT - 1) / (ENC_RB * RT), ndir), dim3(C::NW * 64), C::LDS_BYTES, st, gp);
-    TT_LAUNCH_CHECK();
-    return TT_OK;
+    if (gp.gi_ids && gp.gi_rows == 0)
+        return tt_fail(TT_ERR_BAD_SHAPE, "gru16_launch: projected table without rows");
+    return gp.gi_ids ? launch16g<H, RT, true>(gp, ndir, st) : launch16g<H, RT, false>(gp, ndir, st);
 }
 
 } // namespace

@@ -419,6 +419,9 @@ __device__ unsigned long long x4_dbg[16];
 #else
 #define X4_T(i) do { } while (0)
 #endif
+// GATHER: projections from the projected table (GruParams::gi_ids, gru16.hip): the id of a row's token at step s + 2 is asked
+// for at the top of step s, right behind the loads of step s + 1's projections that use the id fetched one step earlier.
+template <bool GATHER>
 __global__ __launch_bounds__(512, 1) void gru_seq16x4p_kernel(GruSplitParams sp)
 {
 #ifdef TT_X4_DBG
@@ -508,20 +511,33 @@ __global__ __launch_bounds__(512, 1) void gru_seq16x4p_kernel(GruSplitParams sp)
     __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): the resident fragments have landed (no such waits inside the loop)
     __syncthreads();
 
+    int nrow[2] = {0, 0}; // GATHER: the projected-table rows of the step gi_load is asked for next
+    auto tok_at = [&](int e, int s) {
+        const bool a = s < len_e[e];
+        const int t = d.reverse ? len_e[e] - 1 - s : s;
+        return off_e[e] + (a ? t : 0); // (a valid token even when the row is done)
+    };
+    auto id_load = [&](int s) {
+        if constexpr (GATHER) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+                nrow[e] = p.gi_ids[tok_at(e, s)];
+        }
+    };
     auto gi_load = [&](int s, float (&gv)[3][2]) {
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
-            const bool a = s < len_e[e];
-            const int t = d.reverse ? len_e[e] - 1 - s : s;
-            const size_t tk = (size_t)(off_e[e] + (a ? t : 0)); // (a valid token even when the row is done)
+            const size_t tk = GATHER ? (size_t)min((unsigned)nrow[e], p.gi_rows - 1u) : (size_t)tok_at(e, s);
 #pragma unroll
             for (int g = 0; g < 3; ++g)
                 gv[g][e] = d.gi[tk * H3 + g * H + unit];
         }
     };
     float giv[3][2], gnx[3][2];
+    id_load(0);
     if (steps > 0)
         gi_load(0, giv);
+    id_load(1);
     __builtin_amdgcn_s_waitcnt(0x0F70);
 
     int cur = 0;
@@ -535,8 +551,10 @@ __global__ __launch_bounds__(512, 1) void gru_seq16x4p_kernel(GruSplitParams sp)
             tok[e] = (size_t)(off_e[e] + (act[e] ? t : 0));
         }
         X4_T(0);
-        if (s + 1 < steps)
+        if (s + 1 < steps) {
             gi_load(s + 1, gnx); // in flight under this step's MFMAs and hand-off
+            id_load(s + 2);      // (GATHER) consumed at the top of the next step
+        }
         const char *img = lds + cur * 2 * XF_IMG + kq * XF_PLANE + j * XF_ROWB; // (row j, fragment lane group kq: conflict-free b128 reads)
         h8 a_hi[2], a_lo[2]; // by k-step parity
         a_hi[0] = *(const h8 *)(img);
@@ -1594,7 +1612,8 @@ int gru16x4_launch(const GruParams &gp, int ndir, void *xch, int32_t *status, hi
 #ifdef TT_AB
         TT_HIP_CHECK(hipFuncSetAttribute((const void *)gru_seq16x4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, X4_LDS + 16));
 #endif
-        TT_HIP_CHECK(hipFuncSetAttribute((const void *)gru_seq16x4p_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, XF_LDS + 16));
+        TT_HIP_CHECK(hipFuncSetAttribute((const void *)gru_seq16x4p_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, XF_LDS + 16));
+        TT_HIP_CHECK(hipFuncSetAttribute((const void *)gru_seq16x4p_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, XF_LDS + 16));
         attr_done = true;
     }
 #ifdef TT_X4_DBG
@@ -1613,15 +1632,20 @@ int gru16x4_launch(const GruParams &gp, int ndir, void *xch, int32_t *status, hi
         hipLaunchKernelGGL(gru_seq16x4_kernel, dim3((sp.nteams + 7) / 8 * 32, ndir), dim3(256), X4_LDS + 16, st, sp);
     else
 #endif
-    if (gru16x4_launches(gp.B, gp.H, ndir) == 2) { // one direction after the other, each with its own exchange slots
-        for (int d = 0; d < 2; ++d) {
-            GruSplitParams one = sp;
-            one.g.dir[0] = gp.dir[d];
-            one.xch = (char *)xch + (size_t)d * gru16x4_xch_bytes(gp.B, gp.H, 1);
-            hipLaunchKernelGGL(gru_seq16x4p_kernel, dim3((sp.nteams + 7) / 8 * 32, 1), dim3(512), XF_LDS + 16, st, one);
-        }
-    } else
-        hipLaunchKernelGGL(gru_seq16x4p_kernel, dim3((sp.nteams + 7) / 8 * 32, ndir), dim3(512), XF_LDS + 16, st, sp);
+    {
+        if (gp.gi_ids && gp.gi_rows == 0)
+            return tt_fail(TT_ERR_BAD_SHAPE, "gru16x4_launch: projected table without rows");
+        void (*const kern)(GruSplitParams) = gp.gi_ids ? gru_seq16x4p_kernel<true> : gru_seq16x4p_kernel<false>;
+        if (gru16x4_launches(gp.B, gp.H, ndir) == 2) { // one direction after the other, each with its own exchange slots
+            for (int d = 0; d < 2; ++d) {
+                GruSplitParams one = sp;
+                one.g.dir[0] = gp.dir[d];
+                one.xch = (char *)xch + (size_t)d * gru16x4_xch_bytes(gp.B, gp.H, 1);
+                hipLaunchKernelGGL(kern, dim3((sp.nteams + 7) / 8 * 32, 1), dim3(512), XF_LDS + 16, st, one);
+            }
+        } else
+            hipLaunchKernelGGL(kern, dim3((sp.nteams + 7) / 8 * 32, ndir), dim3(512), XF_LDS + 16, st, sp);
+    }
     TT_LAUNCH_CHECK();
     return TT_OK;
 }

@@ -168,8 +168,14 @@ class RNNEncoder(nn.Module):
 
     def __init__(self, vocab_size: int, embed_dim: int, hidden_dim: int,
                  pretrained_embeddings: Optional[np.ndarray] = None, rnn_type: str = "GRU", num_layers: int = 1,
-                 dropout: float = 0.0, bidirectional: bool = False, normalize_output: bool = True):
+                 dropout: float = 0.0, bidirectional: bool = False, normalize_output: bool = True, arith: str = "split16"):
+        """The reference's signature (backend/model.py:11-22) plus `arith`: "split16" (default: GRU towers with H = 128 / 256
+        take every product as three f16 MFMAs on fp16 hi/lo splits, fp32-grade) or "f32" (every product on the fp32-MFMA
+        kernels: nn.GRU's own fp32 arithmetic, include/tt.h TT_ENC_F32; also settable later as `encoder.arith`)."""
         super().__init__()
+        if arith not in ("split16", "f32"):
+            raise ValueError(f"arith={arith!r} (supported: 'split16', 'f32')")
+        self.arith = arith
         self.embedding = nn.Embedding(vocab_size, embed_dim, padding_idx=0)  # parameter owner only
         if pretrained_embeddings is not None:
             # every row is copied, row 0 included (it is the GloVe word "the"), and the table is frozen
@@ -191,6 +197,14 @@ class RNNEncoder(nn.Module):
         # inference keeps the weights in kernel form (tt_encoder_prepare_f32) until they change: see _prepared_weights
         self.cache_prepared = True
         self._prep: dict = {}
+        # inference, layer 0: the input projection of EVERY vocabulary row, computed once per weight version (the projected
+        # table, include/tt.h: tt_encoder_project_table_f32) and gathered by the recurrence kernels, instead of a GEMM over the
+        # batch's tokens in every call.  None = when it pays and is safe by construction: the table is frozen (GloVe loaded,
+        # backend/model.py:25-27), the configuration has one (GRU, H = 128 / 256) and it fits PROJECTED_MAX_BYTES
+        # (V x 3H x 4 bytes per direction: 1.23 GB for the north-star tower).  True / False force it on (any table: its version
+        # counter is part of the cache key) / off.  Results are bit-identical either way.
+        self.projected_table: Optional[bool] = None
+        self._proj: dict = {}
         self._deferred_status = None  # a list while a caller (trainer.train_step) batches the status reads
         # a list owned by an optimizer that watches this encoder (FusedClipAdam.watch): TRAINING calls hand their status words
         # over instead of raising here, and optimizer.step() decides -- together with the other ranks -- whether the step happens
@@ -206,15 +220,24 @@ class RNNEncoder(nn.Module):
             ps += [self.projection.weight, self.projection.bias]
         return ps
 
+    def _arith_bit(self) -> int:
+        return _lib.TT_ENC_F32 if self.arith == "f32" else 0
+
     def _opts(self) -> int:
-        return _lib.TT_ENC_ONE_WORKGROUP if self.one_workgroup else 0
+        return (_lib.TT_ENC_ONE_WORKGROUP if self.one_workgroup else 0) | self._arith_bit()
 
     def _opts_bwd(self) -> int:
         one = self.one_workgroup if self.one_workgroup_bwd is None else self.one_workgroup_bwd
-        return _lib.TT_ENC_ONE_WORKGROUP if one else 0
+        return (_lib.TT_ENC_ONE_WORKGROUP if one else 0) | self._arith_bit()
+
+    def split_workgroups(self, B: int) -> int:
+        """CUs the column-split recurrence of a B-row call of this encoder occupies (0: it runs the one-workgroup kernels)."""
+        if self.arith == "f32":
+            return 0
+        return _lib.lib().tt_encoder_split_workgroups(int(B), self.hidden_dim, int(self.bidirectional), self._cell)
 
     def _backward_may_time_out(self, B: int, opts: int) -> bool:
-        if opts & _lib.TT_ENC_ONE_WORKGROUP:
+        if opts & (_lib.TT_ENC_ONE_WORKGROUP | _lib.TT_ENC_F32):
             return False
         return _lib.lib().tt_encoder_split_workgroups(B, self.hidden_dim, int(self.bidirectional), self._cell) > 0
 
@@ -236,6 +259,42 @@ class RNNEncoder(nn.Module):
         storage (an optimizer's flat buffer: FusedClipAdam.mark_params_changed does the bump for its own), or through raw
         pointers."""
         self._prep = {}
+        self._proj = {}
+
+    PROJECTED_MAX_BYTES = 8 << 30
+
+    def _projected_table(self, device: torch.device, quads, wptr, prepared: torch.Tensor) -> Optional[torch.Tensor]:
+        """P[V, 3H] per direction = table W_ih^T + b_ih of layer 0, keyed on the table's and every weight's (address, version)."""
+        if self.projected_table is False or (self.projected_table is None and self.embedding.weight.requires_grad):
+            return None
+        table = self.embedding.weight
+        key = (table.data_ptr(), table._version) + tuple((w.data_ptr(), w._version) for w in quads)
+        ent = self._proj.get(device)
+        if ent is not None and ent[0] == key:
+            return ent[1]
+        if torch.cuda.is_current_stream_capturing():
+            return None
+        L = _lib.lib()
+        V, E = table.shape
+        need = L.tt_encoder_projected_bytes(V, E, self.hidden_dim, int(self.bidirectional), self._cell)
+        if need == 0 or (self.projected_table is None and need > self.PROJECTED_MAX_BYTES):
+            return None
+        with _PREP_LOCK:
+            ent = self._proj.get(device)
+            if ent is not None and ent[0] == key:
+                return ent[1]
+            # (the table this one replaces is dropped here: every call records its stream on the table it reads -- _run_forward --
+            #  so the caching allocator hands the 1.2 GB out again only when the calls queued on it have finished)
+            self._proj.pop(device, None)
+            del ent
+            blob = torch.empty(need, dtype=torch.uint8, device=device)
+            with torch.cuda.device(device):
+                _lib.check(L.tt_encoder_project_table_f32(table.detach().data_ptr(), V, E, self.hidden_dim, self.num_layers,
+                                                          int(self.bidirectional), self._cell, wptr, prepared.data_ptr(),
+                                                          blob.data_ptr(), blob.numel(), _stream(device)))
+                torch.cuda.current_stream(device).synchronize()  # once per weight version: any stream may read it now
+            self._proj[device] = (key, blob)
+        return blob
 
     def _prepared_weights(self, device: torch.device, quads, wptr) -> Optional[torch.Tensor]:
         """The weights converted once into what the forward kernels read (W_ih fp16 hi/lo fragment stream, packed W_hh,
@@ -285,8 +344,13 @@ class RNNEncoder(nn.Module):
         drop = int(train and dropout_p > 0.0 and self.num_layers > 1)
         # train = 2: the workspace also holds the gradient w.r.t. the gathered vectors (trainable embedding table)
         train_mode = (2 if self.embedding.weight.requires_grad else 1) if train else 0
+        quads = [w.detach().contiguous() for quad in self.rnn.quads() for w in quad]
+        wptr = _ptr_array(quads)
+        prepared = self._prepared_weights(ids.device, quads, wptr) if (
+            train_mode == 0 and self.cache_prepared and resume is None and not (opts & _lib.TT_ENC_F32)) else None
+        projected = self._projected_table(ids.device, quads, wptr, prepared) if prepared is not None else None
         need = L.tt_encoder_workspace_bytes(B, max(T, 1), E, H, self.num_layers, int(self.bidirectional), self._cell,
-                                            train_mode, drop)
+                                            train_mode | (_lib.TT_ENC_PROJECTED if projected is not None else 0), drop)
         # One workspace per call, from torch's caching allocator (a cached block: microseconds).  In train mode the
         # autograd node owns it; in eval mode a per-call buffer keeps concurrent callers apart -- the reference serves
         # queries from a thread pool (frontend/main.py:103), and a buffer shared across threads or streams would be
@@ -299,14 +363,18 @@ class RNNEncoder(nn.Module):
             # (not zeroed: every call that returns TT_OK WRITES the word on the stream -- include/tt.h, `status` -- and a call that
             #  does not raises below before anyone reads it; the fill was one more ~5 us launch in front of every tower call)
             status = torch.empty(1, dtype=torch.int32, device=ids.device)
-        quads = [w.detach().contiguous() for quad in self.rnn.quads() for w in quad]
-        wptr = _ptr_array(quads)
         pw = self.projection.weight.detach().contiguous() if self.projection is not None else None
         pb = self.projection.bias.detach().contiguous() if self.projection is not None else None
         table = self.embedding.weight.detach()
-        prepared = self._prepared_weights(ids.device, quads, wptr) if (train_mode == 0 and self.cache_prepared) else None
         with torch.cuda.device(ids.device):
-            if prepared is not None:
+            if projected is not None:
+                projected.record_stream(torch.cuda.current_stream(ids.device))
+                _lib.check(L.tt_encoder_forward_projected_f32(
+                    ids.data_ptr(), B, T, projected.data_ptr(), V, E, H, self.num_layers, int(self.bidirectional),
+                    self._cell, wptr, prepared.data_ptr(), pw.data_ptr() if pw is not None else None,
+                    pb.data_ptr() if pb is not None else None, int(self.normalize_output), opts, out.data_ptr(),
+                    ws.data_ptr(), ws.numel(), status.data_ptr(), _stream(ids.device)))
+            elif prepared is not None:
                 _lib.check(L.tt_encoder_forward_prepared_f32(
                     ids.data_ptr(), B, T, table.data_ptr(), V, E, H, self.num_layers, int(self.bidirectional),
                     self._cell, wptr, prepared.data_ptr(), pw.data_ptr() if pw is not None else None,
@@ -402,6 +470,7 @@ class TwoTowerModel(nn.Module):
             "dropout": config.get("DROPOUT", 0.0),
             "bidirectional": config.get("BIDIRECTIONAL", False),
             "normalize_output": config.get("NORMALIZE_OUTPUT", True),
+            "arith": config.get("ARITH", "split16"),   # (not a reference key: "f32" = every product on the fp32-MFMA kernels)
         }
         self.query_encoder = RNNEncoder(**encoder_args)
         self.doc_encoder = RNNEncoder(**encoder_args)

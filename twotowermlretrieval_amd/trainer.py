@@ -377,8 +377,8 @@ class _towers_in_flight:
         elif self.rows and encs[0].embedding.weight.is_cuda:
             L = _lib.lib()
             cus = torch.cuda.get_device_properties(encs[0].embedding.weight.device).multi_processor_count
-            self._need = {e: (0 if (e.one_workgroup and e.one_workgroup_bwd is not False) else L.tt_encoder_split_workgroups(
-                int(B), e.hidden_dim, int(e.bidirectional), e._cell)) for e, B in self.rows.items()}
+            self._need = {e: (0 if (e.one_workgroup and e.one_workgroup_bwd is not False) else e.split_workgroups(B))
+                          for e, B in self.rows.items()}
             self.needs_order = sum(self._need.values()) > cus
             if self.needs_order and any(e.num_layers > 1 for e in encs):
                 # stacked layers: the ordering event is recorded behind a call's LAST recurrence launch, i.e. behind ALL the layers
