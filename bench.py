@@ -194,6 +194,11 @@ def cpu_baseline(q_gpu, docs_gpu, enc_inputs=None):
     t64f = torch_ref.time_scoring_idiom(q64, dfull, TOPK, warmup=1, reps=3)
     legs["scoring_b64_n10m"] = {"value": round(64 / t64f, 2), "unit": "queries/s",
                                 "sample": f"B=64 x N={dfull.shape[0]} (2.6 GB score matrix), as run, median of 3 = {t64f:.3f} s"}
+    q1 = qs[:1].contiguous()
+    t1 = torch_ref.time_scoring_idiom(q1, dfull, TOPK, warmup=1, reps=5)
+    legs["scoring_b1_n10m"] = {"value": round(1 / t1, 2), "unit": "queries/s",
+                               "sample": f"B=1 x N={dfull.shape[0]} (the reference's serving batch, frontend/main.py:152), as run, "
+                                         f"median of 5 = {t1 * 1e3:.1f} ms per query"}
     del dfull, ds
     if enc_inputs is not None:
         table, q_ids, p_ids, n_ids = enc_inputs
@@ -216,6 +221,7 @@ def cpu_baseline(q_gpu, docs_gpu, enc_inputs=None):
 # ---- secondary metrics: synthetic MS-MARCO-shaped token batches, north-star model shape ----
 ENC_V, ENC_E, ENC_H = 400_003, 300, 256
 FLOP_PER_TOKEN_FWD = 2.0 * 3 * ENC_H * (ENC_E + ENC_H)             # input projection + recurrence
+FLOP_PER_TOKEN_REC = 2.0 * 3 * ENC_H * ENC_H                       # the recurrence alone (inference with the projected table)
 FLOP_PER_TOKEN_TRAIN = FLOP_PER_TOKEN_FWD + 2.0 * 3 * ENC_H * (ENC_E + 2 * ENC_H)  # + dW_ih, dW_hh, dh (table frozen)
 
 
@@ -566,8 +572,11 @@ def encoder_legs(dev):
         t_q = _time_gpu(lambda: m.encode_query(qd), 10, 3)
         t_big = _time_gpu(lambda: m.encode_document(bigd), 3, 1)
 
+    projected = dev in m.doc_encoder._proj and dev in m.query_encoder._proj
+    fpt = FLOP_PER_TOKEN_REC if projected else FLOP_PER_TOKEN_FWD
+
     def leg(tokens, t, extra):
-        tf = tokens * FLOP_PER_TOKEN_FWD / t / 1e12
+        tf = tokens * fpt / t / 1e12
         return {"tokens_per_s": round(tokens / t), "ms": round(t * 1e3, 3), "tokens": tokens,
                 "TFLOPs": round(tf, 2), "frac_f32_mfma": round(tf / MFMA_F32_PEAK_TFLOPS, 4),
                 "frac_f16_mfma_3x": round(3.0 * tf / MFMA_F16_PEAK_TFLOPS, 4), **extra}
@@ -575,9 +584,21 @@ def encoder_legs(dev):
            "arith": "fp32-grade: every product is three f16 MFMAs on fp16 hi/lo splits of the fp32 operands (DESIGN 4); "
                     "TFLOPs counts each fp32 multiply-add once, so frac_f32_mfma may exceed 1; frac_f16_mfma_3x = 3 x "
                     "TFLOPs / f16 peak is the share of the matrix pipes actually used",
+           "input_projection": ("projected table: table W_ih^T + b_ih of every vocabulary row computed once per weight version "
+                                f"({ENC_V * 3 * ENC_H * 4 / 1e9:.2f} GB per tower), gathered by the recurrence kernels -- the flops "
+                                "counted are the recurrence's only (2*3H*H per token)") if projected else "a GEMM over the batch's tokens in every call",
            "doc_tower_b512": leg(pt, t_doc, {"batch": B, "T": int(p.shape[1])}),
            "query_tower_b512": leg(qt, t_q, {"batch": B, "T": int(q.shape[1]), "queries_per_s": round(B / t_q)}),
            "index_build_b8192": leg(bt, t_big, {"batch": 8192, "T": int(big.shape[1]), "docs_per_s": round(8192 / t_big)})}
+    # one serving query (frontend/main.py:152: batch 1) and the index build's own batch size
+    with torch.no_grad():
+        q1 = qd[:1].contiguous()
+        t_q1 = _time_gpu(lambda: m.encode_query(q1), 50, 5)
+        big4 = torch.cat([bigd] * 4, 0)
+        t_b4 = _time_gpu(lambda: m.encode_document(big4), 3, 1)
+        del big4
+    enc["query_tower_b1"] = {"ms": round(t_q1 * 1e3, 4), "tokens": int((q1 != 0).sum())}
+    enc["index_build_b32768"] = leg(4 * bt, t_b4, {"batch": 32768, "T": int(big.shape[1]), "docs_per_s": round(32768 / t_b4)})
     m.train()
     opt = tt.FusedClipAdam(m.parameters(), lr=5e-5, max_norm=1.0)
     t_tr = _time_gpu(lambda: tt.train_step(m, opt, qd, pd, nd, margin=0.5), 5, 2)
@@ -766,6 +787,83 @@ def collective_legs(dev, rank, world, a):
     return legs
 
 
+class _SynthPassages:
+    """documents.pkl's list for a synthetic corpus too large to hold as Python strings: passage i is a window (start and length
+    derived from i) of ONE pre-generated stream of Zipf(1.07) words, ~Poisson(70) words long -- the same text every time it is
+    asked for, a few microseconds to produce (the serving leg times the reference's handler, not a text generator)."""
+
+    def __init__(self, n, words, seed=4):
+        import numpy as np
+        rs = np.random.RandomState(seed)
+        self.n = int(n)
+        self.stream = [words[j] for j in rs.zipf(1.07, 1 << 21) % len(words)]
+        self.lens = np.clip(rs.poisson(70, 1 << 16), 10, 250)
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, i):
+        i = int(i)
+        if not 0 <= i < self.n:
+            raise IndexError(i)
+        L = int(self.lens[i & 0xFFFF])
+        start = (i * 7919) % (len(self.stream) - 256)
+        return " ".join(self.stream[start:start + L])
+
+
+def serve_b1_leg(dev, index, n_queries=200, warm=20):
+    """The reference's /search handler with alpha != 0 (frontend/main.py:150-198) for ONE query, host clock, result on the host:
+    string -> tokenise -> query tower (QueryInferencer.get_query_embedding: a numpy vector, as the reference's) -> exact top-50
+    over the resident 10M-passage corpus (in place of Chroma's HNSW top-50) -> TF-IDF of the query against the 50 candidates'
+    texts (sklearn, CPU, as the reference) -> alpha blend -> top-10.  GloVe-size vocabulary, north-star tower, artifacts written
+    and read back through the reference's formats.  The only number the reference publishes is for this path: 0.32 s per query
+    on its author's machine, corpus size unknown -- context, not a like-for-like baseline."""
+    import tempfile
+    import numpy as np
+    import twotowermlretrieval_amd as tt
+    from sklearn.feature_extraction.text import TfidfVectorizer
+    from twotowermlretrieval_amd.evaluators import save_inference_artifacts
+    words = ["the", ",", ".", "of", "and"] + [f"w{i}" for i in range(5, ENC_V - 1)]
+    tok = tt.PretrainedTokenizer(word2idx={w: i for i, w in enumerate(words)})
+    cfg = {"HIDDEN_DIM": ENC_H, "NUM_LAYERS": 1, "BIDIRECTIONAL": False, "BATCH_SIZE": 64}
+    table = (np.random.RandomState(1).standard_normal((tok.vocab_size(), ENC_E)) * 0.3).astype(np.float32)
+    torch.manual_seed(0)
+    m = tt.TwoTowerModel({**cfg, "VOCAB_SIZE": tok.vocab_size(), "EMBED_DIM": ENC_E}, table).to(dev)
+    with tempfile.TemporaryDirectory() as d:
+        save_inference_artifacts(d, m, cfg, tok, ["w5 w6"], dev, tfidf=False)
+        del m, table
+        inf = tt.QueryInferencer(d, device=dev)
+    docs = _SynthPassages(index.ntotal, words)
+    vec = TfidfVectorizer(stop_words="english", max_features=20000).fit([docs[i] for i in range(0, 20000)])
+    hs = tt.HybridSearcher(inf, docs, tfidf_vectorizer=vec, doc_tfidf_matrix=None, n_candidates=50, index=index)
+    rs = np.random.RandomState(0)
+    queries = [" ".join(words[i] for i in (rs.zipf(1.07, rs.randint(3, 12)) % (ENC_V - 6)) + 5) for _ in range(n_queries + warm)]
+    lat, enc, srch = [], [], []
+    for i, qs in enumerate(queries):
+        t0 = time.perf_counter()
+        res = hs.search(qs, alpha=0.5, n_results=10)
+        t1 = time.perf_counter()
+        qv = torch.from_numpy(inf.get_query_embedding(qs)).to(dev)            # the stages again, separately
+        t2 = time.perf_counter()
+        index.search(qv, 50)[1].tolist()
+        t3 = time.perf_counter()
+        assert len(res) == 10
+        if i >= warm:
+            lat.append(t1 - t0); enc.append(t2 - t1); srch.append(t3 - t2)
+    lat, enc, srch = (np.array(x) * 1e3 for x in (lat, enc, srch))
+    del hs, inf
+    torch.cuda.empty_cache()
+    return {"what": "one query string -> top-10 of the hybrid rerank over the resident corpus (frontend/main.py:150-198 with the exact "
+                    "GPU top-50 in place of Chroma), host clock, result on the host",
+            "docs": index.ntotal, "queries": n_queries, "p50_ms": round(float(np.median(lat)), 3), "p99_ms": round(float(np.percentile(lat, 99)), 3),
+            "mean_ms": round(float(lat.mean()), 3), "queries_per_s_one_caller": round(1e3 / float(lat.mean()), 1),
+            "stage_p50_ms": {"tokenise_query_tower_to_numpy": round(float(np.median(enc)), 3),
+                             "exact_top50_to_host": round(float(np.median(srch)), 3),
+                             "tfidf_blend_on_cpu": round(float(np.median(lat) - np.median(enc) - np.median(srch)), 3)},
+            "reference_published_s_per_query": 0.32,
+            "reference_published_note": "README.md:9 screenshot: author's machine, corpus size unknown, Chroma HNSW top-50 (approximate)"}
+
+
 def launch_ranks(n: int) -> int:
     """`python bench.py --gpus N` from a bare shell: this parent makes NO GPU call; it starts N fresh rank processes
     (never an exec of itself), relays rank 0's JSON line and fails if any rank fails."""
@@ -951,6 +1049,11 @@ def main():
         #   index_build_from_strings  text -> tokeniser threads -> document tower, as a fraction of the GPU-only rate
         #   encoder, train  SURVEY 8d's secondary metrics (tower / index-build tokens/s, training triplets/s)
         roof["legs"] = {"hbm_screen": roof_hbm, "hbm_exact_f32": roof_hbm_f32, "mfma_exact_f32": roof_f32, **shared_legs}
+        if world == 1 and not a.no_secondary:
+            try:
+                roof["legs"]["serve_b1"] = serve_b1_leg(dev, local_index)
+            except Exception as e:  # noqa: BLE001 -- (sklearn missing, ...): say so in the line
+                roof["legs"]["serve_b1"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         enc_inputs = None
         # N = 1 only: these legs build optimizers and trainers on rank 0 alone, and with a process group up every such object is
         # a COLLECTIVE construction (FusedClipAdam(group=None) means the default group, as DDP's does): rank 0 would wait for

@@ -70,9 +70,14 @@ int tt_event_elapsed_ms(void *start, void *stop, float *ms); /* blocks until `st
  * Inputs must be finite (a NaN score is never selected).
  * Every wait between waves inside the kernels is bounded.  One of them cannot be skipped without losing documents (a wave
  * waiting ~2 us for a neighbour's draw from the shared tile pool, B >= 96 only): should its budget (~4 ms) ever run out, the
- * affected queries come back with out_val = +inf and out_idx >= TT_TOPK_INVALID_INDEX in their first places instead of a
- * silently incomplete result.  Never observed; a host that wants to be sure checks out_idx[.,0] < N.
+ * wave marks its partial lists (+inf, index >= TT_TOPK_INVALID_INDEX) and tt_score_topk_f32 itself redoes the affected
+ * 32-query tiles, on the device and on the stream, with the static split of the corpus (no pool, nobody to wait for): the
+ * results are complete and exact either way, and no caller has to look for the marker.  (Never observed outside the test that
+ * forces it.  tt_score_topk_partials_f32 hands its partial lists out as they are, marker included.)
  */
+/* Diagnostic: byte offset, in the workspace of a finished tt_score_topk_f32 call of this shape, of one int32 per 32-query tile
+ * that is non-zero when the tile was done again for that reason; (size_t)-1 = the shape never draws from a shared pool. */
+size_t tt_score_topk_redo_flags_offset(int B, int64_t N, int d, int k);
 /* Diagnostic: byte offset, in the workspace of a finished exact search of this shape, of an int32 counting the waves whose
  * chunk-pacing wait timed out (the pacing counters are coherent only among waves on one XCD: a launch whose chunks straddle
  * XCDs -- partition modes, tiny grids -- still returns exact results, each wave ~0.15 ms late once); (size_t)-1 = shape not paced. */
@@ -416,7 +421,7 @@ int tt_clip_adam_step_gated_f32(float *params, float *grads, float *exp_avg, flo
                                 float grad_scale, float *total_norm_out, const float *gate /*nullable*/, void *scratch,
                                 tt_stream_t stream);
 /*
- * gate[b] = number of the n_status status words (HOST array of DEVICE int32 pointers, n_status <= 8, null entries skipped)
+ * gate[b] = number of the n_status status words (HOST array of DEVICE int32 pointers, any number -- eight per launch --, null entries skipped)
  * that have bit b set, b = 0 .. 2 (tt_encoder_forward_f32's bits; the backward ORs bit 2 into the same words); gate[3] = 0.
  * One launch, on `stream`, behind the encoder calls it looks at.
  */

@@ -222,3 +222,38 @@ def test_wide_embeddings_16_query_tiles_bit_exact(oracle, d, B, N, k):
     assert np.array_equal(i.cpu().numpy(), oi) and np.array_equal(v.cpu().numpy(), ov)
     if N > 1000:
         assert list(oi[0][:2]) == [12, N // 2 + 5]
+
+
+def test_a_wave_that_gives_up_its_pool_draw_is_redone_on_the_device(tt, oracle):
+    """The one wait of the exact kernel that cannot be skipped without losing documents (a wave waiting for a chunk-mate's draw
+    from the shared tile pool, B >= 96) is bounded; a wave whose budget runs out marks its lists (+inf, TT_TOPK_INVALID_INDEX)
+    and tt_score_topk_f32 redoes the affected query tiles on the static split, on the device (round 4's marker was read by
+    nobody: the merge would have ranked it first).  The comparison build forces the give-up for EVERY wave that did not draw
+    itself (TT_DRAW_POLLS=-1): the redo flags are then raised and the results are still the product run's, bit for bit, and the
+    oracle's."""
+    import ctypes as C
+    from conftest import ab_library
+    from twotowermlretrieval_amd import _lib
+    B, N, d, k = 200, 700_000, 128, 10
+    L = _lib.lib()
+    off = L.tt_score_topk_redo_flags_offset(B, N, d, k)
+    assert off != C.c_size_t(-1).value, "this shape should draw from a shared pool"
+    assert L.tt_score_topk_redo_flags_offset(32, N, d, k) == C.c_size_t(-1).value       # fewer than three query tiles: no pool
+    Q, D = synth.unit_rows(71, B, d), synth.unit_rows(72, N, d)
+    D[600_000] = Q[5]                                  # a document deep in the pool's part of the corpus is query 5's best
+    qd, dd = dev(Q), dev(D)
+    ws = torch.zeros(L.tt_score_topk_workspace_bytes(B, N, d, k), dtype=torch.uint8, device="cuda")
+    ntile = (B + 31) // 32
+    v0, i0 = tt.score_topk(qd, dd, k, 0, ws)
+    torch.cuda.synchronize()
+    assert int(ws[off:off + 4 * ntile].view(torch.int32).ne(0).sum()) == 0            # an ordinary run redoes nothing
+    with ab_library(TT_DRAW_POLLS=-1):
+        v1, i1 = tt.score_topk(qd, dd, k, 0, ws)
+        torch.cuda.synchronize()
+        redone = int(ws[off:off + 4 * ntile].view(torch.int32).ne(0).sum())
+    assert redone > 0, "the forced give-up did not happen"
+    assert torch.equal(i1, i0) and torch.equal(v1, v0)
+    assert int(i1.max()) < N and int(i1[5, 0]) == 600_000 and bool(torch.isfinite(v1).all())
+    for q in (0, 5, 199):
+        ov, oi = oracle.score_topk(Q[q:q + 1], D, k)
+        assert np.array_equal(i1[q].cpu().numpy(), oi[0]) and np.array_equal(v1[q].cpu().numpy(), ov[0]), q

@@ -4,6 +4,7 @@
 # only the kernel durations matter.  Interleaved with the product library on one box.
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 cp twotowermlretrieval_amd/libtt.so /tmp/libtt_keep.so
+trap 'cp /tmp/libtt_keep.so twotowermlretrieval_amd/libtt.so' EXIT   # (whatever ends the script: the package never stays on the experiment's wrong-results library)
 for rep in 1 2; do
   for v in product wgpre; do
     if [ $v = product ]; then cp /tmp/libtt_keep.so twotowermlretrieval_amd/libtt.so; else cp ab/libtt_$v.so twotowermlretrieval_amd/libtt.so; fi

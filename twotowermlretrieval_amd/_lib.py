@@ -37,6 +37,7 @@ SIGNATURES = {
     "tt_last_error": (C.c_char_p, []),
     "tt_score_topk_workspace_bytes": (_sz, [_i, _i64, _i, _i]),
     "tt_score_topk_pace_timeouts_offset": (_sz, [_i, _i64, _i, _i]),
+    "tt_score_topk_redo_flags_offset": (_sz, [_i, _i64, _i, _i]),
     "tt_score_topk_f32": (_i, [_vp, _i, _i, _vp, _i64, _i, _i64, _vp, _vp, _vp, _sz, _vp]),
     "tt_score_topk_partials_f32": (_i, [_vp, _i, _i, _vp, _i64, _i, _i64, _vp, _sz, _vp, _vp, _vp, _vp, _vp]),
     "tt_index_build_f16": (_i, [_vp, _i64, _i, _vp, _vp, _vp]),

@@ -87,6 +87,7 @@ struct ScoreParams {
     const float *thr0;  // optional per-query lower bound of the final k-th score
     int thr0_stride, thr0_off;
     const int *run_if;  // optional device predicate per 32-query tile: tile t is skipped while run_if[t] == 0
+    int draw_polls;     // bound of the wait for a chunk-mate's pool draw (DRAW_POLLS; the comparison build can force a give-up)
 };
 
 __device__ __forceinline__ int xcd_remap(int b, int nblk)
@@ -413,19 +414,24 @@ __global__ __launch_bounds__(WPB * 64, 2) void score_topk_kernel(ScoreParams p)
         if (lane == 0) {
             int *slot = p.grp_blk + (size_t)chunk * p.grp_maxseg + seg;
             int v = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            bool drew = false;
             if (v == 0) {
                 int expected = 0;
                 if (__hip_atomic_compare_exchange_strong(slot, &expected, -1, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
                                                          __HIP_MEMORY_SCOPE_AGENT)) {
                     v = atomicAdd(p.tail_ctr, 1) + 1;
                     __hip_atomic_store(slot, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    drew = true;
                 } else {
                     v = expected;
                 }
             }
             // the drawing wave is between its two atomics (it waits for nobody: ~2 us).  Bounded like every other cross-wave
-            // wait of the library: DRAW_POLLS sleeps (~4 ms) and the wave gives up -- its partial lists then say so (below)
-            for (int polls = 0; v < 0 && polls < DRAW_POLLS; ++polls) {
+            // wait of the library: DRAW_POLLS sleeps (~4 ms) and the wave gives up -- its partial lists then say so (below), and
+            // tt_score_topk_f32 redoes the wave's query tile on the static split, which waits for nobody
+            if (p.draw_polls < 0 && !drew) // (comparison build, TT_DRAW_POLLS=-1: every wave that did not draw itself gives up)
+                v = -1;
+            for (int polls = 0; v < 0 && polls < p.draw_polls; ++polls) {
                 __builtin_amdgcn_s_sleep(2);
                 v = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
@@ -477,7 +483,8 @@ __global__ __launch_bounds__(WPB * 64, 2) void score_topk_kernel(ScoreParams p)
         if (t < n)
             c = cand_load_l2(p.cand + ((size_t)task * 32 + q) * CAP + t);
         // a wave that gave up a pool draw has not seen every document: its lists carry (+inf, TT_TOPK_INVALID_INDEX + t),
-        // which the merge ranks first -- the results for these queries are visibly invalid instead of silently short
+        // which the merge ranks first -- tt_score_topk_f32 looks for them in the merged lists and redoes those query tiles
+        // (redo_flag_kernel below); a caller of the partials entry point sees them as they are
         p.pval[o] = gave_up ? INFINITY : c.v;
         p.pidx[o] = gave_up ? (int64_t)TT_TOPK_INVALID_INDEX + t : (t < n ? p.idx_offset + c.x : -1);
     }
@@ -1095,6 +1102,7 @@ struct Plan {
     int pace_g, pace_lag;
     int grp_maxseg;
     size_t pace_off, grp_off, ctr_bytes; // ctr_bytes: pool counter(s) + pacing + draws, zeroed together before the main pass
+    size_t redo_off; // one int per query tile: a wave of the tile gave up a pool draw -> the static-split pass redoes the tile
 };
 
 int device_cus()
@@ -1221,6 +1229,8 @@ Plan make_plan(int B, int64_t N, int k, int d)
         }
     }
     pl.ctr_bytes = off - pl.tailctr_off;
+    pl.redo_off = off;
+    off = tt_align_up(off + (size_t)pl.main.n_qtiles * sizeof(int), 256);
     pl.ws_bytes = off;
     return pl;
 }
@@ -1331,6 +1341,7 @@ ScoreParams pass_params(const Pass &ps, const float *Q, int B, const float *D, i
     sp.thr0_stride = 0;
     sp.thr0_off = 0;
     sp.run_if = nullptr;
+    sp.draw_polls = TT_AB_SWITCH(TT_DRAW_POLLS, DRAW_POLLS);
     return sp;
 }
 
@@ -1417,6 +1428,16 @@ TT_EXPORT size_t tt_score_topk_pace_timeouts_offset(int B, int64_t N, int d, int
     return pl.paced ? pl.pace_off + (size_t)pl.main.n_chunks * PACE_R * sizeof(int) : (size_t)-1;
 }
 
+// Diagnostic: byte offset of the per-query-tile flags (int32 each) that say which tiles the last tt_score_topk_f32 call of this
+// shape did again because a wave had given up a pool draw; (size_t)-1 = the shape never draws from a shared pool.
+TT_EXPORT size_t tt_score_topk_redo_flags_offset(int B, int64_t N, int d, int k)
+{
+    if (B <= 0 || N <= 0 || k <= 0)
+        return (size_t)-1;
+    const Plan pl = make_plan(B, N, k, d);
+    return (pl.paced && pl.main.tail_blocks > 0) ? pl.redo_off : (size_t)-1;
+}
+
 TT_EXPORT size_t tt_score_topk_workspace_bytes(int B, int64_t N, int d, int k)
 {
     if (B <= 0 || N < 0 || k <= 0)
@@ -1442,6 +1463,18 @@ TT_EXPORT int tt_score_topk_partials_f32(const float *Q, int B, int d, const flo
         *part_m = pl.main.n_chunks * k;
     return TT_OK;
 }
+
+namespace {
+// flags[t] = 1 when a query of 32-query tile t came out of the merge with the give-up marker in its first place
+__global__ __launch_bounds__(64) void redo_flag_kernel(const int64_t *__restrict__ out_idx, int B, int k, int qt, int *__restrict__ flags)
+{
+    const int t = blockIdx.x, q = t * qt + threadIdx.x;
+    const bool bad = threadIdx.x < qt && q < B && out_idx[(size_t)q * k] >= (int64_t)TT_TOPK_INVALID_INDEX;
+    const unsigned long long any = __ballot(bad);
+    if (threadIdx.x == 0)
+        flags[t] = any != 0ull;
+}
+} // namespace
 
 // Exact path, optionally predicated on a device flag (the screened path's fallback).
 int tt_score_topk_f32_pred(const float *Q, int B, int d, const float *D, int64_t N, int k, int64_t idx_offset,
@@ -1485,6 +1518,18 @@ int tt_score_topk_f32_pred(const float *Q, int B, int d, const float *D, int64_t
                        (const int64_t *)(ws + pl.pidx_off), pl.main.n_chunks * k, k, out_val, out_idx, run_if,
                        pl.main.n_chunks * k, (size_t)0);
     TT_LAUNCH_CHECK();
+    if (!run_if && pl.paced && pl.main.tail_blocks > 0 && tt_score_pacing()) {
+        // The one wait of this path that cannot be skipped without losing documents is a wave's wait for a chunk-mate's pool
+        // draw; a wave whose budget ran out marked its lists (+inf, TT_TOPK_INVALID_INDEX + t).  Nothing downstream reads that
+        // marker, so it is dealt with HERE, on the device: the query tiles whose merged list starts with it are done again on
+        // the static split (the predicated form: no pool, no pacing, nobody to wait for) -- three small launches that find
+        // nothing to do in every run observed so far (~10 us behind a search of >= 4 ms).
+        int *redo = (int *)((char *)workspace + pl.redo_off);
+        const int qt = d > 256 ? 16 : 32;
+        hipLaunchKernelGGL(redo_flag_kernel, dim3(pl.main.n_qtiles), dim3(64), 0, st, (const int64_t *)out_idx, B, k, qt, redo);
+        TT_LAUNCH_CHECK();
+        return tt_score_topk_f32_pred(Q, B, d, D, N, k, idx_offset, out_val, out_idx, workspace, workspace_bytes, redo, st);
+    }
     return TT_OK;
 }
 

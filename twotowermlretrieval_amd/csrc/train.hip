@@ -254,25 +254,29 @@ namespace {
 struct GateWords {
     const int32_t *w[8];
 };
-__global__ void step_gate_kernel(GateWords g, int n, float *gate)
+__global__ void step_gate_kernel(GateWords g, int n, float *gate, int accumulate)
 {
     const int b = threadIdx.x; // 0 .. TT_STEP_GATE_WORDS - 1
     int count = 0;
     for (int i = 0; i < n; ++i)
         if (g.w[i] && b < 3 && ((*g.w[i] >> b) & 1))
             ++count;
-    gate[b] = (float)count;
+    gate[b] = (accumulate ? gate[b] : 0.0f) + (float)count;
 }
 } // namespace
 
 TT_EXPORT int tt_step_gate_f32(const int32_t *const *status_words, int n_status, float *gate, tt_stream_t stream)
 {
-    if (n_status < 0 || n_status > 8 || !gate || (n_status && !status_words))
-        return tt_fail(TT_ERR_BAD_SHAPE, "tt_step_gate_f32: n_status=%d (0..8), gate=%p", n_status, (void *)gate);
-    GateWords g = {};
-    for (int i = 0; i < n_status; ++i)
-        g.w[i] = status_words[i];
-    hipLaunchKernelGGL(step_gate_kernel, dim3(1), dim3(TT_STEP_GATE_WORDS), 0, (hipStream_t)stream, g, n_status, gate);
+    if (n_status < 0 || !gate || (n_status && !status_words))
+        return tt_fail(TT_ERR_BAD_SHAPE, "tt_step_gate_f32: n_status=%d, gate=%p", n_status, (void *)gate);
+    // any number of words (gradient accumulation over many tower calls), eight per launch (they travel as kernel arguments)
+    for (int base = 0; base == 0 || base < n_status; base += 8) {
+        GateWords g = {};
+        const int m = n_status - base < 8 ? n_status - base : 8;
+        for (int i = 0; i < m; ++i)
+            g.w[i] = status_words[base + i];
+        hipLaunchKernelGGL(step_gate_kernel, dim3(1), dim3(TT_STEP_GATE_WORDS), 0, (hipStream_t)stream, g, m, gate, base > 0);
+    }
     TT_LAUNCH_CHECK();
     return TT_OK;
 }

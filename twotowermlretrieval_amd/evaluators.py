@@ -108,20 +108,23 @@ def embed_corpus(model, tokenizer, documents: Sequence[str], device: torch.devic
     if stats is not None:
         stats.update(producers=producers, threads_per_producer=nt, host_cores=cores, batch_size=batch_size)
 
-    # a ring of pinned staging buffers, kept across calls: page-locking a fresh 15-30 MB block per batch (what a pinned
-    # torch.empty does whenever the host allocator has no free block of that size) costs more than tokenising the batch
+    # pinned staging buffers, kept across calls: page-locking a fresh 15-30 MB block per batch (what a pinned torch.empty does
+    # whenever the host allocator has no free block of that size) costs more than tokenising the batch.  A call OWNS its buffers:
+    # they are taken out of the process-wide pool for the call's duration (two builds at once -- or one that follows a build that
+    # died -- never stage into the same block) and handed back only when no producer and no copy can still touch them.
     import queue
     cap = batch_size * 160                      # int64 ids: ~21 MB per buffer at the default batch size
-    ring = _PINNED_RINGS.setdefault((str(device), cap), [])
-    while len(ring) < window + 6:
-        ring.append(torch.empty(cap, dtype=torch.int64, pin_memory=True))
+    ring_key = (str(device), cap)
+    mine = _take_staging(ring_key, window + 6, cap)
     free: "queue.SimpleQueue" = queue.SimpleQueue()
-    for buf in ring[:window + 6]:
+    for buf in mine:
         free.put(buf)
 
     def make(i):
         buf = free.get(timeout=120)             # (at most `window` jobs are outstanding and 3 batches in flight behind them; the
         #                                         time-out only ends a job whose consumer died: the pool's threads outlive the call)
+        if buf is None:                         # the call is over (it failed): nothing to stage into
+            raise RuntimeError("embed_corpus: the build this batch belonged to has ended")
         return tokenizer.encode_batch(documents[i[0]:i[1]], pin=True, n_threads=nt, out=buf, ids32=True), buf
 
     inflight = collections.deque()
@@ -136,12 +139,12 @@ def embed_corpus(model, tokenizer, documents: Sequence[str], device: torch.devic
         pool = _PRODUCER_POOLS[producers] = ThreadPoolExecutor(max_workers=producers, thread_name_prefix="tt-tok")
     with torch.no_grad():
         pending = collections.deque()
+        staged = collections.deque()     # batches whose copy to the device has been issued: (rows, ids, copy event, pinned, buf)
         nxt = 0
         try:
             while nxt < len(starts) and len(pending) < window:
                 pending.append((starts[nxt], pool.submit(make, starts[nxt])))
                 nxt += 1
-            staged = collections.deque()     # batches whose copy to the device has been issued: (rows, ids, copy event, pinned, buf)
 
             def stage(block: bool) -> bool:
                 """Issue the copy of the next tokenised batch (block: wait for its producer; else only if it is ready)."""
@@ -187,14 +190,58 @@ def embed_corpus(model, tokenizer, documents: Sequence[str], device: torch.devic
                     done[1].synchronize()
                     free.put(done[2])
         finally:
+            # Hand the staging buffers back only when nothing can write or read them any more: producer jobs that have not started
+            # are cancelled, the ones that are waiting for a buffer are released with a sentinel, the running ones are waited for
+            # (fut.cancel() does not stop a running job: it would go on writing into a block the next call already owns), and
+            # the copies / encoder calls queued on the device are drained.
             for _, fut in pending:
                 fut.cancel()
-    while inflight:
-        inflight.popleft()[1].synchronize()
+            for _ in pending:
+                free.put(None)
+            for _, fut in pending:
+                if not fut.cancelled():
+                    try:
+                        fut.result()
+                    except BaseException:  # noqa: BLE001 -- (its own failure, or the sentinel's: the call is ending anyway)
+                        pass
+            if pending or staged:          # (only after a failure: a completed build has consumed everything)
+                torch.cuda.synchronize(device)
+            while inflight:
+                inflight.popleft()[1].synchronize()
+            _give_staging(ring_key, mine)
     return res
 
 
+_STAGING_KEEP_BYTES = 768 << 20   # pinned host memory kept between builds (the default batch size's ring is 377 MB)
+
+
+def _take_staging(key, count: int, cap: int) -> list:
+    """`count` pinned int64 buffers of `cap` elements that belong to the caller until _give_staging: from the pool, else fresh."""
+    with _STAGING_LOCK:
+        pool = _PINNED_RINGS.setdefault(key, [])
+        mine = [pool.pop() for _ in range(min(count, len(pool)))]
+    while len(mine) < count:
+        mine.append(torch.empty(cap, dtype=torch.int64, pin_memory=True))
+    return mine
+
+
+def _give_staging(key, bufs: list) -> None:
+    """Back into the pool, most recently used size first; buffers beyond _STAGING_KEEP_BYTES (other batch sizes' first) are freed."""
+    with _STAGING_LOCK:
+        pool = _PINNED_RINGS.pop(key, [])
+        pool.extend(bufs)
+        _PINNED_RINGS[key] = pool          # (re-inserted: most recently used key last)
+        total = sum(b.numel() * 8 for p_ in _PINNED_RINGS.values() for b in p_)
+        for k in list(_PINNED_RINGS):
+            p_ = _PINNED_RINGS[k]
+            while p_ and total > _STAGING_KEEP_BYTES:
+                total -= p_.pop().numel() * 8
+            if not p_ and k != key:
+                del _PINNED_RINGS[k]
+
+
 _PINNED_RINGS: Dict = {}
+_STAGING_LOCK = __import__("threading").Lock()
 _PRODUCER_POOLS: Dict = {}
 
 

@@ -25,13 +25,22 @@ from .index import BruteForceIndex, score_all
 
 
 class HybridSearcher:
-    def __init__(self, inferencer, documents: Sequence[str], doc_embeddings: torch.Tensor, tfidf_vectorizer=None,
-                 doc_tfidf_matrix=None, n_candidates: int = 50, dense_score: str = "cosine"):
+    def __init__(self, inferencer, documents: Sequence[str], doc_embeddings: torch.Tensor = None, tfidf_vectorizer=None,
+                 doc_tfidf_matrix=None, n_candidates: int = 50, dense_score: str = "cosine", index: BruteForceIndex = None):
+        """documents: documents.pkl's list (row i of the embeddings <-> documents[i]); any object with __len__ and __getitem__
+        is used as it is (a corpus too large for a Python list: an mmap-backed or generated sequence), other iterables are
+        listed.  index: an existing BruteForceIndex over the embedding matrix instead of doc_embeddings (one is built otherwise)."""
         if dense_score not in ("cosine", "chroma_l2"):
             raise ValueError("dense_score must be 'cosine' or 'chroma_l2'")
+        if (index is None) == (doc_embeddings is None):
+            raise ValueError("HybridSearcher wants doc_embeddings or index (exactly one)")
         self.inferencer = inferencer
-        self.documents = list(documents)
-        self.index = BruteForceIndex(doc_embeddings, screen=True)  # single-query searches stream the fp16 shadow corpus
+        indexable = hasattr(documents, "__getitem__") and hasattr(documents, "__len__") and not isinstance(documents, (str, bytes))
+        self.documents = documents if indexable else list(documents)
+        # single-query searches stream the fp16 shadow corpus
+        self.index = index if index is not None else BruteForceIndex(doc_embeddings, screen=True)
+        if len(self.documents) != self.index.ntotal:
+            raise ValueError(f"{len(self.documents)} documents for {self.index.ntotal} embedding rows")
         self.n_candidates = int(n_candidates)
         self.dense_score = dense_score
         if tfidf_vectorizer is None:  # same construction as backend/main.py:142-143

@@ -138,7 +138,11 @@ class _FlatClipAdam:
         """The RNNEncoders inside `modules` hand the status words of their TRAINING calls to this optimizer instead of raising
         at the call: step() reduces them over the ranks with the gradients and raises -- on every rank -- what the reference
         would have raised.  DataParallelTrainer and train_step do this for their model; a hand-written loop around
-        FusedClipAdam(group=...) must, or a bad batch on one rank leaves the others waiting in the all-reduce."""
+        FusedClipAdam(group=...) must, or a bad batch on one rank leaves the others waiting in the all-reduce.
+        What a watched encoder hands over is EVERY grad-enabled forward since the last step(): all of them (any number:
+        gradient accumulation) decide the next step() together.  Forwards that belong to no step -- validation -- must run under
+        torch.no_grad() (as the reference's evaluators do, backend/evaluators.py:31), or their bad batch vetoes the next training
+        step instead of raising where it happened; unwatch() ends the hand-over."""
         from .model import RNNEncoder
         for mod in modules:
             for enc in mod.modules():
@@ -238,24 +242,32 @@ class _FlatClipAdam:
     def snapshot_gate(self, redo: Optional[Callable] = None) -> None:
         """Copy the (reduced) gate words of the step just enqueued to pinned host memory, asynchronously on the current stream, and
         make them THE pending check of this optimizer; the previous pending check -- whose step has long finished -- is settled
-        first (it raises here, one call late).  redo: called instead of raising when the words say "recurrence time-out"."""
-        self.settle()
+        afterwards (it raises here, one call late).  redo: called instead of raising when the words say "recurrence time-out".
+        Order matters: THIS step's copy is enqueued and registered first, so neither an exception out of the previous check nor
+        its redo (which runs a whole step: new gate words in the same device buffer) can lose it -- the copy is already in the
+        stream in front of anything the redo enqueues, and it stays pending for the next call's settle().  A redone step is
+        applied BEHIND the step enqueued in this call (it was skipped on the device when its turn came; the weights it now starts
+        from include this call's update): the order of two updates changes, none is lost."""
         if self._gate_host is None:
             self._gate_host = [torch.zeros(self.GATE, dtype=torch.float32).pin_memory() if self.gate.is_cuda
                                else torch.zeros(self.GATE, dtype=torch.float32) for _ in range(2)]
             self._gate_ev = [torch.cuda.Event() if self.gate.is_cuda else None for _ in range(2)]
-        slot = self._gate_n & 1
+        slot = self._gate_n & 1          # (the other slot holds the previous pending check, if there is one)
         self._gate_n += 1
         self._gate_host[slot].copy_(self.gate, non_blocking=True)
         if self._gate_ev[slot] is not None:
             self._gate_ev[slot].record(torch.cuda.current_stream(self.gate.device))
-        self._deferred = (slot, redo)
+        previous, self._deferred = self._deferred, (slot, redo)
+        self._settle_one(previous)
 
     def settle(self):
         """Look at the pending check, if any: raises what its step would have raised (IndexError / RuntimeError), or returns
         redo()'s result after a recurrence time-out, or None."""
-        from .model import SplitRecurrenceTimeout
         pending, self._deferred = self._deferred, None
+        return self._settle_one(pending)
+
+    def _settle_one(self, pending):
+        from .model import SplitRecurrenceTimeout
         if pending is None:
             return None
         slot, redo = pending
