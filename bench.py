@@ -993,7 +993,12 @@ def main():
         roof = {"bound": "mfma", "kernel": "screen_kernel<false> (f16 MFMA 16x16x32, fp32 accumulate)",
                 "achieved": round(flops / ms_s / 1e9, 2), "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(flops / ms_s / 1e9 / MFMA_F16_PEAK_TFLOPS, 4), "traffic": pmc_traffic("screen_b1024") if world == 1 else None,
-                "traffic_source": "static: committed rocprofv3 PMC pass (profiles/pmc_traffic.json), not this run",
+                "traffic_source": "static: committed rocprofv3 PMC passes, not this run -- " + str(pmc_traffic("_source"))[:60].split(" : ")[0],
+                # what the chip sustains on this kernel (committed SQ / GRBM pass over the same launch, profiles/pmc_traffic.json
+                # `_sq_source`): the share of cycles the matrix pipes are busy, and the clock it holds meanwhile -- the datasheet
+                # peak assumes 2400 MHz, so frac ~= mfma_busy x clock_MHz / 2400 (under the profiler the clock reads 2-3 % lower)
+                "mfma_busy": pmc_traffic("screen_b1024_mfma_busy") if world == 1 else None,
+                "clock_MHz": pmc_traffic("screen_b1024_clock_MHz") if world == 1 else None,
                 "kernel_ms": round(ms_s, 4), "batch": BATCH, "docs_per_gpu": n_shard,
                 "hbm_GBps_same_launch": round((-(-BATCH // 512) * n_shard * DIM * 2) / ms_s / 1e6, 1),
                 "exact_fallback_tiles": flags}

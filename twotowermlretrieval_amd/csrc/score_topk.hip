@@ -38,6 +38,10 @@ namespace {
 constexpr int TILE_DOCS = 32;
 constexpr int SLAB_BYTES = 32 * 128; // 32 docs x 32 f32
 constexpr int NSTAGE = 4;            // ring depth (slabs); NSTAGE-1 in flight
+#ifndef TT_K4_NT_NSTAGE
+#define TT_K4_NT_NSTAGE 4
+#endif
+constexpr int NSTAGE_NT = TT_K4_NT_NSTAGE; // the one-query-tile build's ring (its waves re-read nothing: more bytes in flight per CU)
 constexpr int WPB = 4;               // waves per block
 constexpr int DMA_PER_SLAB = 4;      // global_load_lds_dwordx4 per slab per wave
 constexpr int PACE_R = 16;            // pacing counter slots per chunk (> pace_lag + 1)
@@ -183,7 +187,8 @@ template <int NS, int CAP, bool MAXONLY, bool NT = false>
 __global__ __launch_bounds__(WPB * 64, 2) void score_topk_kernel(ScoreParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int WAVE_LDS = NSTAGE * SLAB_BYTES;
+    constexpr int NST = NT ? NSTAGE_NT : NSTAGE;
+    constexpr int WAVE_LDS = NST * SLAB_BYTES;
     constexpr int ROW_BYTES = NS * 128;
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -321,7 +326,7 @@ __global__ __launch_bounds__(WPB * 64, 2) void score_topk_kernel(ScoreParams p)
     if (t0 < t1) {
         set_rows(t0);
 #pragma unroll
-        for (int g = 0; g < NSTAGE - 1; ++g)
+        for (int g = 0; g < NST - 1; ++g)
             dma_issue(g);
 
         // read address: lane (i=j, h) wants logical chunk c of row i
@@ -335,17 +340,19 @@ __global__ __launch_bounds__(WPB * 64, 2) void score_topk_kernel(ScoreParams p)
             f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
-                // slab (tile,s) has landed once at most (NSTAGE-2) younger slabs are pending
+                // slab (tile,s) has landed once at most (NST-2) younger slabs are pending
                 // (candidate stores also count in vmcnt: they only make this wait stricter)
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_SLAB * (NSTAGE - 2)) : "memory");
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_SLAB * (NST - 2)) : "memory");
                 const char *buf = rd_row + stage * SLAB_BYTES;
                 f32x4 frag[8];
 #pragma unroll
                 for (int c = 0; c < 8; ++c)
                     frag[c] = *(const f32x4 *)(buf + ((c ^ rd_swz) << 4));
                 // the ring slot consumed one step ago is free once its reads have returned
+#ifndef TT_K4_NO_LGKM0
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                dma_issue((stage + NSTAGE - 1) % NSTAGE);
+#endif
+                dma_issue((stage + NST - 1) % NST);
 #pragma unroll
                 for (int c = 0; c < 8; ++c) {
                     float a0 = h ? frag[c].y : frag[c].x;
@@ -353,7 +360,7 @@ __global__ __launch_bounds__(WPB * 64, 2) void score_topk_kernel(ScoreParams p)
                     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, qreg[16 * s + 2 * c], acc, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, qreg[16 * s + 2 * c + 1], acc, 0, 0, 0);
                 }
-                stage = (stage + 1) % NSTAGE;
+                stage = (stage + 1) % NST;
             }
 
             // ---- epilogue: acc[r] = score(doc tile*32 + (r&3)+8(r>>2)+4h, query j) ----
@@ -1239,9 +1246,10 @@ template <int NS, int CAP, bool MAXONLY, bool NT = false>
 int launch_score_t(const ScoreParams &sp, const Plan &pl, hipStream_t st)
 {
     auto kern = score_topk_kernel<NS, CAP, MAXONLY, NT>;
-    TT_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.smem));
+    const size_t smem = NT ? (size_t)WPB * NSTAGE_NT * SLAB_BYTES : pl.smem;
+    TT_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     const int grid = (sp.n_tasks + WPB - 1) / WPB;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(WPB * 64), pl.smem, st, sp);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(WPB * 64), smem, st, sp);
     TT_LAUNCH_CHECK();
     return TT_OK;
 }
