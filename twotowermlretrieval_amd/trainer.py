@@ -335,6 +335,12 @@ def _concat_ids(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
 
 _ORDER_EVENTS = {}
 _TWO_PHASE = True   # (tools/experiments: False issues the query tower first instead of splitting the document tower's call)
+# How the two towers' FORWARD recurrences share the CUs when both column-split would not fit (tools/experiments/fwd_order_ab.py):
+#   "query_first"  the query tower's recurrence first, the document tower's waits for it (event inside the calls); default
+#   "doc_first"    the document tower's first, the query tower's waits (it has slack at the END of the step, none here: the
+#                  loss needs its output)
+#   "query_one_wg" no ordering: the query tower on the one-workgroup recurrence beside the document tower's split one
+_FWD_ORDER = "query_first"
 
 
 def _order_events(device):
@@ -478,10 +484,19 @@ def _train_step_direct(model: TwoTowerModel, optimizer, queries, pos_docs, neg_d
     s_main = cur if join_on_caller else s_doc     # where the towers meet: loss, optimizer
     ordered = plan is not None and plan.needs_order
     sync_f = sync_b = {}
+    fwd_opts = {}
+    two_phase = _TWO_PHASE
     if ordered:
         ev_f, ev_b = _order_events(dev)
         q_enc, d_enc = model.query_encoder, model.doc_encoder
-        sync_f = {id(q_enc): _lib.EncSync(None, ev_f), id(d_enc): _lib.EncSync(ev_f, None)}   # query records, document waits
+        if _FWD_ORDER == "doc_first":
+            sync_f = {id(d_enc): _lib.EncSync(None, ev_f), id(q_enc): _lib.EncSync(ev_f, None)}   # document records, query waits
+            two_phase = None
+        elif _FWD_ORDER == "query_one_wg":
+            fwd_opts[id(q_enc)] = q_enc._opts() | _lib.TT_ENC_ONE_WORKGROUP
+            two_phase = None
+        else:
+            sync_f = {id(q_enc): _lib.EncSync(None, ev_f), id(d_enc): _lib.EncSync(ev_f, None)}   # query records, document waits
         # (backward: no events -- the plan gave the smaller tower the one-workgroup recurrence, _towers_in_flight)
 
     def join():   # s_main waits for both towers
@@ -510,8 +525,8 @@ def _train_step_direct(model: TwoTowerModel, optimizer, queries, pos_docs, neg_d
         # work), the query tower (records behind its recurrence), FINISH (waits, then recurrence + head).
         fw = [None, None]
         begun = None
-        for k, half in (((0, _lib.TT_ENC_PHASE_BEGIN), (1, 0), (0, _lib.TT_ENC_PHASE_FINISH)) if (ordered and _TWO_PHASE) else
-                         (((1, 0), (0, 0)) if ordered else ((0, 0), (1, 0)))):
+        for k, half in (((0, 0), (1, 0)) if (not ordered or two_phase is None) else
+                        (((0, _lib.TT_ENC_PHASE_BEGIN), (1, 0), (0, _lib.TT_ENC_PHASE_FINISH)) if two_phase else ((1, 0), (0, 0)))):
             enc, ids, s = encs[k], ids_of[k], streams[k]
             if s is not cur and half != _lib.TT_ENC_PHASE_FINISH:
                 s.wait_stream(cur)
@@ -521,7 +536,7 @@ def _train_step_direct(model: TwoTowerModel, optimizer, queries, pos_docs, neg_d
                 seed = seeds[id(enc)]
                 # (the encoders are watched -- _towers_in_flight -- so the status word goes to the optimizer instead of a read here)
                 res = enc._run_forward(ids, train=True, dropout_p=p_drop, dropout_seed=seed, sync=sync_f.get(id(enc)) if half != _lib.TT_ENC_PHASE_BEGIN else None,
-                                       phase=half, resume=begun if half == _lib.TT_ENC_PHASE_FINISH else None)
+                                       phase=half, resume=begun if half == _lib.TT_ENC_PHASE_FINISH else None, opts=fwd_opts.get(id(enc)))
                 if half == _lib.TT_ENC_PHASE_BEGIN:
                     begun = res
                     continue
