@@ -30,7 +30,7 @@ m = tt.TwoTowerModel({"HIDDEN_DIM": H, "VOCAB_SIZE": tok.vocab_size(), "EMBED_DI
 embed_corpus(m, tok, docs[:20000], dev)
 torch.cuda.synchronize()
 from twotowermlretrieval_amd.tokenizer import host_cores
-for prod, tpp in ((0, 0), (1, 0), (1, 8), (2, 0), (4, 0), (2, 16), (3, 16), (0, 0)):
+for prod, tpp in [tuple(map(int, x.split("x"))) for x in (sys.argv[3].split(",") if len(sys.argv) > 3 else "0x0,1x0,1x8,2x0,4x0,2x16,3x16,0x0".split(","))]:
     st = {}
     embed_corpus(m, tok, docs, dev, producers=prod, threads_per_producer=tpp)
     torch.cuda.synchronize()

@@ -84,7 +84,9 @@ def embed_corpus(model, tokenizer, documents: Sequence[str], device: torch.devic
     table lookups, 16-byte slots on huge pages, the texts read in place (tt_tok_encode_ptrs: no join under the GIL): the native
     part does 590 M tokens/s on 8 threads and 1 050 M on 16 (tools/experiments/tok_harness.sh), every producer setting from
     1 x 16 to 4 x 4 builds at the GPU's rate (3.3-3.8 M passages/s, profiles/r04_w_index_build.log), and one producer with all
-    the threads is the fastest of them (fewer Python threads trading the GIL with the consumer).
+    the threads is the fastest of them (fewer Python threads trading the GIL with the consumer).  Round 5: with the projected
+    table the document tower consumes 9-10 M passages/s and the front end binds again; 1 x 16 builds at 5.0-5.5 M passages/s,
+    2 x 16 (the default from 12 cores up) at 6.7-7.7 M, 3 x 10 7.6 M, 4 x 8 6.5-6.7 M, 2 x 24 6.3 M (profiles/r05_g_index_build.log).
     batch_size 32 768: per-batch costs (launches, the copy's place in the queue, the recurrence's tail, two row tiles per workgroup
     from 16 384 passages up) amortise -- 1 M passages 3.55-3.67 M passages/s at 16 384 per batch, 3.89-3.92 M at 32 768, 3.83-3.90 at
     49 152 / 65 536 (tools/experiments/index_build_batch.py); 377 MB of pinned staging, ~10 GB of workspace.
@@ -98,8 +100,10 @@ def embed_corpus(model, tokenizer, documents: Sequence[str], device: torch.devic
     from .tokenizer import host_cores
     cores = host_cores()
     if producers <= 0:
-        producers = 1 if cores < 32 else 2
-    nt = threads_per_producer if threads_per_producer > 0 else max(1, min(16, cores // producers))
+        producers = 1 if cores < 12 else 2
+    # (two producers on a 16-core share take 16 threads EACH: a producer's native section uses the whole share while the other
+    #  is in its Python section -- text pointers, slicing, the hand-over)
+    nt = threads_per_producer if threads_per_producer > 0 else max(1, min(16, cores if producers <= 2 else 2 * cores // producers))
     # (a quarter- and a half-size first batch, so that the GPU starts sooner, was measured and dropped: 0.844 -> 0.848 of the
     #  GPU-only rate; what is left of the gap is the copies running beside the kernels -- 62 ms resident, 67 ms with the pinned
     #  batches copied on the side stream, 74 ms with the tokenising: tools/experiments/index_build_gap.py)
