@@ -238,6 +238,12 @@ def _streamed_worker(rank, world, port, tmp):
     mixed = tt.ShardedIndex(D[lo:hi].to(torch.float32).to(dev) if rank == 0 else D[lo:hi], lo, shard_k=50, screen=True,
                             block_docs=50000)
     assert mixed.streamed == (rank != 0) and mixed._seed_exchange is False
+    # the same rows resident on both ranks, PRODUCT DEFAULTS untouched: 150 k rows per shard is above SCREEN_MIN_DOCS, so the
+    # union-seed exchange is agreed on and runs (every other sharded test lowers the minimum to reach it with small corpora)
+    from twotowermlretrieval_amd import index as _index
+    assert _index.SCREEN_MIN_DOCS == 65536
+    rx = tt.ShardedIndex(D[lo:hi].to(torch.float32).to(dev), lo, shard_k=50, screen=True)
+    assert rx._seed_exchange is True and not rx.streamed
     for B in (7, 130):
         Q = torch.from_numpy(synth.unit_rows(42 + B, B, 256).copy())
         Q[0] = D[19].to(torch.float32)
@@ -245,8 +251,11 @@ def _streamed_worker(rank, world, port, tmp):
         pend = sx.submit(Q.to(dev), k=10)
         mv, mi = mixed.search(Q.to(dev), k=10)
         pv, pi = pend.result()
+        rv, ri = rx.search(Q.to(dev), k=10)
+        rpv, rpi = rx.submit(Q.to(dev), k=10).result()
         torch.cuda.synchronize()
         assert torch.equal(pv, v) and torch.equal(pi, i) and torch.equal(mv, v) and torch.equal(mi, i)
+        assert torch.equal(rv, v) and torch.equal(ri, i) and torch.equal(rpv, v) and torch.equal(rpi, i)
         res[f"v{B}"], res[f"i{B}"] = v.cpu().numpy(), i.cpu().numpy()
     np.savez(os.path.join(tmp, f"st{rank}.npz"), **res)
     dist.barrier()

@@ -50,6 +50,22 @@ def test_sharded_index_through_rccl(nccl_group, oracle, screen, B):
     assert np.array_equal(pi.cpu().numpy(), oi) and np.array_equal(pv.cpu().numpy(), ov)
 
 
+def test_streamed_shard_through_rccl(nccl_group, oracle):
+    """BASELINE configs[4]'s composition on a real RCCL communicator (one rank): the shard stays in host memory as bf16 rows, is
+    streamed through the GPU per search, and its list goes through tt_allgather_topk + the in-place merge."""
+    import twotowermlretrieval_amd as tt
+    D = torch.from_numpy(synth.unit_rows(8, 90_001, 256)).to(torch.bfloat16)
+    Q = synth.unit_rows(9, 70, 256)
+    idx = tt.ShardedIndex.from_host_bf16(D, shard_k=50, block_docs=32768)
+    assert idx.streamed and idx._seed_exchange is False and idx.collective.startswith("rccl-c-abi"), idx.collective
+    v, i = idx.search(torch.from_numpy(Q).cuda(), k=10)
+    pv, pi = idx.submit(torch.from_numpy(Q).cuda(), k=10).result()
+    torch.cuda.synchronize()
+    ov, oi = oracle.score_topk(Q, D.to(torch.float32).numpy(), 10)
+    assert np.array_equal(i.cpu().numpy(), oi) and np.array_equal(v.cpu().numpy(), ov)
+    assert torch.equal(pv, v) and torch.equal(pi, i)
+
+
 def test_fused_optimizer_allreduce_through_rccl(nccl_group):
     from twotowermlretrieval_amd.trainer import FusedClipAdam
     p = [torch.nn.Parameter(torch.randn(50, 7, device="cuda")), torch.nn.Parameter(torch.randn(9, device="cuda"))]

@@ -5,6 +5,8 @@
 #   gpurun_out/TAG_bench_profiled.json      the bench line of that same run
 #   gpurun_out/TAG_pmc_summary.txt          FETCH_SIZE / WRITE_SIZE per launch (separate --pmc passes, --kernel-trace only) over
 #                                           tools/screen_probe.py (B=1024; B=32) and tools/pmc_probe.py (K4 at B=32 and B=1024)
+#   gpurun_out/TAG_pmc_sq_summary.txt       SQ / GRBM pass over tools/screen_probe.py (B=1024): mfma_busy, clock_MHz (tools/pmc_sq_parse.py)
+#   then: python tools/pmc_traffic_update.py profiles/TAG_pmc_summary.txt profiles/TAG_pmc_sq_summary.txt  -> profiles/pmc_traffic.json
 TAG=${1:-evidence}
 OUT=gpurun_out
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
@@ -26,4 +28,10 @@ done
   done
 } > $OUT/${TAG}_pmc_summary.txt
 rm -rf $OUT/${TAG}_pmc_FETCH_SIZE_* $OUT/${TAG}_pmc_WRITE_SIZE_* $OUT/${TAG}_prof
+# matrix-pipe utilisation and clock of the headline kernel: ONE pass of SQ / GRBM counters (their own run, --kernel-trace only)
+rm -rf $OUT/${TAG}_sq
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $OUT/${TAG}_sq -- python3 tools/screen_probe.py 10000000 1024 > /dev/null 2>&1 || exit 7
+python3 tools/pmc_sq_parse.py $OUT/${TAG}_sq screen_kernel > $OUT/${TAG}_pmc_sq_summary.txt
+rm -rf $OUT/${TAG}_sq
+tail -1 $OUT/${TAG}_pmc_sq_summary.txt | cut -c1-400
 cat $OUT/${TAG}_pmc_summary.txt | grep -v "grid=.*mean=0.0$" | cut -c1-150

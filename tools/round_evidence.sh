@@ -8,7 +8,7 @@
 TAG=${1:-evidence}
 OUT=gpurun_out
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
-timeout -k 10 600 python -m pytest tests -m gpu -x -q > $OUT/${TAG}_tests.log 2>&1; rc=$?; tail -3 $OUT/${TAG}_tests.log; [ $rc = 0 ] || exit 2
+timeout -k 10 1000 python -m pytest tests -m gpu -x -q > $OUT/${TAG}_tests.log 2>&1; rc=$?; tail -3 $OUT/${TAG}_tests.log; [ $rc = 0 ] || exit 2
 cp $OUT/tolerance_report.json $OUT/${TAG}_tolerance_report.json 2>/dev/null
 timeout -k 10 300 python3 -c "import __graft_entry__ as g; g.smoke()" > $OUT/${TAG}_smoke.log 2>&1 || { tail -5 $OUT/${TAG}_smoke.log; exit 6; }
 tail -1 $OUT/${TAG}_smoke.log
@@ -17,6 +17,8 @@ python3 -c "
 import json; d = json.load(open('$OUT/${TAG}_bench_n1.json')); L = d['roofline']['legs']
 print('value', d['value'], 'ms/step', d['ms_per_step'], 'roofline.frac', d['roofline']['frac'], 'hbm_screen', L['hbm_screen']['frac'], 'hbm_exact', L['hbm_exact_f32']['frac'], 'mfma_exact', L['mfma_exact_f32']['frac'])
 print('train', L['train']['ms_per_step'], L['train'].get('graphed'))
+print('streamed_bf16', L.get('streamed_bf16', {}).get('achieved'), 'dp_train', L.get('dp_train', {}).get('ms_per_step'), 'serve_b1', {k: L.get('serve_b1', {}).get(k) for k in ('p50_ms', 'p99_ms', 'stage_p50_ms', 'error')})
+print('encoder', {k: (v.get('ms'), v.get('docs_per_s')) for k, v in L['encoder'].items() if isinstance(v, dict)})
 print('index_build_from_strings', L.get('index_build_from_strings'))
 print('cpu', d.get('cpu_baseline', {}).get('value'))"
 bash tools/collect_evidence.sh $TAG || exit 4
