@@ -5,7 +5,7 @@ products are compiled out of any one f16-split kernel (csrc/tt_common.h: TT_MUTA
     python tools/mutation_guard.py build        # here (no GPU): ab/libtt_mut{1,2,4,8,16}.so
     python tools/mutation_guard.py run          # on the GPU box: swaps each variant in, runs the encoder / training parity
                                                 # tests WITHOUT -x, restores the product library; writes
-                                                # gpurun_out/r04_mutation_guard.json with every failing test of every mutant
+                                                # gpurun_out/mutation_guard.json with every failing test of every mutant
 
 Exit code 0 = every mutant was caught by a test of the kind it damages (MUST_FAIL below: a forward test for the forward
 kernels, a GRADIENT test for the backward / weight-gradient kernels) AND the product library passes the same tests."""
@@ -62,5 +62,5 @@ try:
 finally:
     target.write_bytes(keep)
 (root / "gpurun_out").mkdir(exist_ok=True)
-(root / "gpurun_out" / "r04_mutation_guard.json").write_text(json.dumps(out, indent=1))
+(root / "gpurun_out" / "mutation_guard.json").write_text(json.dumps(out, indent=1))
 sys.exit(0 if ok else 1)
