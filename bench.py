@@ -12,6 +12,9 @@ oracle), and for N > 1 the per-shard top-50 lists are all-gathered over RCCL and
 global top-10 on every rank (strong scaling: the corpus is fixed, the shard shrinks with N).
 Rank 0 prints ONE JSON line.
 
+Legs EVERY rank executes after the timed loop (collectives; reported under `roofline.legs`): `streamed_bf16` (BASELINE configs[4]:
+each GPU's 12.5M-row bf16 shard streamed from pinned host DRAM through a ShardedIndex, GB/s per GPU against PCIe, resident variant
+beside it) and `dp_train` (BASELINE configs[2]: data-parallel triplet training, 512 triplets per GPU, all-reduce share).
 Extra legs on rank 0 (untimed w.r.t. `value`): `roofline` (the step's dominant kernel,
 screen_kernel<false>, timed alone with HIP events recorded around its launch) and, nested under `roofline.legs` so that
 the driver's record carries them: `mfma_exact_f32` (the plain fp32-MFMA kernel on the same batch), `hbm_screen` (a
@@ -22,7 +25,8 @@ MS-MARCO-shaped batches, each with its fp32-MFMA fraction), `encoder_corpus` (th
 document-tower outputs with query-tower outputs as queries: queries/s, what the filter let through, fallback count);
 and at N=1 `cpu_baseline` (the reference's torch CPU idioms: `value` = the bench batch on a 1M-document sample scaled
 x10; `cpu_baseline.legs` holds BASELINE.md section 2's rows run at their own sizes, incl. B=64 over all 10M documents,
-the 512-passage doc-tower forward and the 512-triplet train step).
+the 512-passage doc-tower forward and the 512-triplet train step, and B=1 over all 10M documents).  `serve_b1` (N = 1): one query
+string end to end through QueryInferencer + HybridSearcher over the resident corpus, p50 / p99.
 """
 from __future__ import annotations
 
@@ -671,7 +675,7 @@ def streamed_leg(dev, rank, world, n_shard=STREAM_DOCS_PER_GPU, iters=3):
     64 GB/s of a Gen5 x16 link; beside it the same shard widened once into HBM (it is 19.2 GB of 288) and searched resident."""
     import twotowermlretrieval_amd as tt
     lo = rank * n_shard
-    host = torch.empty((n_shard, DIM), dtype=torch.bfloat16).pin_memory()
+    host = torch.empty((n_shard, DIM), dtype=torch.bfloat16, pin_memory=True)
     for b0 in range(0, n_shard, GEN_BLOCK):
         b1 = min(n_shard, b0 + GEN_BLOCK)
         g = torch.Generator(device=dev).manual_seed(5000 + (lo + b0) // GEN_BLOCK)
