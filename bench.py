@@ -791,6 +791,34 @@ def collective_legs(dev, rank, world, a):
     return legs
 
 
+def resident_100m_leg(dev, n=100_000_000):
+    """BASELINE configs[4]'s WHOLE corpus (100M x 256) resident on ONE MI355X: fp32 rows + fp16 shadow = 153.6 GB of the 288 GB
+    (what the sharded / streamed forms are the alternative to).  Screened exact top-10 at the bench batch and a serving batch;
+    the serving batch is compared bit for bit with the plain fp32 kernel, planted documents must come back first."""
+    import twotowermlretrieval_amd as tt
+    D = gen_rows(0, n, dev)
+    Q = gen_queries(BATCH, dev, seed=12)
+    planted = torch.tensor([0, 77, n // 2 + 1, n - 1], device=dev)
+    D[planted] = Q[:4]
+    ix = tt.BruteForceIndex(D, screen=True)
+    out = {"docs": n, "hbm_GB": round(n * DIM * 6 / 1e9, 1), "what": "exact top-10 over 100M x 256 passages resident on one GPU (fp32 rows + fp16 shadow)"}
+    for B in (BATCH, 32):
+        q = Q[:B].contiguous()
+        t = time_search(ix, q, TOPK, iters=4, warm=2)
+        v, i = ix.search(q, TOPK)
+        ok = i[:4, 0].tolist() == planted.tolist() and bool((v[:, 1:] <= v[:, :-1]).all())
+        leg = {"search_ms": round(t, 3), "queries_per_s": round(B / t * 1e3, 1), "exact_fallback_tiles": int(ix.fallback_flags.ne(0).sum().item()),
+               "planted_first_and_sorted": ok}
+        if B == 32:
+            ev, ei = tt.score_topk(q, D, TOPK)
+            leg["identical_to_exact_f32"] = bool(torch.equal(v, ev) and torch.equal(i, ei))
+            leg["fp16_stream_GBps"] = round(n * DIM * 2 / t / 1e6, 1)
+        out[f"b{B}"] = leg
+    del ix, D
+    torch.cuda.empty_cache()
+    return out
+
+
 class _SynthPassages:
     """documents.pkl's list for a synthetic corpus too large to hold as Python strings: passage i is a window (start and length
     derived from i) of ONE pre-generated stream of Zipf(1.07) words, ~Poisson(70) words long -- the same text every time it is
@@ -1063,6 +1091,9 @@ def main():
                 roof["legs"]["serve_b1"] = serve_b1_leg(dev, local_index)
             except Exception as e:  # noqa: BLE001 -- (sklearn missing, ...): say so in the line
                 roof["legs"]["serve_b1"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+            free_b, total_b = torch.cuda.mem_get_info(dev)
+            if not a.no_encoder_corpus and free_b > 170e9:   # (153.6 GB + workspaces; a smaller card skips the leg)
+                roof["legs"]["resident_100m"] = resident_100m_leg(dev)
         enc_inputs = None
         # N = 1 only: these legs build optimizers and trainers on rank 0 alone, and with a process group up every such object is
         # a COLLECTIVE construction (FusedClipAdam(group=None) means the default group, as DDP's does): rank 0 would wait for
