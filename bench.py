@@ -1091,6 +1091,7 @@ def main():
                 roof["legs"]["serve_b1"] = serve_b1_leg(dev, local_index)
             except Exception as e:  # noqa: BLE001 -- (sklearn missing, ...): say so in the line
                 roof["legs"]["serve_b1"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+            torch.cuda.empty_cache()
             free_b, total_b = torch.cuda.mem_get_info(dev)
             if not a.no_encoder_corpus and free_b > 170e9:   # (153.6 GB + workspaces; a smaller card skips the leg)
                 roof["legs"]["resident_100m"] = resident_100m_leg(dev)
