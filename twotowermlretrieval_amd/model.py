@@ -214,6 +214,13 @@ class RNNEncoder(nn.Module):
         self.one_workgroup_bwd = None  # None: as one_workgroup; True / False: the reverse-time recurrence alone (any mix is valid)
 
     # ---- plumbing ---------------------------------------------------------------
+    def __getstate__(self):
+        """copy.deepcopy / pickling of the module leave the per-device caches behind (kernel-form weights, the 1.2 GB projected
+        table): the copy derives its own on first use."""
+        state = self.__dict__.copy()
+        state["_prep"], state["_proj"] = {}, {}
+        return state
+
     def _flat_params(self):
         ps = [w for quad in self.rnn.quads() for w in quad]
         if self.projection is not None:
