@@ -231,3 +231,26 @@ def test_seed_plan_of_a_sharded_search():
             if pl is not None:
                 ks, kth = pl
                 assert 1 <= ks <= k and kth == k and world * ks <= 512 and world * ks >= k
+
+
+def test_committed_pmc_traffic_json_follows_from_the_committed_counter_summaries(tmp_path):
+    """bench.py's `roofline.traffic`, `mfma_busy` and `clock_MHz` are read from profiles/pmc_traffic.json; that file must be what
+    tools/pmc_traffic_update.py derives from the rocprofv3 summaries its `_source` / `_sq_source` name (evidence chain: counters
+    -> summary -> json -> bench line), with the guide's gfx950 correction (FETCH_SIZE x 1024 x 2 + WRITE_SIZE x 1024)."""
+    import json, shutil, subprocess, sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    have = json.loads((root / "profiles" / "pmc_traffic.json").read_text())
+    src = root / have["_source"].split(" : ")[0]
+    sq = root / have["_sq_source"].split(" : ")[0]
+    assert src.exists() and sq.exists(), (src, sq)
+    (tmp_path / "profiles").mkdir()
+    for f in (src, sq):
+        shutil.copy(f, tmp_path / "profiles" / f.name)
+    subprocess.run([sys.executable, str(root / "tools" / "pmc_traffic_update.py"), f"profiles/{src.name}", f"profiles/{sq.name}"],
+                   cwd=tmp_path, check=True, capture_output=True)
+    again = json.loads((tmp_path / "profiles" / "pmc_traffic.json").read_text())
+    for k in ("b32", "b1024", "screen_b1024", "stream_b32", "screen_b1024_mfma_busy", "screen_b1024_clock_MHz"):
+        assert again[k] == have[k], k
+    # 5.12 GB fp16 shadow read about once; the busy share is the exact MFMA cycle count over SIMD-cycles
+    assert 1.0 <= have["screen_b1024"] / 5.12e9 < 1.2 and 0.5 < have["screen_b1024_mfma_busy"] < 1.0
