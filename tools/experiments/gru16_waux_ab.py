@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Interleaved A/B of the cache policy of gru_seq16_kernel's streamed W_hh fragment loads (-DTT_G16_W_AUX=n variants of the library,
+tools/build_variant.py) on the index build's document-tower calls (projected table: the recurrence is all of the call).
+    python tools/experiments/gru16_waux_ab.py product g16aux1 g16aux2 g16aux16"""
+import ctypes as C, json, sys, time
+from pathlib import Path
+ROOT = Path(__file__).resolve().parent.parent.parent
+sys.path.insert(0, str(ROOT))
+import torch
+import bench
+from twotowermlretrieval_amd import _lib
+
+
+def load(name):
+    if name == "product":
+        return _lib.lib()
+    lib = C.CDLL(str(ROOT / "ab" / f"libtt_{name}.so"))
+    for n, (res, args) in _lib.SIGNATURES.items():
+        fn = getattr(lib, n)
+        fn.restype, fn.argtypes = res, args
+    return lib
+
+
+def main():
+    names = sys.argv[1:] or ["product"]
+    dev = torch.device("cuda:0")
+    inp = bench.make_encoder_inputs(dev)
+    enc = inp["model"].eval().doc_encoder
+    big = inp["big"].to(dev)
+    cases = {"b8192": big, "b32768": torch.cat([big] * 4, 0)}
+    libs = {n: load(n) for n in names}
+    keep = _lib._lib
+    ref = {}
+    out = {n: {c: [] for c in cases} for n in names}
+    with torch.no_grad():
+        for rep in range(3):
+            for n in names:
+                _lib._lib = libs[n]
+                for c, ids in cases.items():
+                    for _ in range(2):
+                        y = enc(ids)
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for _ in range(4):
+                        y = enc(ids)
+                    torch.cuda.synchronize()
+                    out[n][c].append(round((time.perf_counter() - t0) / 4 * 1e3, 4))
+                    if c not in ref:
+                        ref[c] = y.clone()
+                    assert torch.equal(y, ref[c]), (n, c)
+    _lib._lib = keep
+    for n in names:
+        print(json.dumps({"variant": n, **{c: out[n][c] for c in cases}}), flush=True)
+
+
+if __name__ == "__main__":
+    main()

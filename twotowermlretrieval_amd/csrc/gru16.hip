@@ -36,9 +36,21 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // One B fragment (1 KiB per wave) through a buffer load: SGPR resource + ONE VGPR lane offset + a constant that the
 // compiler puts into the scalar / immediate offset fields.  (With flat 64-bit addresses hipcc hoists the ~60
 // per-fragment addresses of the unrolled step out of the loop: 120 VGPRs of pointers, and spills.)
+// Cache policy of the forward recurrence's per-step W_hh stream (tools/experiments/gru16_waux_ab.py, profiles/r05_k_gru16_waux.log,
+// interleaved on one box each): nt (aux 2) is 37-42 % SLOWER (1.11 -> 1.52 ms at 8 192 passages: the fragments must STAY in L2,
+// every workgroup of the XCD re-reads them every step); sc0 (1), sc1 (16: past the CU's L1) and sc0|sc1 (17) are within 1 % of the
+// default on a second box (a first box had sc1 4 % ahead with the variants in another order): no robust gain, default kept.
+#ifndef TT_G16_W_AUX
+#define TT_G16_W_AUX 0
+#endif
 __device__ __forceinline__ h8 frag_load(__amdgpu_buffer_rsrc_t rsrc, int lane_off, int byte_off)
 {
     return __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane_off, byte_off, 0));
+}
+// the per-step stream alone (the resident fragments are loaded once with the default policy)
+__device__ __forceinline__ h8 frag_stream(__amdgpu_buffer_rsrc_t rsrc, int lane_off, int byte_off)
+{
+    return __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane_off, byte_off, TT_G16_W_AUX));
 }
 
 #ifndef TT_G16_R
@@ -225,7 +237,7 @@ __global__ __launch_bounds__(H / 32 * 64) void gru_seq16_kernel(GruParams p)
         static_for<0, C::NR>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
             constexpr int off = P::value.sfrag[i] * 1024;
-            ring[i] = frag_load(wsrc, loff, off);
+            ring[i] = frag_stream(wsrc, loff, off);
         });
     __syncthreads();
 
@@ -349,7 +361,7 @@ __global__ __launch_bounds__(H / 32 * 64) void gru_seq16_kernel(GruParams p)
                 constexpr int kind = P::value.kind[f], idx = P::value.idx[f];
                 if constexpr (kind == K_STR) {
                     constexpr int off = P::value.sfrag[(idx + C::NR) % C::NS] * 1024;
-                    ring[idx % C::NR] = frag_load(wsrc, loff, off);
+                    ring[idx % C::NR] = frag_stream(wsrc, loff, off);
                 }
             });
             if constexpr (RT == 2 && q == C::GI_Q0 - GI_AHEAD)
