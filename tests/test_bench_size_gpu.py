@@ -114,10 +114,11 @@ def test_index_build_batch_b8192_rows_vs_oracle(oracle):
 
 
 def test_two_tile_batch_b16384_rows_vs_oracle_and_vs_the_b8192_call(oracle):
-    """From four rounds of 16-row workgroups up (16 384 rows on 256 CUs: evaluators.embed_corpus's batch) the forward recurrence
-    takes TWO row tiles per workgroup (gru_seq16_kernel<256, 2>).  The 8192-passage batch twice -- the second copy in another
-    row order -- in one call: 64 rows against the oracle, and EVERY row the same bits as in the 8192-row call (one tile per
-    workgroup): a passage's embedding depends on nothing but the passage, whatever the batch it travels in."""
+    """From two rounds of 16-row workgroups up (8 192 rows on 256 CUs; four rounds until round 5) the forward recurrence takes TWO
+    row tiles per workgroup (gru_seq16_kernel<256, 2>).  The 8192-passage batch twice -- the second copy in another row order --
+    in one call: 64 rows against the oracle, EVERY row the same bits as in the 8192-row call, and the first 4096 rows the same
+    bits as in a 4096-row call (one round: ONE tile per workgroup): a passage's embedding depends on nothing but the passage,
+    whatever the batch it travels in and whichever form of the kernel runs it."""
     import bench
     dev = torch.device("cuda:0")
     inp = bench.make_encoder_inputs(dev)
@@ -127,9 +128,11 @@ def test_two_tile_batch_b16384_rows_vs_oracle_and_vs_the_b8192_call(oracle):
     both = torch.cat([big, big[perm]], 0)
     assert both.shape[0] == 16384
     with torch.no_grad():
+        y4 = m.encode_document(big[:4096].to(dev))
         y8 = m.encode_document(big.to(dev))
         y16 = m.encode_document(both.to(dev))
     assert torch.equal(y16[:8192], y8) and torch.equal(y16[8192:], y8[perm.to(dev)])
+    assert torch.equal(y8[:4096], y4)
     lens = (both.numpy() != 0).sum(1)
     rs = np.random.RandomState(12)
     rows = np.unique(np.concatenate([[int(lens.argmax()), int(lens.argmin()), 0, 16383], rs.choice(16384, 62, replace=False)]))[:64]

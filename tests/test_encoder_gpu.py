@@ -512,7 +512,7 @@ def test_two_row_tiles_per_workgroup_vs_one(B, T, layers, bi):
     """gru_seq16_kernel<256, 2> (big batches: a workgroup takes 32 rows, every streamed W_hh fragment multiplies both tiles' h
     fragments) against the one-tile form: a row's products and their order are the same -> the SAME BITS, eval and train, stash
     included (the backward pass of both runs is the same kernel: every gradient the same bits).  The product library takes two
-    tiles from four rounds of one-tile workgroups up (B >= 16 384 on 256 CUs: tests/test_bench_size_gpu.py runs that size
+    tiles from two rounds of one-tile workgroups up (B >= 8 192 on 256 CUs; four rounds until round 5: tests/test_bench_size_gpu.py runs that size
     against the oracle); here the comparison build forces either form (TT_GRU16_RT = 3 / 1) on small shapes: a half-empty
     second tile, a one-row batch, both directions in one launch, stacked layers, ragged lengths."""
     from conftest import ab_library

@@ -95,7 +95,11 @@ struct G16 {
     static constexpr int NR = NS == 0 ? 1 : (H == 256 && RT == 1 ? TT_G16_NR : 6); // streamed fragments in flight per wave
     static constexpr int LDS_BYTES = H_BYTES + NW * NL * 1024;
 #ifndef TT_G16_RT2_ROUNDS
-#define TT_G16_RT2_ROUNDS 4 // two tiles per workgroup from this many rounds of one-tile workgroups up
+// two tiles per workgroup from this many rounds of one-tile workgroups up.  4 until round 5; with the projected table (no Gi buffer
+// to write and read back: the W_hh stream is all the recurrence waits for) the shared fragments pay earlier and more
+// (tools/experiments/gru16_rt.py, profiles/r05_l_gru16_rt.log, one vs two tiles): 6 144 passages 1.00 vs 1.13 ms, 8 192: 1.21 vs
+// 1.16, 12 288: 1.66 vs 1.56, 16 384: 2.16 vs 1.85, 32 768: 4.12 vs 3.56 ms (round 4, projecting calls: +3-6 % from 16 384 up)
+#define TT_G16_RT2_ROUNDS 2
 #endif
 #ifndef TT_G16_GI_Q0
 #define TT_G16_GI_Q0 14
