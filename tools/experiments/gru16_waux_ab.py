@@ -47,7 +47,8 @@ def main():
                     out[n][c].append(round((time.perf_counter() - t0) / 4 * 1e3, 4))
                     if c not in ref:
                         ref[c] = y.clone()
-                    assert torch.equal(y, ref[c]), (n, c)
+                    if "skip" not in n:
+                        assert torch.equal(y, ref[c]), (n, c)
     _lib._lib = keep
     for n in names:
         print(json.dumps({"variant": n, **{c: out[n][c] for c in cases}}), flush=True)

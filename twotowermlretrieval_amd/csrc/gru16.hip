@@ -365,6 +365,9 @@ __global__ __launch_bounds__(H / 32 * 64) void gru_seq16_kernel(GruParams p)
                 constexpr int kind = P::value.kind[f], idx = P::value.idx[f];
                 if constexpr (kind == K_STR) {
                     constexpr int off = P::value.sfrag[(idx + C::NR) % C::NS] * 1024;
+#ifdef TT_G16_EXP_SKIP_STREAM // MEASUREMENT ONLY (wrong results): every TT_G16_EXP_SKIP_STREAM-th streamed fragment is not fetched
+                    if constexpr (idx % TT_G16_EXP_SKIP_STREAM != 0)
+#endif
                     ring[idx % C::NR] = frag_stream(wsrc, loff, off);
                 }
             });
