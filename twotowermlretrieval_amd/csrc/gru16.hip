@@ -169,6 +169,12 @@ __global__ __launch_bounds__(256) void pack_whh16_kernel(const float *__restrict
 __device__ __forceinline__ float fast_sigmoid16(float x) { return tt_fast_sigmoid(x); }
 __device__ __forceinline__ float fast_tanh16(float x) { return tt_fast_tanh(x); }
 
+#ifdef TT_G16_DBG // a measuring build: s_memtime clocks per phase of the step (wave 0 and wave 4 of every workgroup), printed by gru16_launch
+__device__ unsigned long long g16_dbg[16];
+#define G16_T(i) do { __builtin_amdgcn_sched_barrier(0); tm[i] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define G16_T(i) do { } while (0)
+#endif
 // GATHER: the projections come from the projected table (GruParams::gi_ids): one more dependent load per row and step, the
 // id, asked for well ahead of the row loads that need it -- RT = 1: during the previous step (4 registers across the step
 // boundary); RT = 2: GI_AHEAD multiply groups in front of the tile's projection loads (no registers to spare at the boundary).
@@ -264,7 +270,11 @@ __global__ __launch_bounds__(H / 32 * 64) void gru_seq16_kernel(GruParams p)
     };
     if constexpr (GATHER && RT == 1)
         load_ids(std::integral_constant<int, 0>{}, 0);
+#ifdef TT_G16_DBG
+    unsigned long long tm[5], tacc[4] = {0, 0, 0, 0};
+#endif
     for (int s = 0; s < steps; ++s) {
+        G16_T(0);
         float giv[RT][3][2][4];
         // this step's token of row e of tile rt (a valid token even when the row is done); RT = 2 recomputes it where it is used
         // instead of keeping it through the multiply
@@ -304,6 +314,7 @@ __global__ __launch_bounds__(H / 32 * 64) void gru_seq16_kernel(GruParams p)
         // by scheduling fences (left alone, hipcc hoists every load of the step and spills): group q issues the LDS
         // reads of group q + 1 (its LDS-resident B fragments; the next k-step's A fragments one group early), then its
         // own six MFMAs per row tile, then refills the ring slots it consumed.
+        G16_T(1);
         h8 a_hi[2][RT], a_lo[2][RT]; // by k-step parity
         h8 lbuf[2][4];               // LDS-resident B fragments of the current / next group
 #pragma unroll
@@ -339,12 +350,16 @@ __global__ __launch_bounds__(H / 32 * 64) void gru_seq16_kernel(GruParams p)
             static_for<0, 4>([&](auto ic) {
                 constexpr int i = decltype(ic)::value, f = f0 + i;
                 constexpr int kind = P::value.kind[f], idx = P::value.idx[f];
+#ifdef TT_G16_EXP_NO_OPERAND_WAIT // MEASUREMENT ONLY (wrong results): every B fragment is register 0 -- what the multiply costs without operand latency
+                b[i] = wreg[0];
+#else
                 if constexpr (kind == K_REG)
                     b[i] = wreg[idx];
                 else if constexpr (kind == K_LDS)
                     b[i] = lbuf[q & 1][i];
                 else
                     b[i] = ring[idx % C::NR];
+#endif
             });
             constexpr int t0 = 2 * pair, t1 = 2 * pair + 1;
 #pragma unroll
@@ -382,6 +397,7 @@ __global__ __launch_bounds__(H / 32 * 64) void gru_seq16_kernel(GruParams p)
             __builtin_amdgcn_sched_barrier(0);
         });
 
+        G16_T(2);
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
             char *nimg = lds + rt * 4 * C::IMG + (cur ^ 1) * 2 * C::IMG;
@@ -415,9 +431,22 @@ __global__ __launch_bounds__(H / 32 * 64) void gru_seq16_kernel(GruParams p)
                     dst[C::IMG / 2] = lo;
                 }
         }
+        G16_T(3);
         __syncthreads();
+        G16_T(4);
+#ifdef TT_G16_DBG
+        for (int i = 0; i < 4; ++i)
+            tacc[i] += tm[i + 1] - tm[i];
+#endif
         cur ^= 1;
     }
+#ifdef TT_G16_DBG
+    if (lane == 0 && (w == 0 || w == 4)) { // [setup, multiply, gate math + image writes, barrier] and the step count, per wave half
+        for (int i = 0; i < 4; ++i)
+            atomicAdd(&g16_dbg[8 * (w >> 2) + i], tacc[i]);
+        atomicAdd(&g16_dbg[8 * (w >> 2) + 4], (unsigned long long)steps);
+    }
+#endif
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
@@ -805,6 +834,20 @@ int gru16_pack(const float *W_hh, int H, unsigned *absmax /*zeroed by the caller
 
 int gru16_launch(const GruParams &gp, int ndir, hipStream_t st)
 {
+#ifdef TT_G16_DBG
+    static int calls = 0;
+    if (++calls % 4 == 0) {
+        unsigned long long h[16];
+        if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g16_dbg), sizeof h) == hipSuccess)
+            for (int k = 0; k < 2; ++k)
+                if (h[8 * k + 4])
+                    fprintf(stderr, "g16dbg waves %d: clocks per step: setup %.0f, multiply %.0f, gates + images %.0f, barrier %.0f (steps %llu)\n", 4 * k,
+                            (double)h[8 * k] / h[8 * k + 4], (double)h[8 * k + 1] / h[8 * k + 4], (double)h[8 * k + 2] / h[8 * k + 4],
+                            (double)h[8 * k + 3] / h[8 * k + 4], h[8 * k + 4]);
+        unsigned long long z[16] = {};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g16_dbg), z, sizeof z);
+    }
+#endif
     const bool two = gru16_two_tiles(gp.B, ndir);
     if (gp.H == 256)
         return two ? launch16<256, 2>(gp, ndir, st) : launch16<256, 1>(gp, ndir, st);
