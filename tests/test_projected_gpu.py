@@ -166,3 +166,25 @@ def test_projected_table_through_the_c_abi():
         outs.append((out, ws_bytes))
     assert torch.equal(outs[0][0], outs[1][0])
     assert outs[1][1] < outs[0][1] - B * T * 3 * H * 4 + 4096        # a one-layer projected call needs no [tokens][3H] scratch
+
+
+def test_projected_forward_on_random_shapes():
+    """Twenty seeded random configurations (batch 1 .. 2 600 rows across the three recurrence kernels' ranges, sequence length,
+    vocabulary, layers, directions, H in {128, 256}, one-workgroup option, interior id-0 tokens, rows of length 1): the projected
+    call returns the projecting call's bits every time."""
+    rs = np.random.RandomState(2025)
+    for trial in range(20):
+        B = int(rs.choice([1, 2, 15, 16, 17, 100, 513, 1024, 1025, 2600]))
+        T = int(rs.randint(1, 60))
+        H = int(rs.choice([128, 256]))
+        E = int(rs.choice([52, 200, 300]))
+        layers, bi = int(rs.randint(1, 3)), bool(rs.randint(0, 2))
+        V = int(rs.randint(40, 3000))
+        enc, _, _ = make_encoder(V, E, H, 7000 + trial, layers, bi)
+        enc.one_workgroup = bool(rs.randint(0, 2))
+        ids_np = synth.make_ids(7100 + trial, B, T, V, zero_inside=0.1)
+        ids_np[rs.randint(0, B), 1:] = 0                      # a row of length 1
+        proj, plain = both_ways(enc, torch.from_numpy(ids_np).cuda())
+        assert torch.equal(proj, plain), (trial, B, T, E, H, layers, bi, V)
+        del enc
+    torch.cuda.empty_cache()

@@ -143,3 +143,28 @@ def test_streamed_search_rejects_what_it_cannot_answer():
     empty = tt.StreamedIndex(D[:0], block_docs=128, idx_offset=4)   # a rank whose shard is empty lists only padding
     v, i = empty.search(torch.from_numpy(synth.unit_rows(6, 3, 256)).cuda(), 4)
     assert bool((i == -1).all()) and bool(torch.isinf(v).all())
+
+
+def test_streamed_and_sharded_streamed_on_random_shapes(oracle):
+    """Fifteen seeded random (rows, block size, batch, k, shard-list length) combinations -- blocks of one row, blocks larger than the
+    corpus, k larger than a block, k' < k, batches on both sides of the two screen forms: StreamedIndex and a ShardedIndex over it
+    equal the oracle over the widened rows, bit for bit."""
+    import twotowermlretrieval_amd as tt
+    rs = np.random.RandomState(77)
+    for trial in range(15):
+        N = int(rs.choice([1, 7, 300, 4097, 20000, 70001]))
+        block = int(rs.choice([1, 5, 256, 4096, 65536, 200000])) if N < 5000 else int(rs.choice([4096, 16384, 65536, 200000]))
+        B = int(rs.choice([1, 3, 32, 33, 64, 65, 130]))
+        k = int(rs.choice([1, 5, 10, 50, 64]))
+        shard_k = int(rs.choice([1, 10, 50]))
+        off = int(rs.randint(0, 10 ** 9))
+        D = torch.from_numpy(synth.unit_rows(300 + trial, N, 256)).to(torch.bfloat16)
+        Q = synth.unit_rows(400 + trial, B, 256)
+        ix = tt.StreamedIndex(D, block_docs=block, idx_offset=off)
+        v, i = ix.search(torch.from_numpy(Q).cuda(), k)
+        sv, si = tt.ShardedIndex(ix, off, shard_k=shard_k).search(torch.from_numpy(Q).cuda(), k)
+        torch.cuda.synchronize()
+        ov, oi = oracle.score_topk(Q, D.to(torch.float32).numpy(), k, idx_offset=off)
+        what = (trial, N, block, B, k, shard_k)
+        assert np.array_equal(i.cpu().numpy(), oi) and np.array_equal(v.cpu().numpy(), ov), what
+        assert np.array_equal(si.cpu().numpy(), oi) and np.array_equal(sv.cpu().numpy(), ov), what
