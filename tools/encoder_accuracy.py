@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Error of the encoder against the CPU oracle (fp32 throughout) on a north-star-shaped batch, for the two arithmetic
-paths: TT_GRU_F32=1 (fp32 MFMA everywhere) and the default (fp16 hi/lo split on the f16 pipes for the input projection,
-the recurrence, its backward and the weight-gradient products).  One process per setting (the switch is read once):
-    python tools/encoder_accuracy.py            # runs both as child processes and prints one JSON line each"""
+paths of the PRODUCT library: RNNEncoder(arith="f32") (TT_ENC_F32: fp32 MFMA everywhere) and the default (fp16 hi/lo split on the
+f16 pipes for the input projection, the recurrence, its backward and the weight-gradient products).
+    python tools/encoder_accuracy.py            # one JSON line per path"""
 import json
 import os
 import subprocess
@@ -13,7 +13,7 @@ ROOT = Path(__file__).resolve().parent.parent
 sys.path[:0] = [str(ROOT), str(ROOT / "tests" / "golden")]
 
 
-def child():
+def child(arith):
     import numpy as np
     import torch
     import synth
@@ -23,7 +23,7 @@ def child():
     V, E, H, B, T = 2000, 300, 256, 48, 120
     table = synth.make_table(3, V, E)
     sd = synth.make_encoder_state(4, E, H)
-    enc = RNNEncoder(V, E, H, pretrained_embeddings=table)
+    enc = RNNEncoder(V, E, H, pretrained_embeddings=table, arith=arith)
     full = {"embedding.weight": torch.from_numpy(table)}
     full.update({k: torch.from_numpy(v) for k, v in sd.items()})
     enc.load_state_dict(full)
@@ -39,15 +39,11 @@ def child():
     rel = {}
     for (name, got), ref in zip(grads.items(), og[0]):
         rel[name] = float(np.abs(got - ref).max() / np.abs(ref).max())
-    print(json.dumps({"path": "fp32 MFMA (TT_GRU_F32=1)" if os.environ.get("TT_GRU_F32") == "1" else "fp16 hi/lo split on f16 MFMA",
+    print(json.dumps({"path": "fp32 MFMA (arith='f32', TT_ENC_F32)" if arith == "f32" else "fp16 hi/lo split on f16 MFMA (default)",
                       "shape": dict(B=B, T=T, E=E, H=H), "out_max_abs_err": float(np.abs(y.detach().cpu().numpy() - want).max()),
                       "grad_max_err_over_max": rel}), flush=True)
 
 
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "child":
-        child()
-    else:
-        for v in ("1", "0"):
-            env = dict(os.environ, TT_GRU_F32=v)
-            subprocess.run([sys.executable, __file__, "child"], env=env, check=True)
+    for arith in ("f32", "split16"):
+        child(arith)
